@@ -1,0 +1,1878 @@
+// aic_oracle.cpp -- CPU ORACLE: a restatement of the reference raytracer hot path.
+//
+// *** TEST INFRASTRUCTURE, NOT PRODUCT CODE. ***
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+// library (as the checker / the reported CPU baseline). The product (all_is_cubes_amd/)
+// never includes, links or calls anything in oracle/.
+//
+// Reference: kpreid/all-is-cubes v0.10.0 (Rust). The reference cannot be compiled in the
+// authoring container (no rustc/cargo) and its euclid/rand dependencies are not vendored,
+// so this file restates the algorithm from the cited lines and is PINNED by the
+// reference's own known-answer tests and golden images (see tests/test_oracle_*.py):
+//   raycast/tests.rs step tables, surface.rs iterator tables, accum.rs depth table,
+//   raytracer_components.rs apply_transmittance cases, text.rs 80x40 ASCII frames,
+//   camera/tests.rs (exact view_frustum values), test-renderers/expected/renderers/*.png.
+// Parity status of third-party arithmetic: euclid 0.22.14 Transform3D::{then,inverse},
+// Rotation3D, RigidTransform3D are restated from their published algorithms; pinned by the
+// exact frustum corner values of camera/tests.rs:78-108 and the ASCII frames.
+// LightingOption::Bounce (rand 0.10.1 SmallRng + rand_distr UnitSphere) is NOT restated:
+// "parity unpinned" -- the reference itself has no image test for it
+// (test-renderers/cases/src/lib.rs:45-50); the oracle reports an error for it.
+//
+// Build: g++ -O2 -std=c++17 -ffp-contract=off -fno-fast-math -shared -fPIC -pthread
+// All f64 traversal arithmetic keeps the reference's operation order; no FMA contraction.
+
+#include "aic_oracle.h"
+
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <vector>
+
+namespace {
+
+typedef double f64;
+typedef float f32;
+
+const f64 INF = std::numeric_limits<f64>::infinity();
+const f64 NAN64 = std::numeric_limits<f64>::quiet_NaN();
+
+struct V3 {
+    f64 v[3];
+    f64 &operator[](int a) { return v[a]; }
+    f64 operator[](int a) const { return v[a]; }
+};
+struct I3 {
+    int32_t v[3];
+    int32_t &operator[](int a) { return v[a]; }
+    int32_t operator[](int a) const { return v[a]; }
+};
+inline V3 v3(f64 x, f64 y, f64 z) { return V3{{x, y, z}}; }
+inline I3 i3(int32_t x, int32_t y, int32_t z) { return I3{{x, y, z}}; }
+
+// euclid Vector3D::dot : x*x' + y*y' + z*z' (left to right)
+inline f64 dot(const V3 &a, const V3 &b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+// euclid Vector3D::length = square_length().sqrt()
+inline f64 length(const V3 &a) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+
+// GridAab: lower inclusive, upper exclusive (grid_aab.rs:20)
+struct GridAab {
+    I3 lo, hi;
+};
+const int32_t I32_MIN = std::numeric_limits<int32_t>::min();
+const int32_t I32_MAX = std::numeric_limits<int32_t>::max();
+// raycast.rs:485-499
+const GridAab MAXIMUM_BOUNDS = {{{I32_MIN + 1, I32_MIN + 1, I32_MIN + 1}},
+                                {{I32_MAX - 1, I32_MAX - 1, I32_MAX - 1}}};
+const GridAab ORIGIN_EMPTY = {{{0, 0, 0}}, {{0, 0, 0}}};
+
+// grid_aab.rs:436-442
+inline bool contains_cube(const GridAab &b, const I3 &c) {
+    for (int a = 0; a < 3; a++)
+        if (!(c[a] >= b.lo[a] && c[a] < b.hi[a])) return false;
+    return true;
+}
+// grid_aab.rs:506-515
+inline bool intersection_cubes(const GridAab &x, const GridAab &y, GridAab *out) {
+    GridAab r;
+    for (int a = 0; a < 3; a++) {
+        r.lo[a] = x.lo[a] > y.lo[a] ? x.lo[a] : y.lo[a];
+        r.hi[a] = x.hi[a] < y.hi[a] ? x.hi[a] : y.hi[a];
+    }
+    for (int a = 0; a < 3; a++)
+        if (r.hi[a] <= r.lo[a]) return false;
+    *out = r;
+    return true;
+}
+
+enum Face7 : int32_t { WITHIN = 0, NX = 1, NY = 2, NZ = 3, PX = 4, PY = 5, PZ = 6 };  // face.rs:105-120
+inline int face_axis(int f) { return f == WITHIN ? -1 : (f - 1) % 3; }
+inline I3 face_normal(int f) {
+    switch (f) {
+        case NX: return i3(-1, 0, 0);
+        case NY: return i3(0, -1, 0);
+        case NZ: return i3(0, 0, -1);
+        case PX: return i3(1, 0, 0);
+        case PY: return i3(0, 1, 0);
+        case PZ: return i3(0, 0, 1);
+        default: return i3(0, 0, 0);
+    }
+}
+// face.rs:733-746
+inline f64 face_dot(int f, const V3 &v) {
+    switch (f) {
+        case NX: return -v[0];
+        case NY: return -v[1];
+        case NZ: return -v[2];
+        case PX: return v[0];
+        case PY: return v[1];
+        case PZ: return v[2];
+        default: return 0.0;
+    }
+}
+
+// cube.rs:97-119  Cube::containing
+inline bool cube_containing(const V3 &p, I3 *out) {
+    const f64 MIN_INCLUSIVE = (f64)I32_MIN;
+    const f64 MAX_EXCLUSIVE = (f64)I32_MAX + 1.0;
+    if ((MIN_INCLUSIVE <= p[0]) & (MIN_INCLUSIVE <= p[1]) & (MIN_INCLUSIVE <= p[2]) &
+        (p[0] < MAX_EXCLUSIVE) & (p[1] < MAX_EXCLUSIVE) & (p[2] < MAX_EXCLUSIVE)) {
+        *out = i3((int32_t)std::floor(p[0]), (int32_t)std::floor(p[1]), (int32_t)std::floor(p[2]));
+        return true;
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------------------------
+// raycast.rs
+
+struct Ray {
+    V3 origin, direction;
+};
+
+// raycast.rs:782-788
+inline int32_t signum_101(f64 x) {
+    if (x == 0.0) return 0;
+    if (x != x) return 0;  // NaN.signum() is NaN; `NaN as i32` == 0
+    return std::signbit(x) ? -1 : 1;
+}
+
+// Rust f64::rem_euclid(rhs): r = self % rhs; if r < 0 { r + rhs.abs() } else { r }
+inline f64 rem_euclid(f64 x, f64 rhs) {
+    f64 r = std::fmod(x, rhs);
+    return r < 0.0 ? r + std::fabs(rhs) : r;
+}
+
+// raycast.rs:797-819
+f64 scale_to_integer_step(f64 s, f64 ds) {
+    if (ds == 0.0 && !(s != s)) {
+        return INF;
+    } else if (ds < 0.0) {
+        s = -s;
+        ds = -ds;
+    }
+    s = rem_euclid(s, 1.0);
+    return (1.0 - s) / ds;
+}
+
+// raycast.rs:126-148
+struct Parameters {
+    Ray ray;
+    I3 step;
+    V3 t_delta;
+};
+// raycast.rs:99-121
+struct State {
+    Parameters param;
+    GridAab bounds;
+    V3 t_max;
+    I3 cube;
+    int32_t last_face;
+    f64 last_t_distance;
+};
+enum FirstLast { BEGINNING, INBOUNDS, ENDED };  // raycast.rs:153-165
+
+// raycast.rs:301-310
+struct RaycastStep {
+    I3 cube;
+    int32_t face;
+    f64 t_distance;
+    V3 t_max;
+};
+
+// raycast.rs:735-746
+Parameters parameters_zero() {
+    Parameters p;
+    p.ray.origin = v3(0, 0, 0);
+    p.ray.direction = v3(0, 0, 0);
+    p.step = i3(0, 0, 0);
+    p.t_delta = v3(INF, INF, INF);
+    return p;
+}
+// raycast.rs:502-509
+State state_empty() {
+    State s;
+    s.param = parameters_zero();
+    s.cube = i3(0, 0, 0);
+    s.t_max = v3(0., 0., 0.);
+    s.last_face = WITHIN;
+    s.last_t_distance = 0.0;
+    s.bounds = ORIGIN_EMPTY;
+    return s;
+}
+
+// raycast.rs:749-771
+Parameters parameters_new(const V3 &origin, V3 direction) {
+    bool all_small = true;
+    for (int a = 0; a < 3; a++) {
+        f64 d = std::fabs(direction[a]);
+        if (!(d < 1e100)) all_small = false;  // partial_cmp == Some(Less)
+    }
+    if (!all_small) direction = v3(0, 0, 0);
+    Parameters p;
+    p.ray.origin = origin;
+    p.ray.direction = direction;
+    for (int a = 0; a < 3; a++) {
+        p.step[a] = signum_101(direction[a]);
+        p.t_delta[a] = 1.0 / std::fabs(direction[a]);  // x.abs().recip()
+    }
+    return p;
+}
+
+// raycast.rs:513-545
+State state_from_parameters(const Parameters &param) {
+    I3 cube;
+    if (!cube_containing(param.ray.origin, &cube) || !contains_cube(MAXIMUM_BOUNDS, cube)) {
+        return state_empty();
+    }
+    State s;
+    s.param = param;
+    s.cube = cube;
+    for (int a = 0; a < 3; a++)
+        s.t_max[a] = scale_to_integer_step(param.ray.origin[a], param.ray.direction[a]);
+    s.last_face = WITHIN;
+    s.last_t_distance = 0.0;
+    s.bounds = MAXIMUM_BOUNDS;
+    return s;
+}
+
+// raycast.rs:548-557
+inline RaycastStep state_current(const State &s) {
+    RaycastStep r;
+    r.cube = s.cube;
+    r.face = s.last_face;
+    r.t_distance = s.last_t_distance;
+    r.t_max = s.t_max;
+    return r;
+}
+
+// raycast.rs:563-570
+inline bool valid_for_stepping(const State &s) {
+    bool step_nonzero = s.param.step[0] != 0 || s.param.step[1] != 0 || s.param.step[2] != 0;
+    bool any_nan = false, any_finite = false;
+    for (int a = 0; a < 3; a++) {
+        if (s.t_max[a] != s.t_max[a]) any_nan = true;
+        if (std::isfinite(s.t_max[a])) any_finite = true;
+    }
+    return step_nonzero && !any_nan && any_finite;
+}
+
+// raycast.rs:577-626. Returns false on i32 overflow (Err(())).
+inline bool state_step(State &s) {
+    int axis;
+    if (s.t_max[0] < s.t_max[1]) {
+        axis = (s.t_max[0] < s.t_max[2]) ? 0 : 2;
+    } else {
+        axis = (s.t_max[1] < s.t_max[2]) ? 1 : 2;
+    }
+    // (the reference asserts param.step[axis] != 0 here)
+    s.last_t_distance = s.t_max[axis];
+    int64_t moved = (int64_t)s.cube[axis] + (int64_t)s.param.step[axis];
+    if (moved < I32_MIN || moved > I32_MAX) return false;  // checked_add
+    s.cube[axis] = (int32_t)moved;
+    s.t_max[axis] += s.param.t_delta[axis];
+    static const int32_t FACE_TABLE[3][2] = {{PX, NX}, {PY, NY}, {PZ, NZ}};
+    s.last_face = FACE_TABLE[axis][s.param.step[axis] > 0 ? 1 : 0];
+    return true;
+}
+
+// raycast.rs:821-832
+inline f64 ray_plane_intersection(const Ray &ray, const I3 &plane_origin, const I3 &plane_normal) {
+    V3 po = v3((f64)plane_origin[0], (f64)plane_origin[1], (f64)plane_origin[2]);
+    V3 pn = v3((f64)plane_normal[0], (f64)plane_normal[1], (f64)plane_normal[2]);
+    V3 rel = v3(po[0] - ray.origin[0], po[1] - ray.origin[1], po[2] - ray.origin[2]);
+    return dot(rel, pn) / dot(ray.direction, pn);
+}
+
+// raycast.rs:632-704
+void fast_forward(State &s) {
+    I3 plane_origin = i3(0, 0, 0);
+    for (int a = 0; a < 3; a++) plane_origin[a] = (s.param.step[a] < 0) ? s.bounds.hi[a] : s.bounds.lo[a];
+
+    f64 max_t = 0.0;
+    for (int a = 0; a < 3; a++) {
+        int32_t direction = s.param.step[a];
+        if (direction == 0) continue;
+        I3 plane_normal = i3(0, 0, 0);
+        plane_normal[a] = direction;
+        f64 intersection_t = ray_plane_intersection(s.param.ray, plane_origin, plane_normal);
+        max_t = std::fmax(max_t, intersection_t);  // f64::max ignores NaN
+    }
+
+    if (max_t > s.last_t_distance) {
+        f64 t_start = max_t - 0.5 / length(s.param.ray.direction);
+        if (!std::isfinite(t_start)) t_start = max_t;
+        // Ray::advance (ray.rs:107-112)
+        Ray ff_ray;
+        for (int a = 0; a < 3; a++) ff_ray.origin[a] = s.param.ray.origin[a] + s.param.ray.direction[a] * t_start;
+        ff_ray.direction = s.param.ray.direction;
+
+        I3 cube;
+        if (!cube_containing(ff_ray.origin, &cube)) {
+            s = state_empty();
+            return;
+        }
+        State n;
+        n.param = s.param;
+        n.param.ray = ff_ray;
+        n.last_face = s.last_face;
+        n.cube = cube;
+        for (int a = 0; a < 3; a++)
+            n.t_max[a] = scale_to_integer_step(ff_ray.origin[a], ff_ray.direction[a]) + t_start;
+        n.last_t_distance = t_start;
+        n.bounds = s.bounds;
+        s = n;
+    }
+}
+
+// raycast.rs:711-728
+inline void is_out_of_bounds_ahead(const State &s, bool *enter, bool *exit) {
+    bool oob_enter = false, oob_exit = false;
+    for (int a = 0; a < 3; a++) {
+        bool oob_low = s.cube[a] < s.bounds.lo[a];
+        bool oob_high = s.cube[a] >= s.bounds.hi[a];
+        int32_t st = s.param.step[a];
+        bool e, x;
+        if (st == 0) {
+            e = oob_low | oob_high;
+            x = oob_low | oob_high;
+        } else if (st < 0) {
+            e = oob_high;
+            x = oob_low;
+        } else {
+            e = oob_low;
+            x = oob_high;
+        }
+        oob_enter |= e;
+        oob_exit |= x;
+    }
+    *enter = oob_enter;
+    *exit = oob_exit;
+}
+
+// raycast.rs:63-75
+struct Raycaster {
+    State state;
+    FirstLast first_last;
+    bool include_exit;
+
+    // raycast.rs:196-202
+    static Raycaster make(const V3 &origin, const V3 &direction) {
+        Raycaster r;
+        r.state = state_from_parameters(parameters_new(origin, direction));
+        r.first_last = BEGINNING;
+        r.include_exit = true;
+        return r;
+    }
+    // raycast.rs:223-230
+    Raycaster within(const GridAab &bounds, bool include_exit_) const {
+        Raycaster r = *this;
+        GridAab nb;
+        if (!intersection_cubes(r.state.bounds, bounds, &nb)) nb = ORIGIN_EMPTY;
+        r.state.bounds = nb;
+        r.first_last = BEGINNING;
+        r.include_exit = include_exit_;
+        fast_forward(r.state);
+        return r;
+    }
+    // raycast.rs:239-284
+    bool next(RaycastStep *out) {
+        for (;;) {
+            bool oob_enter, oob_exit;
+            is_out_of_bounds_ahead(state, &oob_enter, &oob_exit);
+            if ((first_last == INBOUNDS || first_last == BEGINNING) && !oob_enter && !oob_exit) {
+                RaycastStep item = state_current(state);
+                if (!valid_for_stepping(state)) {
+                    first_last = ENDED;
+                    if (state.last_face == WITHIN) {
+                        *out = item;
+                        return true;
+                    }
+                    return false;
+                }
+                (void)state_step(state);
+                first_last = INBOUNDS;
+                *out = item;
+                return true;
+            } else if (first_last == BEGINNING && oob_enter && !oob_exit) {
+                if (!valid_for_stepping(state)) {
+                    first_last = ENDED;
+                    return false;
+                }
+                if (!state_step(state)) return false;  // .ok()?
+            } else if (first_last == INBOUNDS && !oob_enter && oob_exit) {
+                first_last = ENDED;
+                if (include_exit) {
+                    *out = state_current(state);
+                    return true;
+                }
+                return false;
+            } else {
+                // (Ended, _, _) | (_, _, true); (InBounds, true, false) is unreachable
+                return false;
+            }
+        }
+    }
+};
+
+// raycast.rs:409-439
+V3 intersection_point(const RaycastStep &st, const Ray &ray) {
+    int current_face_axis = face_axis(st.face);
+    if (current_face_axis < 0) return ray.origin;
+    V3 ip = v3((f64)st.cube[0], (f64)st.cube[1], (f64)st.cube[2]);
+    for (int axis = 0; axis < 3; axis++) {
+        int32_t step_direction = signum_101(ray.direction[axis]);
+        if (axis == current_face_axis) {
+            if (step_direction < 0) ip[axis] += 1.0;
+        } else if (step_direction == 0) {
+            ip[axis] = ray.origin[axis];
+        } else {
+            f64 offset_inside_cube = (st.t_max[axis] - st.t_distance) * ray.direction[axis];
+            // f64::clamp(0,1): NaN stays NaN
+            if (step_direction > 0) {
+                f64 c = offset_inside_cube;
+                if (c < 0.0) c = 0.0;
+                if (c > 1.0) c = 1.0;
+                ip[axis] += 1. - c;
+            } else {
+                f64 c = -offset_inside_cube;
+                if (c < 0.0) c = 0.0;
+                if (c > 1.0) c = 1.0;
+                ip[axis] += c;
+            }
+        }
+    }
+    return ip;
+}
+
+// raycast.rs:458-476
+Raycaster recursive_raycast(const RaycastStep &st, const Ray &ray, int32_t resolution,
+                            const GridAab &bounds, Ray *sub_ray_out) {
+    Ray sub_ray;
+    for (int a = 0; a < 3; a++) sub_ray.origin[a] = (ray.origin[a] - (f64)st.cube[a]) * (f64)resolution;
+    sub_ray.direction = ray.direction;
+    *sub_ray_out = sub_ray;
+    return Raycaster::make(sub_ray.origin, sub_ray.direction).within(bounds, true);
+}
+
+// ------------------------------------------------------------------------------------
+// colour, light  (math/color.rs, space/light/data.rs, raytracer_components.rs)
+
+struct Rgb {
+    f32 r, g, b;
+};
+struct Rgba {
+    f32 r, g, b, a;
+};
+
+// restricted_number.rs:240-248
+inline f32 ps_new_clamped(f32 v) { return v > 0.f ? v : 0.f; }  // NaN would panic in the reference
+// restricted_number.rs:315-326
+inline f32 zo_new_clamped(f32 v) {
+    if (v > 0.f && v <= 1.f) return v;
+    if (v <= 0.f) return 0.f;
+    return 1.f;
+}
+// PositiveSign::mul (restricted_number.rs:275-284): NaN (0*inf) => 0
+inline f32 ps_mul(f32 a, f32 b) {
+    f32 v = a * b;
+    return (v != v) ? 0.f : v;
+}
+
+// light/data.rs PACKED_LIGHT_SCALAR_LOOKUP_TABLE is *defined* as libm::exp2f((v-144)/10),
+// 0 -> 0 (data.rs:239-249). Generated here; pinned against the literal table by the tests.
+f32 g_light_lut[256];
+struct LutInit {
+    LutInit() {
+        g_light_lut[0] = 0.f;
+        for (int v = 1; v < 256; v++) {
+            f32 arg = ((f32)v - 144.0f) / 10.0f;
+            g_light_lut[v] = (f32)std::exp2((double)arg);
+        }
+    }
+} g_lut_init;
+
+// data.rs:214-218 scalar_in
+inline uint8_t packed_scalar_in(f32 value) {
+    f32 x = std::round(std::log2(value) * 10.0f + 144.0f);  // f32::round = half away from zero
+    if (x != x) return 0;
+    if (x <= 0.f) return 0;
+    if (x >= 255.f) return 255;
+    return (uint8_t)x;
+}
+
+struct PackedLight {
+    uint8_t r, g, b, status;  // status: 0 Uninitialized, 1 NoRays, 128 Opaque, 255 Visible
+};
+const PackedLight PL_NO_RAYS = {0, 0, 0, 1};
+const PackedLight PL_UNINIT = {0, 0, 0, 0};
+inline PackedLight pl_some(Rgb v) { return PackedLight{packed_scalar_in(v.r), packed_scalar_in(v.g), packed_scalar_in(v.b), 255}; }
+inline bool pl_valid(PackedLight p) { return p.status == 255; }  // data.rs:127-135
+inline Rgb pl_value(PackedLight p) { return Rgb{g_light_lut[p.r], g_light_lut[p.g], g_light_lut[p.b]}; }
+// data.rs:145-158
+inline void pl_value_ao(PackedLight p, f32 out[4]) {
+    out[0] = g_light_lut[p.r];
+    out[1] = g_light_lut[p.g];
+    out[2] = g_light_lut[p.b];
+    out[3] = p.status == 255 ? 1.0f : (p.status == 128 ? 0.25f : 0.0f);
+}
+
+// raytracer_components.rs:20-39
+struct ColorBuf {
+    f32 light[3];
+    f32 transmittance;
+    ColorBuf() : light{0.f, 0.f, 0.f}, transmittance(1.0f) {}
+    // raytracer_components.rs:87-92
+    void add_color_internal(const ColorBuf &s) {
+        for (int i = 0; i < 3; i++) light[i] += s.light[i] * transmittance;
+        transmittance *= s.transmittance;
+    }
+    // raytracer_components.rs:105-109
+    bool opaque() const { return transmittance < 1.0f / 256.0f; }
+};
+// raytracer_components.rs:149-163
+inline ColorBuf colorbuf_from_rgba(Rgba v) {
+    ColorBuf c;
+    c.light[0] = v.r * v.a;
+    c.light[1] = v.g * v.a;
+    c.light[2] = v.b * v.a;
+    c.transmittance = 1.0f - v.a;
+    return c;
+}
+// raytracer_components.rs:122-147
+inline Rgba rgba_from_colorbuf(const ColorBuf &buf) {
+    if (buf.transmittance >= 1.0f) return Rgba{0, 0, 0, 0};
+    f32 color_alpha = 1.0f - buf.transmittance;
+    f32 c[3];
+    bool ok = true;
+    for (int i = 0; i < 3; i++) {
+        f32 v = buf.light[i] / color_alpha;
+        if (v > 0.f) c[i] = v;
+        else if (v == 0.f) c[i] = 0.f;
+        else ok = false;  // negative or NaN
+    }
+    Rgba out;
+    if (ok) { out.r = c[0]; out.g = c[1]; out.b = c[2]; }
+    else { out.r = 1.0f; out.g = 0.0f; out.b = 0.0f; }
+    // ZeroOne::try_from(color_alpha).unwrap_or(1.0)
+    if (color_alpha > 0.f && color_alpha <= 1.f) out.a = color_alpha;
+    else if (color_alpha == 0.f) out.a = 0.f;
+    else out.a = 1.0f;
+    return out;
+}
+// color.rs:288-297
+inline f32 luminance(f32 r, f32 g, f32 b) { return g * 0.7152f + (r * 0.2126f + b * 0.0722f); }
+
+// raytracer_components.rs:215-258
+void apply_transmittance(Rgba color, f32 thickness, Rgba *out_color, f32 *out_coeff) {
+    thickness = std::fmax(thickness, 0.0f);  // f32::max
+    if (thickness == 0.0f) {
+        if (color.a == 1.0f) { *out_color = color; *out_coeff = 1.0f; }
+        else { *out_color = Rgba{0, 0, 0, 0}; *out_coeff = 0.0f; }
+        return;
+    }
+    // color.clamp().alpha(): clamp affects rgb only (color.rs:692-697)
+    f32 unit_transmittance = 1.0f - color.a;
+    f32 depth_transmittance = std::pow(unit_transmittance, thickness);  // f32::powf
+    f32 alpha = zo_new_clamped(1.0f - depth_transmittance);
+    Rgba modified = Rgba{color.r, color.g, color.b, alpha};
+    f32 emission_coeff;
+    if (unit_transmittance == 1.0f) emission_coeff = thickness;
+    else emission_coeff = (depth_transmittance - 1.f) / (unit_transmittance - 1.f);
+    *out_color = modified;
+    *out_coeff = std::fmax(emission_coeff, 0.0f);
+}
+
+// color.rs:1038-1054
+inline f32 component_to_srgb(f32 c) {
+    if (c <= 0.0031308f) return c * (323.f / 25.f);
+    return (211.f * std::pow(c, 5.f / 12.f) - 11.f) / 200.f;
+}
+inline uint8_t round_sat_u8(f32 x) {
+    f32 r = std::round(x);
+    if (r != r) return 0;
+    if (r <= 0.f) return 0;
+    if (r >= 255.f) return 255;
+    return (uint8_t)r;
+}
+// color.rs:669-676
+inline void to_srgb8(Rgba c, uint8_t out[4]) {
+    out[0] = round_sat_u8(component_to_srgb(c.r) * 255.f);
+    out[1] = round_sat_u8(component_to_srgb(c.g) * 255.f);
+    out[2] = round_sat_u8(component_to_srgb(c.b) * 255.f);
+    out[3] = round_sat_u8(c.a * 255.0f);
+}
+
+// camera_struct.rs:376-382 + graphics_options.rs:352-368
+inline Rgba post_process_color(Rgba c, const orc_options &o) {
+    f32 r = ps_mul(c.r, o.exposure), g = ps_mul(c.g, o.exposure), b = ps_mul(c.b, o.exposure);
+    if (std::isfinite(o.maximum_intensity)) {
+        f32 m = o.maximum_intensity;
+        if (o.tone_mapping == 0) {
+            // PositiveSign::clamp(0, max)
+            r = r < 0.f ? 0.f : (r > m ? m : r);
+            g = g < 0.f ? 0.f : (g > m ? m : g);
+            b = b < 0.f ? 0.f : (b > m ? m : b);
+        } else {
+            f32 scale = 1.0f / (1.0f + luminance(r, g, b) / m);
+            f32 s = ps_new_clamped(scale);
+            r = ps_mul(r, s); g = ps_mul(g, s); b = ps_mul(b, s);
+        }
+    }
+    return Rgba{r, g, b, c.a};
+}
+
+// surface.rs:509-520
+inline f64 coarsestep(f64 x) {
+    const f64 STEPS = 4.0;
+    f64 f = std::floor(x * STEPS);
+    if (f < 0.0) f = 0.0;
+    if (f > STEPS - 1.0) f = STEPS - 1.0;
+    return (f + 0.5) / STEPS;
+}
+inline f64 smoothstep(f64 x) {
+    if (x < 0.0) x = 0.0;
+    if (x > 1.0) x = 1.0;
+    return 3. * (x * x) - 2. * (x * x * x);
+}
+
+// ------------------------------------------------------------------------------------
+// Sky (space/sky.rs)
+
+struct BlockSky {
+    PackedLight faces[6];  // nx ny nz px py pz
+    PackedLight mean;
+};
+
+// face.rs:395-404 + rotation.rs:213-273,405-416 : Face::rotation_from_nz().transform_vector
+inline void rot_from_nz_basis(int face, I3 *bx, I3 *by, I3 *bz) {
+    // images of +X, +Y, +Z unit vectors under the rotation
+    switch (face) {
+        case NX: *bx = i3(0, 1, 0); *by = i3(0, 0, 1); *bz = i3(1, 0, 0); break;   // RYZX
+        case NY: *bx = i3(0, 0, 1); *by = i3(1, 0, 0); *bz = i3(0, 1, 0); break;   // RZXY
+        case NZ: *bx = i3(1, 0, 0); *by = i3(0, 1, 0); *bz = i3(0, 0, 1); break;   // RXYZ
+        case PX: *bx = i3(0, -1, 0); *by = i3(0, 0, 1); *bz = i3(-1, 0, 0); break; // RyZx
+        case PY: *bx = i3(0, 0, 1); *by = i3(-1, 0, 0); *bz = i3(0, -1, 0); break; // RZxy
+        case PZ: *bx = i3(1, 0, 0); *by = i3(0, -1, 0); *bz = i3(0, 0, -1); break; // RXyz
+        default: *bx = i3(1, 0, 0); *by = i3(0, 1, 0); *bz = i3(0, 0, 1); break;
+    }
+}
+
+// sky.rs:32-41
+inline Rgb sky_sample(const orc_space &sp, const V3 &d) {
+    if (sp.sky_kind == 0) return Rgb{sp.sky[0][0], sp.sky[0][1], sp.sky[0][2]};
+    int idx = ((d[0] >= 0.0 ? 1 : 0) << 2) + ((d[1] >= 0.0 ? 1 : 0) << 1) + (d[2] >= 0.0 ? 1 : 0);
+    return Rgb{sp.sky[idx][0], sp.sky[idx][1], sp.sky[idx][2]};
+}
+
+// sky.rs:45-82
+BlockSky sky_for_blocks(const orc_space &sp) {
+    BlockSky bs;
+    if (sp.sky_kind == 0) {
+        Rgb c = Rgb{sp.sky[0][0], sp.sky[0][1], sp.sky[0][2]};
+        for (int f = 0; f < 6; f++) bs.faces[f] = pl_some(c);
+        bs.mean = pl_some(c);
+        return bs;
+    }
+    static const int32_t P[4][3] = {{-1, -1, -1}, {-1, 1, -1}, {1, -1, -1}, {1, 1, -1}};
+    for (int f = 0; f < 6; f++) {
+        I3 bx, by, bz;
+        rot_from_nz_basis(f + 1, &bx, &by, &bz);
+        f32 acc[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < 4; k++) {
+            V3 d;
+            for (int a = 0; a < 3; a++) d[a] = (f64)(P[k][0] * bx[a] + P[k][1] * by[a] + P[k][2] * bz[a]);
+            Rgb s = sky_sample(sp, d);
+            acc[0] = acc[0] + s.r; acc[1] = acc[1] + s.g; acc[2] = acc[2] + s.b;
+        }
+        bs.faces[f] = pl_some(Rgb{ps_mul(acc[0], 0.25f), ps_mul(acc[1], 0.25f), ps_mul(acc[2], 0.25f)});
+    }
+    f32 acc[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < 8; k++) { acc[0] = acc[0] + sp.sky[k][0]; acc[1] = acc[1] + sp.sky[k][1]; acc[2] = acc[2] + sp.sky[k][2]; }
+    bs.mean = pl_some(Rgb{ps_mul(acc[0], 1.0f / 8.0f), ps_mul(acc[1], 1.0f / 8.0f), ps_mul(acc[2], 1.0f / 8.0f)});
+    return bs;
+}
+
+// sky.rs:113-147
+PackedLight light_outside(const BlockSky &bs, const GridAab &bounds, const I3 &cube) {
+    // lower: cmp(bl-1, cl): -1 Less, 0 Equal, 1 Greater ; checked_sub failure => Less
+    int lower[3], upper[3];
+    for (int a = 0; a < 3; a++) {
+        if (bounds.lo[a] == I32_MIN) lower[a] = -1;
+        else {
+            int32_t beyond = bounds.lo[a] - 1;
+            lower[a] = beyond < cube[a] ? -1 : (beyond == cube[a] ? 0 : 1);
+        }
+        upper[a] = cube[a] < bounds.hi[a] ? -1 : (cube[a] == bounds.hi[a] ? 0 : 1);
+    }
+    int key[6] = {lower[0], lower[1], lower[2], upper[0], upper[1], upper[2]};
+    int n_less = 0, n_equal = 0, which = -1;
+    for (int i = 0; i < 6; i++) {
+        if (key[i] == -1) n_less++;
+        else if (key[i] == 0) { n_equal++; which = i; }
+    }
+    if (n_less == 5 && n_equal == 1) return bs.faces[which];  // order nx ny nz px py pz
+    if (n_less == 6) return PL_UNINIT;
+    return PL_NO_RAYS;
+}
+
+// ------------------------------------------------------------------------------------
+// SpaceRaytracer snapshot (sr.rs:51-60) over the flat scene
+
+struct Counters {
+    uint64_t n_outer = 0, n_inner = 0, n_hits = 0, n_light = 0;
+};
+
+struct SR {
+    const orc_space *sp;
+    orc_options opt;
+    GridAab bounds;
+    BlockSky block_sky;
+    explicit SR(const orc_space *s, const orc_options *o) : sp(s) {
+        if (o) opt = *o;
+        else {
+            std::memset(&opt, 0, sizeof(opt));
+            opt.transparency = 1; opt.lighting = 3; opt.fog = 1;  // GraphicsOptions::default()
+            opt.maximum_intensity = std::numeric_limits<f32>::infinity();
+            opt.exposure = 1.0f; opt.view_distance = 200.0;
+        }
+        for (int a = 0; a < 3; a++) { bounds.lo[a] = s->lo[a]; bounds.hi[a] = s->lo[a] + s->size[a]; }
+        block_sky = sky_for_blocks(*s);
+    }
+    // vol.rs:988-1023
+    bool cube_index(const I3 &c, size_t *idx) const {
+        uint32_t dx = (uint32_t)c[0] - (uint32_t)sp->lo[0];
+        uint32_t dy = (uint32_t)c[1] - (uint32_t)sp->lo[1];
+        uint32_t dz = (uint32_t)c[2] - (uint32_t)sp->lo[2];
+        if ((dx >= (uint32_t)sp->size[0]) | (dy >= (uint32_t)sp->size[1]) | (dz >= (uint32_t)sp->size[2])) return false;
+        *idx = ((size_t)dx * (size_t)sp->size[1] + dy) * (size_t)sp->size[2] + dz;
+        return true;
+    }
+    // sr.rs:241-246
+    PackedLight get_packed_light(const I3 &cube, Counters *cn) const {
+        size_t idx;
+        if (cn) cn->n_light++;
+        if (cube_index(cube, &idx)) {
+            const uint8_t *t = sp->light + 4 * idx;
+            return PackedLight{t[0], t[1], t[2], t[3]};
+        }
+        return light_outside(block_sky, bounds, cube);
+    }
+};
+
+struct Evoxel {
+    Rgba color;
+    Rgb emission;
+};
+inline Evoxel palette_entry(const orc_space *sp, uint32_t idx) {
+    const f32 *p = sp->palette + 8 * (size_t)idx;
+    return Evoxel{Rgba{p[0], p[1], p[2], p[3]}, Rgb{p[4], p[5], p[6]}};
+}
+inline bool evoxel_invisible(const Evoxel &v) {
+    // color.fully_transparent() && emission == Rgb::ZERO
+    return v.color.a == 0.f && v.emission.r == 0.f && v.emission.g == 0.f && v.emission.b == 0.f;
+}
+// voxel_storage.rs:364-385 single_voxel()
+inline bool block_single_voxel(const orc_space *sp, const orc_block &b, Evoxel *out) {
+    if (b.is_one) { *out = palette_entry(sp, b.pal_off); return true; }
+    if (b.resolution == 1) {
+        // indices.get([0,0,0]) or AIR
+        uint32_t dx = (uint32_t)0 - (uint32_t)b.vlo[0], dy = (uint32_t)0 - (uint32_t)b.vlo[1], dz = (uint32_t)0 - (uint32_t)b.vlo[2];
+        if ((dx >= (uint32_t)b.vsize[0]) | (dy >= (uint32_t)b.vsize[1]) | (dz >= (uint32_t)b.vsize[2])) {
+            *out = Evoxel{Rgba{0, 0, 0, 0}, Rgb{0, 0, 0}};
+        } else {
+            size_t i = ((size_t)dx * b.vsize[1] + dy) * b.vsize[2] + dz;
+            *out = palette_entry(sp, b.pal_off + sp->voxels[b.vox_off + i]);
+        }
+        return true;
+    }
+    return false;
+}
+inline GridAab block_voxel_bounds(const orc_block &b) {
+    GridAab g;
+    if (b.is_one) { g.lo = i3(0, 0, 0); g.hi = i3(1, 1, 1); return g; }
+    for (int a = 0; a < 3; a++) { g.lo[a] = b.vlo[a]; g.hi[a] = b.vlo[a] + b.vsize[a]; }
+    return g;
+}
+
+// ------------------------------------------------------------------------------------
+// surface.rs iterators
+
+// surface.rs:25-46
+struct Surface {
+    int32_t block_index;  // stands in for block_data
+    Rgba diffuse_color;
+    Rgb emission;
+    I3 cube;
+    int32_t resolution;
+    I3 voxel;
+    f64 t_distance;
+    V3 intersection_point;
+    int32_t normal;
+};
+enum TraceKind { ENTER_SURFACE = 0, INVISIBLE = 1, ENTER_BLOCK = 2 };
+struct TraceStep {
+    TraceKind kind;
+    Surface surface;    // EnterSurface
+    f64 t_distance;     // Invisible / EnterBlock
+    int32_t block_index;  // EnterBlock
+};
+
+// surface.rs:361-411
+struct VoxelSurfaceIter {
+    Ray voxel_ray;
+    Raycaster voxel_raycaster;
+    int32_t block_index;
+    const orc_block *block;
+    I3 block_cube;
+    const orc_space *sp;
+
+    bool next(TraceStep *out, Counters *cn) {
+        RaycastStep rc;
+        if (!voxel_raycaster.next(&rc)) return false;
+        f64 antiscale = 1.0 / (f64)block->resolution;  // recip_f64: exact power of two
+        f64 t_distance = rc.t_distance * antiscale;
+        // get_opt_evoxel
+        uint32_t dx = (uint32_t)rc.cube[0] - (uint32_t)block->vlo[0];
+        uint32_t dy = (uint32_t)rc.cube[1] - (uint32_t)block->vlo[1];
+        uint32_t dz = (uint32_t)rc.cube[2] - (uint32_t)block->vlo[2];
+        if ((dx >= (uint32_t)block->vsize[0]) | (dy >= (uint32_t)block->vsize[1]) | (dz >= (uint32_t)block->vsize[2])) {
+            out->kind = INVISIBLE;
+            out->t_distance = t_distance;
+            return true;
+        }
+        if (cn) cn->n_inner++;
+        size_t i = ((size_t)dx * block->vsize[1] + dy) * block->vsize[2] + dz;
+        Evoxel voxel = palette_entry(sp, block->pal_off + sp->voxels[block->vox_off + i]);
+        if (evoxel_invisible(voxel)) {
+            out->kind = INVISIBLE;
+            out->t_distance = t_distance;
+            return true;
+        }
+        out->kind = ENTER_SURFACE;
+        Surface &s = out->surface;
+        s.block_index = block_index;
+        s.diffuse_color = voxel.color;
+        s.emission = voxel.emission;
+        s.cube = block_cube;
+        s.resolution = block->resolution;
+        s.voxel = rc.cube;
+        s.t_distance = t_distance;
+        V3 ip = intersection_point(rc, voxel_ray);
+        for (int a = 0; a < 3; a++) s.intersection_point[a] = ip[a] * antiscale + (f64)block_cube[a];
+        s.normal = rc.face;
+        return true;
+    }
+};
+
+// surface.rs:251-354
+struct SurfaceIter {
+    Ray ray;
+    Raycaster block_raycaster;
+    bool has_current;
+    VoxelSurfaceIter current_block;
+    const SR *rt;
+
+    SurfaceIter(const SR *rt_, const Ray &ray_) : ray(ray_), has_current(false), rt(rt_) {
+        block_raycaster = Raycaster::make(ray.origin, ray.direction).within(rt->bounds, true);
+    }
+
+    bool next(TraceStep *out, Counters *cn) {
+        if (has_current) {
+            if (current_block.next(out, cn)) return true;
+        }
+        has_current = false;
+
+        RaycastStep rc;
+        if (!block_raycaster.next(&rc)) return false;
+
+        size_t idx;
+        if (!rt->cube_index(rc.cube, &idx)) {
+            out->kind = INVISIBLE;
+            out->t_distance = rc.t_distance;
+            return true;
+        }
+        if (cn) cn->n_outer++;
+        if (rt->sp->always_invisible && rt->sp->always_invisible[idx]) {
+            out->kind = INVISIBLE;
+            out->t_distance = rc.t_distance;
+            return true;
+        }
+        int32_t bi = rt->sp->block_index[idx];
+        const orc_block &tb = rt->sp->blocks[bi];
+        Evoxel single;
+        if (block_single_voxel(rt->sp, tb, &single)) {
+            if (evoxel_invisible(single)) {
+                out->kind = INVISIBLE;
+                out->t_distance = rc.t_distance;
+            } else {
+                out->kind = ENTER_SURFACE;
+                Surface &s = out->surface;
+                s.block_index = bi;
+                s.diffuse_color = single.color;
+                s.emission = single.emission;
+                s.cube = rc.cube;
+                s.resolution = 1;
+                s.voxel = i3(0, 0, 0);
+                s.t_distance = rc.t_distance;
+                s.intersection_point = intersection_point(rc, ray);
+                s.normal = rc.face;
+            }
+            return true;
+        }
+        Ray sub_ray;
+        Raycaster sub = recursive_raycast(rc, ray, tb.resolution, block_voxel_bounds(tb), &sub_ray);
+        current_block.voxel_ray = sub_ray;
+        current_block.voxel_raycaster = sub;
+        current_block.block_index = bi;
+        current_block.block = &tb;
+        current_block.block_cube = rc.cube;
+        current_block.sp = rt->sp;
+        has_current = true;
+        out->kind = ENTER_BLOCK;
+        out->t_distance = rc.t_distance;
+        out->block_index = bi;
+        return true;
+    }
+};
+
+// surface.rs:493-504
+enum DepthKind { D_INVISIBLE = 10, D_SPAN = 11, D_ENTER_BLOCK = 12 };
+struct DepthStep {
+    DepthKind kind;
+    Surface surface;      // Span
+    f64 exit_t_distance;  // Span
+    f64 t_distance;       // EnterBlock
+    int32_t block_index;  // EnterBlock
+};
+
+// surface.rs:414-491
+struct DepthIter {
+    SurfaceIter surface_iter;
+    bool has_last;
+    Surface last_surface;
+    bool has_buffered;
+    DepthStep buffered_next;
+
+    explicit DepthIter(const SurfaceIter &si) : surface_iter(si), has_last(false), has_buffered(false) {}
+
+    DepthStep flush_last_surface(f64 t_distance) {
+        DepthStep d;
+        if (has_last) {
+            has_last = false;
+            d.kind = D_SPAN;
+            d.surface = last_surface;
+            d.exit_t_distance = t_distance;
+        } else {
+            d.kind = D_INVISIBLE;
+        }
+        return d;
+    }
+
+    bool next(DepthStep *out, Counters *cn) {
+        if (has_buffered) {
+            has_buffered = false;
+            *out = buffered_next;
+            return true;
+        }
+        TraceStep ts;
+        if (!surface_iter.next(&ts, cn)) return false;
+        switch (ts.kind) {
+            case ENTER_SURFACE: {
+                f64 exit_t = ts.surface.t_distance;
+                if (has_last) {
+                    out->kind = D_SPAN;
+                    out->surface = last_surface;
+                    out->exit_t_distance = exit_t;
+                } else {
+                    out->kind = D_INVISIBLE;
+                }
+                last_surface = ts.surface;
+                has_last = true;
+                return true;
+            }
+            case INVISIBLE:
+                *out = flush_last_surface(ts.t_distance);
+                return true;
+            case ENTER_BLOCK: {
+                *out = flush_last_surface(ts.t_distance);
+                buffered_next.kind = D_ENTER_BLOCK;
+                buffered_next.t_distance = ts.t_distance;
+                buffered_next.block_index = ts.block_index;
+                has_buffered = true;
+                return true;
+            }
+        }
+        return false;
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// accumulators (accum.rs, hit.rs, text.rs)
+
+enum Exception { EX_NONE = 0, EX_ENTER_SPACE, EX_INCOMPLETE, EX_SKY, EX_DEBUG_OVERRIDE_RG, EX_BACKDROP, EX_PAINT };
+
+struct Position {
+    I3 cube;
+    int32_t resolution;
+    I3 voxel;
+    int32_t face;
+};
+struct Hit {
+    Exception exception;
+    ColorBuf surface;
+    bool has_t;
+    f64 t_distance;
+    int32_t block;  // block index, or -1 for exceptions
+    bool has_position;
+    Position position;
+};
+
+struct Accumulate {
+    virtual ~Accumulate() {}
+    virtual bool opaque() const = 0;
+    virtual void add(const Hit &hit) = 0;
+    virtual void enter_block(int32_t) {}
+};
+
+// accum.rs:217-245
+struct ColorAccum : Accumulate {
+    ColorBuf buf;
+    // observer (not part of the reference semantics): first hit carrying a Position
+    bool seen_position = false;
+    Position first_position;
+    int32_t first_block = -1;
+    f64 first_t = 0.0;
+    bool opaque() const override { return buf.opaque(); }
+    void add(const Hit &hit) override {
+        if (hit.has_position && !seen_position) {
+            seen_position = true;
+            first_position = hit.position;
+            first_block = hit.block;
+            first_t = hit.t_distance;
+        }
+        if (hit.exception == EX_DEBUG_OVERRIDE_RG) {
+            f32 red = ps_new_clamped(hit.surface.light[0]);
+            f32 green = ps_new_clamped(hit.surface.light[1]);
+            Rgba cur = rgba_from_colorbuf(buf);
+            f32 blue = ps_new_clamped(luminance(cur.r, cur.g, cur.b) * 0.2f);
+            buf.light[0] = red; buf.light[1] = green; buf.light[2] = blue;
+            buf.transmittance = 0.0f;
+        } else {
+            buf.add_color_internal(hit.surface);
+        }
+    }
+};
+
+// accum.rs:254-298
+struct DepthAccum : Accumulate {
+    f64 depth = INF;
+    bool opaque() const override { return depth < INF; }
+    void add(const Hit &hit) override {
+        if (hit.has_t) depth = std::fmin(depth, hit.t_distance);  // f64::min
+    }
+};
+
+// text.rs:52-128  CharacterBuf; characters are ints: -2 Empty('.') -1 EnteredSpace(' ')
+struct CharAccum : Accumulate {
+    int32_t state = -2;
+    bool is_hit = false;
+    const orc_space *sp;
+    explicit CharAccum(const orc_space *s) : sp(s) {}
+    bool opaque() const override { return is_hit; }
+    void add(const Hit &hit) override {
+        if (hit.exception == EX_ENTER_SPACE && !is_hit) { state = -1; return; }
+        if (hit.exception == EX_SKY) return;
+        if (is_hit) return;
+        int32_t ch;
+        if (hit.exception == EX_INCOMPLETE) ch = 'X';
+        else if (hit.exception != EX_NONE) ch = ' ';
+        else ch = sp->blocks[hit.block].name_char;
+        is_hit = true;
+        state = ch;
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// sr.rs: trace_ray_impl / TracingState / get_interpolated_light; surface.rs: to_light
+
+inline void mix4(const f32 a[4], const f32 b[4], f32 amount, f32 out[4]) {  // sr.rs:491-497
+    for (int i = 0; i < 4; i++) out[i] = a[i] + (b[i] - a[i]) * amount;
+}
+
+// sr.rs:248-359
+Rgb get_interpolated_light(const SR &rt, const I3 &cube, const V3 &surface_point, int face, int modifier, Counters *cn) {
+    const f64 above_surface_epsilon = 0.5 / 256.0;
+    I3 bx, by, bz;
+    rot_from_nz_basis(face == WITHIN ? NZ : face, &bx, &by, &bz);  // Within => IDENTITY == NZ's RXYZ
+    V3 rfx = v3((f64)bx[0], (f64)bx[1], (f64)bx[2]);
+    V3 rfy = v3((f64)by[0], (f64)by[1], (f64)by[2]);
+
+    f64 mix_1 = rem_euclid(dot(surface_point, rfx) - 0.5, 1.0);
+    f64 mix_2 = rem_euclid(dot(surface_point, rfy) - 0.5, 1.0);
+    V3 dir_1 = rfx, dir_2 = rfy;
+    if (mix_1 > 0.5) { mix_1 = 1.0 - mix_1; dir_1 = v3(-rfx[0], -rfx[1], -rfx[2]); }
+    if (mix_2 > 0.5) { mix_2 = 1.0 - mix_2; dir_2 = v3(-rfy[0], -rfy[1], -rfy[2]); }
+    if (modifier == 2) { mix_1 = coarsestep(mix_1); mix_2 = coarsestep(mix_2); }
+    else if (modifier == 4) { mix_1 = smoothstep(mix_1); mix_2 = smoothstep(mix_2); }
+
+    const f64 lin_lo = -0.5, lin_hi = 0.5;
+    V3 off_near12, off_near1far2, off_near2far1, off_far12;
+    for (int a = 0; a < 3; a++) {
+        off_near12[a] = dir_1[a] * lin_lo + dir_2[a] * lin_lo;
+        off_near1far2[a] = dir_1[a] * lin_lo + dir_2[a] * lin_hi;
+        off_near2far1[a] = dir_1[a] * lin_hi + dir_2[a] * lin_lo;
+        off_far12[a] = dir_1[a] * lin_hi + dir_2[a] * lin_hi;
+    }
+    V3 center = v3((f64)cube[0] + 0.5, (f64)cube[1] + 0.5, (f64)cube[2] + 0.5);
+    f64 height_in_cube = face_dot(face, surface_point) - face_dot(face, center) + 0.5;
+
+    auto get_light = [&](const V3 &p) -> PackedLight {
+        I3 c;
+        if (cube_containing(p, &c)) return rt.get_packed_light(c, cn);
+        return rt.block_sky.mean;
+    };
+    auto fetch2d = [&](const V3 &origin_2d, f32 out[4]) {
+        auto at = [&](const V3 &off) { return v3(origin_2d[0] + off[0], origin_2d[1] + off[1], origin_2d[2] + off[2]); };
+        PackedLight near12 = get_light(at(off_near12));
+        PackedLight near1far2 = get_light(at(off_near1far2));
+        PackedLight near2far1 = get_light(at(off_near2far1));
+        PackedLight far12 = get_light(at(off_far12));
+        if (!pl_valid(near1far2) && !pl_valid(near2far1)) far12 = near12;
+        f32 a[4], b[4], c[4], d[4], m1[4], m2[4];
+        pl_value_ao(near12, a); pl_value_ao(near1far2, b); pl_value_ao(near2far1, c); pl_value_ao(far12, d);
+        mix4(a, b, (f32)mix_2, m1);
+        mix4(c, d, (f32)mix_2, m2);
+        mix4(m1, m2, (f32)mix_1, out);
+    };
+
+    I3 n = face_normal(face);
+    V3 normal = v3((f64)n[0], (f64)n[1], (f64)n[2]);
+    f32 front[4], final_mix[4];
+    {
+        f64 k = 1.0 - above_surface_epsilon;
+        V3 p = v3(surface_point[0] + normal[0] * k, surface_point[1] + normal[1] * k, surface_point[2] + normal[2] * k);
+        fetch2d(p, front);
+    }
+    if (height_in_cube > (1.0 - above_surface_epsilon)) {
+        for (int i = 0; i < 4; i++) final_mix[i] = front[i];
+    } else {
+        f32 same[4];
+        f64 k = above_surface_epsilon;
+        V3 p = v3(surface_point[0] + normal[0] * k, surface_point[1] + normal[1] * k, surface_point[2] + normal[2] * k);
+        fetch2d(p, same);
+        mix4(same, front, (f32)height_in_cube, final_mix);
+    }
+    f32 w = std::fmax(final_mix[3], 0.1f);
+    return Rgb{final_mix[0] / w, final_mix[1] / w, final_mix[2] / w};
+}
+
+// sr.rs:595-622
+struct TracingState {
+    f64 t_to_absolute_distance;
+    f32 t_to_view_distance;
+    bool has_fog_light;
+    Rgb distance_fog_light;
+    f32 distance_fog_blend;
+    size_t primary_cubes_traced;
+    Accumulate *accumulator;
+    Counters *cn;
+
+    // sr.rs:625-656
+    bool count_step_should_stop() {
+        if (primary_cubes_traced == 0) {
+            Hit h{};
+            h.exception = EX_ENTER_SPACE;
+            h.surface = colorbuf_from_rgba(Rgba{0, 0, 0, 0});
+            h.has_t = false; h.block = -1; h.has_position = false;
+            accumulator->add(h);
+        }
+        primary_cubes_traced += 1;
+        if (primary_cubes_traced > 1000) {
+            Hit h{};
+            h.exception = EX_INCOMPLETE;
+            h.surface = colorbuf_from_rgba(Rgba{0, 0, 0, 0});
+            h.has_t = false; h.block = -1; h.has_position = false;
+            accumulator->add(h);
+            return true;
+        }
+        return accumulator->opaque();
+    }
+
+    // sr.rs:745-768
+    bool distance_fog(f64 t_distance, Rgb *fog_light, f32 *fog_amount) const {
+        if (!has_fog_light) return false;
+        f32 rel = (f32)t_distance * t_to_view_distance;
+        if (rel < 0.0f) rel = 0.0f;
+        if (rel > 1.0f) rel = 1.0f;
+        f32 fog_exponential = 1.0f - std::exp(-1.6f * rel);
+        f32 fog_exp_fudged = fog_exponential / 0.79810348f;
+        f32 sq = rel * rel;
+        f32 p4 = sq * sq;  // powi(4)
+        *fog_light = distance_fog_light;
+        *fog_amount = zo_new_clamped(fog_exp_fudged * (1.0f - distance_fog_blend) + p4 * distance_fog_blend);
+        return true;
+    }
+};
+
+// surface.rs:73-106 to_light + 113-206 compute_illumination
+bool surface_to_light(const Surface &s, const SR &rt, TracingState &ts, ColorBuf *out) {
+    // graphics_options.rs:496-507 limit_alpha
+    Rgba diffuse = s.diffuse_color;
+    if (rt.opt.transparency == 2) {
+        if (diffuse.a > rt.opt.threshold) diffuse.a = 1.0f;
+        else diffuse = Rgba{0, 0, 0, 0};
+    }
+    if (diffuse.a == 0.f && s.emission.r == 0.f && s.emission.g == 0.f && s.emission.b == 0.f) return false;
+    if (ts.cn) ts.cn->n_hits++;
+
+    Rgb illumination;
+    switch (rt.opt.lighting) {
+        case 0: illumination = Rgb{1.f, 1.f, 1.f}; break;
+        case 1:
+        case 5: {  // Flat (Bounce is unsupported here and falls to Flat only when disallowed)
+            I3 n = face_normal(s.normal);
+            illumination = pl_value(rt.get_packed_light(i3(s.cube[0] + n[0], s.cube[1] + n[1], s.cube[2] + n[2]), ts.cn));
+            break;
+        }
+        default:
+            illumination = get_interpolated_light(rt, s.cube, s.intersection_point, s.normal, rt.opt.lighting, ts.cn);
+            break;
+    }
+    // color.rs:708-710 reflect: rgb * illumination * alpha
+    Rgb outgoing;
+    outgoing.r = ps_mul(ps_mul(diffuse.r, illumination.r), diffuse.a) + s.emission.r;
+    outgoing.g = ps_mul(ps_mul(diffuse.g, illumination.g), diffuse.a) + s.emission.g;
+    outgoing.b = ps_mul(ps_mul(diffuse.b, illumination.b), diffuse.a) + s.emission.b;
+    f32 transmittance = 1.0f - diffuse.a;
+
+    Rgb fog_light; f32 fog_amount;
+    if (ts.distance_fog(s.t_distance, &fog_light, &fog_amount)) {
+        f32 comp = 1.0f - fog_amount;
+        outgoing.r = ps_mul(outgoing.r, comp) + ps_mul(fog_light.r, fog_amount);
+        outgoing.g = ps_mul(outgoing.g, comp) + ps_mul(fog_light.g, fog_amount);
+        outgoing.b = ps_mul(outgoing.b, comp) + ps_mul(fog_light.b, fog_amount);
+        transmittance *= comp;
+    }
+    out->light[0] = outgoing.r; out->light[1] = outgoing.g; out->light[2] = outgoing.b;
+    out->transmittance = transmittance;
+    return true;
+}
+
+// sr.rs:697-717
+void trace_through_surface(TracingState &ts, const Surface &s, const SR &rt) {
+    ColorBuf light;
+    if (surface_to_light(s, rt, ts, &light)) {
+        Hit h{};
+        h.exception = EX_NONE;
+        h.surface = light;
+        h.has_t = true;
+        h.t_distance = s.t_distance;
+        h.block = s.block_index;
+        h.has_position = true;
+        h.position = Position{s.cube, s.resolution, s.voxel, s.normal};
+        ts.accumulator->add(h);
+    }
+}
+
+// sr.rs:720-740
+void trace_through_span(TracingState &ts, Surface surface, f64 exit_t_distance, const SR &rt) {
+    f32 thickness = (f32)((exit_t_distance - surface.t_distance) * ts.t_to_absolute_distance);
+    Rgba adjusted; f32 coeff;
+    apply_transmittance(surface.diffuse_color, thickness, &adjusted, &coeff);
+    surface.diffuse_color = adjusted;
+    // Rgb * f32 (color.rs:912-925): PositiveSign::new_clamped(scalar)
+    f32 c = ps_new_clamped(coeff);
+    surface.emission = Rgb{ps_mul(surface.emission.r, c), ps_mul(surface.emission.g, c), ps_mul(surface.emission.b, c)};
+    trace_through_surface(ts, surface, rt);
+}
+
+// sr.rs:135-238 (+ finish 658-693). Returns cubes_traced.
+size_t trace_ray_impl(const SR &rt, const Ray &ray, Accumulate *accumulator, bool include_sky, Counters *cn) {
+    Rgb sky_light = sky_sample(*rt.sp, ray.direction);
+    TracingState state;
+    state.t_to_absolute_distance = length(ray.direction);
+    state.t_to_view_distance = (f32)(state.t_to_absolute_distance / rt.opt.view_distance);
+    state.has_fog_light = (rt.opt.fog != 0) && include_sky;
+    state.distance_fog_light = sky_light;
+    state.distance_fog_blend = rt.opt.fog == 1 ? 1.0f : (rt.opt.fog == 2 ? 0.5f : 0.0f);
+    state.primary_cubes_traced = 0;
+    state.accumulator = accumulator;
+    state.cn = cn;
+
+    SurfaceIter surface_iter(&rt, ray);
+    if (rt.opt.transparency == 1) {
+        DepthIter it(surface_iter);
+        DepthStep step;
+        while (it.next(&step, cn)) {
+            if (state.count_step_should_stop()) break;
+            switch (step.kind) {
+                case D_INVISIBLE: break;
+                case D_SPAN: trace_through_span(state, step.surface, step.exit_t_distance, rt); break;
+                case D_ENTER_BLOCK: accumulator->enter_block(step.block_index); break;
+            }
+        }
+    } else {
+        TraceStep step;
+        while (surface_iter.next(&step, cn)) {
+            if (state.count_step_should_stop()) break;
+            switch (step.kind) {
+                case INVISIBLE: break;
+                case ENTER_BLOCK: accumulator->enter_block(step.block_index); break;
+                case ENTER_SURFACE: trace_through_surface(state, step.surface, rt); break;
+            }
+        }
+    }
+    // finish()
+    {
+        Hit h{};
+        h.exception = EX_SKY;
+        h.surface = include_sky ? colorbuf_from_rgba(Rgba{sky_light.r, sky_light.g, sky_light.b, 1.0f})
+                                : colorbuf_from_rgba(Rgba{0, 0, 0, 0});
+        h.has_t = true; h.t_distance = INF; h.block = -1; h.has_position = false;
+        accumulator->add(h);
+    }
+    if (rt.opt.debug_pixel_cost) {
+        Hit h{};
+        h.exception = EX_DEBUG_OVERRIDE_RG;
+        f32 n = ps_new_clamped((f32)state.primary_cubes_traced);
+        h.surface = colorbuf_from_rgba(Rgba{ps_mul(0.02f, n), ps_mul(0.002f, n), ps_mul(0.0f, n), 1.0f});
+        h.has_t = false; h.block = -1; h.has_position = false;
+        accumulator->add(h);
+    }
+    return state.primary_cubes_traced;
+}
+
+// ------------------------------------------------------------------------------------
+// camera (camera_struct.rs, viewport.rs) + euclid 0.22 restatement
+
+struct Mat4 {
+    f64 m[16];  // m11 m12 m13 m14 m21 ... m44
+};
+#define M(t, r, c) ((t).m[((r)-1) * 4 + ((c)-1)])
+
+// euclid Transform3D::then : self * other (row-vector convention)
+Mat4 mat_then(const Mat4 &a, const Mat4 &b) {
+    Mat4 o;
+    for (int r = 1; r <= 4; r++)
+        for (int c = 1; c <= 4; c++)
+            M(o, r, c) = M(a, r, 1) * M(b, 1, c) + M(a, r, 2) * M(b, 2, c) + M(a, r, 3) * M(b, 3, c) + M(a, r, 4) * M(b, 4, c);
+    return o;
+}
+
+// euclid Transform3D::determinant / inverse (adjugate * (1/det))
+bool mat_inverse(const Mat4 &t, Mat4 *out) {
+    const f64 m11 = M(t,1,1), m12 = M(t,1,2), m13 = M(t,1,3), m14 = M(t,1,4);
+    const f64 m21 = M(t,2,1), m22 = M(t,2,2), m23 = M(t,2,3), m24 = M(t,2,4);
+    const f64 m31 = M(t,3,1), m32 = M(t,3,2), m33 = M(t,3,3), m34 = M(t,3,4);
+    const f64 m41 = M(t,4,1), m42 = M(t,4,2), m43 = M(t,4,3), m44 = M(t,4,4);
+    f64 det = m14 * m23 * m32 * m41 - m13 * m24 * m32 * m41 - m14 * m22 * m33 * m41 + m12 * m24 * m33 * m41 +
+              m13 * m22 * m34 * m41 - m12 * m23 * m34 * m41 - m14 * m23 * m31 * m42 + m13 * m24 * m31 * m42 +
+              m14 * m21 * m33 * m42 - m11 * m24 * m33 * m42 - m13 * m21 * m34 * m42 + m11 * m23 * m34 * m42 +
+              m14 * m22 * m31 * m43 - m12 * m24 * m31 * m43 - m14 * m21 * m32 * m43 + m11 * m24 * m32 * m43 +
+              m12 * m21 * m34 * m43 - m11 * m22 * m34 * m43 - m13 * m22 * m31 * m44 + m12 * m23 * m31 * m44 +
+              m13 * m21 * m32 * m44 - m11 * m23 * m32 * m44 - m12 * m21 * m33 * m44 + m11 * m22 * m33 * m44;
+    if (det == 0.0) return false;
+    Mat4 a;
+    M(a,1,1) = m23*m34*m42 - m24*m33*m42 + m24*m32*m43 - m22*m34*m43 - m23*m32*m44 + m22*m33*m44;
+    M(a,1,2) = m14*m33*m42 - m13*m34*m42 - m14*m32*m43 + m12*m34*m43 + m13*m32*m44 - m12*m33*m44;
+    M(a,1,3) = m13*m24*m42 - m14*m23*m42 + m14*m22*m43 - m12*m24*m43 - m13*m22*m44 + m12*m23*m44;
+    M(a,1,4) = m14*m23*m32 - m13*m24*m32 - m14*m22*m33 + m12*m24*m33 + m13*m22*m34 - m12*m23*m34;
+    M(a,2,1) = m24*m33*m41 - m23*m34*m41 - m24*m31*m43 + m21*m34*m43 + m23*m31*m44 - m21*m33*m44;
+    M(a,2,2) = m13*m34*m41 - m14*m33*m41 + m14*m31*m43 - m11*m34*m43 - m13*m31*m44 + m11*m33*m44;
+    M(a,2,3) = m14*m23*m41 - m13*m24*m41 - m14*m21*m43 + m11*m24*m43 + m13*m21*m44 - m11*m23*m44;
+    M(a,2,4) = m13*m24*m31 - m14*m23*m31 + m14*m21*m33 - m11*m24*m33 - m13*m21*m34 + m11*m23*m34;
+    M(a,3,1) = m22*m34*m41 - m24*m32*m41 + m24*m31*m42 - m21*m34*m42 - m22*m31*m44 + m21*m32*m44;
+    M(a,3,2) = m14*m32*m41 - m12*m34*m41 - m14*m31*m42 + m11*m34*m42 + m12*m31*m44 - m11*m32*m44;
+    M(a,3,3) = m12*m24*m41 - m14*m22*m41 + m14*m21*m42 - m11*m24*m42 - m12*m21*m44 + m11*m22*m44;
+    M(a,3,4) = m14*m22*m31 - m12*m24*m31 - m14*m21*m32 + m11*m24*m32 + m12*m21*m34 - m11*m22*m34;
+    M(a,4,1) = m23*m32*m41 - m22*m33*m41 - m23*m31*m42 + m21*m33*m42 + m22*m31*m43 - m21*m32*m43;
+    M(a,4,2) = m12*m33*m41 - m13*m32*m41 + m13*m31*m42 - m11*m33*m42 - m12*m31*m43 + m11*m32*m43;
+    M(a,4,3) = m13*m22*m41 - m12*m23*m41 - m13*m21*m42 + m11*m23*m42 + m12*m21*m43 - m11*m22*m43;
+    M(a,4,4) = m12*m23*m31 - m13*m22*m31 + m13*m21*m32 - m11*m23*m32 - m12*m21*m33 + m11*m22*m33;
+    f64 inv_det = 1.0 / det;
+    for (int i = 0; i < 16; i++) out->m[i] = a.m[i] * inv_det;
+    return true;
+}
+
+// euclid Transform3D::transform_point3d: homogeneous then divide if w > 0
+bool mat_transform_point(const Mat4 &t, const V3 &p, V3 *out) {
+    f64 x = p[0] * M(t,1,1) + p[1] * M(t,2,1) + p[2] * M(t,3,1) + M(t,4,1);
+    f64 y = p[0] * M(t,1,2) + p[1] * M(t,2,2) + p[2] * M(t,3,2) + M(t,4,2);
+    f64 z = p[0] * M(t,1,3) + p[1] * M(t,2,3) + p[2] * M(t,3,3) + M(t,4,3);
+    f64 w = p[0] * M(t,1,4) + p[1] * M(t,2,4) + p[2] * M(t,3,4) + M(t,4,4);
+    if (w > 0.0) {
+        *out = v3(x / w, y / w, z / w);
+        return true;
+    }
+    return false;
+}
+
+struct Quat { f64 i, j, k, r; };
+// euclid Rotation3D::then (self first, then other)
+Quat quat_then(const Quat &s, const Quat &o) {
+    Quat q;
+    q.i = o.i * s.r + o.r * s.i + o.j * s.k - o.k * s.j;
+    q.j = o.j * s.r + o.r * s.j + o.k * s.i - o.i * s.k;
+    q.k = o.k * s.r + o.r * s.k + o.i * s.j - o.j * s.i;
+    q.r = o.r * s.r - o.i * s.i - o.j * s.j - o.k * s.k;
+    return q;
+}
+// euclid Rotation3D::transform_point3d
+V3 quat_rotate(const Quat &q, const V3 &p) {
+    f64 cx = (q.j * p[2] - q.k * p[1]) * 2.0;
+    f64 cy = (q.k * p[0] - q.i * p[2]) * 2.0;
+    f64 cz = (q.i * p[1] - q.j * p[0]) * 2.0;
+    return v3(p[0] + q.r * cx + q.j * cz - q.k * cy,
+              p[1] + q.r * cy + q.k * cx - q.i * cz,
+              p[2] + q.r * cz + q.i * cy - q.j * cx);
+}
+// euclid Rotation3D::to_transform
+Mat4 quat_to_transform(const Quat &q) {
+    f64 i2 = q.i + q.i, j2 = q.j + q.j, k2 = q.k + q.k;
+    f64 ii = q.i * i2, ij = q.i * j2, ik = q.i * k2, jj = q.j * j2, jk = q.j * k2, kk = q.k * k2;
+    f64 ri = q.r * i2, rj = q.r * j2, rk = q.r * k2;
+    Mat4 t;
+    M(t,1,1) = 1.0 - (jj + kk); M(t,1,2) = ij + rk; M(t,1,3) = ik - rj; M(t,1,4) = 0.0;
+    M(t,2,1) = ij - rk; M(t,2,2) = 1.0 - (ii + kk); M(t,2,3) = jk + ri; M(t,2,4) = 0.0;
+    M(t,3,1) = ik + rj; M(t,3,2) = jk - ri; M(t,3,3) = 1.0 - (ii + jj); M(t,3,4) = 0.0;
+    M(t,4,1) = 0.0; M(t,4,2) = 0.0; M(t,4,3) = 0.0; M(t,4,4) = 1.0;
+    return t;
+}
+
+// camera_struct.rs:459-471
+Quat look_at_y_up(const V3 &eye, const V3 &target) {
+    V3 look = v3(target[0] - eye[0], target[1] - eye[1], target[2] - eye[2]);
+    f64 yaw = std::atan2(look[0], -look[2]);
+    f64 pitch = std::atan2(-look[1], std::sqrt(look[0] * look[0] + look[2] * look[2]));
+    // Rotation3D::around_x(-pitch).then(&Rotation3D::around_y(-yaw))
+    f64 hx = (-pitch) / 2.0, hy = (-yaw) / 2.0;
+    Quat rx = Quat{std::sin(hx), 0.0, 0.0, std::cos(hx)};
+    Quat ry = Quat{0.0, std::sin(hy), 0.0, std::cos(hy)};
+    return quat_then(rx, ry);
+}
+
+// camera_struct.rs:387-416
+bool camera_matrices(f64 fov_y, f64 view_distance, f64 aspect, const Quat &rot, const V3 &translation,
+                     Mat4 *projection, Mat4 *world_to_eye, Mat4 *inverse_projection_view) {
+    f64 fov_cot = 1.0 / std::tan((fov_y / 2.) * (M_PI / 180.0));  // to_radians: x * (PI/180)
+    f64 near = 1.0 / 32.0;
+    f64 far = view_distance;
+    Mat4 p;
+    std::memset(&p, 0, sizeof(p));
+    M(p,1,1) = fov_cot / aspect;
+    M(p,2,2) = fov_cot;
+    M(p,3,3) = far / (near - far); M(p,3,4) = -1.0;
+    M(p,4,3) = (far * near) / (near - far);
+    *projection = p;
+
+    // RigidTransform3D::inverse: rotation^-1, rotation^-1 * (-translation); then to_transform
+    Quat inv = Quat{-rot.i, -rot.j, -rot.k, rot.r};
+    V3 it = quat_rotate(inv, v3(-translation[0], -translation[1], -translation[2]));
+    Mat4 w2e = quat_to_transform(inv);
+    M(w2e,4,1) = it[0]; M(w2e,4,2) = it[1]; M(w2e,4,3) = it[2];
+    *world_to_eye = w2e;
+
+    Mat4 pv = mat_then(w2e, p);
+    return mat_inverse(pv, inverse_projection_view);
+}
+
+// camera_struct.rs:238-257
+Ray project_ndc_into_world(const Mat4 &inv, f64 x, f64 y) {
+    V3 n, f;
+    if (!mat_transform_point(inv, v3(x, y, 0.0), &n)) n = v3(NAN64, NAN64, NAN64);
+    if (!mat_transform_point(inv, v3(x, y, 1.0), &f)) f = v3(NAN64, NAN64, NAN64);
+    Ray r;
+    r.origin = n;
+    r.direction = v3(f[0] - n[0], f[1] - n[1], f[2] - n[2]);
+    return r;
+}
+
+// viewport.rs:89-113
+inline f64 normalize_fb_x(uint32_t w, size_t x) { return ((f64)x + 0.5) / (f64)w * 2.0 - 1.0; }
+inline f64 normalize_fb_y(uint32_t h, size_t y) { return -(((f64)y + 0.5) / (f64)h * 2.0 - 1.0); }
+inline f64 normalize_fb_x_edge(uint32_t w, size_t x) { return ((f64)x) / (f64)w * 2.0 - 1.0; }
+inline f64 normalize_fb_y_edge(uint32_t h, size_t y) { return -(((f64)y) / (f64)h * 2.0 - 1.0); }
+
+// ------------------------------------------------------------------------------------
+// renderer.rs: RtScene::trace_patch / trace_ray_through_layers / image loop
+
+struct Scene {
+    const SR *world;
+    const SR *ui;
+    Mat4 world_inv, ui_inv;
+    bool has_backdrop;
+    ColorBuf backdrop;
+};
+
+const f32 NO_WORLD_TO_SHOW_LIN = 0.5028865f;  // palette.rs:76 srgb[0xBC..] through the decode LUT
+
+// renderer.rs:454-478
+void trace_ray_through_layers(const Scene &sc, size_t *cubes, ColorAccum *accum, f64 px, f64 py, Counters *cn) {
+    if (sc.ui) *cubes += trace_ray_impl(*sc.ui, project_ndc_into_world(sc.ui_inv, px, py), accum, false, cn);
+    if (sc.has_backdrop) {
+        Hit h{};
+        h.exception = EX_BACKDROP;
+        h.surface = sc.backdrop;
+        h.has_t = false; h.block = -1; h.has_position = false;
+        accum->add(h);
+    }
+    if (sc.world) *cubes += trace_ray_impl(*sc.world, project_ndc_into_world(sc.world_inv, px, py), accum, true, cn);
+    if (!accum->opaque()) {
+        // P::paint(NO_WORLD_TO_SHOW): default + add
+        ColorBuf fresh;
+        fresh.add_color_internal(colorbuf_from_rgba(Rgba{NO_WORLD_TO_SHOW_LIN, NO_WORLD_TO_SHOW_LIN, NO_WORLD_TO_SHOW_LIN, 1.0f}));
+        accum->buf = fresh;
+    }
+}
+
+// renderer.rs:424-451
+void trace_patch(const Scene &sc, bool aa, f64 x0, f64 y0, f64 x1, f64 y1, ColorBuf *pixel, size_t *cubes,
+                 ColorAccum *first_sample, Counters *cn) {
+    if (aa) {
+        static const f64 SP[4][2] = {{1. / 8., 5. / 8.}, {3. / 8., 1. / 8.}, {5. / 8., 7. / 8.}, {7. / 8., 3. / 8.}};
+        ColorBuf samples[4];
+        for (int i = 0; i < 4; i++) {
+            ColorAccum acc;
+            // point_within_patch: min + (max - min).component_mul(uv)
+            f64 px = x0 + (x1 - x0) * SP[i][0];
+            f64 py = y0 + (y1 - y0) * SP[i][1];
+            trace_ray_through_layers(sc, cubes, &acc, px, py, cn);
+            samples[i] = acc.buf;
+            if (i == 0 && first_sample) *first_sample = acc;
+        }
+        // ColorBuf::mean (raytracer_components.rs:97-102): sum from zero, / N
+        ColorBuf m;
+        f32 l[3] = {0.f, 0.f, 0.f}, t = 0.f;
+        for (int i = 0; i < 4; i++) {
+            for (int c = 0; c < 3; c++) l[c] = l[c] + samples[i].light[c];
+            t = t + samples[i].transmittance;
+        }
+        for (int c = 0; c < 3; c++) m.light[c] = l[c] / 4.0f;
+        m.transmittance = t / 4.0f;
+        *pixel = m;
+    } else {
+        ColorAccum acc;
+        // Box2D::center = (min + max) / 2
+        f64 px = (x0 + x1) / 2.0;
+        f64 py = (y0 + y1) / 2.0;
+        trace_ray_through_layers(sc, cubes, &acc, px, py, cn);
+        *pixel = acc.buf;
+        if (first_sample) *first_sample = acc;
+    }
+}
+
+Mat4 mat_from(const double *p) {
+    Mat4 m;
+    std::memcpy(m.m, p, sizeof(m.m));
+    return m;
+}
+
+void fill_steps(const RaycastStep &st, const Ray &ray, orc_rc_step *o) {
+    for (int a = 0; a < 3; a++) {
+        o->cube[a] = st.cube[a];
+        o->t_max[a] = st.t_max[a];
+    }
+    o->face = st.face;
+    o->t_distance = st.t_distance;
+    V3 ip = intersection_point(st, ray);
+    for (int a = 0; a < 3; a++) o->intersection_point[a] = ip[a];
+}
+
+void fill_surface(const Surface &s, orc_trace_step *o) {
+    o->block_index = s.block_index;
+    o->t_distance = s.t_distance;
+    o->color[0] = s.diffuse_color.r; o->color[1] = s.diffuse_color.g; o->color[2] = s.diffuse_color.b; o->color[3] = s.diffuse_color.a;
+    o->emission[0] = s.emission.r; o->emission[1] = s.emission.g; o->emission[2] = s.emission.b;
+    for (int a = 0; a < 3; a++) {
+        o->cube[a] = s.cube[a];
+        o->voxel[a] = s.voxel[a];
+        o->intersection_point[a] = s.intersection_point[a];
+    }
+    o->resolution = s.resolution;
+    o->normal = s.normal;
+}
+
+}  // namespace
+
+// ======================================================================================
+// C interface
+
+extern "C" {
+
+double orc_scale_to_integer_step(double s, double ds) { return scale_to_integer_step(s, ds); }
+
+int32_t orc_raycast(const double origin[3], const double direction[3], int32_t use_bounds,
+                    const int32_t lo[3], const int32_t hi[3], int32_t include_exit,
+                    int32_t max_steps, orc_rc_step *out, int32_t *ended) {
+    Ray ray{v3(origin[0], origin[1], origin[2]), v3(direction[0], direction[1], direction[2])};
+    Raycaster r = Raycaster::make(ray.origin, ray.direction);
+    if (use_bounds) {
+        GridAab b{{{lo[0], lo[1], lo[2]}}, {{hi[0], hi[1], hi[2]}}};
+        r = r.within(b, include_exit != 0);
+    }
+    int32_t n = 0;
+    *ended = 0;
+    while (n < max_steps) {
+        RaycastStep st;
+        if (!r.next(&st)) {
+            *ended = 1;
+            break;
+        }
+        fill_steps(st, ray, &out[n]);
+        n++;
+    }
+    return n;
+}
+
+int32_t orc_recursive_raycast(const double origin[3], const double direction[3],
+                              int32_t outer_index, int32_t resolution, const int32_t lo[3],
+                              const int32_t hi[3], double sub_origin[3], int32_t max_steps,
+                              orc_rc_step *out, int32_t *ended) {
+    Ray ray{v3(origin[0], origin[1], origin[2]), v3(direction[0], direction[1], direction[2])};
+    Raycaster outer = Raycaster::make(ray.origin, ray.direction);
+    RaycastStep st;
+    for (int i = 0; i <= outer_index; i++)
+        if (!outer.next(&st)) return -1;
+    GridAab b{{{lo[0], lo[1], lo[2]}}, {{hi[0], hi[1], hi[2]}}};
+    Ray sub_ray;
+    Raycaster inner = recursive_raycast(st, ray, resolution, b, &sub_ray);
+    for (int a = 0; a < 3; a++) sub_origin[a] = sub_ray.origin[a];
+    int32_t n = 0;
+    *ended = 0;
+    while (n < max_steps) {
+        RaycastStep is;
+        if (!inner.next(&is)) {
+            *ended = 1;
+            break;
+        }
+        fill_steps(is, sub_ray, &out[n]);
+        n++;
+    }
+    return n;
+}
+
+int32_t orc_surface_iter(const orc_space *space, const double origin[3], const double direction[3],
+                         int32_t max_steps, orc_trace_step *out) {
+    SR rt(space, nullptr);
+    Ray ray{v3(origin[0], origin[1], origin[2]), v3(direction[0], direction[1], direction[2])};
+    SurfaceIter it(&rt, ray);
+    int32_t n = 0;
+    TraceStep ts;
+    while (n < max_steps && it.next(&ts, nullptr)) {
+        orc_trace_step *o = &out[n++];
+        std::memset(o, 0, sizeof(*o));
+        o->kind = ts.kind;
+        if (ts.kind == ENTER_SURFACE) fill_surface(ts.surface, o);
+        else {
+            o->t_distance = ts.t_distance;
+            o->block_index = ts.kind == ENTER_BLOCK ? ts.block_index : -1;
+        }
+    }
+    return n;
+}
+
+int32_t orc_depth_iter(const orc_space *space, const double origin[3], const double direction[3],
+                       int32_t max_steps, orc_trace_step *out) {
+    SR rt(space, nullptr);
+    Ray ray{v3(origin[0], origin[1], origin[2]), v3(direction[0], direction[1], direction[2])};
+    DepthIter it{SurfaceIter(&rt, ray)};
+    int32_t n = 0;
+    DepthStep ds;
+    while (n < max_steps && it.next(&ds, nullptr)) {
+        orc_trace_step *o = &out[n++];
+        std::memset(o, 0, sizeof(*o));
+        o->kind = ds.kind;
+        if (ds.kind == D_SPAN) {
+            fill_surface(ds.surface, o);
+            o->exit_t_distance = ds.exit_t_distance;
+        } else if (ds.kind == D_ENTER_BLOCK) {
+            o->t_distance = ds.t_distance;
+            o->block_index = ds.block_index;
+        } else {
+            o->block_index = -1;
+        }
+    }
+    return n;
+}
+
+uint64_t orc_trace_ray(const orc_space *space, const orc_options *opt, const double origin[3],
+                       const double direction[3], int32_t include_sky, float out_light_t[4],
+                       double *out_depth) {
+    SR rt(space, opt);
+    Ray ray{v3(origin[0], origin[1], origin[2]), v3(direction[0], direction[1], direction[2])};
+    ColorAccum c;
+    uint64_t n = trace_ray_impl(rt, ray, &c, include_sky != 0, nullptr);
+    if (out_light_t) {
+        out_light_t[0] = c.buf.light[0]; out_light_t[1] = c.buf.light[1]; out_light_t[2] = c.buf.light[2];
+        out_light_t[3] = c.buf.transmittance;
+    }
+    if (out_depth) {
+        DepthAccum d;
+        trace_ray_impl(rt, ray, &d, include_sky != 0, nullptr);
+        *out_depth = d.depth;
+    }
+    return n;
+}
+
+int32_t orc_render(const orc_space *world, const orc_options *world_opt, const orc_camera *world_cam,
+                   const orc_space *ui, const orc_options *ui_opt, const orc_camera *ui_cam,
+                   const float backdrop[4], uint32_t row_begin, uint32_t row_end, int32_t threads,
+                   uint8_t *rgba8, float *linear, orc_pixel_aux *aux, orc_info *info) {
+    if (!world_cam || !world_opt) return -1;
+    if (world_opt->lighting == 5 || (ui_opt && ui_opt->lighting == 5)) return -2;  // Bounce: unpinned
+    const uint32_t w = world_cam->width, h = world_cam->height;
+    if (row_end > h) row_end = h;
+    SR *wrt = world ? new SR(world, world_opt) : nullptr;
+    SR *urt = (ui && ui_opt && ui_cam) ? new SR(ui, ui_opt) : nullptr;
+    Scene sc;
+    sc.world = wrt;
+    sc.ui = urt;
+    sc.world_inv = mat_from(world_cam->inverse_projection_view);
+    if (urt) sc.ui_inv = mat_from(ui_cam->inverse_projection_view);
+    sc.has_backdrop = backdrop && !(backdrop[0] == 0.f && backdrop[1] == 0.f && backdrop[2] == 0.f && backdrop[3] == 0.f);
+    if (sc.has_backdrop) sc.backdrop = colorbuf_from_rgba(Rgba{backdrop[0], backdrop[1], backdrop[2], backdrop[3]});
+    const bool aa = world_opt->antialiasing == 2;
+    const orc_options enc_opt = *world_opt;
+
+    std::atomic<uint32_t> next_row(row_begin);
+    std::atomic<uint64_t> total_cubes(0), t_outer(0), t_inner(0), t_hits(0), t_light(0);
+    auto worker = [&]() {
+        uint64_t my_cubes = 0;
+        Counters cn;
+        for (;;) {
+            uint32_t y = next_row.fetch_add(1);
+            if (y >= row_end) break;
+            f64 y0 = normalize_fb_y_edge(h, y), y1 = normalize_fb_y_edge(h, (size_t)y + 1);
+            for (uint32_t x = 0; x < w; x++) {
+                f64 x0 = normalize_fb_x_edge(w, x), x1 = normalize_fb_x_edge(w, (size_t)x + 1);
+                ColorBuf pixel;
+                size_t cubes = 0;
+                ColorAccum first;
+                trace_patch(sc, aa, x0, y0, x1, y1, &pixel, &cubes, aux ? &first : nullptr, &cn);
+                my_cubes += cubes;
+                size_t pi = (size_t)y * w + x;
+                Rgba lin = rgba_from_colorbuf(pixel);
+                if (linear) {
+                    linear[4 * pi + 0] = lin.r; linear[4 * pi + 1] = lin.g; linear[4 * pi + 2] = lin.b; linear[4 * pi + 3] = lin.a;
+                }
+                if (rgba8) to_srgb8(post_process_color(lin, enc_opt), rgba8 + 4 * pi);
+                if (aux) {
+                    orc_pixel_aux &a = aux[pi];
+                    std::memset(&a, 0, sizeof(a));
+                    a.cubes_traced = (uint32_t)cubes;
+                    if (first.seen_position) {
+                        a.hit = 1;
+                        for (int k = 0; k < 3; k++) { a.cube[k] = first.first_position.cube[k]; a.voxel[k] = first.first_position.voxel[k]; }
+                        a.resolution = first.first_position.resolution;
+                        a.face = first.first_position.face;
+                        a.block_index = first.first_block;
+                        a.t_distance = first.first_t;
+                    }
+                }
+            }
+        }
+        total_cubes += my_cubes;
+        t_outer += cn.n_outer; t_inner += cn.n_inner; t_hits += cn.n_hits; t_light += cn.n_light;
+    };
+    if (w > 0 && row_end > row_begin) {
+        if (threads <= 1) worker();
+        else {
+            std::vector<std::thread> pool;
+            for (int i = 0; i < threads; i++) pool.emplace_back(worker);
+            for (auto &t : pool) t.join();
+        }
+    }
+    if (info) {
+        info->cubes_traced = total_cubes.load();
+        info->n_outer = t_outer.load(); info->n_inner = t_inner.load();
+        info->n_hits = t_hits.load(); info->n_light = t_light.load();
+    }
+    delete wrt;
+    delete urt;
+    return 0;
+}
+
+int32_t orc_render_text(const orc_space *space, const orc_options *opt, const orc_camera *cam, int32_t *out) {
+    SR rt(space, opt);
+    Mat4 inv = mat_from(cam->inverse_projection_view);
+    for (uint32_t ych = 0; ych < cam->height; ych++) {
+        f64 y = normalize_fb_y(cam->height, ych);
+        for (uint32_t xch = 0; xch < cam->width; xch++) {
+            f64 x = normalize_fb_x(cam->width, xch);
+            CharAccum buf(space);
+            trace_ray_impl(rt, project_ndc_into_world(inv, x, y), &buf, true, nullptr);
+            out[(size_t)ych * cam->width + xch] = buf.state;
+        }
+    }
+    return 0;
+}
+
+void orc_look_at_y_up(const double eye[3], const double target[3], double out_quat_ijkr[4]) {
+    Quat q = look_at_y_up(v3(eye[0], eye[1], eye[2]), v3(target[0], target[1], target[2]));
+    out_quat_ijkr[0] = q.i; out_quat_ijkr[1] = q.j; out_quat_ijkr[2] = q.k; out_quat_ijkr[3] = q.r;
+}
+
+// all-is-cubes/src/camera.rs:34-40
+void orc_eye_for_look_at(const int32_t lo[3], const int32_t hi[3], const double direction[3], double out_eye[3]) {
+    f64 space_radius = 0.0;
+    for (int a = 0; a < 3; a++) space_radius = std::fmax(space_radius, (f64)(hi[a] - lo[a]));
+    V3 d = v3(direction[0], direction[1], direction[2]);
+    f64 len = length(d);
+    for (int a = 0; a < 3; a++) {
+        f64 center = ((f64)lo[a] + (f64)hi[a]) / 2.;  // grid_aab.rs:391-395
+        out_eye[a] = center + (d[a] / len) * space_radius;
+    }
+}
+
+int32_t orc_camera_matrices(double fov_y_degrees, double view_distance, double aspect,
+                            const double quat_ijkr[4], const double translation[3],
+                            double out_projection[16], double out_world_to_eye[16],
+                            double out_inverse_projection_view[16]) {
+    Mat4 p, w, inv;
+    Quat q{quat_ijkr[0], quat_ijkr[1], quat_ijkr[2], quat_ijkr[3]};
+    bool ok = camera_matrices(fov_y_degrees, view_distance, aspect, q, v3(translation[0], translation[1], translation[2]), &p, &w, &inv);
+    std::memcpy(out_projection, p.m, sizeof(p.m));
+    std::memcpy(out_world_to_eye, w.m, sizeof(w.m));
+    if (ok) std::memcpy(out_inverse_projection_view, inv.m, sizeof(inv.m));
+    return ok ? 1 : 0;
+}
+
+void orc_project_ndc_into_world(const double inverse_projection_view[16], double ndc_x, double ndc_y,
+                                double out_origin[3], double out_direction[3]) {
+    Ray r = project_ndc_into_world(mat_from(inverse_projection_view), ndc_x, ndc_y);
+    for (int a = 0; a < 3; a++) { out_origin[a] = r.origin[a]; out_direction[a] = r.direction[a]; }
+}
+
+void orc_unproject(const double inverse_projection_view[16], const double ndc[3], double out[3]) {
+    V3 o;
+    if (!mat_transform_point(mat_from(inverse_projection_view), v3(ndc[0], ndc[1], ndc[2]), &o)) o = v3(NAN64, NAN64, NAN64);
+    for (int a = 0; a < 3; a++) out[a] = o[a];
+}
+
+void orc_apply_transmittance(const float color[4], float thickness, float out_color[4], float *out_coeff) {
+    Rgba o;
+    apply_transmittance(Rgba{color[0], color[1], color[2], color[3]}, thickness, &o, out_coeff);
+    out_color[0] = o.r; out_color[1] = o.g; out_color[2] = o.b; out_color[3] = o.a;
+}
+
+void orc_to_srgb8(const float rgba[4], uint8_t out[4]) { to_srgb8(Rgba{rgba[0], rgba[1], rgba[2], rgba[3]}, out); }
+float orc_packed_light_scalar_out(uint8_t v) { return g_light_lut[v]; }
+uint8_t orc_packed_light_scalar_in(float v) { return packed_scalar_in(v); }
+
+void orc_block_sky(const orc_space *space, uint8_t out_faces_mean[7][4]) {
+    BlockSky bs = sky_for_blocks(*space);
+    for (int f = 0; f < 6; f++) {
+        out_faces_mean[f][0] = bs.faces[f].r; out_faces_mean[f][1] = bs.faces[f].g;
+        out_faces_mean[f][2] = bs.faces[f].b; out_faces_mean[f][3] = bs.faces[f].status;
+    }
+    out_faces_mean[6][0] = bs.mean.r; out_faces_mean[6][1] = bs.mean.g; out_faces_mean[6][2] = bs.mean.b; out_faces_mean[6][3] = bs.mean.status;
+}
+
+double orc_smoothstep(double x) { return smoothstep(x); }
+double orc_coarsestep(double x) { return coarsestep(x); }
+
+}  // extern "C"

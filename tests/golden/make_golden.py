@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/ from the reference checkout.
+
+Run ONLY in the authoring container (needs /root/reference and Pillow); the outputs are
+committed so that nothing on the GPU box ever reads /root/reference.
+
+What is extracted (all of it is DATA held by the reference's own tests, no source text):
+
+* ``png_<case>.npy``  -- decoded RGBA8 pixels of
+  ``test-renderers/expected/renderers/<case>.png`` (the image-comparison goldens used by
+  ``test-renderers/tests/ray-render.rs`` through ``cases/src/lib.rs``).
+* ``ascii_print_space.txt`` / ``ascii_partial_voxels.txt`` -- the two 80x40 expected
+  character frames asserted in ``all-is-cubes-render/src/raytracer/text.rs:216-258,297-340``.
+* ``srgb_decode_lut.npy`` -- the 256-entry sRGB8 -> linear table
+  (``all-is-cubes-base/src/math/color.rs`` ``CONST_SRGB_LOOKUP_TABLE``), needed to restate
+  scenes whose blocks are declared as sRGB8 colours (``color_srgb_ramp``, ``emission``).
+* ``packed_light_lut.npy`` -- the 256-entry ``PACKED_LIGHT_SCALAR_LOOKUP_TABLE``
+  (``all-is-cubes/src/space/light/data.rs:301-354``); the product *generates* its table from
+  the defining formula and the test asserts equality with this fixture.
+"""
+import re
+import sys
+from pathlib import Path
+
+import numpy as np
+
+REF = Path("/root/reference")
+OUT = Path(__file__).resolve().parent
+
+PNG_CASES = [
+    "transparent_one-surf-all",
+    "transparent_one-vol-all",
+    "emission-all",
+    "emission_only-surf-all",
+    "emission_only-vol-all",
+    "emission_semi-surf-all",
+    "emission_semi-vol-all",
+    "color_srgb_ramp-all",
+    "viewport_prime-all",
+    "layers_all-all",
+    "layers_hidden_ui-all",
+    "layers_ui_only-all",
+    "no_character_but_ui-ray",
+]
+
+
+def floats_after(text: str, marker: str, count: int, wrapped: str = "") -> np.ndarray:
+    start = text.index(marker)
+    start = re.search(r"=\s*&?\[", text[start:]).end() + start
+    end = text.index("];", start)
+    body = text[start:end]
+    if wrapped:
+        vals = re.findall(re.escape(wrapped) + r"\(([^)]+)\)", body)
+    else:
+        vals = [v for v in re.split(r"[,\s]+", body) if v]
+    arr = np.array([float(v) for v in vals], dtype=np.float32)
+    assert arr.shape == (count,), arr.shape
+    return arr
+
+
+def ascii_frames() -> list[str]:
+    src = (REF / "all-is-cubes-render/src/raytracer/text.rs").read_text()
+    frames = []
+    for m in re.finditer(r'assert_eq!\(\s*output,\s*"\\\n(.*?)\n\s*"\s*\);', src, re.S):
+        lines = []
+        for line in m.group(1).split("\n"):
+            line = line.strip()
+            assert line.endswith("\\n\\"), repr(line)
+            lines.append(line[: -len("\\n\\")])
+        assert len(lines) == 40 and all(len(l) == 80 for l in lines)
+        frames.append("\n".join(lines) + "\n")
+    assert len(frames) == 2
+    return frames
+
+
+def main() -> int:
+    from PIL import Image
+
+    for case in PNG_CASES:
+        im = Image.open(REF / "test-renderers/expected/renderers" / f"{case}.png").convert("RGBA")
+        np.save(OUT / f"png_{case}.npy", np.asarray(im, dtype=np.uint8))
+
+    color_rs = (REF / "all-is-cubes-base/src/math/color.rs").read_text()
+    np.save(OUT / "srgb_decode_lut.npy", floats_after(color_rs, "static CONST_SRGB_LOOKUP_TABLE", 256))
+    light_rs = (REF / "all-is-cubes/src/space/light/data.rs").read_text()
+    np.save(
+        OUT / "packed_light_lut.npy",
+        floats_after(light_rs, "static PACKED_LIGHT_SCALAR_LOOKUP_TABLE", 256, wrapped="ps32"),
+    )
+    a, b = ascii_frames()
+    (OUT / "ascii_print_space.txt").write_text(a)
+    (OUT / "ascii_partial_voxels.txt").write_text(b)
+    print("golden fixtures written to", OUT)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,311 @@
+"""Scene restatements shared by the oracle tests and the GPU parity tests.
+
+Each builder cites the reference test whose scene it restates. All return
+`all_is_cubes_amd.flat.FlatSpace` objects (plain numpy data)."""
+from __future__ import annotations
+
+from pathlib import Path
+
+import numpy as np
+
+from all_is_cubes_amd import flat
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def srgb_lut() -> np.ndarray:
+    return np.load(GOLDEN / "srgb_decode_lut.npy")
+
+
+def from_srgb8(rgb) -> tuple:
+    """Rgb::from_srgb8 / Rgb01::from_srgb8 via the reference's decode table (color.rs:301-308)."""
+    lut = srgb_lut()
+    return tuple(float(lut[c]) for c in rgb)
+
+
+# -- all-is-cubes-render/src/raytracer/surface.rs:541-570 ---------------------------------
+def surface_iter_basic_space() -> flat.FlatSpace:
+    sp = flat.FlatSpace((0, 0, 0), (1, 3, 1))
+    a = sp.add_block(flat.air())
+    solid = sp.add_block(flat.atom((1.0, 0.0, 0.0, 1.0)))
+    # slab_with_extra_space: R4; `cube.y >= 2 && cube.x != 0` is AIR, else the slab colour
+    vox = np.zeros((4, 4, 4), np.uint16)
+    for x in range(4):
+        for y in range(4):
+            for z in range(4):
+                vox[x, y, z] = 0 if (y >= 2 and x != 0) else 1
+    pal = np.stack([flat.evoxel((0, 0, 0, 0)), flat.evoxel((1.0, 1.0, 0.0, 1.0))])
+    slab = sp.add_block(flat.voxel_block(4, vox, pal))
+    sp.block_index[...] = a
+    sp.set((0, 1, 0), solid)
+    sp.set((0, 2, 0), slab)
+    return sp
+
+
+# surface.rs:682-689
+def one_red_cube_space() -> flat.FlatSpace:
+    sp = flat.FlatSpace((0, 0, 0), (1, 1, 1))
+    sp.block_index[...] = sp.add_block(flat.atom((1.0, 0.0, 0.0, 1.0)))
+    return sp
+
+
+# all-is-cubes/src/content.rs:165-211 make_slab(universe, numerator, denominator): voxel
+# volume is [denominator, numerator, denominator] in a checkerboard of two opaque colours.
+def slab_block(numerator: int, denominator: int, name: str = "S") -> flat.BlockDef:
+    vox = np.zeros((denominator, numerator, denominator), np.uint16)
+    for x in range(denominator):
+        for y in range(numerator):
+            for z in range(denominator):
+                vox[x, y, z] = (x + y + z) % 2
+    pal = np.stack([flat.evoxel((0.6, 0.4, 0.2, 1.0)), flat.evoxel((0.636, 0.424, 0.212, 1.0))])
+    return flat.voxel_block(denominator, vox, pal, name=name)
+
+
+# surface.rs:713-721, accum.rs:442-450
+def slab_cube_space() -> flat.FlatSpace:
+    sp = flat.FlatSpace((0, 0, 0), (1, 1, 1))
+    sp.block_index[...] = sp.add_block(slab_block(1, 2))
+    return sp
+
+
+# surface.rs:755-777
+def half_transparent_slab_space() -> flat.FlatSpace:
+    sp = flat.FlatSpace((0, 0, 0), (1, 3, 1))
+    a = sp.add_block(flat.air())
+    # voxels_fn(R2): y > 0 is AIR, else colour (1,1,0,0.5); bounds auto-shrink to y in [0,1)
+    vox = np.ones((2, 1, 2), np.uint16)
+    pal = np.stack([flat.evoxel((0, 0, 0, 0)), flat.evoxel((1.0, 1.0, 0.0, 0.5))])
+    slab = sp.add_block(flat.voxel_block(2, vox, pal))
+    sp.block_index[...] = a
+    sp.set((0, 1, 0), slab)
+    return sp
+
+
+# raytracer/text.rs:195-208 (make_some_blocks names "0","1","2"; colours are opaque)
+def print_space_test_space() -> flat.FlatSpace:
+    sp = flat.FlatSpace((0, 0, 0), (3, 1, 1))
+    for i in range(3):
+        sp.set((i, 0, 0), sp.add_block(flat.atom((0.5, 0.5, 0.5, 1.0), name=str(i))))
+    return sp
+
+
+# text.rs:262-289
+def partial_voxels_space() -> flat.FlatSpace:
+    sp = flat.FlatSpace((0, 0, 0), (2, 1, 1))
+    b0 = sp.add_block(flat.atom((0.5, 0.5, 0.5, 1.0), name="0"))
+    vox = np.zeros((4, 2, 4), np.uint16)
+    pal = flat.evoxel((1.0, 1.0, 1.0, 1.0))[None, :]
+    p = sp.add_block(flat.voxel_block(4, vox, pal, name="P"))
+    sp.set((0, 0, 0), b0)
+    sp.set((1, 0, 0), p)
+    return sp
+
+
+# -- test-renderers/cases/src/lib.rs --------------------------------------------------------
+# one_cube_space() 1239-1248: sky (0.5,0.5,0.5), filled with opaque green unless replaced
+def one_cube_space(block: flat.BlockDef | None = None) -> flat.FlatSpace:
+    sp = flat.FlatSpace((0, 0, 0), (1, 1, 1))
+    sp.set_sky_uniform((0.5, 0.5, 0.5))
+    sp.block_index[...] = sp.add_block(block if block is not None else flat.atom((0.0, 1.0, 0.0, 1.0)))
+    return sp
+
+
+# transparent_one 1138-1147
+def transparent_one_space() -> flat.FlatSpace:
+    return one_cube_space(flat.atom((1.0, 0.0, 0.0, 0.5)))
+
+
+# emission 297-334
+def emission_space() -> flat.FlatSpace:
+    e_refl = flat.evoxel((*from_srgb8((200, 0, 0)), 1.0), from_srgb8((0, 200, 0)))
+    e_only = flat.evoxel((0.0, 0.0, 0.0, 1.0), from_srgb8((0, 200, 0)))
+    white = flat.evoxel((1.0, 1.0, 1.0, 1.0))
+    pal = np.stack([white, e_refl, e_only])
+    # Vol::from_y_flipped_array([[ "....", ".E..", "..e.", "...." ]]): rows are listed top (y=3) first,
+    # columns are x; the same pattern for every z (p.z = 0)
+    rows = ["....", ".E..", "..e.", "...."]
+    vox = np.zeros((4, 4, 4), np.uint16)
+    for row_i, row in enumerate(rows):
+        y = 3 - row_i
+        for x, ch in enumerate(row):
+            vox[x, y, :] = {".": 0, "E": 1, "e": 2}[ch]
+    return one_cube_space(flat.voxel_block(4, vox, pal))
+
+
+# voxel_shape_test 371-418 with the atoms of emission_only (351-357) / emission_semi (360-367)
+def voxel_shape_space(kind: str) -> flat.FlatSpace:
+    if kind == "only":
+        ev = flat.evoxel((0.0, 0.0, 0.0, 0.0), from_srgb8((0, 200, 0)))
+    elif kind == "semi":
+        ev = flat.evoxel((0.0, 0.0, 0.0, 1.0 - 2.0 ** -3), from_srgb8((0, 200, 0)))
+    else:
+        raise ValueError(kind)
+    sp = flat.FlatSpace((-1, 0, 0), (4, 1, 1))
+    sp.set_sky_uniform(from_srgb8((0, 0, 127)))
+    a = sp.add_block(flat.air())
+    atom_block = sp.add_block(flat.BlockDef(1, (0, 0, 0), np.zeros((1, 1, 1), np.uint16), ev[None, :], is_one=True))
+    vox = np.zeros((2, 2, 2), np.uint16)
+    for x in range(2):
+        for y in range(2):
+            for z in range(2):
+                vox[x, y, z] = 1 if (x == 0 or y == 0 or z == 0) else 0
+    pal = np.stack([flat.evoxel((0, 0, 0, 0)), ev])
+    vb = sp.add_block(flat.voxel_block(2, vox, pal))
+    sp.block_index[...] = a
+    sp.set((-1, 0, 0), atom_block)
+    sp.set((1, 0, 0), vb)
+    return sp
+
+
+# color_srgb_ramp 205-233
+def color_srgb_ramp_space() -> flat.FlatSpace:
+    sp = flat.FlatSpace((0, 0, 0), (32, 32, 1))
+    a = sp.add_block(flat.air())
+    sp.block_index[...] = a
+    lut = srgb_lut()
+    cache = {}
+
+    def blk(rgb):
+        if rgb not in cache:
+            cache[rgb] = sp.add_block(flat.atom((float(lut[rgb[0]]), float(lut[rgb[1]]), float(lut[rgb[2]]), 1.0)))
+        return cache[rgb]
+
+    for i in range(256):
+        px, py = (i % 16) * 2, (i // 16) * 2
+        sp.set((px, py, 0), blk((i, i, i)))
+        sp.set((px + 1, py, 0), blk((i, 0, 0)))
+        sp.set((px + 1, py + 1, 0), blk((0, i, 0)))
+        sp.set((px, py + 1, 0), blk((0, 0, i)))
+    return sp
+
+
+# ui_space 1260-1268
+def ui_space() -> flat.FlatSpace:
+    sp = flat.FlatSpace((-3, -3, -4), (1, 1, 1))
+    sp.set_sky_uniform((1.0, 1.0, 0.5))
+    sp.block_index[...] = sp.add_block(flat.atom((0.0, 1.0, 0.0, 1.0)))
+    return sp
+
+
+# -- synthetic scenes for parity / bench (SURVEY.md 8d "S256") ------------------------------
+def _splitmix64(state: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = state + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _hash3(x, y, z, seed) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        h = (x.astype(np.uint64) * np.uint64(0x9E3779B1) ^ y.astype(np.uint64) * np.uint64(0x85EBCA77)
+             ^ z.astype(np.uint64) * np.uint64(0xC2B2AE3D) ^ np.uint64(seed))
+    return _splitmix64(h)
+
+
+def synthetic_blocks(resolution: int, count: int, seed: int = 1, palette_size: int = 16, translucent: bool = True):
+    """`count` distinct recursive blocks at `resolution`: spheres / slabs / lattices / 30% random fill."""
+    r = resolution
+    g = np.arange(r)
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    blocks = []
+    rng = np.random.default_rng(seed)
+    for k in range(count):
+        pal = np.zeros((palette_size, 8), np.float32)
+        cols = rng.uniform(0.05, 1.0, (palette_size, 3)).astype(np.float32)
+        pal[:, 0:3] = cols
+        pal[:, 3] = 1.0
+        pal[0] = 0.0  # index 0 = empty voxel
+        if translucent and k % 4 == 3:
+            pal[1:, 3] = np.float32(0.5)
+        if k % 8 == 5:
+            pal[1, 4:7] = (0.0, 0.8, 0.2)  # an emissive entry
+        shape = k % 4
+        hv = _hash3(X, Y, Z, seed * 1000 + k)
+        colour = (1 + (hv >> np.uint64(40)) % np.uint64(palette_size - 1)).astype(np.uint16)
+        if shape == 0:
+            c = (r - 1) / 2.0
+            mask = (X - c) ** 2 + (Y - c) ** 2 + (Z - c) ** 2 <= (0.48 * r) ** 2
+        elif shape == 1:
+            mask = Y < max(1, (r * (1 + k % 3)) // 4)
+        elif shape == 2:
+            q = max(1, r // 4)
+            mask = ((X % q == 0) & (Y % q == 0)) | ((Y % q == 0) & (Z % q == 0)) | ((X % q == 0) & (Z % q == 0))
+        else:
+            mask = (hv % np.uint64(100)) < np.uint64(30)
+        vox = np.where(mask, colour, 0).astype(np.uint16)
+        blocks.append(flat.voxel_block(r, vox, pal, name=chr(ord("a") + k % 26)))
+    return blocks
+
+
+def synthetic_space(n: int = 256, resolution: int = 32, n_blocks: int = 64, seed: int = 1, light: str = "one") -> flat.FlatSpace:
+    """S<n>: [0,n)^3, heightfield terrain <= n/2 high + 5% floating blocks (about 45% non-air)."""
+    sp = flat.FlatSpace((0, 0, 0), (n, n, n))
+    sp.set_sky_uniform((0.9, 0.9, 1.0))
+    a = sp.add_block(flat.air())
+    atoms = [sp.add_block(flat.atom(c)) for c in [(0.3, 0.6, 0.2, 1.0), (0.5, 0.45, 0.4, 1.0), (0.8, 0.75, 0.5, 1.0), (0.3, 0.5, 0.9, 0.5)]]
+    recs = [sp.add_block(b) for b in synthetic_blocks(resolution, n_blocks, seed)]
+    g = np.arange(n)
+    # smooth heightfield from a few seeded sinusoids
+    rng = np.random.default_rng(seed)
+    H = np.zeros((n, n))
+    for _ in range(6):
+        fx, fz = rng.uniform(0.5, 4.0, 2) * 2 * np.pi / n
+        ph = rng.uniform(0, 2 * np.pi, 2)
+        H += rng.uniform(0.3, 1.0) * np.sin(g[:, None] * fx + ph[0]) * np.cos(g[None, :] * fz + ph[1])
+    H = (H - H.min()) / (H.max() - H.min())
+    height = (0.15 * n + 0.35 * n * H).astype(np.int64)  # <= n/2
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    hv = _hash3(X, Y, Z, seed)
+    pick = (hv >> np.uint64(20)) % np.uint64(len(atoms) + len(recs))
+    table = np.array(atoms + recs, dtype=np.uint16)
+    solid = Y < height[:, None, :]
+    # top two layers recursive-heavy, interior atoms
+    surface_layer = Y >= (height[:, None, :] - 2)
+    rec_pick = table[len(atoms) + ((hv >> np.uint64(33)) % np.uint64(len(recs))).astype(np.int64)]
+    any_pick = table[pick.astype(np.int64)]
+    grid = np.where(solid, np.where(surface_layer, rec_pick, any_pick), a)
+    floating = (~solid) & ((hv % np.uint64(100)) < np.uint64(5)) & (Y < (3 * n) // 4)
+    grid = np.where(floating, rec_pick, grid)
+    sp.block_index[...] = grid.astype(np.uint16)
+    if light == "field":
+        nonair = sp.block_index != a
+        lv = (120 + 40 * np.sin(X * 0.05) * np.cos(Z * 0.07) + 20 * (Y / n)).clip(1, 200).astype(np.uint8)
+        sp.light[..., 0] = lv
+        sp.light[..., 1] = lv
+        sp.light[..., 2] = np.minimum(lv.astype(np.int64) + 6, 255).astype(np.uint8)
+        sp.light[..., 3] = np.where(nonair, flat.STATUS_OPAQUE, flat.STATUS_VISIBLE)
+        sp.light[nonair, 0:3] = 0
+    return sp
+
+
+def atrium_like_space(seed: int = 7) -> flat.FlatSpace:
+    """S-atrium-like: 19x35x51 cubes, R16 blocks, an open hall with floors,
+    arches and balconies; stands in for UniverseTemplate::Atrium (whose generator needs the
+    un-vendored noise crate and the block-evaluation engine)."""
+    lo = (-9, -1, -25)
+    size = (19, 35, 51)
+    sp = flat.FlatSpace(lo, size)
+    sp.set_sky_uniform(from_srgb8((243, 243, 255)))  # DAY_SKY_COLOR palette.rs:63
+    a = sp.add_block(flat.air())
+    stone = sp.add_block(flat.atom((0.55, 0.53, 0.5, 1.0)))
+    recs = [sp.add_block(b) for b in synthetic_blocks(16, 24, seed, translucent=True)]
+    sx, sy, sz = size
+    gx, gy, gz = np.arange(sx), np.arange(sy), np.arange(sz)
+    X, Y, Z = np.meshgrid(gx, gy, gz, indexing="ij")
+    hv = _hash3(X, Y, Z, seed)
+    rec = np.array(recs, np.uint16)[((hv >> np.uint64(30)) % np.uint64(len(recs))).astype(np.int64)]
+    grid = np.full(size, a, np.uint16)
+    wall = (X == 0) | (X == sx - 1) | (Z == 0) | (Z == sz - 1)
+    grid[wall] = stone
+    grid[:, 0, :] = rec[:, 0, :]  # detailed floor
+    for fy in (8, 16, 24):  # balconies along the walls
+        ring = (Y == fy) & ((X < 4) | (X >= sx - 4) | (Z < 4) | (Z >= sz - 4))
+        grid[ring] = rec[ring]
+    pillars = ((X % 6 == 3) & (Z % 6 == 3)) & (Y < 25) & ((X < 5) | (X > sx - 6))
+    grid[pillars] = rec[pillars]
+    arches = (Y == 7) & (Z % 6 == 3) & (X > 3) & (X < sx - 4)
+    grid[arches] = rec[arches]
+    grid[:, sy - 1, :] = np.where((X[:, 0, :] + Z[:, 0, :]) % 3 == 0, a, stone)  # skylights
+    sp.block_index[...] = grid
+    return sp
