@@ -1,0 +1,356 @@
+"""ctypes binding of the C ABI in include/aic_hip.h (libaic_hip.so).
+
+This is plumbing for the Python-side tests and bench: it adds nothing to the boundary.
+There is NO fallback: if the HIP library is missing or no MI355X is usable the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libaic_hip.so"
+
+AIC_OK = 0
+ERR_NAMES = {1: "AIC_ERR_INVALID", 2: "AIC_ERR_NO_DEVICE", 3: "AIC_ERR_OOM", 4: "AIC_ERR_DEVICE", 5: "AIC_ERR_UNSUPPORTED"}
+LAYER_WORLD, LAYER_UI = 0, 1
+FLAW_UNSUPPORTED, FLAW_NO_BLOOM = 1, 2
+FRAME_COUNTERS, FRAME_AUX = 1, 2
+
+# every symbol include/aic_hip.h declares
+ABI_SYMBOLS = [
+    "aic_abi_version", "aic_create", "aic_destroy", "aic_last_error", "aic_device_name", "aic_upload_space",
+    "aic_clear_space", "aic_update_cubes", "aic_update_light_volume", "aic_replace_block", "aic_set_options",
+    "aic_render", "aic_partition_rows", "aic_assemble_strips", "aic_read_aux", "aic_synchronize", "aic_stream",
+    "aic_probe_raycast", "aic_probe_light_lut",
+]
+
+
+class AicError(RuntimeError):
+    """Maps to `RenderError` on the reference side (all-is-cubes-render/src/lib.rs:46-54)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+class BlockDesc(C.Structure):
+    _fields_ = [("resolution", C.c_int32), ("vlo", C.c_int32 * 3), ("vsize", C.c_int32 * 3), ("vox_off", C.c_uint32),
+                ("pal_off", C.c_uint32), ("pal_len", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_int32)]
+
+
+class SpaceDesc(C.Structure):
+    _fields_ = [("lo", C.c_int32 * 3), ("size", C.c_int32 * 3), ("block_index", C.c_void_p), ("light", C.c_void_p),
+                ("n_blocks", C.c_uint32), ("blocks", C.c_void_p), ("voxels", C.c_void_p), ("n_voxels", C.c_uint64),
+                ("palette", C.c_void_p), ("n_palette", C.c_uint64), ("sky_kind", C.c_int32), ("sky", (C.c_float * 3) * 8),
+                ("block_sky", (C.c_uint8 * 4) * 7)]
+
+
+class Options(C.Structure):
+    _fields_ = [("fog", C.c_int32), ("transparency", C.c_int32), ("threshold", C.c_float), ("lighting", C.c_int32),
+                ("bounce_samples", C.c_int32), ("antialiasing", C.c_int32), ("debug_pixel_cost", C.c_int32),
+                ("tone_mapping", C.c_int32), ("maximum_intensity", C.c_float), ("bloom_intensity", C.c_float),
+                ("view_distance", C.c_double)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("inverse_projection_view", C.c_double * 16), ("exposure", C.c_float), ("reserved", C.c_int32)]
+
+
+class Partition(C.Structure):
+    _fields_ = [("strip_rows", C.c_uint32), ("n_parts", C.c_uint32), ("part", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class FrameDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("world", Camera), ("ui", Camera), ("backdrop", C.c_float * 4),
+                ("partition", Partition), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class FrameInfo(C.Structure):
+    _fields_ = [("cubes_traced", C.c_uint64), ("n_outer", C.c_uint64), ("n_inner", C.c_uint64), ("n_hits", C.c_uint64),
+                ("n_light", C.c_uint64), ("kernel_ms", C.c_float), ("total_ms", C.c_float), ("rows_rendered", C.c_uint32),
+                ("flaws", C.c_uint32)]
+
+
+PIXEL_AUX_DTYPE = np.dtype(
+    [("hit", "<i4"), ("cube", "<i4", (3,)), ("voxel", "<i4", (3,)), ("resolution", "<i4"), ("face", "<i4"),
+     ("block_index", "<i4"), ("cubes_traced", "<u4"), ("pad", "<u4"), ("t_distance", "<f8")],
+    align=True,
+)
+RC_STEP_DTYPE = np.dtype([("cube", "<i4", (3,)), ("face", "<i4"), ("t_distance", "<f8"), ("intersection_point", "<f8", (3,))], align=True)
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Loads libaic_hip.so; raises if it has not been built (run `python __graft_entry__.py`)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() (hipcc, gfx950)")
+        lib = C.CDLL(str(LIB_PATH))
+        lib.aic_create.restype = C.c_void_p
+        lib.aic_create.argtypes = [C.c_int, C.POINTER(C.c_int)]
+        lib.aic_destroy.argtypes = [C.c_void_p]
+        lib.aic_destroy.restype = None
+        lib.aic_last_error.restype = C.c_char_p
+        lib.aic_last_error.argtypes = [C.c_void_p]
+        lib.aic_stream.restype = C.c_void_p
+        lib.aic_stream.argtypes = [C.c_void_p]
+        lib.aic_partition_rows.restype = C.c_uint32
+        lib.aic_partition_rows.argtypes = [C.c_uint32, C.POINTER(Partition)]
+        lib.aic_upload_space.argtypes = [C.c_void_p, C.c_int, C.POINTER(SpaceDesc)]
+        lib.aic_clear_space.argtypes = [C.c_void_p, C.c_int]
+        lib.aic_update_cubes.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.aic_update_light_volume.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.aic_replace_block.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(BlockDesc), C.c_void_p, C.c_void_p]
+        lib.aic_set_options.argtypes = [C.c_void_p, C.c_int, C.POINTER(Options)]
+        lib.aic_render.argtypes = [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.c_int, C.POINTER(FrameInfo)]
+        lib.aic_assemble_strips.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        lib.aic_read_aux.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        lib.aic_synchronize.argtypes = [C.c_void_p]
+        lib.aic_device_name.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
+        lib.aic_probe_raycast.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+        lib.aic_probe_light_lut.argtypes = [C.c_void_p, C.c_void_p]
+        assert C.sizeof(BlockDesc) == 48
+        _lib = lib
+    return _lib
+
+
+def packed_light_scalar_in(value: float) -> int:
+    """PackedLight::scalar_in (all-is-cubes/src/space/light/data.rs:214-218)."""
+    v = np.float32(value)
+    if not v > 0:
+        return 0
+    x = float(np.float32(np.float32(np.log2(v)) * np.float32(10.0)) + np.float32(144.0))
+    x = float(np.float32(x))
+    r = math.floor(abs(x) + 0.5) * (1 if x >= 0 else -1)  # f32::round: half away from zero
+    return int(min(max(r, 0), 255))
+
+
+def block_sky_texels(sky_kind: int, sky: np.ndarray) -> np.ndarray:
+    """Sky::for_blocks (all-is-cubes/src/space/sky.rs:45-82) as 7 texels: nx ny nz px py pz mean."""
+    sky = np.asarray(sky, np.float32).reshape(8, 3)
+    out = np.zeros((7, 4), np.uint8)
+    out[:, 3] = 255  # LightStatus::Visible
+
+    def some(rgb):
+        return [packed_light_scalar_in(float(c)) for c in rgb]
+
+    if sky_kind == 0:
+        out[:, 0:3] = some(sky[0])
+        return out
+    # images of +X,+Y,+Z under Face::rotation_from_nz (face.rs:395-404)
+    bases = {
+        0: ((0, 1, 0), (0, 0, 1), (1, 0, 0)),  # NX RYZX
+        1: ((0, 0, 1), (1, 0, 0), (0, 1, 0)),  # NY RZXY
+        2: ((1, 0, 0), (0, 1, 0), (0, 0, 1)),  # NZ RXYZ
+        3: ((0, -1, 0), (0, 0, 1), (-1, 0, 0)),  # PX RyZx
+        4: ((0, 0, 1), (-1, 0, 0), (0, -1, 0)),  # PY RZxy
+        5: ((1, 0, 0), (0, -1, 0), (0, 0, -1)),  # PZ RXyz
+    }
+    pts = [(-1, -1, -1), (-1, 1, -1), (1, -1, -1), (1, 1, -1)]
+    for f in range(6):
+        bx, by, bz = (np.array(v) for v in bases[f])
+        acc = np.zeros(3, np.float32)
+        for p in pts:
+            d = p[0] * bx + p[1] * by + p[2] * bz
+            idx = ((1 if d[0] >= 0 else 0) << 2) + ((1 if d[1] >= 0 else 0) << 1) + (1 if d[2] >= 0 else 0)
+            acc = (acc + sky[idx]).astype(np.float32)
+        out[f, 0:3] = some(acc * np.float32(0.25))
+    acc = np.zeros(3, np.float32)
+    for k in range(8):
+        acc = (acc + sky[k]).astype(np.float32)
+    out[6, 0:3] = some(acc * np.float32(1.0 / 8.0))
+    return out
+
+
+def make_options(fog=1, transparency=1, threshold=0.5, lighting=3, bounce_samples=0, antialiasing=0, debug_pixel_cost=False,
+                 tone_mapping=0, maximum_intensity=float("inf"), bloom_intensity=0.125, view_distance=200.0) -> Options:
+    """Defaults = GraphicsOptions::default() (camera/graphics_options.rs:256-280)."""
+    o = Options()
+    o.fog, o.transparency, o.threshold, o.lighting = fog, transparency, threshold, lighting
+    o.bounce_samples, o.antialiasing, o.debug_pixel_cost = bounce_samples, antialiasing, int(debug_pixel_cost)
+    o.tone_mapping, o.maximum_intensity, o.bloom_intensity = tone_mapping, maximum_intensity, bloom_intensity
+    o.view_distance = min(max(view_distance, 1.0), 10000.0)  # GraphicsOptions::repair
+    return o
+
+
+def unaltered_colors(**kw) -> Options:
+    """GraphicsOptions::UNALTERED_COLORS (graphics_options.rs:168-190)."""
+    base = dict(fog=0, lighting=0, transparency=1, bloom_intensity=0.0)
+    base.update(kw)
+    return make_options(**base)
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None or a.size == 0 else a.ctypes.data
+
+
+class Context:
+    """One device-resident renderer state = `RtRenderer` minus cameras."""
+
+    def __init__(self, device_id: int = -1):
+        self._lib = load()
+        st = C.c_int(0)
+        self._h = self._lib.aic_create(device_id, C.byref(st))
+        if not self._h:
+            raise AicError(st.value, "aic_create failed (no usable MI355X / HIP device?)")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.aic_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int) -> None:
+        if rc != AIC_OK:
+            raise AicError(rc, self._lib.aic_last_error(self._h).decode())
+
+    @property
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        self._check(self._lib.aic_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.aic_stream(self._h) or 0)
+
+    # -- scene ---------------------------------------------------------------------------
+    def upload_space(self, layer: int, flat_space) -> None:
+        p = flat_space.pack() if hasattr(flat_space, "pack") else flat_space
+        d = SpaceDesc()
+        d.lo[:] = [int(v) for v in p.lo]
+        d.size[:] = [int(v) for v in p.size]
+        d.block_index = _ptr(p.block_index)
+        d.light = _ptr(p.light)
+        d.n_blocks = len(p.blocks)
+        d.blocks = _ptr(p.blocks)
+        d.voxels = _ptr(p.voxels)
+        d.n_voxels = p.voxels.size
+        d.palette = _ptr(p.palette)
+        d.n_palette = len(p.palette)
+        d.sky_kind = p.sky_kind
+        for i in range(8):
+            for j in range(3):
+                d.sky[i][j] = float(p.sky[i, j])
+        bs = block_sky_texels(p.sky_kind, p.sky)
+        for i in range(7):
+            for j in range(4):
+                d.block_sky[i][j] = int(bs[i, j])
+        self._check(self._lib.aic_upload_space(self._h, layer, C.byref(d)))
+
+    def clear_space(self, layer: int) -> None:
+        self._check(self._lib.aic_clear_space(self._h, layer))
+
+    def update_cubes(self, layer: int, xyz, block_index=None, light=None) -> None:
+        xyz = np.ascontiguousarray(xyz, np.int32).reshape(-1, 3)
+        bi = None if block_index is None else np.ascontiguousarray(block_index, np.uint16)
+        lt = None if light is None else np.ascontiguousarray(light, np.uint8).reshape(-1, 4)
+        self._check(self._lib.aic_update_cubes(self._h, layer, len(xyz), _ptr(xyz), _ptr(bi), _ptr(lt)))
+
+    def update_light_volume(self, layer: int, light: np.ndarray) -> None:
+        lt = np.ascontiguousarray(light, np.uint8)
+        self._check(self._lib.aic_update_light_volume(self._h, layer, _ptr(lt)))
+
+    def replace_block(self, layer: int, index: int, block) -> None:
+        from . import flat
+
+        d = BlockDesc()
+        d.resolution = block.resolution
+        d.vlo[:] = list(block.vlo)
+        d.vsize[:] = list(block.voxels.shape)
+        d.pal_len = len(block.palette)
+        d.flags = (flat.FLAG_ONE if block.is_one else 0) | (flat.FLAG_AIR if block.is_air else 0)
+        vox = np.ascontiguousarray(block.voxels, np.uint16)
+        pal = np.ascontiguousarray(block.palette, np.float32)
+        self._check(self._lib.aic_replace_block(self._h, layer, index, C.byref(d), _ptr(vox), _ptr(pal)))
+
+    def set_options(self, layer: int, options: Options) -> None:
+        self._check(self._lib.aic_set_options(self._h, layer, C.byref(options)))
+
+    # -- drawing ---------------------------------------------------------------------------
+    @staticmethod
+    def make_frame(width, height, world_inv=None, ui_inv=None, exposure=1.0, ui_exposure=1.0, backdrop=(0, 0, 0, 0),
+                   partition=None, flags=0) -> FrameDesc:
+        f = FrameDesc()
+        f.width, f.height = int(width), int(height)
+        ident = np.eye(4).reshape(16)
+        w = ident if world_inv is None else np.ascontiguousarray(world_inv, np.float64).reshape(16)
+        u = ident if ui_inv is None else np.ascontiguousarray(ui_inv, np.float64).reshape(16)
+        f.world.inverse_projection_view[:] = [float(v) for v in w]
+        f.ui.inverse_projection_view[:] = [float(v) for v in u]
+        f.world.exposure, f.ui.exposure = exposure, ui_exposure
+        f.backdrop[:] = [float(v) for v in backdrop]
+        if partition is not None:
+            f.partition.strip_rows, f.partition.n_parts, f.partition.part = (int(v) for v in partition)
+        f.flags = flags
+        return f
+
+    def partition_rows(self, height: int, partition) -> int:
+        p = Partition(int(partition[0]), int(partition[1]), int(partition[2]), 0)
+        return int(self._lib.aic_partition_rows(height, C.byref(p)))
+
+    def render(self, frame: FrameDesc, want_aux: bool = False, counters: bool = False):
+        """Returns dict(rgba8 [rows,w,4], info FrameInfo, aux or None)."""
+        if want_aux:
+            frame.flags |= FRAME_AUX
+        if counters:
+            frame.flags |= FRAME_COUNTERS
+        rows = int(self._lib.aic_partition_rows(frame.height, C.byref(frame.partition)))
+        out = np.zeros((rows, frame.width, 4), np.uint8)
+        info = FrameInfo()
+        self._check(self._lib.aic_render(self._h, C.byref(frame), _ptr(out), 0, C.byref(info)))
+        aux = None
+        if want_aux:
+            aux = np.zeros((rows, frame.width), PIXEL_AUX_DTYPE)
+            if aux.size:
+                self._check(self._lib.aic_read_aux(self._h, _ptr(aux), aux.size))
+        return {"rgba8": out, "info": info, "aux": aux}
+
+    def render_to_device(self, frame: FrameDesc, device_ptr: int) -> FrameInfo:
+        """Leaves the RGBA8 rows in HBM at `device_ptr` (e.g. a torch tensor's data_ptr())."""
+        info = FrameInfo()
+        self._check(self._lib.aic_render(self._h, C.byref(frame), C.c_void_p(device_ptr), 1, C.byref(info)))
+        return info
+
+    def assemble_strips(self, gathered_ptr: int, out_ptr: int, width: int, height: int, strip_rows: int, n_parts: int) -> None:
+        self._check(self._lib.aic_assemble_strips(self._h, C.c_void_p(gathered_ptr), C.c_void_p(out_ptr), width, height, strip_rows, n_parts))
+
+    def synchronize(self) -> None:
+        self._check(self._lib.aic_synchronize(self._h))
+
+    # -- probes ----------------------------------------------------------------------------
+    def probe_raycast(self, origin, direction, bounds=None, include_exit=True, max_steps=64):
+        o = np.ascontiguousarray(origin, np.float64).reshape(3)
+        d = np.ascontiguousarray(direction, np.float64).reshape(3)
+        lo = np.zeros(3, np.int32) if bounds is None else np.ascontiguousarray(bounds[0], np.int32)
+        hi = np.zeros(3, np.int32) if bounds is None else np.ascontiguousarray(bounds[1], np.int32)
+        out = np.zeros(max_steps, RC_STEP_DTYPE)
+        n = C.c_uint32(0)
+        ended = C.c_int(0)
+        self._check(self._lib.aic_probe_raycast(self._h, o.ctypes.data, d.ctypes.data, int(bounds is not None), lo.ctypes.data,
+                                                hi.ctypes.data, int(include_exit), max_steps, out.ctypes.data, C.byref(n), C.byref(ended)))
+        return out[: n.value], bool(ended.value)
+
+    def probe_light_lut(self) -> np.ndarray:
+        out = np.zeros(256, np.float32)
+        self._check(self._lib.aic_probe_light_lut(self._h, out.ctypes.data))
+        return out

@@ -1,0 +1,660 @@
+// aic_abi.cpp -- host side of the C ABI declared in include/aic_hip.h.
+//
+// Owns the device-resident snapshot of up to two Spaces (world + UI), i.e. what the
+// reference keeps in `RtRenderer.rts: Layers<Option<UpdatingSpaceRaytracer>>`
+// (all-is-cubes-render/src/raytracer/renderer.rs:35-54), and launches the kernels of
+// aic_trace.hip on a private HIP stream. No CPU rendering path exists here: every entry
+// point fails with AIC_ERR_NO_DEVICE / AIC_ERR_DEVICE when HIP is unusable.
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/aic_hip.h"
+#include "aic_device.h"
+
+namespace aic {
+void launch_trace_image(const DevFrame &F, bool diag, hipStream_t stream);
+void launch_scatter_cubes(uint16_t *grid, uint32_t *light, const int32_t *xyz, const uint16_t *bi, const uint32_t *lt,
+                          uint32_t n, const int lo[3], const int size[3], hipStream_t stream);
+void launch_assemble_strips(const uint32_t *gathered, uint32_t *out, uint32_t w, uint32_t h, uint32_t strip_rows,
+                            uint32_t n_parts, uint32_t max_rows, hipStream_t stream);
+void launch_probe_raycast(const double *od, int use_bounds, const int *lohi, int include_exit, uint32_t max_steps,
+                          double *out_rec, uint32_t *n_out, int *ended, hipStream_t stream);
+}  // namespace aic
+
+using namespace aic;
+
+static_assert(sizeof(aic_pixel_aux) == sizeof(DevAux), "aux record layout");
+static_assert(sizeof(aic_block_desc) == 48, "aic_block_desc is 48 bytes");
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;    // elements in use
+    size_t cap = 0;  // elements allocated
+    hipError_t ensure(size_t count, bool keep = false, hipStream_t stream = nullptr) {
+        n = count;
+        if (count <= cap) return hipSuccess;
+        size_t new_cap = count + count / 4 + 16;
+        T *np_ = nullptr;
+        hipError_t e = hipMalloc((void **)&np_, new_cap * sizeof(T));
+        if (e != hipSuccess) return e;
+        if (keep && p && cap) {
+            e = hipMemcpyAsync(np_, p, cap * sizeof(T), hipMemcpyDeviceToDevice, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) {
+                (void)hipFree(np_);
+                return e;
+            }
+        }
+        if (p) (void)hipFree(p);
+        p = np_;
+        cap = new_cap;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = cap = 0;
+    }
+};
+
+struct Layer {
+    bool present = false;
+    int32_t lo[3] = {0, 0, 0}, size[3] = {0, 0, 0};
+    DevBuf<uint16_t> grid;
+    DevBuf<uint32_t> light;
+    DevBuf<DevBlock> blocks;
+    DevBuf<uint16_t> voxels;
+    DevBuf<DevPaletteEntry> palette;
+    std::vector<DevBlock> host_blocks;  // mirror of the block table (for replace/append)
+    int32_t air_index = -1;
+    int32_t sky_kind = 0;
+    float sky[8][3] = {};
+    uint32_t block_sky[7] = {};
+    aic_options opt;
+    bool opt_set = false;
+    size_t n_cubes() const { return (size_t)size[0] * (size_t)size[1] * (size_t)size[2]; }
+    void release() {
+        grid.release(); light.release(); blocks.release(); voxels.release(); palette.release();
+        host_blocks.clear();
+        present = false;
+    }
+};
+
+aic_options default_options() {
+    // GraphicsOptions::default() (graphics_options.rs:256-280)
+    aic_options o;
+    std::memset(&o, 0, sizeof(o));
+    o.fog = 1;
+    o.transparency = 1;
+    o.threshold = 0.5f;
+    o.lighting = 3;
+    o.maximum_intensity = INFINITY;
+    o.bloom_intensity = 0.125f;
+    o.view_distance = 200.0;
+    return o;
+}
+
+}  // namespace
+
+struct aic_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    Layer layers[2];
+    DevBuf<float> lut;
+    DevBuf<DevCounters> counters;
+    DevBuf<uint32_t> out;      // internal RGBA8 target when the caller wants a host copy
+    DevBuf<DevAux> aux;
+    DevBuf<float4> acc;        // UI pre-pass accumulators
+    DevBuf<unsigned char> staging;  // scratch for scatter updates / probes
+    uint64_t aux_records = 0;
+    std::string err;
+    char devname[256] = {0};
+};
+
+namespace {
+
+int fail(aic_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
+    if (c) {
+        c->err = what;
+        if (e != hipSuccess) {
+            c->err += ": ";
+            c->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+int hip_fail(aic_ctx *c, const char *what, hipError_t e) {
+    return fail(c, e == hipErrorOutOfMemory ? AIC_ERR_OOM : AIC_ERR_DEVICE, what, e);
+}
+#define HIP_TRY(ctx, expr)                                    \
+    do {                                                      \
+        hipError_t e_ = (expr);                               \
+        if (e_ != hipSuccess) return hip_fail(ctx, #expr, e_); \
+    } while (0)
+
+bool valid_layer(int l) { return l == AIC_LAYER_WORLD || l == AIC_LAYER_UI; }
+bool valid_resolution(int r) { return r >= 1 && r <= 128 && (r & (r - 1)) == 0; }
+
+inline bool invisible(const float *e) { return e[3] == 0.f && e[4] == 0.f && e[5] == 0.f && e[6] == 0.f; }
+
+// Builds the device form of one block: palette reordered "invisible entries first", voxel
+// codes remapped accordingly (aic_device.h). Appends to vox/pal pools at the given offsets.
+int convert_block(aic_ctx *c, const aic_block_desc &d, const uint16_t *voxels, const float *palette, uint32_t vox_off,
+                  uint32_t pal_off, DevBlock *out, std::vector<uint16_t> *vox_out, std::vector<DevPaletteEntry> *pal_out) {
+    std::memset(out, 0, sizeof(*out));
+    if (!valid_resolution(d.resolution)) return fail(c, AIC_ERR_INVALID, "block resolution must be a power of two in 1..128");
+    const bool one = (d.flags & AIC_BLOCK_ONE) != 0;
+    size_t nvox = one ? 1 : (size_t)d.vsize[0] * (size_t)d.vsize[1] * (size_t)d.vsize[2];
+    for (int a = 0; a < 3 && !one; a++) {
+        if (d.vsize[a] < 0 || d.vlo[a] < 0 || d.vlo[a] + d.vsize[a] > d.resolution)
+            return fail(c, AIC_ERR_INVALID, "block voxel bounds exceed GridAab::for_block(resolution)");
+    }
+    if (d.pal_len == 0 && nvox > 0) return fail(c, AIC_ERR_INVALID, "block has voxels but an empty palette");
+    if (one || d.resolution == 1) {
+        // Evoxels::single_voxel() (voxel_storage.rs:364-385)
+        const float *e = nullptr;
+        static const float air[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (one) e = palette;
+        else {
+            // indices.get([0,0,0]) or Evoxel::AIR
+            bool inb = nvox > 0 && d.vlo[0] <= 0 && d.vlo[1] <= 0 && d.vlo[2] <= 0 && d.vlo[0] + d.vsize[0] > 0 &&
+                       d.vlo[1] + d.vsize[1] > 0 && d.vlo[2] + d.vsize[2] > 0;
+            if (inb) {
+                size_t i = ((size_t)(0 - d.vlo[0]) * d.vsize[1] + (size_t)(0 - d.vlo[1])) * d.vsize[2] + (size_t)(0 - d.vlo[2]);
+                uint16_t idx = voxels[i];
+                if (idx >= d.pal_len) return fail(c, AIC_ERR_INVALID, "voxel index exceeds palette");
+                e = palette + 8 * (size_t)idx;
+            } else e = air;
+        }
+        out->kind = 0;
+        for (int k = 0; k < 4; k++) out->color[k] = e[k];
+        for (int k = 0; k < 3; k++) out->emission[k] = e[4 + k];
+        return AIC_OK;
+    }
+    // recursive block
+    std::vector<uint32_t> remap(d.pal_len);
+    uint32_t n_inv = 0;
+    for (uint32_t i = 0; i < d.pal_len; i++)
+        if (invisible(palette + 8 * (size_t)i)) n_inv++;
+    uint32_t next_inv = 0, next_vis = n_inv;
+    size_t pal_base = pal_out->size();
+    pal_out->resize(pal_base + d.pal_len);
+    for (uint32_t i = 0; i < d.pal_len; i++) {
+        const float *e = palette + 8 * (size_t)i;
+        uint32_t dst = invisible(e) ? next_inv++ : next_vis++;
+        remap[i] = dst;
+        DevPaletteEntry &pe = (*pal_out)[pal_base + dst];
+        for (int k = 0; k < 4; k++) pe.color[k] = e[k];
+        for (int k = 0; k < 3; k++) pe.emission[k] = e[4 + k];
+        pe.pad = 0.f;
+    }
+    size_t vox_base = vox_out->size();
+    vox_out->resize(vox_base + nvox);
+    for (size_t i = 0; i < nvox; i++) {
+        uint16_t idx = voxels[i];
+        if (idx >= d.pal_len) return fail(c, AIC_ERR_INVALID, "voxel index exceeds palette");
+        (*vox_out)[vox_base + i] = (uint16_t)remap[idx];
+    }
+    out->kind = (uint32_t)d.resolution;
+    out->vlo_packed = (uint32_t)d.vlo[0] | ((uint32_t)d.vlo[1] << 8) | ((uint32_t)d.vlo[2] << 16);
+    out->vsize_packed = (uint32_t)d.vsize[0] | ((uint32_t)d.vsize[1] << 8) | ((uint32_t)d.vsize[2] << 16);
+    out->vox_off = vox_off;
+    out->pal_off = pal_off;
+    out->n_invisible = n_inv;
+    return AIC_OK;
+}
+
+void fill_dev_layer(const aic_ctx *c, const Layer &l, const aic_camera &cam, DevLayer *d, uint32_t *flaws) {
+    std::memset(d, 0, sizeof(*d));
+    d->present = l.present ? 1 : 0;
+    d->grid = l.grid.p;
+    d->light = l.light.p;
+    d->blocks = l.blocks.p;
+    d->voxels = l.voxels.p;
+    d->palette = l.palette.p;
+    for (int a = 0; a < 3; a++) { d->lo[a] = l.lo[a]; d->size[a] = l.size[a]; }
+    d->air_index = l.air_index;
+    d->sky_kind = l.sky_kind;
+    std::memcpy(d->sky, l.sky, sizeof(d->sky));
+    std::memcpy(d->block_sky, l.block_sky, sizeof(d->block_sky));
+    const aic_options o = l.opt_set ? l.opt : default_options();
+    d->opt.fog = o.fog;
+    d->opt.transparency = o.transparency;
+    d->opt.threshold = o.threshold;
+    d->opt.lighting = o.lighting;
+    if (o.lighting == 5) {  // Bounce unsupported: "the renderer should substitute Linear" (graphics_options.rs:460-467)
+        d->opt.lighting = 3;
+        *flaws |= AIC_FLAW_UNSUPPORTED;
+    }
+    d->opt.antialiasing = o.antialiasing;
+    d->opt.debug_pixel_cost = o.debug_pixel_cost;
+    d->opt.tone_mapping = o.tone_mapping;
+    d->opt.maximum_intensity = o.maximum_intensity;
+    d->opt.view_distance = o.view_distance;
+    std::memcpy(d->inv, cam.inverse_projection_view, sizeof(d->inv));
+    d->exposure = cam.exposure;
+    (void)c;
+}
+
+}  // namespace
+
+extern "C" {
+
+int aic_abi_version(void) { return AIC_ABI_VERSION; }
+
+aic_ctx *aic_create(int device_id, int *status) {
+    int st_dummy;
+    if (!status) status = &st_dummy;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        *status = AIC_ERR_NO_DEVICE;
+        return nullptr;
+    }
+    if (device_id < 0) {
+        if (hipGetDevice(&device_id) != hipSuccess) device_id = 0;
+    }
+    if (device_id >= n) {
+        *status = AIC_ERR_INVALID;
+        return nullptr;
+    }
+    if (hipSetDevice(device_id) != hipSuccess) {
+        *status = AIC_ERR_DEVICE;
+        return nullptr;
+    }
+    aic_ctx *c = new aic_ctx();
+    c->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) std::snprintf(c->devname, sizeof(c->devname), "%s (%s)", prop.name, prop.gcnArchName);
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&c->ev0) == hipSuccess &&
+              hipEventCreate(&c->ev1) == hipSuccess;
+    // PackedLight decode table: PACKED_LIGHT_SCALAR_LOOKUP_TABLE is *defined* as
+    // exp2f((v - 144) / 10) with 0 -> 0 (light/data.rs:239-249, 301-354); correctly rounded.
+    float lut[256];
+    lut[0] = 0.f;
+    for (int v = 1; v < 256; v++) {
+        float arg = ((float)v - 144.0f) / 10.0f;
+        lut[v] = (float)std::exp2((double)arg);
+    }
+    ok = ok && c->lut.ensure(256) == hipSuccess && hipMemcpy(c->lut.p, lut, sizeof(lut), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && c->counters.ensure(1) == hipSuccess;
+    if (!ok) {
+        *status = AIC_ERR_DEVICE;
+        aic_destroy(c);
+        return nullptr;
+    }
+    for (auto &l : c->layers) l.opt = default_options();
+    *status = AIC_OK;
+    return c;
+}
+
+void aic_destroy(aic_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &l : c->layers) l.release();
+    c->lut.release(); c->counters.release(); c->out.release(); c->aux.release(); c->acc.release(); c->staging.release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *aic_last_error(const aic_ctx *c) { return c ? c->err.c_str() : "no context"; }
+
+int aic_device_name(const aic_ctx *c, char *buf, uint32_t buf_len) {
+    if (!c || !buf || !buf_len) return AIC_ERR_INVALID;
+    std::snprintf(buf, buf_len, "%s", c->devname);
+    return AIC_OK;
+}
+
+int aic_upload_space(aic_ctx *c, int layer, const aic_space_desc *s) {
+    if (!c || !s || !valid_layer(layer)) return fail(c, AIC_ERR_INVALID, "aic_upload_space: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (int a = 0; a < 3; a++)
+        if (s->size[a] < 0 || (int64_t)s->lo[a] + s->size[a] > 2147483647LL) return fail(c, AIC_ERR_INVALID, "space bounds out of range");
+    Layer &l = c->layers[layer];
+    const size_t n = (size_t)s->size[0] * (size_t)s->size[1] * (size_t)s->size[2];
+    if (n && (!s->block_index || !s->light)) return fail(c, AIC_ERR_INVALID, "space has cubes but no block_index/light");
+    if (s->n_blocks > 65536) return fail(c, AIC_ERR_INVALID, "more than 65536 blocks");
+    if (s->n_blocks && !s->blocks) return fail(c, AIC_ERR_INVALID, "blocks is null");
+
+    // block table + pools
+    std::vector<DevBlock> blocks(s->n_blocks);
+    std::vector<uint16_t> vox;
+    std::vector<DevPaletteEntry> pal;
+    vox.reserve((size_t)s->n_voxels);
+    pal.reserve((size_t)s->n_palette);
+    int32_t air_index = -1;
+    for (uint32_t i = 0; i < s->n_blocks; i++) {
+        const aic_block_desc &d = s->blocks[i];
+        const bool one = (d.flags & AIC_BLOCK_ONE) != 0;
+        size_t nvox = one ? 1 : (size_t)(d.vsize[0] > 0 ? d.vsize[0] : 0) * (size_t)(d.vsize[1] > 0 ? d.vsize[1] : 0) * (size_t)(d.vsize[2] > 0 ? d.vsize[2] : 0);
+        if ((uint64_t)d.vox_off + nvox > s->n_voxels || (uint64_t)d.pal_off + d.pal_len > s->n_palette)
+            return fail(c, AIC_ERR_INVALID, "block voxel/palette range exceeds the pools");
+        if (vox.size() > 0xffffffffull || pal.size() > 0xffffffffull) return fail(c, AIC_ERR_INVALID, "pool too large");
+        int rc = convert_block(c, d, s->voxels ? s->voxels + d.vox_off : nullptr, s->palette ? s->palette + 8 * (size_t)d.pal_off : nullptr,
+                               (uint32_t)vox.size(), (uint32_t)pal.size(), &blocks[i], &vox, &pal);
+        if (rc != AIC_OK) return rc;
+        if ((d.flags & AIC_BLOCK_AIR) && air_index < 0) air_index = (int32_t)i;
+    }
+    // validate cube indices on the host copy (the reference indexes `blocks[...]` with a bounds check)
+    for (size_t i = 0; i < n; i++)
+        if (s->block_index[i] >= s->n_blocks) return fail(c, AIC_ERR_INVALID, "cube block index out of range");
+
+    hipError_t e;
+    if ((e = l.grid.ensure(n)) != hipSuccess) return hip_fail(c, "alloc grid", e);
+    if ((e = l.light.ensure(n)) != hipSuccess) return hip_fail(c, "alloc light", e);
+    if ((e = l.blocks.ensure(blocks.size())) != hipSuccess) return hip_fail(c, "alloc blocks", e);
+    if ((e = l.voxels.ensure(vox.size())) != hipSuccess) return hip_fail(c, "alloc voxels", e);
+    if ((e = l.palette.ensure(pal.size())) != hipSuccess) return hip_fail(c, "alloc palette", e);
+    if (n) {
+        HIP_TRY(c, hipMemcpyAsync(l.grid.p, s->block_index, n * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(l.light.p, s->light, n * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    if (!blocks.empty()) HIP_TRY(c, hipMemcpyAsync(l.blocks.p, blocks.data(), blocks.size() * sizeof(DevBlock), hipMemcpyHostToDevice, c->stream));
+    if (!vox.empty()) HIP_TRY(c, hipMemcpyAsync(l.voxels.p, vox.data(), vox.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    if (!pal.empty()) HIP_TRY(c, hipMemcpyAsync(l.palette.p, pal.data(), pal.size() * sizeof(DevPaletteEntry), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // host buffers may be released on return
+
+    for (int a = 0; a < 3; a++) { l.lo[a] = s->lo[a]; l.size[a] = s->size[a]; }
+    l.host_blocks.swap(blocks);
+    l.air_index = air_index;
+    l.sky_kind = s->sky_kind;
+    std::memcpy(l.sky, s->sky, sizeof(l.sky));
+    for (int f = 0; f < 7; f++)
+        l.block_sky[f] = (uint32_t)s->block_sky[f][0] | ((uint32_t)s->block_sky[f][1] << 8) | ((uint32_t)s->block_sky[f][2] << 16) |
+                         ((uint32_t)s->block_sky[f][3] << 24);
+    l.present = true;
+    return AIC_OK;
+}
+
+int aic_clear_space(aic_ctx *c, int layer) {
+    if (!c || !valid_layer(layer)) return fail(c, AIC_ERR_INVALID, "aic_clear_space: bad argument");
+    c->layers[layer].present = false;
+    return AIC_OK;
+}
+
+int aic_update_cubes(aic_ctx *c, int layer, uint32_t n, const int32_t *xyz, const uint16_t *block_index, const uint8_t *light) {
+    if (!c || !valid_layer(layer) || (n && !xyz)) return fail(c, AIC_ERR_INVALID, "aic_update_cubes: bad argument");
+    Layer &l = c->layers[layer];
+    if (!l.present) return fail(c, AIC_ERR_INVALID, "aic_update_cubes: no space uploaded for this layer");
+    if (!n) return AIC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (block_index)
+        for (uint32_t i = 0; i < n; i++)
+            if (block_index[i] >= l.host_blocks.size()) return fail(c, AIC_ERR_INVALID, "cube block index out of range");
+    const size_t b_xyz = (size_t)n * 12, b_bi = block_index ? (((size_t)n * 2 + 15) & ~(size_t)15) : 0, b_lt = light ? (size_t)n * 4 : 0;
+    hipError_t e = c->staging.ensure(b_xyz + b_bi + b_lt + 64);
+    if (e != hipSuccess) return hip_fail(c, "alloc staging", e);
+    unsigned char *base = c->staging.p;
+    HIP_TRY(c, hipMemcpyAsync(base, xyz, b_xyz, hipMemcpyHostToDevice, c->stream));
+    if (block_index) HIP_TRY(c, hipMemcpyAsync(base + b_xyz, block_index, (size_t)n * 2, hipMemcpyHostToDevice, c->stream));
+    if (light) HIP_TRY(c, hipMemcpyAsync(base + b_xyz + b_bi, light, b_lt, hipMemcpyHostToDevice, c->stream));
+    launch_scatter_cubes(l.grid.p, l.light.p, (const int32_t *)base, block_index ? (const uint16_t *)(base + b_xyz) : nullptr,
+                         light ? (const uint32_t *)(base + b_xyz + b_bi) : nullptr, n, l.lo, l.size, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return AIC_OK;
+}
+
+int aic_update_light_volume(aic_ctx *c, int layer, const uint8_t *light) {
+    if (!c || !valid_layer(layer) || !light) return fail(c, AIC_ERR_INVALID, "aic_update_light_volume: bad argument");
+    Layer &l = c->layers[layer];
+    if (!l.present) return fail(c, AIC_ERR_INVALID, "aic_update_light_volume: no space uploaded for this layer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(l.light.p, light, l.n_cubes() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return AIC_OK;
+}
+
+int aic_replace_block(aic_ctx *c, int layer, uint32_t index, const aic_block_desc *desc, const uint16_t *voxels, const float *palette) {
+    if (!c || !valid_layer(layer) || !desc) return fail(c, AIC_ERR_INVALID, "aic_replace_block: bad argument");
+    Layer &l = c->layers[layer];
+    if (!l.present) return fail(c, AIC_ERR_INVALID, "aic_replace_block: no space uploaded for this layer");
+    if (index > l.host_blocks.size() || index >= 65536) return fail(c, AIC_ERR_INVALID, "aic_replace_block: index out of range");
+    HIP_TRY(c, hipSetDevice(c->device));
+    // new data is appended to the pools (the old ranges become garbage until the next full upload)
+    std::vector<uint16_t> vox;
+    std::vector<DevPaletteEntry> pal;
+    DevBlock db;
+    const uint32_t vox_off = (uint32_t)l.voxels.n, pal_off = (uint32_t)l.palette.n;
+    int rc = convert_block(c, *desc, voxels, palette, vox_off, pal_off, &db, &vox, &pal);
+    if (rc != AIC_OK) return rc;
+    hipError_t e;
+    if (!vox.empty()) {
+        if ((e = l.voxels.ensure(vox_off + vox.size(), true, c->stream)) != hipSuccess) return hip_fail(c, "grow voxels", e);
+        HIP_TRY(c, hipMemcpyAsync(l.voxels.p + vox_off, vox.data(), vox.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    }
+    if (!pal.empty()) {
+        if ((e = l.palette.ensure(pal_off + pal.size(), true, c->stream)) != hipSuccess) return hip_fail(c, "grow palette", e);
+        HIP_TRY(c, hipMemcpyAsync(l.palette.p + pal_off, pal.data(), pal.size() * sizeof(DevPaletteEntry), hipMemcpyHostToDevice, c->stream));
+    }
+    if (index == l.host_blocks.size()) {
+        l.host_blocks.push_back(db);
+        if ((e = l.blocks.ensure(l.host_blocks.size(), true, c->stream)) != hipSuccess) return hip_fail(c, "grow blocks", e);
+    } else {
+        l.host_blocks[index] = db;
+    }
+    HIP_TRY(c, hipMemcpyAsync(l.blocks.p + index, &db, sizeof(db), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (desc->flags & AIC_BLOCK_AIR) {
+        if (l.air_index < 0) l.air_index = (int32_t)index;
+    } else if (l.air_index == (int32_t)index) {
+        l.air_index = -1;
+    }
+    return AIC_OK;
+}
+
+int aic_set_options(aic_ctx *c, int layer, const aic_options *o) {
+    if (!c || !valid_layer(layer) || !o) return fail(c, AIC_ERR_INVALID, "aic_set_options: bad argument");
+    if (o->fog < 0 || o->fog > 3 || o->transparency < 0 || o->transparency > 2 || o->lighting < 0 || o->lighting > 5 ||
+        o->antialiasing < 0 || o->antialiasing > 2 || o->tone_mapping < 0 || o->tone_mapping > 1 || !(o->view_distance > 0.0))
+        return fail(c, AIC_ERR_INVALID, "aic_set_options: enum or view_distance out of range");
+    c->layers[layer].opt = *o;
+    c->layers[layer].opt_set = true;
+    return AIC_OK;
+}
+
+uint32_t aic_partition_rows(uint32_t height, const aic_partition *p) {
+    if (!p || p->n_parts <= 1 || p->strip_rows == 0) return height;
+    if (p->part >= p->n_parts) return 0;
+    uint32_t rows = 0;
+    const uint32_t n_strips = (height + p->strip_rows - 1) / p->strip_rows;
+    for (uint32_t s = p->part; s < n_strips; s += p->n_parts) {
+        uint32_t r0 = s * p->strip_rows;
+        uint32_t r1 = r0 + p->strip_rows;
+        if (r1 > height) r1 = height;
+        rows += r1 - r0;
+    }
+    return rows;
+}
+
+int aic_render(aic_ctx *c, const aic_frame_desc *f, void *out_rgba8, int out_is_device, aic_frame_info *info) {
+    if (!c || !f) return fail(c, AIC_ERR_INVALID, "aic_render: bad argument");
+    const auto t_begin = std::chrono::steady_clock::now();
+    HIP_TRY(c, hipSetDevice(c->device));
+    aic_partition part = f->partition;
+    if (part.n_parts <= 1 || part.strip_rows == 0) {
+        part.n_parts = 1;
+        part.part = 0;
+        part.strip_rows = f->height ? f->height : 1;
+    }
+    if (part.part >= part.n_parts) return fail(c, AIC_ERR_INVALID, "aic_render: partition.part >= n_parts");
+    const uint32_t local_rows = aic_partition_rows(f->height, &part);
+    const size_t npix = (size_t)f->width * local_rows;
+    if (info) std::memset(info, 0, sizeof(*info));
+    if (npix && !out_rgba8) return fail(c, AIC_ERR_INVALID, "aic_render: output buffer is null");
+
+    uint32_t flaws = 0;
+    DevFrame F;
+    std::memset(&F, 0, sizeof(F));
+    fill_dev_layer(c, c->layers[AIC_LAYER_WORLD], f->world, &F.world, &flaws);
+    fill_dev_layer(c, c->layers[AIC_LAYER_UI], f->ui, &F.ui, &flaws);
+    {
+        const aic_options &wo = c->layers[AIC_LAYER_WORLD].opt;
+        if (wo.bloom_intensity != 0.0f) flaws |= AIC_FLAW_NO_BLOOM;  // renderer.rs:293-297
+    }
+    F.width = f->width;
+    F.height = f->height;
+    std::memcpy(F.backdrop, f->backdrop, sizeof(F.backdrop));
+    F.has_backdrop = !(f->backdrop[0] == 0.f && f->backdrop[1] == 0.f && f->backdrop[2] == 0.f && f->backdrop[3] == 0.f);
+    F.strip_rows = part.strip_rows;
+    F.n_parts = part.n_parts;
+    F.part = part.part;
+    F.local_rows = local_rows;
+    F.tiles_x = (f->width + kTile - 1) / kTile;
+    F.tiles_y = (local_rows + kTile - 1) / kTile;
+    F.light_lut = c->lut.p;
+    F.counters = c->counters.p;
+
+    const bool want_aux = (f->flags & AIC_FRAME_AUX) != 0;
+    const bool diag = want_aux || (f->flags & AIC_FRAME_COUNTERS) != 0;
+    float kernel_ms = 0.f;
+    if (npix) {
+        hipError_t e;
+        if (out_is_device) F.out = (uint32_t *)out_rgba8;
+        else {
+            if ((e = c->out.ensure(npix)) != hipSuccess) return hip_fail(c, "alloc output", e);
+            F.out = c->out.p;
+        }
+        if (want_aux) {
+            if ((e = c->aux.ensure(npix)) != hipSuccess) return hip_fail(c, "alloc aux", e);
+            F.aux = c->aux.p;
+        }
+        HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(DevCounters), c->stream));
+        const bool ui = F.ui.present != 0;
+        if (ui) {
+            const size_t samples = (F.world.opt.antialiasing == 2) ? 4 : 1;
+            if ((e = c->acc.ensure(samples * npix)) != hipSuccess) return hip_fail(c, "alloc accumulators", e);
+            F.acc_buf = c->acc.p;
+        }
+        HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+        if (ui) {
+            F.pass = 1;
+            F.use_init = 0;
+            launch_trace_image(F, diag, c->stream);
+            F.use_init = 1;
+        }
+        F.pass = 0;
+        launch_trace_image(F, diag, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+        if (!out_is_device) HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->out.p, npix * 4, hipMemcpyDeviceToHost, c->stream));
+        DevCounters hc;
+        HIP_TRY(c, hipMemcpyAsync(&hc, c->counters.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipEventElapsedTime(&kernel_ms, c->ev0, c->ev1));
+        if (info) {
+            info->cubes_traced = hc.cubes_traced;
+            info->n_outer = hc.n_outer;
+            info->n_inner = hc.n_inner;
+            info->n_hits = hc.n_hits;
+            info->n_light = hc.n_light;
+        }
+        c->aux_records = want_aux ? npix : 0;
+    } else {
+        c->aux_records = 0;
+    }
+    if (info) {
+        info->kernel_ms = kernel_ms;
+        info->rows_rendered = local_rows;
+        info->flaws = flaws;
+        info->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    }
+    return AIC_OK;
+}
+
+int aic_assemble_strips(aic_ctx *c, const void *gathered_device, void *out_device, uint32_t width, uint32_t height,
+                        uint32_t strip_rows, uint32_t n_parts) {
+    if (!c || !gathered_device || !out_device || !strip_rows || !n_parts) return fail(c, AIC_ERR_INVALID, "aic_assemble_strips: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t max_rows = 0;
+    for (uint32_t p = 0; p < n_parts; p++) {
+        aic_partition pp = {strip_rows, n_parts, p, 0};
+        uint32_t r = aic_partition_rows(height, &pp);
+        if (r > max_rows) max_rows = r;
+    }
+    launch_assemble_strips((const uint32_t *)gathered_device, (uint32_t *)out_device, width, height, strip_rows, n_parts, max_rows, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return AIC_OK;
+}
+
+int aic_read_aux(aic_ctx *c, aic_pixel_aux *out, uint64_t n_records) {
+    if (!c || !out) return fail(c, AIC_ERR_INVALID, "aic_read_aux: bad argument");
+    if (n_records > c->aux_records) return fail(c, AIC_ERR_INVALID, "aic_read_aux: more records requested than the last frame produced");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpy(out, c->aux.p, n_records * sizeof(aic_pixel_aux), hipMemcpyDeviceToHost));
+    return AIC_OK;
+}
+
+int aic_synchronize(aic_ctx *c) {
+    if (!c) return AIC_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return AIC_OK;
+}
+
+void *aic_stream(aic_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int aic_probe_raycast(aic_ctx *c, const double origin[3], const double direction[3], int use_bounds, const int32_t lo[3],
+                      const int32_t hi[3], int include_exit, uint32_t max_steps, aic_rc_step *out, uint32_t *n_out, int *ended) {
+    if (!c || !origin || !direction || !out || !n_out || !ended) return fail(c, AIC_ERR_INVALID, "aic_probe_raycast: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t bytes = 6 * sizeof(double) + 8 * sizeof(int) + (size_t)max_steps * 8 * sizeof(double) + 64;
+    hipError_t e = c->staging.ensure(bytes);
+    if (e != hipSuccess) return hip_fail(c, "alloc staging", e);
+    unsigned char *base = c->staging.p;
+    double od[6] = {origin[0], origin[1], origin[2], direction[0], direction[1], direction[2]};
+    int lohi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (use_bounds && lo && hi) {
+        for (int a = 0; a < 3; a++) { lohi[a] = lo[a]; lohi[3 + a] = hi[a]; }
+    }
+    double *d_od = (double *)base;
+    int *d_lohi = (int *)(base + 48);
+    uint32_t *d_n = (uint32_t *)(base + 48 + 24);
+    int *d_end = (int *)(base + 48 + 28);
+    double *d_rec = (double *)(base + 48 + 32);
+    HIP_TRY(c, hipMemcpyAsync(d_od, od, sizeof(od), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_lohi, lohi, 24, hipMemcpyHostToDevice, c->stream));
+    launch_probe_raycast(d_od, use_bounds, d_lohi, include_exit, max_steps, d_rec, d_n, d_end, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    std::vector<double> rec((size_t)max_steps * 8);
+    uint32_t n = 0;
+    int en = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&en, d_end, 4, hipMemcpyDeviceToHost, c->stream));
+    if (max_steps) HIP_TRY(c, hipMemcpyAsync(rec.data(), d_rec, rec.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < n && i < max_steps; i++) {
+        const double *r = rec.data() + 8 * (size_t)i;
+        out[i].cube[0] = (int32_t)r[0]; out[i].cube[1] = (int32_t)r[1]; out[i].cube[2] = (int32_t)r[2];
+        out[i].face = (int32_t)r[3];
+        out[i].t_distance = r[4];
+        out[i].intersection_point[0] = r[5]; out[i].intersection_point[1] = r[6]; out[i].intersection_point[2] = r[7];
+    }
+    *n_out = n;
+    *ended = en;
+    return AIC_OK;
+}
+
+int aic_probe_light_lut(aic_ctx *c, float out[256]) {
+    if (!c || !out) return AIC_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpy(out, c->lut.p, 256 * sizeof(float), hipMemcpyDeviceToHost));
+    return AIC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,112 @@
+// aic_device.h -- device-side data layout shared by the host ABI code and the kernels.
+//
+// HBM layout of one uploaded Space ("layer"):
+//   grid    : u16  [n cubes]  block index, Z-major (same linearisation as the reference's Vol)
+//   light   : u32  [n cubes]  PackedLight texel r | g<<8 | b<<16 | status<<24
+//   blocks  : DevBlock [n blocks], 64 B each (one cache line per block entry)
+//   voxels  : u16 pool; per block a Z-major volume of *device voxel codes*: the block's
+//             palette is reordered at upload so invisible entries (alpha == 0 && emission == 0,
+//             surface.rs:395) come first; code < DevBlock.n_invisible means "invisible voxel"
+//             and needs no palette fetch.
+//   palette : DevPaletteEntry pool, 32 B each (rgba f32x4, emission f32x3, pad)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aic {
+
+struct DevBlock {
+    float color[4];       // single-voxel colour (valid if kind == 0)
+    float emission[3];
+    uint32_t kind;        // 0: single voxel (R1 / Evoxels::One); else the resolution (2..128)
+    uint32_t vlo_packed;  // stored voxel volume lower corner  x | y<<8 | z<<16  (each 0..127)
+    uint32_t vsize_packed;  // stored voxel volume size      x | y<<8 | z<<16  (each 1..128)
+    uint32_t vox_off;     // u16 units into the voxel pool
+    uint32_t pal_off;     // entries into the palette pool
+    uint32_t n_invisible; // device voxel codes below this are invisible
+    uint32_t pad[3];
+};
+static_assert(sizeof(DevBlock) == 64, "DevBlock is one 64-byte line");
+
+struct DevPaletteEntry {
+    float color[4];
+    float emission[3];
+    float pad;
+};
+static_assert(sizeof(DevPaletteEntry) == 32, "palette entry is 32 B");
+
+struct DevOptions {
+    int32_t fog;
+    int32_t transparency;
+    float threshold;
+    int32_t lighting;       // after Bounce->Linear substitution
+    int32_t antialiasing;
+    int32_t debug_pixel_cost;
+    int32_t tone_mapping;
+    float maximum_intensity;
+    double view_distance;
+};
+
+struct DevLayer {
+    const uint16_t *grid;
+    const uint32_t *light;
+    const DevBlock *blocks;
+    const uint16_t *voxels;
+    const DevPaletteEntry *palette;
+    int32_t lo[3];
+    int32_t size[3];
+    int32_t present;        // 0: no space uploaded for this layer
+    int32_t air_index;      // block index flagged AIR, or -1
+    int32_t sky_kind;
+    float sky[8][3];
+    uint32_t block_sky[7];  // texels: nx ny nz px py pz mean
+    DevOptions opt;
+    double inv[16];         // camera inverse_projection_view
+    float exposure;
+    int32_t pad;
+};
+
+struct DevCounters {
+    unsigned long long cubes_traced;
+    unsigned long long n_outer;
+    unsigned long long n_inner;
+    unsigned long long n_hits;
+    unsigned long long n_light;
+};
+
+struct DevAux {  // == aic_pixel_aux
+    int32_t hit;
+    int32_t cube[3];
+    int32_t voxel[3];
+    int32_t resolution;
+    int32_t face;
+    int32_t block_index;
+    uint32_t cubes_traced;
+    uint32_t pad;
+    double t_distance;
+};
+
+struct DevFrame {
+    DevLayer world;
+    DevLayer ui;
+    uint32_t width, height;
+    float backdrop[4];
+    int32_t has_backdrop;
+    uint32_t strip_rows, n_parts, part;
+    uint32_t local_rows;     // rows this launch renders
+    uint32_t tiles_x, tiles_y;  // tile grid over (width, local_rows)
+    int32_t pass;            // 0: final pass (world layer + encode); 1: UI pre-pass
+    int32_t use_init;        // final pass: start each sample from acc_buf (written by the UI pre-pass)
+    float4 *acc_buf;         // [samples][local_rows][width] ColorBuf {light rgb, transmittance}
+    uint32_t *out;           // [local_rows][width] RGBA8
+    DevAux *aux;             // [local_rows][width] or null
+    DevCounters *counters;
+    const float *light_lut;  // 256 floats
+};
+
+// Tile geometry: one wavefront traces an 8x8 pixel tile (coherent rays), a workgroup of 256
+// threads covers 16x16 pixels.
+constexpr int kTile = 16;
+
+}  // namespace aic

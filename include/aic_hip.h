@@ -1,0 +1,226 @@
+/*
+ * aic_hip.h -- C ABI of the MI355X-native voxel raytracer (libaic_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of kpreid/all-is-cubes v0.10.0: the CPU
+ * raytracer behind `HeadlessRenderer` / `RtRenderer`
+ * (all-is-cubes-render/src/headless.rs:17-44, src/raytracer/renderer.rs:35-356).
+ * The reference has no FFI for this path (all-is-cubes-render is #![forbid(unsafe_code)],
+ * lib.rs:21); these entry points are what a new `all-is-cubes-hip` crate implementing
+ * `HeadlessRenderer` would bind (see INTEGRATION.md for the Rust `extern "C"` block).
+ * Each entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *  - plain C, plain pointers and sizes; no C++ / torch types.
+ *  - every function returning `int` returns an AIC_* status; aic_last_error() gives text.
+ *  - host buffers passed in are copied before the call returns; the caller keeps ownership.
+ *  - a context is bound to one HIP device (one process per GPU); it may be moved between
+ *    threads but used by one thread at a time (`&mut self`; RtRenderer is Send+Sync,
+ *    renderer.rs:696-698).
+ *  - all grids are Z-major: index = ((x-lo.x)*size.y + (y-lo.y))*size.z + (z-lo.z)
+ *    (all-is-cubes-base/src/math/vol.rs:988-1023).
+ */
+#ifndef AIC_HIP_H
+#define AIC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AIC_ABI_VERSION 1
+
+/* status codes */
+#define AIC_OK 0
+#define AIC_ERR_INVALID 1      /* bad argument (maps to a panic/assert in the reference) */
+#define AIC_ERR_NO_DEVICE 2    /* no usable HIP device */
+#define AIC_ERR_OOM 3          /* device allocation failed => Flaws::OUT_OF_MEMORY-style degradation */
+#define AIC_ERR_DEVICE 4       /* HIP runtime error / device lost => RenderError (lib.rs:46-54) */
+#define AIC_ERR_UNSUPPORTED 5
+
+/* layers (camera/stdcam.rs:21-28 `Layers { world, ui }`) */
+#define AIC_LAYER_WORLD 0
+#define AIC_LAYER_UI 1
+
+/* Flaws bits reported in aic_frame_info.flaws (all-is-cubes-render/src/flaws.rs:20-80) */
+#define AIC_FLAW_UNSUPPORTED 1u   /* LightingOption::Bounce rendered as Linear (graphics_options.rs:460-467) */
+#define AIC_FLAW_NO_BLOOM 2u      /* renderer.rs:293-297 */
+
+/* block descriptor flags */
+#define AIC_BLOCK_ONE 1u  /* EvoxelsInner::One(voxel): resolution 1, palette[pal_off] is the voxel */
+#define AIC_BLOCK_AIR 2u  /* block == AIR (TracingCubeData.always_invisible, sr.rs:543-564) */
+
+/* One Space block-palette entry = `TracingBlock.voxels: Evoxels`
+ * (sr.rs:568-587; all-is-cubes/src/block/eval/voxel_storage.rs:199-227). 48 bytes. */
+typedef struct aic_block_desc {
+    int32_t resolution;  /* 1..128, power of two (resolution.rs:18-31) */
+    int32_t vlo[3];      /* stored voxel volume: lower corner ... */
+    int32_t vsize[3];    /* ... and size; may be smaller than resolution^3 (outside => AIR) */
+    uint32_t vox_off;    /* offset in u16 elements into aic_space_desc.voxels */
+    uint32_t pal_off;    /* offset in entries into aic_space_desc.palette */
+    uint32_t pal_len;
+    uint32_t flags;      /* AIC_BLOCK_* */
+    int32_t reserved;
+} aic_block_desc;
+
+/* Full snapshot of one Space = the inputs of `SpaceRaytracer::new` (sr.rs:64-88). */
+typedef struct aic_space_desc {
+    int32_t lo[3];
+    int32_t size[3];
+    const uint16_t *block_index; /* [n cubes] `Space` contents (space.rs:77) */
+    const uint8_t *light;        /* [n cubes][4] PackedLight::as_texel r,g,b,status (light/data.rs:160-170) */
+    uint32_t n_blocks;
+    const aic_block_desc *blocks;
+    const uint16_t *voxels;      /* pool of palette indices, Z-major per block */
+    uint64_t n_voxels;
+    const float *palette;        /* pool [n_palette][8]: Evoxel color rgba, emission rgb, pad */
+    uint64_t n_palette;
+    int32_t sky_kind;            /* 0 Sky::Uniform(sky[0]); 1 Sky::Octants (sky.rs:16-21) */
+    float sky[8][3];
+    uint8_t block_sky[7][4];     /* Sky::for_blocks(): faces nx,ny,nz,px,py,pz then mean, as texels (sky.rs:45-82) */
+} aic_space_desc;
+
+/* The subset of GraphicsOptions the raytracer honours (camera/graphics_options.rs:28-152). */
+typedef struct aic_options {
+    int32_t fog;              /* FogOption: 0 None, 1 Abrupt, 2 Compromise, 3 Physical */
+    int32_t transparency;     /* TransparencyOption: 0 Surface, 1 Volumetric, 2 Threshold */
+    float threshold;          /* Threshold(t) */
+    int32_t lighting;         /* LightingOption: 0 None, 1 Flat, 2 Coarse, 3 Linear, 4 Smoothstep, 5 Bounce */
+    int32_t bounce_samples;
+    int32_t antialiasing;     /* AntialiasingOption: 0 None, 1 IfCheap, 2 Always */
+    int32_t debug_pixel_cost;
+    int32_t tone_mapping;     /* ToneMappingOperator: 0 Clamp, 1 Reinhard */
+    float maximum_intensity;  /* may be +inf */
+    float bloom_intensity;    /* only reported back as AIC_FLAW_NO_BLOOM */
+    double view_distance;     /* already `repair()`ed: clamped to 1..10000 (graphics_options.rs:194-198) */
+} aic_options;
+
+/* One Camera as the kernel needs it (camera/camera_struct.rs:43-77). */
+typedef struct aic_camera {
+    double inverse_projection_view[16]; /* euclid order m11..m44; Camera.inverse_projection_view (412-416) */
+    float exposure;                     /* Camera::exposure() (365-367) */
+    int32_t reserved;
+} aic_camera;
+
+/* Which rows of the frame this context renders: rows are grouped into strips of
+ * `strip_rows`; strip s belongs to part (s % n_parts). n_parts = 1 renders everything.
+ * (Image rows are independent work items in the reference too: renderer.rs:537-555.) */
+typedef struct aic_partition {
+    uint32_t strip_rows;
+    uint32_t n_parts;
+    uint32_t part;
+    uint32_t reserved;
+} aic_partition;
+
+typedef struct aic_frame_desc {
+    uint32_t width, height;      /* framebuffer size after size_policy (renderer.rs:226-233) */
+    aic_camera world;            /* used if a world space is uploaded */
+    aic_camera ui;               /* used if a UI space is uploaded */
+    float backdrop[4];           /* UiViewState.backdrop; all-zero = none (renderer.rs:235-253) */
+    aic_partition partition;
+    uint32_t flags;              /* AIC_FRAME_* */
+    uint32_t reserved;
+} aic_frame_desc;
+
+#define AIC_FRAME_COUNTERS 1u /* also accumulate n_outer/n_inner/n_hits/n_light */
+#define AIC_FRAME_AUX 2u      /* also write the per-pixel aic_pixel_aux records */
+
+/* `RaytraceInfo` / `ImageInfo` (sr.rs:508-537; renderer.rs:617-647) + kernel timing. */
+typedef struct aic_frame_info {
+    uint64_t cubes_traced; /* RaytraceInfo.cubes_traced summed over the rendered pixels */
+    uint64_t n_outer;      /* in-bounds cube-grid lookups */
+    uint64_t n_inner;      /* in-bounds voxel lookups */
+    uint64_t n_hits;       /* surfaces converted to light (Surface::to_light returned Some) */
+    uint64_t n_light;      /* light texel fetches */
+    float kernel_ms;       /* HIP-event time of the trace kernel on the context's stream */
+    float total_ms;        /* launch + read-back wall time of the call */
+    uint32_t rows_rendered;
+    uint32_t flaws;        /* AIC_FLAW_* */
+} aic_frame_info;
+
+/* Optional per-pixel record (N4 "other accumulators": first-hit id and depth): the first
+ * Hit carrying a Position that reached the accumulator (raytracer/hit.rs:23-123). */
+typedef struct aic_pixel_aux {
+    int32_t hit;           /* 0 none, 1 surface */
+    int32_t cube[3];
+    int32_t voxel[3];
+    int32_t resolution;
+    int32_t face;          /* Face7 discriminant */
+    int32_t block_index;
+    uint32_t cubes_traced; /* steps taken by this pixel's rays */
+    uint32_t pad;
+    double t_distance;
+} aic_pixel_aux;
+
+typedef struct aic_ctx aic_ctx;
+
+/* --- lifetime ------------------------------------------------------------------------ */
+/* replaces: RtRenderer::new (renderer.rs:65-81). device_id < 0 selects the current device. */
+aic_ctx *aic_create(int device_id, int *status);
+void aic_destroy(aic_ctx *ctx);
+const char *aic_last_error(const aic_ctx *ctx);
+int aic_abi_version(void);
+/* name of the HIP device the context is bound to (for Info / logging) */
+int aic_device_name(const aic_ctx *ctx, char *buf, uint32_t buf_len);
+
+/* --- scene snapshot: RtRenderer::update -> UpdatingSpaceRaytracer::update -------------- */
+/* replaces: SpaceRaytracer::new on SpaceChange::EveryBlock / first update
+ * (updating.rs:107-126; sr.rs:64-88, prepare_cubes 543-549). */
+int aic_upload_space(aic_ctx *ctx, int layer, const aic_space_desc *space);
+/* replaces: `rts.<layer> = None` (renderer.rs:134-135). */
+int aic_clear_space(aic_ctx *ctx, int layer);
+/* replaces: the `todo.cubes` scatter of UpdatingSpaceRaytracer::update (updating.rs:146-166)
+ * fed by SpaceChange::{CubeBlock, CubeLight} (updating.rs:201-219). block_index or light may be
+ * NULL to leave that field unchanged. xyz are absolute cube coordinates. */
+int aic_update_cubes(aic_ctx *ctx, int layer, uint32_t n, const int32_t *xyz, const uint16_t *block_index,
+                     const uint8_t *light);
+/* replaces: a bulk SpaceChange::CubeLight burst after a light-propagation step (config 5):
+ * re-uploads the whole light volume ([n cubes][4]). */
+int aic_update_light_volume(aic_ctx *ctx, int layer, const uint8_t *light);
+/* replaces: the `todo.blocks` re-evaluation of UpdatingSpaceRaytracer::update (updating.rs:128-145)
+ * for SpaceChange::{BlockIndex, BlockEvaluation}: replaces or appends (index == n_blocks) one
+ * palette entry. `voxels`/`palette` hold only this block's data (desc offsets are ignored). */
+int aic_replace_block(aic_ctx *ctx, int layer, uint32_t index, const aic_block_desc *desc, const uint16_t *voxels,
+                      const float *palette);
+/* replaces: the graphics_options DynSource (updating.rs:24,68-73). */
+int aic_set_options(aic_ctx *ctx, int layer, const aic_options *options);
+
+/* --- drawing: RtRenderer::draw_rgba / HeadlessRenderer::draw --------------------------- */
+/* replaces: RtRenderer::draw_rgba -> trace_scene_to_image_impl (renderer.rs:282-308, 516-556):
+ * out_rgba8 receives the rows selected by frame->partition, compacted in increasing row order,
+ * as sRGB RGBA8 row-major (headless.rs:52-67). `out_is_device` != 0: out_rgba8 is a device
+ * pointer on the context's device (no read-back; used for the RCCL gather). */
+int aic_render(aic_ctx *ctx, const aic_frame_desc *frame, void *out_rgba8, int out_is_device, aic_frame_info *info);
+/* number of rows / first rows a partition selects (host-side helper for buffer sizing) */
+uint32_t aic_partition_rows(uint32_t height, const aic_partition *partition);
+/* scatter compacted strips gathered from n_parts contexts back into a full frame, on device:
+ * gathered = [n_parts][max_rows_per_part][width] pixels, out = [height][width]. */
+int aic_assemble_strips(aic_ctx *ctx, const void *gathered_device, void *out_device, uint32_t width, uint32_t height,
+                        uint32_t strip_rows, uint32_t n_parts);
+/* read back the aux records of the last aic_render issued with AIC_FRAME_AUX
+ * ([rows_rendered][width]). */
+int aic_read_aux(aic_ctx *ctx, aic_pixel_aux *out, uint64_t n_records);
+/* blocks until all work queued on the context's stream is complete */
+int aic_synchronize(aic_ctx *ctx);
+/* the context's HIP stream (hipStream_t) for callers that time or order work against it */
+void *aic_stream(aic_ctx *ctx);
+
+/* --- device-side probes used by the parity tests (not part of the render path) --------- */
+/* runs Raycaster::new(origin,dir)[.within(lo,hi,include_exit)] on the device, one ray,
+ * and writes up to max_steps {cube[3], face, t_distance} records (raycast.rs:239-284). */
+typedef struct aic_rc_step {
+    int32_t cube[3];
+    int32_t face;
+    double t_distance;
+    double intersection_point[3];
+} aic_rc_step;
+int aic_probe_raycast(aic_ctx *ctx, const double origin[3], const double direction[3], int use_bounds,
+                      const int32_t lo[3], const int32_t hi[3], int include_exit, uint32_t max_steps,
+                      aic_rc_step *out, uint32_t *n_out, int *ended);
+/* the device's PackedLight decode table (light/data.rs:301-354) */
+int aic_probe_light_lut(aic_ctx *ctx, float out[256]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIC_HIP_H */

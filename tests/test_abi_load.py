@@ -1,0 +1,64 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/aic_hip.h declares; no compute is attempted without a GPU."""
+import ctypes
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from all_is_cubes_amd import abi, flat
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_library_exports_every_declared_symbol():
+    header = (ROOT / "include" / "aic_hip.h").read_text()
+    declared = set(re.findall(r"\b(aic_[a-z_]+)\s*\(", header))
+    assert declared == set(abi.ABI_SYMBOLS)
+    lib = abi.load()
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), sym
+    assert lib.aic_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(abi.BlockDesc) == 48 == flat.BLOCK_DTYPE.itemsize
+    assert abi.PIXEL_AUX_DTYPE.itemsize == 56
+    assert ctypes.sizeof(abi.Options) == 48
+    assert ctypes.sizeof(abi.Camera) == 136
+    assert ctypes.sizeof(abi.FrameInfo) == 56
+
+
+def test_partition_rows_helper():
+    lib = abi.load()
+    for h, strip, n in [(1080, 16, 8), (37, 8, 3), (96, 16, 2), (5, 16, 4), (0, 16, 2)]:
+        total = 0
+        for p in range(n):
+            part = abi.Partition(strip, n, p, 0)
+            total += lib.aic_partition_rows(h, ctypes.byref(part))
+        assert total == h
+
+
+def test_no_gpu_fails_loudly():
+    """Without a usable device the product must raise, never fall back to a CPU path."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(abi.AicError):
+        abi.Context(0)
+
+
+def test_block_sky_host_matches_oracle():
+    import oracle
+    from tests import scenes
+
+    sp = scenes.one_cube_space()
+    rng = np.random.default_rng(5)
+    for kind in (0, 1):
+        if kind == 1:
+            sp.set_sky_octants(rng.uniform(0.0, 4.0, (8, 3)))
+        got = abi.block_sky_texels(sp.sky_kind, sp.sky)
+        ref = oracle.block_sky(oracle.Space(sp))
+        assert (got == ref).all()

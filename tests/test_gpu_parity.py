@@ -1,0 +1,294 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs, and against the reference's golden vectors.
+
+Bar: bit-exact for integer results (hit cube / voxel / face / block index, step counts,
+f64 t-distances); RGBA8 within +-1 LSB (f32 colour math goes through powf/exp whose last bit
+is libm-dependent; the reference itself tolerates 1-2 levels: cases/src/lib.rs:347,1233)."""
+import numpy as np
+import pytest
+
+import oracle
+from all_is_cubes_amd import abi
+from tests import scenes
+from tests.test_oracle_goldens import COMMON_VIEWPORT, camera_for, diff_to, neighbourhood_diff
+
+pytestmark = pytest.mark.gpu
+
+RGBA_TOL = 1  # stated float tolerance, in 8-bit levels
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = abi.Context(0)
+    yield c
+    c.close()
+
+
+def to_abi_options(o: oracle.OrcOptions) -> abi.Options:
+    return abi.make_options(fog=o.fog, transparency=o.transparency, threshold=o.threshold, lighting=o.lighting,
+                            antialiasing=o.antialiasing, debug_pixel_cost=bool(o.debug_pixel_cost), tone_mapping=o.tone_mapping,
+                            maximum_intensity=o.maximum_intensity, bloom_intensity=0.0, view_distance=o.view_distance)
+
+
+def render_both(ctx, space, opt: oracle.OrcOptions, size, eye, quat=(0, 0, 0, 1), fov=90.0, ui=None, ui_eye=(0, 0, 0), backdrop=(0, 0, 0, 0)):
+    w, h = size
+    _, _, inv = oracle.camera_matrices(fov, opt.view_distance, w / h, quat, eye)
+    ui_inv = None
+    if space is not None:
+        ctx.upload_space(abi.LAYER_WORLD, space)
+    else:
+        ctx.clear_space(abi.LAYER_WORLD)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+    if ui is not None:
+        _, _, ui_inv = oracle.camera_matrices(fov, opt.view_distance, w / h, (0, 0, 0, 1), ui_eye)
+        ctx.upload_space(abi.LAYER_UI, ui)
+        ctx.set_options(abi.LAYER_UI, to_abi_options(opt))
+    else:
+        ctx.clear_space(abi.LAYER_UI)
+    opt.exposure = 1.0
+    frame = ctx.make_frame(w, h, world_inv=inv, ui_inv=ui_inv, backdrop=backdrop)
+    got = ctx.render(frame, want_aux=True)
+    ref = oracle.render(
+        oracle.Space(space) if space is not None else None, opt, oracle.make_camera(inv, w, h),
+        ui=oracle.Space(ui) if ui is not None else None, ui_opt=opt if ui is not None else None,
+        ui_cam=oracle.make_camera(ui_inv, w, h) if ui is not None else None, backdrop=backdrop, want_aux=True,
+    )
+    return got, ref
+
+
+def assert_parity(got, ref, tol=RGBA_TOL):
+    ga, ra = got["aux"], ref["aux"]
+    assert (ga["cubes_traced"] == ra["cubes_traced"]).all(), "per-pixel step counts differ"
+    assert got["info"].cubes_traced == int(ref["info"]["cubes_traced"])
+    for k in ("hit", "cube", "voxel", "resolution", "face", "block_index"):
+        assert (ga[k] == ra[k]).all(), f"first-hit {k} differs"
+    hit = ra["hit"] == 1
+    assert (ga["t_distance"][hit].view(np.uint64) == ra["t_distance"][hit].view(np.uint64)).all(), "hit t_distance bits differ"
+    for k in ("n_outer", "n_inner", "n_hits", "n_light"):
+        assert getattr(got["info"], k) == int(ref["info"][k]), k
+    d = np.abs(got["rgba8"].astype(np.int16) - ref["rgba8"].astype(np.int16))
+    assert d.max() <= tol, f"RGBA8 max diff {d.max()}"
+    return int(d.max())
+
+
+# --- device Raycaster vs the reference's known answers (raycast/tests.rs) -----------------
+def test_probe_raycast_kats(ctx):
+    steps, ended = ctx.probe_raycast((0.0, -0.25, -0.5), (1.0, 1.0, 1.0), bounds=((2, -10, -10), (4, 10, 10)))
+    assert ended
+    assert [(tuple(s["cube"]), int(s["face"]), float(s["t_distance"])) for s in steps] == [
+        ((2, 1, 1), 1, 2.0), ((2, 2, 1), 2, 2.25), ((2, 2, 2), 3, 2.5), ((3, 2, 2), 1, 3.0), ((3, 3, 2), 2, 3.25),
+        ((3, 3, 3), 3, 3.5), ((4, 3, 3), 1, 4.0)]
+    steps, _ = ctx.probe_raycast((6.749300603672869e-67, 6.750109954921438e-67, -85891558.96000093),
+                                 (1.1036366354256313e-305, 0.0, 8589152896.000092), bounds=((-10, -20, -30), (10, 20, 30)), max_steps=1)
+    assert tuple(steps[0]["cube"]) == (0, 0, -30) and steps[0]["face"] == 3 and steps[0]["t_distance"] == 0.010000000000000002
+    steps, ended = ctx.probe_raycast((10.5, 20.5, 30.5), (1.0, 2.0, float("nan")), max_steps=3)
+    assert ended and len(steps) == 1 and tuple(steps[0]["cube"]) == (10, 20, 30)
+    steps, ended = ctx.probe_raycast((0.5, 0.5, float(2**31 - 2) - 0.5), (0.0, 0.0, 1.0), max_steps=5)
+    assert ended and [tuple(s["cube"]) for s in steps] == [(0, 0, 2**31 - 3), (0, 0, 2**31 - 2)]
+
+
+def test_probe_raycast_random_vs_oracle(ctx):
+    rng = np.random.default_rng(99)
+    for case in range(200):
+        origin = rng.uniform(-30, 30, 3)
+        direction = rng.normal(size=3) * (10.0 ** rng.uniform(-2, 3))
+        if case % 5 == 0:
+            direction[rng.integers(3)] = 0.0
+        if case % 11 == 0:
+            origin = np.round(origin)  # start exactly on cube edges
+        lo = rng.integers(-10, 5, 3)
+        hi = lo + rng.integers(1, 16, 3)
+        bounds = None if case % 13 == 0 else (lo, hi)
+        g, ge = ctx.probe_raycast(origin, direction, bounds=bounds, max_steps=48)
+        r, re_ = oracle.raycast(origin, direction, bounds=bounds, max_steps=48)
+        assert len(g) == len(r) and ge == re_, case
+        assert (g["cube"] == r["cube"]).all() and (g["face"] == r["face"]).all(), case
+        assert (g["t_distance"].view(np.uint64) == r["t_distance"].view(np.uint64)).all(), case
+        assert (g["intersection_point"].view(np.uint64) == r["intersection_point"].view(np.uint64)).all(), case
+
+
+def test_light_lut_matches_reference_table(ctx, golden_dir):
+    ref = np.load(golden_dir / "packed_light_lut.npy")
+    assert (ctx.probe_light_lut().view(np.uint32) == ref.view(np.uint32)).all()
+
+
+# --- the reference's golden images through the HIP path -----------------------------------
+def gpu_case(ctx, space, opt, size=COMMON_VIEWPORT, eye=(0.5, 0.5, 2.0), **kw):
+    got, ref = render_both(ctx, space, opt, size, eye, **kw)
+    assert_parity(got, ref)
+    return got["rgba8"]
+
+
+def test_golden_transparent_one(ctx, golden_dir):
+    img = gpu_case(ctx, scenes.transparent_one_space(), oracle.unaltered_colors(transparency=0))
+    assert diff_to(golden_dir, "transparent_one-surf-all", img).max() <= RGBA_TOL
+    img = gpu_case(ctx, scenes.transparent_one_space(), oracle.unaltered_colors(transparency=1))
+    assert diff_to(golden_dir, "transparent_one-vol-all", img).max() <= 2
+
+
+def test_golden_emission_and_ramp(ctx, golden_dir):
+    img = gpu_case(ctx, scenes.emission_space(), oracle.unaltered_colors())
+    assert diff_to(golden_dir, "emission-all", img).max() <= RGBA_TOL
+    img = gpu_case(ctx, scenes.color_srgb_ramp_space(), oracle.unaltered_colors(), size=(128, 128), eye=(16.0, 16.0, 17.0))
+    assert diff_to(golden_dir, "color_srgb_ramp-all", img).max() <= RGBA_TOL
+    img = gpu_case(ctx, scenes.one_cube_space(), oracle.unaltered_colors(), size=(101, 37))
+    assert diff_to(golden_dir, "viewport_prime-all", img).max() <= 2
+
+
+@pytest.mark.parametrize("kind", ["only", "semi"])
+@pytest.mark.parametrize("mode,transparency", [("surf", 0), ("vol", 1)])
+def test_golden_voxel_shape(ctx, golden_dir, kind, mode, transparency):
+    img = gpu_case(ctx, scenes.voxel_shape_space(kind), oracle.unaltered_colors(transparency=transparency))
+    ref = np.load(golden_dir / f"png_emission_{kind}-{mode}-all.npy")
+    assert neighbourhood_diff(img, ref).max() <= RGBA_TOL
+
+
+@pytest.mark.parametrize("name,with_world,with_ui", [("layers_all-all", True, True), ("layers_hidden_ui-all", True, False), ("layers_ui_only-all", False, True)])
+def test_golden_layers(ctx, golden_dir, name, with_world, with_ui):
+    opt = oracle.unaltered_colors(lighting=1) if with_world else oracle.unaltered_colors()
+    got, ref = render_both(ctx, scenes.one_cube_space() if with_world else None, opt, COMMON_VIEWPORT, (0.5, 0.5, 2.0),
+                           ui=scenes.ui_space() if with_ui else None)
+    assert_parity(got, ref)
+    d = diff_to(golden_dir, name, got["rgba8"]).max(axis=-1)
+    d[0:26, 0:100] = 0  # host-side info text region (renderer.rs:659-683), outside the hot path
+    assert d.max() <= RGBA_TOL
+
+
+def test_viewport_zero(ctx):
+    ctx.upload_space(abi.LAYER_WORLD, scenes.one_cube_space())
+    got = ctx.render(ctx.make_frame(0, 0, world_inv=np.eye(4)))
+    assert got["rgba8"].shape == (0, 0, 4) and got["info"].cubes_traced == 0
+
+
+# --- seeded synthetic scenes: every option of the path vs the oracle ------------------------
+SYNTH_EYE = (14.5, 22.5, 44.0)
+
+
+def synth_quat():
+    return oracle.look_at_y_up(SYNTH_EYE, (14.0, 8.0, 12.0))
+
+
+@pytest.fixture(scope="module")
+def synth_space():
+    return scenes.synthetic_space(n=28, resolution=8, n_blocks=12, seed=2, light="field")
+
+
+@pytest.mark.parametrize("transparency", [0, 1, 2])
+@pytest.mark.parametrize("lighting", [0, 1, 2, 3, 4])
+def test_synthetic_options_matrix(ctx, synth_space, transparency, lighting):
+    opt = oracle.make_options(fog=1, transparency=transparency, threshold=0.6, lighting=lighting)
+    got, ref = render_both(ctx, synth_space, opt, (160, 96), SYNTH_EYE, synth_quat())
+    assert_parity(got, ref)
+
+
+@pytest.mark.parametrize("fog", [0, 1, 2, 3])
+def test_synthetic_fog_modes(ctx, synth_space, fog):
+    opt = oracle.make_options(fog=fog, view_distance=60.0)
+    got, ref = render_both(ctx, synth_space, opt, (128, 80), SYNTH_EYE, synth_quat())
+    assert_parity(got, ref)
+
+
+def test_synthetic_antialias_tonemap_debug(ctx, synth_space):
+    opt = oracle.make_options(antialiasing=2)
+    got, ref = render_both(ctx, synth_space, opt, (96, 64), SYNTH_EYE, synth_quat())
+    assert_parity(got, ref)
+    opt = oracle.make_options(tone_mapping=1, maximum_intensity=1.0)
+    opt.exposure = 1.0
+    got, ref = render_both(ctx, synth_space, opt, (96, 64), SYNTH_EYE, synth_quat())
+    assert_parity(got, ref)
+    opt = oracle.make_options(debug_pixel_cost=True)
+    got, ref = render_both(ctx, synth_space, opt, (96, 64), SYNTH_EYE, synth_quat())
+    assert_parity(got, ref)
+
+
+def test_synthetic_octant_sky_backdrop_and_ui(ctx, synth_space):
+    sp = scenes.synthetic_space(n=20, resolution=4, n_blocks=6, seed=5)
+    sp.set_sky_octants(np.random.default_rng(1).uniform(0.1, 1.5, (8, 3)))
+    opt = oracle.make_options(lighting=3)
+    got, ref = render_both(ctx, sp, opt, (120, 72), (10.5, 16.5, 32.0), oracle.look_at_y_up((10.5, 16.5, 32.0), (10, 6, 10)),
+                           ui=scenes.ui_space(), backdrop=(0.2, 0.4, 0.6, 0.5))
+    assert_parity(got, ref)
+
+
+def test_step_cap_and_camera_inside_geometry(ctx):
+    # long rays through a mostly empty space with a tiny view frustum exercise the 1000-step cap
+    sp = scenes.synthetic_space(n=40, resolution=32, n_blocks=4, seed=9)
+    opt = oracle.unaltered_colors(view_distance=2000.0)
+    eye = (20.3, 10.2, 20.7)  # inside the terrain
+    got, ref = render_both(ctx, sp, opt, (64, 48), eye, oracle.look_at_y_up(eye, (0.0, 11.0, 0.0)))
+    assert_parity(got, ref)
+    assert int(ref["aux"]["cubes_traced"].max()) >= 1000  # the cap was reached
+
+
+def test_row_partition_matches_full_frame(ctx, synth_space):
+    opt = oracle.make_options()
+    w, h = 100, 70
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, synth_quat(), SYNTH_EYE)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.upload_space(abi.LAYER_WORLD, synth_space)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+    full = ctx.render(ctx.make_frame(w, h, world_inv=inv))["rgba8"]
+    strip, n = 16, 3
+    total = 0
+    for part in range(n):
+        got = ctx.render(ctx.make_frame(w, h, world_inv=inv, partition=(strip, n, part)))
+        rows = [y for y in range(h) if (y // strip) % n == part]
+        assert got["rgba8"].shape[0] == len(rows)
+        assert (got["rgba8"] == full[rows]).all()
+        total += got["info"].cubes_traced
+    assert total == ctx.render(ctx.make_frame(w, h, world_inv=inv))["info"].cubes_traced
+
+
+# --- incremental update protocol (updating.rs:295-332: updated snapshot == fresh snapshot) ---
+def test_incremental_updates_equal_full_upload(ctx):
+    sp = scenes.synthetic_space(n=20, resolution=8, n_blocks=6, seed=4, light="field")
+    opt = oracle.make_options()
+    w, h = 96, 64
+    eye = (10.5, 18.5, 30.0)
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, (10, 6, 10)), eye)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+    rng = np.random.default_rng(3)
+    # SpaceChange::CubeBlock + CubeLight
+    xyz = rng.integers(0, 20, (300, 3)).astype(np.int32)
+    _, first = np.unique(xyz, axis=0, return_index=True)
+    xyz = xyz[np.sort(first)]
+    new_idx = rng.integers(0, len(sp.blocks), len(xyz)).astype(np.uint16)
+    new_light = np.stack([rng.integers(100, 180, len(xyz))] * 3 + [np.full(len(xyz), 255)], axis=1).astype(np.uint8)
+    ctx.update_cubes(abi.LAYER_WORLD, xyz, new_idx, new_light)
+    sp.block_index[xyz[:, 0], xyz[:, 1], xyz[:, 2]] = new_idx
+    sp.light[xyz[:, 0], xyz[:, 1], xyz[:, 2]] = new_light
+    # SpaceChange::BlockEvaluation: replace one palette entry, append another
+    repl = scenes.synthetic_blocks(8, 1, seed=77)[0]
+    victim = len(sp.blocks) - 1
+    ctx.replace_block(abi.LAYER_WORLD, victim, repl)
+    sp.blocks[victim] = repl
+    extra = scenes.synthetic_blocks(4, 1, seed=78)[0]
+    ctx.replace_block(abi.LAYER_WORLD, len(sp.blocks), extra)
+    new_index = sp.add_block(extra)
+    ctx.update_cubes(abi.LAYER_WORLD, np.array([[10, 12, 10]], np.int32), np.array([new_index], np.uint16))
+    sp.set((10, 12, 10), new_index)
+    # whole light volume (config 5's per-frame light re-upload)
+    sp.light[..., 0:3] = np.minimum(sp.light[..., 0:3].astype(int) + 3, 255).astype(np.uint8) * (sp.light[..., 3:4] == 255)
+    ctx.update_light_volume(abi.LAYER_WORLD, sp.light)
+    incremental = ctx.render(ctx.make_frame(w, h, world_inv=inv), want_aux=True)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    fresh = ctx.render(ctx.make_frame(w, h, world_inv=inv), want_aux=True)
+    assert (incremental["rgba8"] == fresh["rgba8"]).all()
+    assert incremental["info"].cubes_traced == fresh["info"].cubes_traced
+    ref = oracle.render(oracle.Space(sp), opt, oracle.make_camera(inv, w, h), want_aux=True)
+    assert_parity(incremental, ref)
+
+
+def test_errors_are_reported_not_swallowed(ctx):
+    with pytest.raises(abi.AicError):
+        ctx.update_cubes(abi.LAYER_UI + 5, np.zeros((1, 3), np.int32), np.zeros(1, np.uint16))
+    bad = scenes.one_cube_space()
+    bad.block_index[...] = 7  # index beyond the palette
+    with pytest.raises((abi.AicError, ValueError)):
+        ctx.upload_space(abi.LAYER_WORLD, bad)
+    o = abi.make_options()
+    o.fog = 9
+    with pytest.raises(abi.AicError):
+        ctx.set_options(abi.LAYER_WORLD, o)
