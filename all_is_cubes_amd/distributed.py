@@ -1,0 +1,59 @@
+"""Row-strip image partition across the GPUs of one node and the final gather.
+
+The reference treats image rows as independent work items (rayon `par_chunks_mut` over rows,
+all-is-cubes-render/src/raytracer/renderer.rs:537-555). Here the rows are grouped into strips
+of `strip_rows`; strip s is rendered by rank (s % world_size) (interleaved, because rows differ
+wildly in cost: sky rows vs. geometry rows). The scene is replicated on every GPU; the only
+exchange step is one gather of the finished RGBA8 strips to rank 0 (RCCL over xGMI through
+torch.distributed's "nccl" backend; "gloo" for the CPU tests) followed by a de-interleave.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+STRIP_ROWS = 16  # one workgroup-tile row (aic_device.h kTile)
+
+
+def partition_rows(height: int, strip_rows: int, n_parts: int, part: int) -> List[int]:
+    """Global row numbers rendered by `part`, in increasing order (== aic_partition_rows)."""
+    return [y for y in range(height) if (y // strip_rows) % n_parts == part]
+
+
+def max_partition_rows(height: int, strip_rows: int, n_parts: int) -> int:
+    return max(len(partition_rows(height, strip_rows, n_parts, p)) for p in range(n_parts))
+
+
+def gather_strips(local: torch.Tensor, height: int, width: int, strip_rows: int, group=None) -> Optional[torch.Tensor]:
+    """`local`: this rank's compacted rows as uint8 [rows_local, width, 4] (device or CPU).
+    Returns on rank 0 the gathered buffer [world, max_rows, width, 4]; None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    max_rows = max_partition_rows(height, strip_rows, world)
+    padded = local
+    if local.shape[0] != max_rows:
+        padded = torch.zeros((max_rows, width, 4), dtype=torch.uint8, device=local.device)
+        padded[: local.shape[0]] = local
+    if world == 1:
+        return padded.unsqueeze(0)
+    if dist.get_backend(group) == "nccl":
+        # one collective: every rank's strips land contiguously in rank 0's buffer
+        out = torch.empty((world, max_rows, width, 4), dtype=torch.uint8, device=local.device) if rank == 0 else None
+        dist.gather(padded, gather_list=list(out.unbind(0)) if rank == 0 else None, dst=0, group=group)
+        return out
+    gathered = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
+    dist.gather(padded, gather_list=gathered, dst=0, group=group)
+    return torch.stack(gathered, 0) if rank == 0 else None
+
+
+def assemble_strips_torch(gathered: torch.Tensor, height: int, width: int, strip_rows: int) -> torch.Tensor:
+    """Reference de-interleave with tensor indexing (used on CPU tensors and to cross-check the
+    device kernel `aic_assemble_strips`)."""
+    world, max_rows = gathered.shape[0], gathered.shape[1]
+    y = torch.arange(height, device=gathered.device)
+    strip = y // strip_rows
+    part = strip % world
+    lrow = (strip // world) * strip_rows + (y % strip_rows)
+    return gathered[part, lrow]

@@ -211,13 +211,26 @@ def test_synthetic_octant_sky_backdrop_and_ui(ctx, synth_space):
 
 
 def test_step_cap_and_camera_inside_geometry(ctx):
-    # long rays through a mostly empty space with a tiny view frustum exercise the 1000-step cap
-    sp = scenes.synthetic_space(n=40, resolution=32, n_blocks=4, seed=9)
-    opt = oracle.unaltered_colors(view_distance=2000.0)
-    eye = (20.3, 10.2, 20.7)  # inside the terrain
-    got, ref = render_both(ctx, sp, opt, (64, 48), eye, oracle.look_at_y_up(eye, (0.0, 11.0, 0.0)))
+    # a corridor of recursive blocks made only of invisible voxels: every voxel is a counted
+    # step, so rays along the corridor run into the 1000-step cap (sr.rs:643)
+    from all_is_cubes_amd import flat
+
+    sp = flat.FlatSpace((0, 0, 0), (64, 3, 3))
+    sp.set_sky_uniform((0.2, 0.5, 0.9))
+    pal = np.stack([flat.evoxel((0, 0, 0, 0)), flat.evoxel((1.0, 0.5, 0.25, 1.0))])
+    vox = np.zeros((32, 32, 32), np.uint16)
+    vox[5, 7, 9] = 1  # one visible voxel so the block is not trivially empty
+    sp.block_index[...] = sp.add_block(flat.voxel_block(32, vox, pal))
+    opt = oracle.unaltered_colors(view_distance=500.0)
+    eye = (-3.0, 1.4, 1.6)
+    got, ref = render_both(ctx, sp, opt, (64, 48), eye, oracle.look_at_y_up(eye, (64.0, 1.5, 1.5)))
     assert_parity(got, ref)
-    assert int(ref["aux"]["cubes_traced"].max()) >= 1000  # the cap was reached
+    assert int(ref["aux"]["cubes_traced"].max()) >= 1001  # the cap was reached
+    # camera inside solid geometry (ray origin within an opaque cube => Face7::Within hits)
+    sp2 = scenes.synthetic_space(n=24, resolution=8, n_blocks=4, seed=9)
+    eye = (12.3, 3.2, 12.7)
+    got, ref = render_both(ctx, sp2, oracle.make_options(), (64, 48), eye, oracle.look_at_y_up(eye, (0.0, 4.0, 0.0)))
+    assert_parity(got, ref)
 
 
 def test_row_partition_matches_full_frame(ctx, synth_space):
@@ -292,3 +305,87 @@ def test_errors_are_reported_not_swallowed(ctx):
     o.fog = 9
     with pytest.raises(abi.AicError):
         ctx.set_options(abi.LAYER_WORLD, o)
+
+
+# --- the C++ host mirror (HeadlessRenderer surface) on the GPU --------------------------------
+def test_hip_rt_renderer_update_and_draw(ctx, synth_space):
+    """HipRtRenderer mirrors RtRenderer: update() snapshots (full, then incremental through
+    SpaceChange notifications, updating.rs:107-219), draw() never touches the scene."""
+    import all_is_cubes_amd as A
+    from all_is_cubes_amd import _host as H
+
+    w, h = 120, 80
+    cams = H.StandardCameras()
+    o = H.GraphicsOptions()
+    cams.graphics_options = o
+    cams.viewport = H.Viewport.with_scale(1.0, w, h)
+    space = A.space_from_flat(synth_space)
+    cams.world_space = space
+    cams.world_view_transform = H.look_at_y_up(SYNTH_EYE, (14.0, 8.0, 12.0))
+    r = H.HipRtRenderer(cams)
+    assert r.update() is True
+    img = r.draw("")
+    assert (img.width, img.height) == (w, h) and img.data.shape == (h, w, 4)
+    assert img.flaws & H.Flaws.NO_BLOOM == H.Flaws.NO_BLOOM  # default bloom_intensity != 0 (renderer.rs:293-297)
+    opt = oracle.make_options()
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(SYNTH_EYE, (14.0, 8.0, 12.0)), SYNTH_EYE)
+    ref = oracle.render(oracle.Space(synth_space), opt, oracle.make_camera(inv, w, h))
+    assert np.abs(img.data.astype(int) - ref["rgba8"].astype(int)).max() <= RGBA_TOL
+    assert img.info.cubes_traced == int(ref["info"]["cubes_traced"])
+    assert "cubes/pixel" in img.info.status_text()
+    # nothing changed => update reports False and the image is identical
+    assert r.update() is False
+    assert (r.draw("").data == img.data).all()
+    # incremental: edit cubes + light through the Space API, compare with the oracle on the edited scene
+    a_idx = 0
+    for (x, y, z) in [(14, 12, 12), (13, 11, 12), (14, 13, 13)]:
+        space.set(x, y, z, a_idx)
+        synth_space.set((x, y, z), a_idx)
+        space.set_light(x, y + 1, z, H.PackedLight(170, 160, 150, 255))
+        synth_space.light[x, y + 1, z] = (170, 160, 150, 255)
+    assert r.update(H.Cursor()) is True
+    img2 = r.draw("hello")
+    ref2 = oracle.render(oracle.Space(synth_space), opt, oracle.make_camera(inv, w, h))
+    assert np.abs(img2.data.astype(int) - ref2["rgba8"].astype(int)).max() <= RGBA_TOL
+    assert img2.info.cubes_traced == int(ref2["info"]["cubes_traced"])
+    assert img2.flaws & H.Flaws.NO_CURSOR == H.Flaws.NO_CURSOR
+    # size_policy + options change (any options change => re-sent, updating.rs:68-73)
+    o.lighting_display = H.LightingOption(H.LightingKind.Bounce, 4)
+    cams.graphics_options = o
+    r.update()
+    img3 = r.draw("")
+    assert img3.flaws & H.Flaws.UNSUPPORTED  # Bounce is rendered as Linear and flagged
+
+
+def test_multi_part_gather_on_one_gpu(ctx, synth_space):
+    """The N>1 data path on a single device: render each partition to device memory, stack as the
+    gather would, de-interleave with the device kernel and with the torch reference."""
+    import torch
+
+    import all_is_cubes_amd as A
+    from all_is_cubes_amd import _host as H
+    from all_is_cubes_amd import distributed as D
+
+    w, h, strip, n = 200, 90, 16, 4
+    cams = H.StandardCameras()
+    cams.graphics_options = H.GraphicsOptions()
+    cams.viewport = H.Viewport.with_scale(1.0, w, h)
+    cams.world_space = A.space_from_flat(synth_space)
+    cams.world_view_transform = H.look_at_y_up(SYNTH_EYE, (14.0, 8.0, 12.0))
+    r = H.HipRtRenderer(cams)
+    r.update()
+    full = torch.from_numpy(r.draw("").data.copy())
+    max_rows = D.max_partition_rows(h, strip, n)
+    gathered = torch.zeros((n, max_rows, w, 4), dtype=torch.uint8, device="cuda")
+    for p in range(n):
+        rows = r.partition_rows(strip, n, p)
+        assert rows == len(D.partition_rows(h, strip, n, p))
+        buf = torch.empty((rows, w, 4), dtype=torch.uint8, device="cuda")
+        r.draw_rows_to_device(buf.data_ptr(), strip, n, p)
+        gathered[p, :rows] = buf
+    out = torch.empty((h, w, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    r.assemble_strips(gathered.data_ptr(), out.data_ptr(), strip, n)
+    torch.cuda.synchronize()
+    assert (out.cpu() == full).all()
+    assert (D.assemble_strips_torch(gathered, h, w, strip).cpu() == full).all()
