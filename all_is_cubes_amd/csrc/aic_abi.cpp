@@ -112,6 +112,7 @@ struct aic_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Layer layers[2];
     DevBuf<float> lut;
+    DevBuf<float> srgb_thr;
     DevBuf<DevCounters> counters;
     DevBuf<uint32_t> out;      // internal RGBA8 target when the caller wants a host copy
     DevBuf<DevAux> aux;
@@ -120,6 +121,7 @@ struct aic_ctx {
     uint64_t aux_records = 0;
     std::string err;
     char devname[256] = {0};
+    uint32_t n_cus = 256;
 };
 
 namespace {
@@ -177,7 +179,7 @@ int convert_block(aic_ctx *c, const aic_block_desc &d, const uint16_t *voxels, c
                 e = palette + 8 * (size_t)idx;
             } else e = air;
         }
-        out->kind = 0;
+        out->kind = invisible(e) ? 0x80000000u : 0u;
         for (int k = 0; k < 4; k++) out->color[k] = e[k];
         for (int k = 0; k < 3; k++) out->emission[k] = e[4 + k];
         return AIC_OK;
@@ -276,6 +278,7 @@ aic_ctx *aic_create(int device_id, int *status) {
     aic_ctx *c = new aic_ctx();
     c->device = device_id;
     hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) std::snprintf(c->devname, sizeof(c->devname), "%s (%s)", prop.name, prop.gcnArchName);
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&c->ev0) == hipSuccess &&
               hipEventCreate(&c->ev1) == hipSuccess;
@@ -288,6 +291,29 @@ aic_ctx *aic_create(int device_id, int *status) {
         lut[v] = (float)std::exp2((double)arg);
     }
     ok = ok && c->lut.ensure(256) == hipSuccess && hipMemcpy(c->lut.p, lut, sizeof(lut), hipMemcpyHostToDevice) == hipSuccess;
+    // sRGB8 encode thresholds: thr[k] = the smallest f32 c with to_srgb8(c) >= k, found by bisection
+    // on the reference formula (color.rs:1038-1054) evaluated here on the host with powf.
+    {
+        auto enc = [](float cc) -> int {
+            float v = cc <= 0.0031308f ? cc * (323.f / 25.f) : (211.f * std::pow(cc, 5.f / 12.f) - 11.f) / 200.f;
+            float r = std::round(v * 255.f);
+            if (!(r > 0.f)) return 0;
+            return r >= 255.f ? 255 : (int)r;
+        };
+        float thr[256];
+        thr[0] = 0.f;
+        for (int k = 1; k < 256; k++) {
+            uint32_t lo_b = 0u, hi_b = 0x40000000u;  // (0.0, 2.0]: enc(lo) < k <= enc(hi)
+            while (hi_b - lo_b > 1u) {
+                const uint32_t mid = lo_b + (hi_b - lo_b) / 2u;
+                float f;
+                std::memcpy(&f, &mid, 4);
+                if (enc(f) >= k) hi_b = mid; else lo_b = mid;
+            }
+            std::memcpy(&thr[k], &hi_b, 4);
+        }
+        ok = ok && c->srgb_thr.ensure(256) == hipSuccess && hipMemcpy(c->srgb_thr.p, thr, sizeof(thr), hipMemcpyHostToDevice) == hipSuccess;
+    }
     ok = ok && c->counters.ensure(1) == hipSuccess;
     if (!ok) {
         *status = AIC_ERR_DEVICE;
@@ -304,7 +330,7 @@ void aic_destroy(aic_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &l : c->layers) l.release();
-    c->lut.release(); c->counters.release(); c->out.release(); c->aux.release(); c->acc.release(); c->staging.release();
+    c->lut.release(); c->srgb_thr.release(); c->counters.release(); c->out.release(); c->aux.release(); c->acc.release(); c->staging.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -496,12 +522,14 @@ int aic_render(aic_ctx *c, const aic_frame_desc *f, void *out_rgba8, int out_is_
     const size_t npix = (size_t)f->width * local_rows;
     if (info) std::memset(info, 0, sizeof(*info));
     if (npix && !out_rgba8) return fail(c, AIC_ERR_INVALID, "aic_render: output buffer is null");
+    if (f->width > 65535u || local_rows > 65535u) return fail(c, AIC_ERR_INVALID, "aic_render: frame dimensions above 65535 are not supported");
 
     uint32_t flaws = 0;
     DevFrame F;
     std::memset(&F, 0, sizeof(F));
-    fill_dev_layer(c, c->layers[AIC_LAYER_WORLD], f->world, &F.world, &flaws);
-    fill_dev_layer(c, c->layers[AIC_LAYER_UI], f->ui, &F.ui, &flaws);
+    DevLayer hl[2];
+    fill_dev_layer(c, c->layers[AIC_LAYER_WORLD], f->world, &hl[0], &flaws);
+    fill_dev_layer(c, c->layers[AIC_LAYER_UI], f->ui, &hl[1], &flaws);
     {
         const aic_options &wo = c->layers[AIC_LAYER_WORLD].opt;
         if (wo.bloom_intensity != 0.0f) flaws |= AIC_FLAW_NO_BLOOM;  // renderer.rs:293-297
@@ -510,6 +538,11 @@ int aic_render(aic_ctx *c, const aic_frame_desc *f, void *out_rgba8, int out_is_
     F.height = f->height;
     std::memcpy(F.backdrop, f->backdrop, sizeof(F.backdrop));
     F.has_backdrop = !(f->backdrop[0] == 0.f && f->backdrop[1] == 0.f && f->backdrop[2] == 0.f && f->backdrop[3] == 0.f);
+    // the encoder and the sampling pattern follow the WORLD camera's options (renderer.rs:283-291, 426)
+    F.antialias = hl[0].opt.antialiasing == 2 ? 1 : 0;
+    F.exposure = hl[0].exposure;
+    F.maximum_intensity = hl[0].opt.maximum_intensity;
+    F.tone_mapping = hl[0].opt.tone_mapping;
     F.strip_rows = part.strip_rows;
     F.n_parts = part.n_parts;
     F.part = part.part;
@@ -517,6 +550,8 @@ int aic_render(aic_ctx *c, const aic_frame_desc *f, void *out_rgba8, int out_is_
     F.tiles_x = (f->width + kTile - 1) / kTile;
     F.tiles_y = (local_rows + kTile - 1) / kTile;
     F.light_lut = c->lut.p;
+    F.n_cus = c->n_cus;
+    F.srgb_thr = c->srgb_thr.p;
     F.counters = c->counters.p;
 
     const bool want_aux = (f->flags & AIC_FRAME_AUX) != 0;
@@ -534,9 +569,9 @@ int aic_render(aic_ctx *c, const aic_frame_desc *f, void *out_rgba8, int out_is_
             F.aux = c->aux.p;
         }
         HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(DevCounters), c->stream));
-        const bool ui = F.ui.present != 0;
+        const bool ui = hl[1].present != 0;
         if (ui) {
-            const size_t samples = (F.world.opt.antialiasing == 2) ? 4 : 1;
+            const size_t samples = F.antialias ? 4 : 1;
             if ((e = c->acc.ensure(samples * npix)) != hipSuccess) return hip_fail(c, "alloc accumulators", e);
             F.acc_buf = c->acc.p;
         }
@@ -544,10 +579,18 @@ int aic_render(aic_ctx *c, const aic_frame_desc *f, void *out_rgba8, int out_is_
         if (ui) {
             F.pass = 1;
             F.use_init = 0;
+            F.layer = hl[1];
+            F.layer_transparency = hl[1].opt.transparency;
+            F.layer_lighting = hl[1].opt.lighting;
+            HIP_TRY(c, hipMemsetAsync(&c->counters.p->tile_next, 0, sizeof(uint32_t), c->stream));
             launch_trace_image(F, diag, c->stream);
             F.use_init = 1;
         }
         F.pass = 0;
+        F.layer = hl[0];
+        F.layer_transparency = hl[0].opt.transparency;
+        F.layer_lighting = hl[0].opt.lighting;
+        HIP_TRY(c, hipMemsetAsync(&c->counters.p->tile_next, 0, sizeof(uint32_t), c->stream));
         launch_trace_image(F, diag, c->stream);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
@@ -562,6 +605,10 @@ int aic_render(aic_ctx *c, const aic_frame_desc *f, void *out_rgba8, int out_is_
             info->n_inner = hc.n_inner;
             info->n_hits = hc.n_hits;
             info->n_light = hc.n_light;
+#ifdef AIC_PROFILE
+            { static const char *names[12] = {"ev_phases","ev_lanes","flush_ph","flush_ln","light_ph","light_ln","enter_ph","enter_ln","finish_ph","finish_ln","step_iters","step_lanes"};
+              for (int i = 0; i < 12; i++) std::fprintf(stderr, "PROF %s %llu\n", names[i], hc.prof[i]); }
+#endif
         }
         c->aux_records = want_aux ? npix : 0;
     } else {

@@ -19,7 +19,8 @@ namespace aic {
 struct DevBlock {
     float color[4];       // single-voxel colour (valid if kind == 0)
     float emission[3];
-    uint32_t kind;        // 0: single voxel (R1 / Evoxels::One); else the resolution (2..128)
+    uint32_t kind;        // low byte: 0 = single voxel (R1 / Evoxels::One), else the resolution (2..128);
+                          // bit 31 (single voxel only): the voxel is invisible (alpha == 0 && emission == 0)
     uint32_t vlo_packed;  // stored voxel volume lower corner  x | y<<8 | z<<16  (each 0..127)
     uint32_t vsize_packed;  // stored voxel volume size      x | y<<8 | z<<16  (each 1..128)
     uint32_t vox_off;     // u16 units into the voxel pool
@@ -73,6 +74,9 @@ struct DevCounters {
     unsigned long long n_inner;
     unsigned long long n_hits;
     unsigned long long n_light;
+    unsigned long long prof[16];  // AIC_PROFILE builds only
+    uint32_t tile_next;           // dynamic tile dispenser of the persistent trace kernel
+    uint32_t pad;
 };
 
 struct DevAux {  // == aic_pixel_aux
@@ -88,14 +92,21 @@ struct DevAux {  // == aic_pixel_aux
 };
 
 struct DevFrame {
-    DevLayer world;
-    DevLayer ui;
+    DevLayer layer;          // the layer this launch traces, BY VALUE: kernarg fields are fetched with
+                             // scalar loads into SGPRs (a pointer to a device-memory struct costs a
+                             // dependent vector load in front of every lookup)
+    int32_t layer_transparency, layer_lighting;  // host-side copy, selects the kernel variant
     uint32_t width, height;
     float backdrop[4];
     int32_t has_backdrop;
+    int32_t antialias;       // world camera options: AntialiasingOption::Always
+    float exposure;          // world Camera::exposure()
+    float maximum_intensity; // world options (encoder)
+    int32_t tone_mapping;
     uint32_t strip_rows, n_parts, part;
     uint32_t local_rows;     // rows this launch renders
     uint32_t tiles_x, tiles_y;  // tile grid over (width, local_rows)
+    uint32_t n_cus;          // compute units of the device (sizes the persistent grid)
     int32_t pass;            // 0: final pass (world layer + encode); 1: UI pre-pass
     int32_t use_init;        // final pass: start each sample from acc_buf (written by the UI pre-pass)
     float4 *acc_buf;         // [samples][local_rows][width] ColorBuf {light rgb, transmittance}
@@ -103,6 +114,7 @@ struct DevFrame {
     DevAux *aux;             // [local_rows][width] or null
     DevCounters *counters;
     const float *light_lut;  // 256 floats
+    const float *srgb_thr;   // 256 floats: srgb_thr[k] = smallest linear value whose sRGB8 encoding is >= k
 };
 
 // Tile geometry: one wavefront traces an 8x8 pixel tile (coherent rays), a workgroup of 256

@@ -79,226 +79,244 @@ AIC_DEV bool cube_containing(const double p[3], int out[3]) {
     return ok;
 }
 
-// Per-ray constants: Parameters::new (raycast.rs:749-771) minus the origin.
+// Per-ray constants: Parameters::new (raycast.rs:749-771) minus the origin. Kept as scalars
+// (never indexed dynamically) so they live in VGPRs.
 struct RayDir {
-    double d[3];       // direction (zeroed if any |component| is not < 1e100)
-    double tdelta[3];  // 1/|d|
-    int step[3];
+    double dx, dy, dz;     // direction (zeroed if any |component| is not < 1e100)
+    double tdx, tdy, tdz;  // t_delta = 1/|d|
+    int sx, sy, sz;        // step = signum_101(d)
 };
 
-AIC_DEV void raydir_init(RayDir &r, const double dir[3]) {
-    bool all_small = (fabs(dir[0]) < 1e100) & (fabs(dir[1]) < 1e100) & (fabs(dir[2]) < 1e100);
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        r.d[a] = all_small ? dir[a] : 0.0;
-        r.step[a] = signum_101(r.d[a]);
-        r.tdelta[a] = 1.0 / fabs(r.d[a]);
-    }
+AIC_DEV RayDir raydir_init(double dx, double dy, double dz) {
+    RayDir r;
+    const bool all_small = (fabs(dx) < 1e100) && (fabs(dy) < 1e100) && (fabs(dz) < 1e100);
+    r.dx = all_small ? dx : 0.0;
+    r.dy = all_small ? dy : 0.0;
+    r.dz = all_small ? dz : 0.0;
+    r.sx = signum_101(r.dx); r.sy = signum_101(r.dy); r.sz = signum_101(r.dz);
+    r.tdx = 1.0 / fabs(r.dx); r.tdy = 1.0 / fabs(r.dy); r.tdz = 1.0 / fabs(r.dz);
+    return r;
 }
 
 // State of one DDA level (raycast.rs:99-121 State + FirstLast), with the step deferred: the
 // reference emits `current()` and then advances; here the advance is performed at the start
-// of the following `next`, which is observationally identical and lets `cube` double as the
+// of the following `next`, which is observationally identical and lets `c*` double as the
 // emitted cube.
-struct Dda {
-    double tmax[3];
+struct Lvl {
+    double tx, ty, tz;  // t_max
     double last_t;
-    int cube[3];
-    int lim[3];    // while INBOUNDS: coordinate value that means "left the bounds" on each axis
-    uint32_t st;   // bits 0-1 first_last | 2-4 last_face | 5-6 pick | 7 need_step | 8 include_exit
+    int cx, cy, cz;
+    uint32_t st;        // bits 0-1 first_last | 2-4 last_face | 5-6 pick | 7 need_step | 8 include_exit
 };
-AIC_DEV uint32_t dda_fl(const Dda &s) { return s.st & 3u; }
-AIC_DEV int dda_face(const Dda &s) { return (int)((s.st >> 2) & 7u); }
-AIC_DEV void dda_set_fl(Dda &s, uint32_t fl) { s.st = (s.st & ~3u) | fl; }
+// While INBOUNDS: the coordinate value that means "left the bounds", per axis.
+struct Lim {
+    int x, y, z;
+};
+AIC_DEV uint32_t lvl_fl(const Lvl &s) { return s.st & 3u; }
+AIC_DEV int lvl_face(const Lvl &s) { return (int)((s.st >> 2) & 7u); }
 
-AIC_DEV int pick_axis(const double t[3]) {  // raycast.rs:584-596
-    if (t[0] < t[1]) return (t[0] < t[2]) ? 0 : 2;
-    return (t[1] < t[2]) ? 1 : 2;
+AIC_DEV int pick_axis(double tx, double ty, double tz) {  // raycast.rs:584-596
+    if (tx < ty) return (tx < tz) ? 0 : 2;
+    return (ty < tz) ? 1 : 2;
 }
 
 // Raycaster::new(origin, dir) [.within(lo,hi, include_exit)]  (raycast.rs:196-230, 513-545, 632-704)
-AIC_DEV void dda_init(Dda &s, const double origin[3], const RayDir &rd, bool bounded, const int lo_in[3],
-                      const int hi_in[3], bool include_exit) {
-    s.st = FL_BEGINNING | ((uint32_t)FACE_WITHIN << 2) | (include_exit ? 256u : 0u);
+struct LvlLim {
+    Lvl s;
+    Lim lim;
+};
+AIC_DEV LvlLim lvl_init(double ox, double oy, double oz, const RayDir rd, bool bounded, int lox, int loy,
+                        int loz, int hix, int hiy, int hiz, bool include_exit) {
+    LvlLim out;
+    Lvl &s = out.s;
+    Lim &lim = out.lim;
+    s.st = FL_ENDED;
     s.last_t = 0.0;
+    s.tx = s.ty = s.tz = 0.0;
+    s.cx = s.cy = s.cz = 0;
+    lim.x = lim.y = lim.z = 0;
+    double p[3] = {ox, oy, oz};
     int cube[3];
-    bool ok = cube_containing(origin, cube);
+    bool ok = cube_containing(p, cube);
     // MAXIMUM_BOUNDS.contains_cube (raycast.rs:485-499, 521-523)
     ok = ok && cube[0] >= I32_MIN_ + 1 && cube[0] < I32_MAX_ - 1 && cube[1] >= I32_MIN_ + 1 && cube[1] < I32_MAX_ - 1 &&
          cube[2] >= I32_MIN_ + 1 && cube[2] < I32_MAX_ - 1;
-    if (!ok) {  // State::EMPTY: produces nothing
-        s.st = FL_ENDED;
-        return;
-    }
+    if (!ok) return out;  // State::EMPTY: produces nothing
     // bounds = MAXIMUM_BOUNDS ∩ given (empty => ORIGIN_EMPTY, which contains no cube)
-    int lo[3], hi[3];
-    bool empty = false;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        lo[a] = bounded ? max(lo_in[a], I32_MIN_ + 1) : I32_MIN_ + 1;
-        hi[a] = bounded ? min(hi_in[a], I32_MAX_ - 1) : I32_MAX_ - 1;
-        empty |= hi[a] <= lo[a];
+    if (bounded) {
+        lox = max(lox, I32_MIN_ + 1); loy = max(loy, I32_MIN_ + 1); loz = max(loz, I32_MIN_ + 1);
+        hix = min(hix, I32_MAX_ - 1); hiy = min(hiy, I32_MAX_ - 1); hiz = min(hiz, I32_MAX_ - 1);
+    } else {
+        lox = loy = loz = I32_MIN_ + 1;
+        hix = hiy = hiz = I32_MAX_ - 1;
     }
-    if (empty) {
-        s.st = FL_ENDED;
-        return;
-    }
-    double o[3] = {origin[0], origin[1], origin[2]};
+    if (hix <= lox || hiy <= loy || hiz <= loz) return out;
     bool have_tmax = false;
     if (bounded) {
-        // fast_forward (raycast.rs:632-704)
+        // fast_forward (raycast.rs:632-704): plane_origin takes the upper bound on axes the ray
+        // descends, else the lower bound; one ray-plane intersection per moving axis.
+        const double pox = (double)((rd.sx < 0) ? hix : lox);
+        const double poy = (double)((rd.sy < 0) ? hiy : loy);
+        const double poz = (double)((rd.sz < 0) ? hiz : loz);
+        const double relx = pox - ox, rely = poy - oy, relz = poz - oz;
+        // ray_plane_intersection (raycast.rs:821-832) with an axis-aligned unit normal n = ±1:
+        // (rel·n)/(dir·n) == rel_a / dir_a exactly (the ±1 factors and the ±0 terms cancel for the
+        // finite values that reach this point).
         double max_t = 0.0;
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            int direction = rd.step[a];
-            if (direction == 0) continue;
-            // plane_origin uses the upper bound on axes the ray descends, else the lower bound
-            double po[3], pn[3];
-#pragma unroll
-            for (int b = 0; b < 3; b++) {
-                po[b] = (double)((rd.step[b] < 0) ? hi[b] : lo[b]);
-                pn[b] = (b == a) ? (double)direction : 0.0;
-            }
-            double rel[3] = {po[0] - o[0], po[1] - o[1], po[2] - o[2]};
-            double num = rel[0] * pn[0] + rel[1] * pn[1] + rel[2] * pn[2];
-            double den = rd.d[0] * pn[0] + rd.d[1] * pn[1] + rd.d[2] * pn[2];
-            double it = num / den;
-            max_t = fmax(max_t, it);
-        }
+        if (rd.sx != 0) max_t = fmax(max_t, relx / rd.dx);
+        if (rd.sy != 0) max_t = fmax(max_t, rely / rd.dy);
+        if (rd.sz != 0) max_t = fmax(max_t, relz / rd.dz);
         if (max_t > 0.0) {  // last_t_distance == 0 at this point
-            double len = sqrt(rd.d[0] * rd.d[0] + rd.d[1] * rd.d[1] + rd.d[2] * rd.d[2]);
+            const double len = sqrt(rd.dx * rd.dx + rd.dy * rd.dy + rd.dz * rd.dz);
             double t_start = max_t - 0.5 / len;
             if (!isfinite(t_start)) t_start = max_t;
-            double ff[3] = {o[0] + rd.d[0] * t_start, o[1] + rd.d[1] * t_start, o[2] + rd.d[2] * t_start};
-            if (!cube_containing(ff, cube)) {
-                s.st = FL_ENDED;
-                return;
-            }
-#pragma unroll
-            for (int a = 0; a < 3; a++) s.tmax[a] = scale_to_integer_step(ff[a], rd.d[a]) + t_start;
+            double ff[3] = {ox + rd.dx * t_start, oy + rd.dy * t_start, oz + rd.dz * t_start};
+            if (!cube_containing(ff, cube)) return out;
+            s.tx = scale_to_integer_step(ff[0], rd.dx) + t_start;
+            s.ty = scale_to_integer_step(ff[1], rd.dy) + t_start;
+            s.tz = scale_to_integer_step(ff[2], rd.dz) + t_start;
             s.last_t = t_start;
             have_tmax = true;
         }
     }
     if (!have_tmax) {
-#pragma unroll
-        for (int a = 0; a < 3; a++) s.tmax[a] = scale_to_integer_step(o[a], rd.d[a]);
+        s.tx = scale_to_integer_step(ox, rd.dx);
+        s.ty = scale_to_integer_step(oy, rd.dy);
+        s.tz = scale_to_integer_step(oz, rd.dz);
     }
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        s.cube[a] = cube[a];
-        // exit coordinate once in bounds: moving up leaves at hi, moving down leaves at lo-1
-        s.lim[a] = rd.step[a] > 0 ? hi[a] : lo[a] - 1;
-    }
+    s.cx = cube[0]; s.cy = cube[1]; s.cz = cube[2];
+    // exit coordinate once in bounds: moving up leaves at hi, moving down leaves at lo-1
+    lim.x = rd.sx > 0 ? hix : lox - 1;
+    lim.y = rd.sy > 0 ? hiy : loy - 1;
+    lim.z = rd.sz > 0 ? hiz : loz - 1;
+    s.st = FL_BEGINNING | ((uint32_t)FACE_WITHIN << 2) | (include_exit ? 256u : 0u);
+    return out;
 }
 
-// The deferred State::step (raycast.rs:577-626)
-AIC_DEV void dda_do_step(Dda &s, const RayDir &rd) {
-    const int axis = (int)((s.st >> 5) & 3u);
-    double t, dt;
-    int st;
-    if (axis == 0) { t = s.tmax[0]; dt = rd.tdelta[0]; st = rd.step[0]; }
-    else if (axis == 1) { t = s.tmax[1]; dt = rd.tdelta[1]; st = rd.step[1]; }
-    else { t = s.tmax[2]; dt = rd.tdelta[2]; st = rd.step[2]; }
-    s.last_t = t;
-    t += dt;
-    if (axis == 0) { s.tmax[0] = t; s.cube[0] += st; }
-    else if (axis == 1) { s.tmax[1] = t; s.cube[1] += st; }
-    else { s.tmax[2] = t; s.cube[2] += st; }
-    // FACE_TABLE: step > 0 -> N<axis> (1+axis), else P<axis> (4+axis)
-    const uint32_t face = (uint32_t)((st > 0 ? 1 : 4) + axis);
-    s.st = (s.st & ~(7u << 2) & ~128u) | (face << 2);
+// The deferred State::step (raycast.rs:577-626) along the axis recorded in `pick`.
+AIC_DEV Lvl lvl_do_step(Lvl s, const RayDir rd) {
+    const uint32_t axis = (s.st >> 5) & 3u;
+    uint32_t face;
+    if (axis == 0) {
+        s.last_t = s.tx; s.tx += rd.tdx; s.cx += rd.sx; face = rd.sx > 0 ? 1u : 4u;
+    } else if (axis == 1) {
+        s.last_t = s.ty; s.ty += rd.tdy; s.cy += rd.sy; face = rd.sy > 0 ? 2u : 5u;
+    } else {
+        s.last_t = s.tz; s.tz += rd.tdz; s.cz += rd.sz; face = rd.sz > 0 ? 3u : 6u;
+    }
+    s.st = (s.st & ~(7u << 2) & ~128u) | (face << 2);  // FACE_TABLE; clears need_step
+    return s;
 }
 
-// Raycaster::next (raycast.rs:239-284). `lo`/`hi` are only consulted before the ray has
-// entered the bounds. Returns true if a step was produced; the produced step is
-// {s.cube, dda_face(s), s.last_t, s.tmax}. *is_exit tells whether it is the include_exit step.
-AIC_DEV bool dda_next(Dda &s, const RayDir &rd, const int lo[3], const int hi[3], bool *is_exit) {
-    *is_exit = false;
+// Raycaster::next (raycast.rs:239-284). lo*/hi* are only consulted before the ray has entered
+// the bounds. Returns true if a step was produced: {c*, lvl_face, last_t, t*}; *is_exit tells
+// whether it is the include_exit step (the only produced step whose cube is out of bounds).
+struct NextResult {
+    Lvl s;
+    bool got, is_exit;
+};
+AIC_DEV NextResult lvl_next(Lvl s, const Lim lim, const RayDir rd, int lox, int loy, int loz, int hix, int hiy, int hiz) {
+    NextResult R;
+    R.got = false;
+    R.is_exit = false;
     for (;;) {
-        uint32_t fl = dda_fl(s);
-        if (fl == FL_ENDED) return false;
-        bool stepped = (s.st & 128u) != 0;
-        int stepped_axis = (int)((s.st >> 5) & 3u);
-        if (stepped) dda_do_step(s, rd);
+        const uint32_t fl = lvl_fl(s);
+        if (fl == FL_ENDED) { R.s = s; return R; }
+        const bool stepped = (s.st & 128u) != 0;
+        const uint32_t stepped_axis = (s.st >> 5) & 3u;
+        if (stepped) s = lvl_do_step(s, rd);
         bool oob_enter = false, oob_exit = false;
         if (fl == FL_INBOUNDS) {
             // only the axis just stepped can have left; it can never be "not yet entered"
-            int c = stepped_axis == 0 ? s.cube[0] : (stepped_axis == 1 ? s.cube[1] : s.cube[2]);
-            int l = stepped_axis == 0 ? s.lim[0] : (stepped_axis == 1 ? s.lim[1] : s.lim[2]);
+            const int c = stepped_axis == 0 ? s.cx : (stepped_axis == 1 ? s.cy : s.cz);
+            const int l = stepped_axis == 0 ? lim.x : (stepped_axis == 1 ? lim.y : lim.z);
             oob_exit = stepped && (c == l);
         } else {
             // is_out_of_bounds_ahead (raycast.rs:711-728)
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                bool low = s.cube[a] < lo[a];
-                bool high = s.cube[a] >= hi[a];
-                int st = rd.step[a];
-                bool e = st == 0 ? (low | high) : (st < 0 ? high : low);
-                bool x = st == 0 ? (low | high) : (st < 0 ? low : high);
-                oob_enter |= e;
-                oob_exit |= x;
+            {
+                const bool low = s.cx < lox, high = s.cx >= hix;
+                oob_enter |= rd.sx == 0 ? (low | high) : (rd.sx < 0 ? high : low);
+                oob_exit |= rd.sx == 0 ? (low | high) : (rd.sx < 0 ? low : high);
+            }
+            {
+                const bool low = s.cy < loy, high = s.cy >= hiy;
+                oob_enter |= rd.sy == 0 ? (low | high) : (rd.sy < 0 ? high : low);
+                oob_exit |= rd.sy == 0 ? (low | high) : (rd.sy < 0 ? low : high);
+            }
+            {
+                const bool low = s.cz < loz, high = s.cz >= hiz;
+                oob_enter |= rd.sz == 0 ? (low | high) : (rd.sz < 0 ? high : low);
+                oob_exit |= rd.sz == 0 ? (low | high) : (rd.sz < 0 ? low : high);
             }
         }
         if (!oob_enter && !oob_exit) {
-            int pick = pick_axis(s.tmax);
-            double tp = pick == 0 ? s.tmax[0] : (pick == 1 ? s.tmax[1] : s.tmax[2]);
+            const int pick = pick_axis(s.tx, s.ty, s.tz);
+            const double tp = pick == 0 ? s.tx : (pick == 1 ? s.ty : s.tz);
             // valid_for_stepping (raycast.rs:563-570): with NaN-free t_max (guaranteed for a
             // non-EMPTY state) it is exactly "the smallest t_max is finite".
-            bool valid = isfinite(tp);
-            if (!valid) {
-                dda_set_fl(s, FL_ENDED);
-                return dda_face(s) == FACE_WITHIN;
+            if (!isfinite(tp)) {
+                s.st = (s.st & ~3u) | FL_ENDED;
+                R.got = lvl_face(s) == FACE_WITHIN;
+                R.s = s;
+                return R;
             }
             s.st = (s.st & ~3u & ~(3u << 5)) | FL_INBOUNDS | ((uint32_t)pick << 5) | 128u;
-            return true;
+            R.got = true;
+            R.s = s;
+            return R;
         } else if (fl == FL_BEGINNING && oob_enter && !oob_exit) {
-            int pick = pick_axis(s.tmax);
-            double tp = pick == 0 ? s.tmax[0] : (pick == 1 ? s.tmax[1] : s.tmax[2]);
+            const int pick = pick_axis(s.tx, s.ty, s.tz);
+            const double tp = pick == 0 ? s.tx : (pick == 1 ? s.ty : s.tz);
             if (!isfinite(tp)) {
-                dda_set_fl(s, FL_ENDED);
-                return false;
+                s.st = (s.st & ~3u) | FL_ENDED;
+                R.s = s;
+                return R;
             }
-            int c = pick == 0 ? s.cube[0] : (pick == 1 ? s.cube[1] : s.cube[2]);
-            int st = pick == 0 ? rd.step[0] : (pick == 1 ? rd.step[1] : rd.step[2]);
+            const int c = pick == 0 ? s.cx : (pick == 1 ? s.cy : s.cz);
+            const int st = pick == 0 ? rd.sx : (pick == 1 ? rd.sy : rd.sz);
             if ((st > 0 && c == I32_MAX_) || (st < 0 && c == I32_MIN_)) {  // checked_add failed
-                dda_set_fl(s, FL_ENDED);
-                return false;
+                s.st = (s.st & ~3u) | FL_ENDED;
+                R.s = s;
+                return R;
             }
             s.st = (s.st & ~(3u << 5)) | ((uint32_t)pick << 5) | 128u;
             continue;
         } else if (fl == FL_INBOUNDS && !oob_enter && oob_exit) {
-            dda_set_fl(s, FL_ENDED);
+            s.st = (s.st & ~3u) | FL_ENDED;
             if (s.st & 256u) {
-                *is_exit = true;
-                return true;
+                R.is_exit = true;
+                R.got = true;
             }
-            return false;
+            R.s = s;
+            return R;
         } else {
-            dda_set_fl(s, FL_ENDED);
-            return false;
+            s.st = (s.st & ~3u) | FL_ENDED;
+            R.s = s;
+            return R;
         }
     }
 }
 
 // RaycastStep::intersection_point (raycast.rs:409-439) for the step currently held in `s`.
-AIC_DEV void intersection_point(const Dda &s, const double origin[3], const double dir[3], double out[3]) {
-    const int face = dda_face(s);
+AIC_DEV void intersection_point(const Lvl s, double ox, double oy, double oz, double dx, double dy, double dz, double out[3]) {
+    const int face = lvl_face(s);
     if (face == FACE_WITHIN) {
-        out[0] = origin[0]; out[1] = origin[1]; out[2] = origin[2];
+        out[0] = ox; out[1] = oy; out[2] = oz;
         return;
     }
     const int face_axis = (face - 1) % 3;
+    const double o[3] = {ox, oy, oz}, d[3] = {dx, dy, dz}, tm[3] = {s.tx, s.ty, s.tz};
+    const int cc[3] = {s.cx, s.cy, s.cz};
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        double v = (double)s.cube[a];
-        int sd = signum_101(dir[a]);
+        double v = (double)cc[a];
+        const int sd = signum_101(d[a]);
         if (a == face_axis) {
             if (sd < 0) v += 1.0;
         } else if (sd == 0) {
-            v = origin[a];
+            v = o[a];
         } else {
-            double off = (s.tmax[a] - s.last_t) * dir[a];
+            const double off = (tm[a] - s.last_t) * d[a];
             if (sd > 0) {
                 double c = off;
                 if (c < 0.0) c = 0.0;
@@ -468,397 +486,169 @@ AIC_DEV void face_frame(int face, int fx[3], int fy[3]) {
     }
 }
 
-// SpaceRaytracer::get_interpolated_light (sr.rs:248-359)
+// SpaceRaytracer::get_interpolated_light (sr.rs:248-359).
+//
+// Same arithmetic as the reference, organised around what is actually distinct: the tangent
+// frame of a face is two signed coordinate axes, so
+//   * dot(surface_point, frame_axis) is  +-surface_point[axis]  (the +-0 terms of the reference's
+//     three-term dot product cannot change the value that `- 0.5` is applied to);
+//   * the four sample offsets dir_1*{-.5,+.5} + dir_2*{-.5,+.5} are exactly +-0.5 on the two
+//     tangent axes and 0 on the normal axis, so the 4 (x2 planes) sample cubes are built from only
+//     5 distinct floor() values per plane instead of 12;
+//   * the light-grid index of a texel is a sum of three per-axis contributions.
+// Texel decode, the light-leak rule, the bilinear/trilinear mix4 chain and the final weight
+// division are unchanged, operation for operation.
 template <bool DIAG>
-AIC_DEV void get_interpolated_light(const DevLayer &L, const float *lut, const int cube[3], const double sp[3], int face,
+AIC_DEV void get_interpolated_light(const DevLayer &L, const float *__restrict__ lut, const int cube[3], const double sp[3], int face,
                                     int mode, float out[3], uint32_t &nlight) {
     const double eps = 0.5 / 256.0;
-    int fxi[3], fyi[3];
-    face_frame(face, fxi, fyi);
-    double rfx[3] = {(double)fxi[0], (double)fxi[1], (double)fxi[2]};
-    double rfy[3] = {(double)fyi[0], (double)fyi[1], (double)fyi[2]};
-    double mix_1 = rem_euclid1((sp[0] * rfx[0] + sp[1] * rfx[1] + sp[2] * rfx[2]) - 0.5);
-    double mix_2 = rem_euclid1((sp[0] * rfy[0] + sp[1] * rfy[1] + sp[2] * rfy[2]) - 0.5);
-    double d1[3] = {rfx[0], rfx[1], rfx[2]}, d2[3] = {rfy[0], rfy[1], rfy[2]};
-    if (mix_1 > 0.5) {
-        mix_1 = 1.0 - mix_1;
-        d1[0] = -d1[0]; d1[1] = -d1[1]; d1[2] = -d1[2];
+    // face -> (normal axis, sign) and the rotation_from_nz tangent frame (face.rs:395-404)
+    int an, a1, a2;
+    double ns, s1, s2;
+    switch (face) {
+        case 1: an = 0; ns = -1.0; a1 = 1; s1 = 1.0; a2 = 2; s2 = 1.0; break;    // NX: +Y, +Z
+        case 2: an = 1; ns = -1.0; a1 = 2; s1 = 1.0; a2 = 0; s2 = 1.0; break;    // NY: +Z, +X
+        case 3: an = 2; ns = -1.0; a1 = 0; s1 = 1.0; a2 = 1; s2 = 1.0; break;    // NZ: +X, +Y
+        case 4: an = 0; ns = 1.0; a1 = 1; s1 = -1.0; a2 = 2; s2 = 1.0; break;    // PX: -Y, +Z
+        case 5: an = 1; ns = 1.0; a1 = 2; s1 = 1.0; a2 = 0; s2 = -1.0; break;    // PY: +Z, -X
+        case 6: an = 2; ns = 1.0; a1 = 0; s1 = 1.0; a2 = 1; s2 = -1.0; break;    // PZ: +X, -Y
+        default: an = 2; ns = 0.0; a1 = 0; s1 = 1.0; a2 = 1; s2 = 1.0; break;    // Within: IDENTITY frame, zero normal
     }
-    if (mix_2 > 0.5) {
-        mix_2 = 1.0 - mix_2;
-        d2[0] = -d2[0]; d2[1] = -d2[1]; d2[2] = -d2[2];
-    }
+    auto pick3d = [](int a, double x, double y, double z) { return a == 0 ? x : (a == 1 ? y : z); };
+    auto pick3i = [](int a, int x, int y, int z) { return a == 0 ? x : (a == 1 ? y : z); };
+    const double spn = pick3d(an, sp[0], sp[1], sp[2]), sp1 = pick3d(a1, sp[0], sp[1], sp[2]), sp2 = pick3d(a2, sp[0], sp[1], sp[2]);
+
+    double mix_1 = rem_euclid1(s1 * sp1 - 0.5);
+    double mix_2 = rem_euclid1(s2 * sp2 - 0.5);
+    double g1 = s1, g2 = s2;  // dir_1 / dir_2 along their axes
+    if (mix_1 > 0.5) { mix_1 = 1.0 - mix_1; g1 = -g1; }
+    if (mix_2 > 0.5) { mix_2 = 1.0 - mix_2; g2 = -g2; }
     if (mode == 2) { mix_1 = coarsestep(mix_1); mix_2 = coarsestep(mix_2); }
     else if (mode == 4) { mix_1 = smoothstep(mix_1); mix_2 = smoothstep(mix_2); }
     const float m1 = (float)mix_1, m2 = (float)mix_2;
 
-    // normal vector / face.dot
-    double nrm[3] = {0.0, 0.0, 0.0};
-    if (face >= 1 && face <= 3) nrm[face - 1] = -1.0;
-    else if (face >= 4) nrm[face - 4] = 1.0;
-    double fdot_sp, fdot_center;
-    {
-        double cx = (double)cube[0] + 0.5, cy = (double)cube[1] + 0.5, cz = (double)cube[2] + 0.5;
-        switch (face) {
-            case 1: fdot_sp = -sp[0]; fdot_center = -cx; break;
-            case 2: fdot_sp = -sp[1]; fdot_center = -cy; break;
-            case 3: fdot_sp = -sp[2]; fdot_center = -cz; break;
-            case 4: fdot_sp = sp[0]; fdot_center = cx; break;
-            case 5: fdot_sp = sp[1]; fdot_center = cy; break;
-            case 6: fdot_sp = sp[2]; fdot_center = cz; break;
-            default: fdot_sp = 0.0; fdot_center = 0.0; break;
-        }
-    }
-    const double height_in_cube = fdot_sp - fdot_center + 0.5;
+    // height of the surface inside its cube: face.dot(sp) - face.dot(cube centre) + 0.5
+    const double cn = (double)pick3i(an, cube[0], cube[1], cube[2]) + 0.5;
+    const double height_in_cube = (ns == 0.0) ? 0.5 : ((ns * spn) - (ns * cn) + 0.5);
 
-    auto fetch2d = [&](const double o2[3], float res[4]) {
-        uint32_t tx[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            // near12, near1far2, near2far1, far12 : dir_1*{lo,lo,hi,hi} + dir_2*{lo,hi,lo,hi}
-            const double a1 = (k & 2) ? 0.5 : -0.5;
-            const double a2 = (k & 1) ? 0.5 : -0.5;
-            double p[3];
-#pragma unroll
-            for (int a = 0; a < 3; a++) p[a] = o2[a] + (d1[a] * a1 + d2[a] * a2);
-            int c[3];
-            if (cube_containing(p, c)) tx[k] = get_packed_light<DIAG>(L, c[0], c[1], c[2], nlight);
-            else tx[k] = L.block_sky[6];
-        }
+    // per-role grid parameters (role = normal / tangent-1 / tangent-2 axis)
+    const int lo_n = pick3i(an, L.lo[0], L.lo[1], L.lo[2]), lo_1 = pick3i(a1, L.lo[0], L.lo[1], L.lo[2]), lo_2 = pick3i(a2, L.lo[0], L.lo[1], L.lo[2]);
+    const uint32_t sz_n = (uint32_t)pick3i(an, L.size[0], L.size[1], L.size[2]), sz_1 = (uint32_t)pick3i(a1, L.size[0], L.size[1], L.size[2]),
+                   sz_2 = (uint32_t)pick3i(a2, L.size[0], L.size[1], L.size[2]);
+    const uint32_t stride_x = (uint32_t)L.size[1] * (uint32_t)L.size[2], stride_y = (uint32_t)L.size[2];
+    const uint32_t st_n = (uint32_t)pick3i(an, (int)stride_x, (int)stride_y, 1), st_1 = (uint32_t)pick3i(a1, (int)stride_x, (int)stride_y, 1),
+                   st_2 = (uint32_t)pick3i(a2, (int)stride_x, (int)stride_y, 1);
+
+    // Cube::containing on one coordinate: in i32 range -> floor, else "no cube" (cube.rs:97-119)
+    auto fl = [](double v, bool &ok) -> int {
+        ok = ok && (v >= -2147483648.0) && (v < 2147483648.0);
+        return (int)floor(v);
+    };
+    // the two tangent axes are shared by both planes: sample positions sp +- 0.5 along dir_1 / dir_2
+    bool ok1n = true, ok1f = true, ok2n = true, ok2f = true;
+    const int v1n = fl(sp1 + g1 * -0.5, ok1n), v1f = fl(sp1 + g1 * 0.5, ok1f);
+    const int v2n = fl(sp2 + g2 * -0.5, ok2n), v2f = fl(sp2 + g2 * 0.5, ok2f);
+    const uint32_t d1n = (uint32_t)v1n - (uint32_t)lo_1, d1f = (uint32_t)v1f - (uint32_t)lo_1;
+    const uint32_t d2n = (uint32_t)v2n - (uint32_t)lo_2, d2f = (uint32_t)v2f - (uint32_t)lo_2;
+
+    auto texel = [&](int vn, bool okn, uint32_t dn, int v1, bool ok1, uint32_t d1, int v2, bool ok2, uint32_t d2) -> uint32_t {
+        if (!(okn && ok1 && ok2)) return L.block_sky[6];  // numerical overflow: BlockSky::mean (sr.rs:307-311)
+        if (DIAG) nlight++;
+        if ((dn < sz_n) & (d1 < sz_1) & (d2 < sz_2)) return L.light[dn * st_n + d1 * st_1 + d2 * st_2];
+        // outside the space: BlockSky::light_outside on the reassembled cube
+        int c[3];
+        c[0] = an == 0 ? vn : (a1 == 0 ? v1 : v2);
+        c[1] = an == 1 ? vn : (a1 == 1 ? v1 : v2);
+        c[2] = an == 2 ? vn : (a1 == 2 ? v1 : v2);
+        return light_outside(L, c[0], c[1], c[2]);
+    };
+    auto fetch2d = [&](double on, float res[4]) {
+        bool okn = true;
+        const int vn = fl(on, okn);
+        const uint32_t dn = (uint32_t)vn - (uint32_t)lo_n;
+        const uint32_t near12 = texel(vn, okn, dn, v1n, ok1n, d1n, v2n, ok2n, d2n);
+        const uint32_t near1far2 = texel(vn, okn, dn, v1n, ok1n, d1n, v2f, ok2f, d2f);
+        const uint32_t near2far1 = texel(vn, okn, dn, v1f, ok1f, d1f, v2n, ok2n, d2n);
+        uint32_t far12 = texel(vn, okn, dn, v1f, ok1f, d1f, v2f, ok2f, d2f);
         // light-leak fix: both side texels invalid => far corner := near corner
-        if ((tx[1] >> 24) != 255u && (tx[2] >> 24) != 255u) tx[3] = tx[0];
+        if ((near1far2 >> 24) != 255u && (near2far1 >> 24) != 255u) far12 = near12;
         float a[4], b[4], c[4], d[4], ab[4], cd[4];
-        texel_value_ao(tx[0], lut, a);
-        texel_value_ao(tx[1], lut, b);
-        texel_value_ao(tx[2], lut, c);
-        texel_value_ao(tx[3], lut, d);
+        texel_value_ao(near12, lut, a);
+        texel_value_ao(near1far2, lut, b);
+        texel_value_ao(near2far1, lut, c);
+        texel_value_ao(far12, lut, d);
         mix4(a, b, m2, ab);
         mix4(c, d, m2, cd);
         mix4(ab, cd, m1, res);
     };
 
     float front[4], fin[4];
-    {
-        const double k = 1.0 - eps;
-        double p[3] = {sp[0] + nrm[0] * k, sp[1] + nrm[1] * k, sp[2] + nrm[2] * k};
-        fetch2d(p, front);
-    }
+    fetch2d(spn + ns * (1.0 - eps), front);
     if (height_in_cube > (1.0 - eps)) {
         fin[0] = front[0]; fin[1] = front[1]; fin[2] = front[2]; fin[3] = front[3];
     } else {
         float same[4];
-        double p[3] = {sp[0] + nrm[0] * eps, sp[1] + nrm[1] * eps, sp[2] + nrm[2] * eps};
-        fetch2d(p, same);
+        fetch2d(spn + ns * eps, same);
         mix4(same, front, (float)height_in_cube, fin);
     }
-    float w = fmaxf(fin[3], 0.1f);
+    const float w = fmaxf(fin[3], 0.1f);
     out[0] = fin[0] / w;
     out[1] = fin[1] / w;
     out[2] = fin[2] / w;
 }
 
-AIC_DEV void sky_sample(const DevLayer &L, const double d[3], float out[3]) {  // sky.rs:32-41
-    int idx = 0;
-    if (L.sky_kind != 0) idx = ((d[0] >= 0.0 ? 1 : 0) << 2) + ((d[1] >= 0.0 ? 1 : 0) << 1) + (d[2] >= 0.0 ? 1 : 0);
-    out[0] = L.sky[idx][0];
-    out[1] = L.sky[idx][1];
-    out[2] = L.sky[idx][2];
-}
-
 // ---------------------------------------------------------------------------------------
-// one ray through one layer: SpaceRaytracer::trace_ray_impl (sr.rs:135-238)
+// The image kernel.
+//
+// Reference semantics per ray = SpaceRaytracer::trace_ray_impl (sr.rs:135-238) driven by
+// RtScene::trace_patch / trace_ray_through_layers and the draw_rgba encoder
+// (renderer.rs:282-308, 424-478, 516-556). Execution model (CDNA4-first):
+//
+//  * A wave64 owns a 16x16-pixel tile (256 rays, x4 with antialiasing) and runs them through
+//    its 64 lanes as a persistent ray pool: a lane that finishes a ray is refilled with the
+//    next pixel of the tile (wave-level __ballot + prefix popcount), so lanes stay busy until
+//    the tile is exhausted instead of idling behind the longest ray of a fixed 8x8 packet.
+//  * Every lane is a small state machine. The *stepping* state is a tight loop body: one
+//    Amanatides-Woo step of whichever DDA level the lane is on (outer cube grid or inner block
+//    voxels share the code and the registers), one 2-byte lookup, the step bookkeeping. Anything
+//    expensive -- entering a block (a new bounded raycaster: divisions, sqrt), lighting a
+//    surface (8 light texels + f64 geometry), compositing a span (powf/exp), finishing a ray
+//    (sky, encode, store), starting a ray (unprojection) -- is an *event*: the lane parks, and
+//    the wave runs the event code only when at least half of its live lanes are parked (or none
+//    can step). Rare heavy paths therefore execute with well-filled waves instead of taxing
+//    every step of every lane.
+//  * The per-lane order of operations is exactly the reference's, so results are bit-identical
+//    to the sequential formulation (hit cubes, t values, step counts).
 
 struct Diag {
     uint32_t n_outer, n_inner, n_hits, n_light;
-    // first Hit carrying a Position
-    int hit;
+    int hit;  // first Hit carrying a Position
     int cube[3], voxel[3], res, face, block;
     double t;
 };
-
-// A visible surface waiting for its exit distance (DepthIter.last_surface, surface.rs:414-427),
-// already reduced to what Surface::to_light needs.
-struct Pending {
-    float r, g, b, a;
-    float e0, e1, e2;
-    float i0, i1, i2;   // illumination
-    double t;
-    // DIAG only
+struct SurfDiag {  // DIAG only: identity of a pending surface
     uint32_t nlight;
     int cube[3], voxel[3], res, face, block;
 };
 
-template <bool VOL, int LMODE, bool DIAG>
-AIC_DEV uint32_t trace_layer(const DevLayer &L, const float *lut, const double origin[3], const double dir[3],
-                             bool include_sky, ColorBuf &acc, Diag &dg) {
-    const DevOptions &opt = L.opt;
-    float sky_light[3];
-    sky_sample(L, dir, sky_light);
-    const double t_abs = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);  // sr.rs:146
-    const float t_view = (float)(t_abs / opt.view_distance);                          // sr.rs:149-151
-    const bool fog_on = (opt.fog != 0) && include_sky;
-    const float fog_blend = opt.fog == 1 ? 1.0f : (opt.fog == 2 ? 0.5f : 0.0f);
-
-    RayDir rd;
-    raydir_init(rd, dir);
-
-    const int olo[3] = {L.lo[0], L.lo[1], L.lo[2]};
-    const int ohi[3] = {L.lo[0] + L.size[0], L.lo[1] + L.size[1], L.lo[2] + L.size[2]};
-
-    Dda cur, saved;  // `cur` = level being stepped; `saved` = outer state while inside a block
-    dda_init(cur, origin, rd, true, olo, ohi, true);
-    saved.st = FL_ENDED;
-    bool in_block = false;
-
-    // inner-level context
-    uint32_t blk_kind = 0, blk_vox_off = 0, blk_pal_off = 0, blk_ninvis = 0, blk_index = 0;
-    int ilo[3] = {0, 0, 0}, ihi[3] = {0, 0, 0};
-    double antiscale = 1.0;
-
-    uint32_t count = 0;  // primary_cubes_traced
-    bool has_last = false, buffered_enter = false;
-    Pending last;
-    last.t = 0.0;
-    last.nlight = 0;
-
-    // Surface::to_light (surface.rs:73-106) + ColorBuf accumulation (sr.rs:697-717)
-    auto accumulate = [&](float r, float g, float b, float a, float e0, float e1, float e2, float i0, float i1, float i2,
-                          double t, const Pending *diag_src) {
-        if (opt.transparency == 2) {  // limit_alpha (graphics_options.rs:496-507)
-            if (a > opt.threshold) a = 1.0f;
-            else { r = g = b = a = 0.f; }
-        }
-        if (a == 0.f && e0 == 0.f && e1 == 0.f && e2 == 0.f) return;
-        float o0 = ps_mul(ps_mul(r, i0), a) + e0;
-        float o1 = ps_mul(ps_mul(g, i1), a) + e1;
-        float o2 = ps_mul(ps_mul(b, i2), a) + e2;
-        float tr = 1.0f - a;
-        if (fog_on) {  // distance_fog (sr.rs:745-768)
-            float rel = (float)t * t_view;
-            rel = rel < 0.0f ? 0.0f : (rel > 1.0f ? 1.0f : rel);
-            float fog_exp = 1.0f - expf_exact(-1.6f * rel);
-            float fudged = fog_exp / 0.79810348f;
-            float sq = rel * rel;
-            float amount = zo_clamped(fudged * (1.0f - fog_blend) + (sq * sq) * fog_blend);
-            float comp = 1.0f - amount;
-            o0 = ps_mul(o0, comp) + ps_mul(sky_light[0], amount);
-            o1 = ps_mul(o1, comp) + ps_mul(sky_light[1], amount);
-            o2 = ps_mul(o2, comp) + ps_mul(sky_light[2], amount);
-            tr *= comp;
-        }
-        cb_add(acc, o0, o1, o2, tr);
-        if (DIAG) {
-            dg.n_hits++;
-            dg.n_light += diag_src->nlight;
-            if (!dg.hit) {
-                dg.hit = 1;
-#pragma unroll
-                for (int a2 = 0; a2 < 3; a2++) { dg.cube[a2] = diag_src->cube[a2]; dg.voxel[a2] = diag_src->voxel[a2]; }
-                dg.res = diag_src->res; dg.face = diag_src->face; dg.block = diag_src->block; dg.t = t;
-            }
-        }
-    };
-
-    for (;;) {
-        // ---- produce the next TraceStep / DepthStep ---------------------------------------
-        // kinds: 0 none/invisible, 1 surface (non-VOL) or span (VOL), 2 enter-block
-        int kind = 0;
-        Pending span;       // the surface to accumulate now
-        double span_exit = 0.0;
-
-        if (VOL && buffered_enter) {
-            buffered_enter = false;  // DepthStep::EnterBlock: counted, nothing to draw
-        } else {
-            // -- SurfaceIter::next (surface.rs:283-354) as ONE dda step of the current level --
-            bool is_exit = false;
-            bool got = dda_next(cur, rd, in_block ? ilo : olo, in_block ? ihi : ohi, &is_exit);
-            if (!got) {
-                if (in_block) {  // current_block exhausted -> resume the outer raycaster
-                    in_block = false;
-                    cur = saved;
-                    continue;
-                }
-                break;  // ray finished
-            }
-            // a TraceStep: Invisible{t} / EnterSurface / EnterBlock{t}
-            int ts_kind = 0;  // 0 Invisible, 1 EnterSurface, 2 EnterBlock
-            double ts_t = in_block ? cur.last_t * antiscale : cur.last_t;
-            Pending surf;
-            surf.nlight = 0;
-            if (!is_exit) {
-                if (!in_block) {
-                    // outer cube lookup (in bounds by construction)
-                    size_t idx = ((size_t)(cur.cube[0] - olo[0]) * (size_t)L.size[1] + (size_t)(cur.cube[1] - olo[1])) *
-                                     (size_t)L.size[2] + (size_t)(cur.cube[2] - olo[2]);
-                    uint32_t bi = L.grid[idx];
-                    if (DIAG) dg.n_outer++;
-                    if ((int)bi != L.air_index) {
-                        const DevBlock *tb = &L.blocks[bi];
-                        const uint32_t k = tb->kind;
-                        if (k == 0) {
-                            const float4 col = *reinterpret_cast<const float4 *>(tb->color);
-                            const float ex = tb->emission[0], ey = tb->emission[1], ez = tb->emission[2];
-                            if (!(col.w == 0.f && ex == 0.f && ey == 0.f && ez == 0.f)) {
-                                ts_kind = 1;
-                                surf.r = col.x; surf.g = col.y; surf.b = col.z; surf.a = col.w;
-                                surf.e0 = ex; surf.e1 = ey; surf.e2 = ez;
-                                if (DIAG) {
-#pragma unroll
-                                    for (int a = 0; a < 3; a++) { surf.cube[a] = cur.cube[a]; surf.voxel[a] = 0; }
-                                    surf.res = 1; surf.face = dda_face(cur); surf.block = (int)bi;
-                                }
-                            }
-                        } else {
-                            // RaycastStep::recursive_raycast (raycast.rs:458-476)
-                            ts_kind = 2;
-                            blk_kind = k;
-                            blk_index = bi;
-                            blk_vox_off = tb->vox_off;
-                            blk_pal_off = tb->pal_off;
-                            blk_ninvis = tb->n_invisible;
-                            const uint32_t vl = tb->vlo_packed, vs = tb->vsize_packed;
-                            ilo[0] = (int)(vl & 255u); ilo[1] = (int)((vl >> 8) & 255u); ilo[2] = (int)((vl >> 16) & 255u);
-                            ihi[0] = ilo[0] + (int)(vs & 255u); ihi[1] = ilo[1] + (int)((vs >> 8) & 255u);
-                            ihi[2] = ilo[2] + (int)((vs >> 16) & 255u);
-                            antiscale = 1.0 / (double)k;
-                            double sub[3];
-#pragma unroll
-                            for (int a = 0; a < 3; a++) sub[a] = (origin[a] - (double)cur.cube[a]) * (double)k;
-                            saved = cur;
-                            in_block = true;
-                            dda_init(cur, sub, rd, true, ilo, ihi, true);
-                        }
-                    }
-                } else {
-                    // voxel lookup (in the stored voxel bounds by construction)
-                    const int sy = ihi[1] - ilo[1], sz = ihi[2] - ilo[2];
-                    uint32_t vidx = (uint32_t)(((cur.cube[0] - ilo[0]) * sy + (cur.cube[1] - ilo[1])) * sz + (cur.cube[2] - ilo[2]));
-                    uint32_t code = L.voxels[(size_t)blk_vox_off + vidx];
-                    if (DIAG) dg.n_inner++;
-                    if (code >= blk_ninvis) {
-                        const DevPaletteEntry *pe = &L.palette[(size_t)blk_pal_off + code];
-                        const float4 col = *reinterpret_cast<const float4 *>(pe->color);
-                        const float4 em = *reinterpret_cast<const float4 *>(pe->emission);
-                        ts_kind = 1;
-                        surf.r = col.x; surf.g = col.y; surf.b = col.z; surf.a = col.w;
-                        surf.e0 = em.x; surf.e1 = em.y; surf.e2 = em.z;
-                        if (DIAG) {
-#pragma unroll
-                            for (int a = 0; a < 3; a++) { surf.cube[a] = saved.cube[a]; surf.voxel[a] = cur.cube[a]; }
-                            surf.res = (int)blk_kind; surf.face = dda_face(cur); surf.block = (int)blk_index;
-                        }
-                    }
-                }
-            }
-            if (ts_kind == 1) {
-                // illumination of this surface (surface.rs:113-206); evaluated at discovery
-                surf.t = ts_t;
-                if (LMODE == 0) {
-                    surf.i0 = surf.i1 = surf.i2 = 1.0f;
-                } else {
-                    const int face = dda_face(cur);
-                    int oc[3];
-#pragma unroll
-                    for (int a = 0; a < 3; a++) oc[a] = in_block ? saved.cube[a] : cur.cube[a];
-                    if (LMODE == 1) {
-                        int nx = 0, ny = 0, nz = 0;
-                        if (face == 1) nx = -1; else if (face == 2) ny = -1; else if (face == 3) nz = -1;
-                        else if (face == 4) nx = 1; else if (face == 5) ny = 1; else if (face == 6) nz = 1;
-                        uint32_t tx = get_packed_light<DIAG>(L, oc[0] + nx, oc[1] + ny, oc[2] + nz, surf.nlight);
-                        surf.i0 = lut[tx & 255u]; surf.i1 = lut[(tx >> 8) & 255u]; surf.i2 = lut[(tx >> 16) & 255u];
-                    } else {
-                        double ip[3];
-                        if (in_block) {
-                            double sub[3];
-#pragma unroll
-                            for (int a = 0; a < 3; a++) sub[a] = (origin[a] - (double)oc[a]) * (double)blk_kind;
-                            double vp[3];
-                            intersection_point(cur, sub, dir, vp);
-#pragma unroll
-                            for (int a = 0; a < 3; a++) ip[a] = vp[a] * antiscale + (double)oc[a];  // surface.rs:406-407
-                        } else {
-                            intersection_point(cur, origin, dir, ip);
-                        }
-                        float il[3];
-                        get_interpolated_light<DIAG>(L, lut, oc, ip, face, opt.lighting, il, surf.nlight);
-                        surf.i0 = il[0]; surf.i1 = il[1]; surf.i2 = il[2];
-                    }
-                }
-            }
-
-            // -- DepthIter::next (surface.rs:453-491) --
-            if (VOL) {
-                if (ts_kind == 1) {
-                    if (has_last) { kind = 1; span = last; span_exit = ts_t; }
-                    last = surf;
-                    has_last = true;
-                } else {
-                    if (has_last) { kind = 1; span = last; span_exit = ts_t; has_last = false; }
-                    if (ts_kind == 2) buffered_enter = true;
-                }
-            } else {
-                if (ts_kind == 1) { kind = 1; span = surf; }
-            }
-        }
-
-        // ---- TracingState::count_step_should_stop (sr.rs:625-656) --------------------------
-        count++;
-        if (count > 1000u) break;  // Exception::Incomplete adds a transparent hit: no-op for ColorBuf
-        if (cb_opaque(acc)) break;
-
-        // ---- act on the step ----------------------------------------------------------------
-        if (kind == 1) {
-            if (VOL) {
-                // trace_through_span (sr.rs:720-740)
-                float thickness = (float)((span_exit - span.t) * t_abs);
-                bool all_transparent;
-                float alpha, coeff;
-                apply_transmittance(span.a, thickness, &all_transparent, &alpha, &coeff);
-                float r = all_transparent ? 0.f : span.r, g = all_transparent ? 0.f : span.g, b = all_transparent ? 0.f : span.b;
-                float c = ps_clamped(coeff);
-                accumulate(r, g, b, alpha, ps_mul(span.e0, c), ps_mul(span.e1, c), ps_mul(span.e2, c), span.i0, span.i1,
-                           span.i2, span.t, &span);
-            } else {
-                accumulate(span.r, span.g, span.b, span.a, span.e0, span.e1, span.e2, span.i0, span.i1, span.i2, span.t, &span);
-            }
-        }
-    }
-
-    // ---- finish (sr.rs:658-693): the sky hit, then the optional cost visualisation ----------
-    if (include_sky) cb_add(acc, sky_light[0] * 1.0f, sky_light[1] * 1.0f, sky_light[2] * 1.0f, 0.0f);
-    else cb_add(acc, 0.f, 0.f, 0.f, 1.0f);
-    if (opt.debug_pixel_cost) {  // accum.rs:228-234
-        float n = ps_clamped((float)count);
-        float red = ps_clamped(ps_mul(0.02f, n) * 1.0f);
-        float green = ps_clamped(ps_mul(0.002f, n) * 1.0f);
-        float cur_rgba[4];
-        cb_to_rgba(acc, cur_rgba);
-        float blue = ps_clamped(luminance(cur_rgba[0], cur_rgba[1], cur_rgba[2]) * 0.2f);
-        acc.l0 = red; acc.l1 = green; acc.l2 = blue; acc.t = 0.0f;
-    }
-    return count;
+AIC_DEV void sky_of(const DevLayer &L, double dx, double dy, double dz, float out[3]) {  // Sky::sample (sky.rs:32-41)
+    int idx = 0;
+    if (L.sky_kind != 0) idx = ((dx >= 0.0 ? 1 : 0) << 2) + ((dy >= 0.0 ? 1 : 0) << 1) + (dz >= 0.0 ? 1 : 0);
+    out[0] = L.sky[idx][0]; out[1] = L.sky[idx][1]; out[2] = L.sky[idx][2];
 }
 
-// ---------------------------------------------------------------------------------------
 // camera (camera_struct.rs:238-257; euclid Transform3D::transform_point3d)
-
-AIC_DEV void unproject(const double *m, double x, double y, double z, double out[3]) {
-    double px = x * m[0] + y * m[4] + z * m[8] + m[12];
-    double py = x * m[1] + y * m[5] + z * m[9] + m[13];
-    double pz = x * m[2] + y * m[6] + z * m[10] + m[14];
-    double pw = x * m[3] + y * m[7] + z * m[11] + m[15];
+AIC_DEV void unproject(const double *__restrict__ m, double x, double y, double z, double out[3]) {
+    const double px = x * m[0] + y * m[4] + z * m[8] + m[12];
+    const double py = x * m[1] + y * m[5] + z * m[9] + m[13];
+    const double pz = x * m[2] + y * m[6] + z * m[10] + m[14];
+    const double pw = x * m[3] + y * m[7] + z * m[11] + m[15];
     if (pw > 0.0) {
         out[0] = px / pw; out[1] = py / pw; out[2] = pz / pw;
     } else {
         const double nan = __longlong_as_double(0x7ff8000000000000LL);
         out[0] = out[1] = out[2] = nan;
     }
-}
-AIC_DEV void project_ndc_into_world(const double *inv, double x, double y, double origin[3], double dir[3]) {
-    double f[3];
-    unproject(inv, x, y, 0.0, origin);
-    unproject(inv, x, y, 1.0, f);
-    dir[0] = f[0] - origin[0]; dir[1] = f[1] - origin[1]; dir[2] = f[2] - origin[2];
 }
 
 constexpr float NO_WORLD_TO_SHOW = 0.5028865f;  // palette.rs:76 #BCBCBC decoded to linear
@@ -867,164 +657,662 @@ constexpr float NO_WORLD_TO_SHOW = 0.5028865f;  // palette.rs:76 #BCBCBC decoded
 AIC_DEV double fb_x_edge(uint32_t w, uint32_t x) { return ((double)x) / (double)w * 2.0 - 1.0; }
 AIC_DEV double fb_y_edge(uint32_t h, uint32_t y) { return -(((double)y) / (double)h * 2.0 - 1.0); }
 
-// The image kernel: trace_scene_to_image_impl + RtScene::trace_patch +
-// trace_ray_through_layers + the draw_rgba encoder (renderer.rs:282-308, 424-478, 516-556).
-//
-// The reference composites, per sample: UI space (include_sky = false) -> backdrop -> world
-// space -> NO_WORLD_TO_SHOW fallback, all into one accumulator. Here one launch traces ONE
-// layer (so the kernel is specialised for that layer's options): with a UI space present the
-// UI pre-pass (F.pass == 1) leaves each sample's ColorBuf in F.acc_buf and the final pass
-// (F.pass == 0) picks it up; without a UI space (the benchmark configurations) there is a
-// single launch and no intermediate buffer.
-template <bool VOL, int LMODE, bool DIAG>
-__global__ __launch_bounds__(256) void trace_image_kernel(const DevFrame F) {
-    // XCD-aware tile order: consecutive workgroup ids are dealt round-robin to the 8 XCDs, so
-    // give XCD x the x-th contiguous eighth of the tile list (shared scene data stays in one L2).
-    const uint32_t n_tiles = F.tiles_x * F.tiles_y;
-    uint32_t tile;
-    {
-        const uint32_t b = blockIdx.x;
-        const uint32_t per = (n_tiles + 7u) / 8u;
-        const uint32_t xcd = b & 7u, within = b >> 3;
-        tile = xcd * per + within;
-        if (within >= per || tile >= n_tiles) return;
-    }
-    const uint32_t tx = tile % F.tiles_x, ty = tile / F.tiles_x;
-    // lane -> pixel: each wave64 is an 8x8 sub-tile of the 16x16 workgroup tile
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t lx = (lane & 7u) + ((wave & 1u) << 3);
-    const uint32_t ly = (lane >> 3) + ((wave >> 1) << 3);
-    const uint32_t x = tx * kTile + lx;
-    const uint32_t lrow = ty * kTile + ly;  // local (compacted) row
-    const bool active = (x < F.width) && (lrow < F.local_rows);
-    const bool ui_pass = F.pass == 1;
-    const DevLayer &L = ui_pass ? F.ui : F.world;
-    const size_t npix = (size_t)F.width * F.local_rows;
-    const size_t pix = (size_t)lrow * F.width + x;
+// Rgba::to_srgb8 colour channel (color.rs:1038-1054) without powf: `thr[k]` (k = 1..255) is
+// the smallest f32 whose reference encoding is >= k (built on the host with the reference
+// formula), so the encoding of c is the number of thresholds <= c. A fast estimate seeds the
+// search; the thresholds make the result exact.
+AIC_DEV uint32_t srgb8_channel(float c, const float *__restrict__ thr) {
+    if (!(c > 0.f)) return 0u;  // 0, negatives (cannot occur) and NaN encode to 0
+    float e = c <= 0.0031308f ? c * 12.92f : 1.055f * __powf(c, 0.41666666f) - 0.055f;
+    int k = (int)(e * 255.f + 0.5f);
+    k = k < 0 ? 0 : (k > 255 ? 255 : k);
+    while (k < 255 && c >= thr[k + 1]) k++;
+    while (k > 0 && c < thr[k]) k--;
+    return (uint32_t)k;
+}
 
-    uint32_t steps = 0, steps_prev = 0;
+// lane event bits
+constexpr uint32_t EV_FLUSH = 1u, EV_LIGHT = 2u, EV_ENTER = 4u, EV_FINISH = 8u, EV_NEWRAY = 16u, EV_DONE = 32u;
+// lane state bits (st): 0-1 first_last | 2-4 last_face | 5-6 pick | 7 need_step | 8 include_exit (unused here)
+constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_BUFFERED = 1u << 11, ST_OPAQUE = 1u << 12, ST_TRACED = 1u << 13;
+
+#ifndef AIC_MIN_WAVES
+#define AIC_MIN_WAVES 2
+#endif
+#ifndef AIC_T_BATCH
+#define AIC_T_BATCH 32  // run a kind of parked work once this many lanes wait on it
+#endif
+#ifndef AIC_N_FEW
+#define AIC_N_FEW 8     // ... or once at most this many lanes can still step
+#endif
+
+template <bool VOL, int LMODE, bool DIAG>
+__global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const DevFrame F) {
+    // ---- persistent waves: each wave pulls 16x16-pixel tiles from a global counter until the
+    // image is exhausted, so cheap (sky) and expensive (geometry) tiles balance dynamically ----
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_tiles = F.tiles_x * F.tiles_y;
+    uint32_t tile_cur = 0xffffffffu;  // wave-uniform: tile the refill is drawing pixels from
+    const DevLayer &L = F.layer;
+    const DevOptions &opt = L.opt;
+    const float *__restrict__ lut = F.light_lut;
+    const bool ui_pass = F.pass == 1;
+    const bool include_sky = !ui_pass;
+    const bool fog_on = (opt.fog != 0) && include_sky;
+    const size_t npix = (size_t)F.width * F.local_rows;
+    const int n_samples = F.antialias ? 4 : 1;
+
+    const int olx = L.lo[0], oly = L.lo[1], olz = L.lo[2];
+    const int ohx = olx + L.size[0], ohy = oly + L.size[1], ohz = olz + L.size[2];
+    const uint32_t osy = (uint32_t)L.size[1], osz = (uint32_t)L.size[2];
+
+    // ---- per-lane ray state ----
+    double ox = 0, oy = 0, oz = 0;     // ray origin
+    RayDir rd;
+    rd.dx = rd.dy = rd.dz = 0.0; rd.tdx = rd.tdy = rd.tdz = 0.0; rd.sx = rd.sy = rd.sz = 0;
+    double dirx = 0, diry = 0, dirz = 0;  // un-sanitised direction (sky, length, intersection point)
+    Lvl cur, saved;
+    cur.tx = cur.ty = cur.tz = cur.last_t = 0.0; cur.cx = cur.cy = cur.cz = 0; cur.st = FL_ENDED;
+    saved = cur;
+    Lim lim;
+    lim.x = lim.y = lim.z = 0;
+    uint32_t blk_index = 0, blk_res = 1, blk_vlo = 0, blk_vsize = 0, blk_vox_off = 0, blk_pal_off = 0, blk_ninvis = 0;
+    ColorBuf acc;
+    acc.l0 = acc.l1 = acc.l2 = 0.f; acc.t = 1.0f;
+    uint32_t count = 0;
+    double t_abs = 0.0;
+    float t_view = 0.f;
+    // surfaces in flight: `last` = DepthIter.last_surface, `span` = the one being composited
+    uint32_t last_ref = 0, span_ref = 0;
+    float last_i0 = 1.f, last_i1 = 1.f, last_i2 = 1.f, span_i0 = 1.f, span_i1 = 1.f, span_i2 = 1.f;
+    double last_t = 0.0, span_t = 0.0, span_exit = 0.0;
+    SurfDiag last_d, span_d;
+    if (DIAG) {
+        last_d.nlight = span_d.nlight = 0; last_d.res = last_d.face = last_d.block = span_d.res = span_d.face = span_d.block = 0;
+        for (int a = 0; a < 3; a++) last_d.cube[a] = last_d.voxel[a] = span_d.cube[a] = span_d.voxel[a] = 0;
+    }
+    // pixel bookkeeping
+    uint32_t pxy = 0;           // this lane's pixel: x | (local row << 16)
+    int sample = 0;             // antialiasing sample being traced
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, st_sum = 0.f;  // ColorBuf::mean accumulators
+    uint32_t px_steps = 0, px_steps_prev = 0;          // DIAG: steps of this pixel
     Diag dg;
     if (DIAG) {
-        dg.n_outer = dg.n_inner = dg.n_hits = dg.n_light = 0;
-        dg.hit = 0;
-        dg.cube[0] = dg.cube[1] = dg.cube[2] = 0;
-        dg.voxel[0] = dg.voxel[1] = dg.voxel[2] = 0;
-        dg.res = dg.face = dg.block = 0;
-        dg.t = 0.0;
+        dg.n_outer = dg.n_inner = dg.n_hits = dg.n_light = 0; dg.hit = 0; dg.res = dg.face = dg.block = 0; dg.t = 0.0;
+        for (int a = 0; a < 3; a++) dg.cube[a] = dg.voxel[a] = 0;
     }
-    if (active) {
-        // global row of this local row under the strip partition
-        const uint32_t strip_local = lrow / F.strip_rows;
-        const uint32_t y = (F.part + strip_local * F.n_parts) * F.strip_rows + (lrow % F.strip_rows);
-        const double x0 = fb_x_edge(F.width, x), x1 = fb_x_edge(F.width, x + 1);
-        const double y0 = fb_y_edge(F.height, y), y1 = fb_y_edge(F.height, y + 1);
-        if (DIAG && F.use_init && F.aux) {  // continue the UI pre-pass's per-pixel record
-            const DevAux &a = F.aux[pix];
-            dg.hit = a.hit;
-#pragma unroll
-            for (int k = 0; k < 3; k++) { dg.cube[k] = a.cube[k]; dg.voxel[k] = a.voxel[k]; }
-            dg.res = a.resolution; dg.face = a.face; dg.block = a.block_index; dg.t = a.t_distance;
-            steps_prev = a.cubes_traced;
+    unsigned long long total_steps = 0;
+    uint32_t tot_outer = 0, tot_inner = 0, tot_hits = 0, tot_light = 0;
+
+    uint32_t ev = EV_NEWRAY | 64u;  // every lane starts by taking a pixel
+#ifdef AIC_PROFILE
+    uint32_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define AIC_PROF(i, v) prof[i] += (uint32_t)(v)
+#else
+#define AIC_PROF(i, v)
+#endif
+    uint32_t next_idx = 256;  // wave-uniform: next unassigned pixel of tile_cur (256 = tile exhausted)
+
+    for (;;) {
+        // ---- wave scheduler: step, or run ONE kind of parked work for all lanes waiting on it ----
+        // Kinds: LIGHT, FLUSH, ENTER, RAY (finish the old ray and/or start a new one). A kind is run
+        // when enough lanes wait on it to fill the wave reasonably (AIC_T_BATCH), or when so few
+        // lanes can still step (AIC_N_FEW) that waiting longer only idles the wave.
+        const unsigned long long m_st = __ballot(ev == 0u);
+        // for !VOL a surface is lit before it is composited, so its FLUSH waits for its LIGHT
+        const unsigned long long b_light = __ballot((ev & EV_LIGHT) != 0u);
+        const unsigned long long b_flush = __ballot((ev & EV_FLUSH) != 0u && (VOL || (ev & EV_LIGHT) == 0u));
+        const unsigned long long b_enter = __ballot((ev & EV_ENTER) != 0u);
+        const unsigned long long b_ray = __ballot((ev & (EV_FINISH | EV_NEWRAY)) != 0u);
+        if ((m_st | b_light | b_flush | b_enter | b_ray) == 0ull) break;
+        const int n_step = __popcll(m_st);
+        const int c_light = __popcll(b_light), c_flush = __popcll(b_flush), c_enter = __popcll(b_enter), c_ray = __popcll(b_ray);
+        uint32_t run = 0u;  // kind to run this trip (an EV_* bit), 0 = step
+        {
+            int best = c_light;
+            uint32_t kind = EV_LIGHT;
+            if (c_flush > best) { best = c_flush; kind = EV_FLUSH; }
+            if (c_enter > best) { best = c_enter; kind = EV_ENTER; }
+            if (c_ray > best) { best = c_ray; kind = EV_FINISH; }
+            if (best > 0 && (best >= AIC_T_BATCH || n_step <= AIC_N_FEW)) run = kind;
         }
-        // sub-sample positions (renderer.rs:428-433 for antialiasing, else the patch centre)
-        const bool aa = F.world.opt.antialiasing == 2;
-        const int n_samples = aa ? 4 : 1;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, st = 0.f;
-        ColorBuf acc;
-        Diag d0 = dg;
-        for (int i = 0; i < n_samples; i++) {
-            double px, py;
-            if (aa) {
-                const double ux = (i == 0) ? 1. / 8. : (i == 1) ? 3. / 8. : (i == 2) ? 5. / 8. : 7. / 8.;
-                const double uy = (i == 0) ? 5. / 8. : (i == 1) ? 1. / 8. : (i == 2) ? 7. / 8. : 3. / 8.;
-                px = x0 + (x1 - x0) * ux;
-                py = y0 + (y1 - y0) * uy;
-            } else {
-                px = (x0 + x1) / 2.0;
-                py = (y0 + y1) / 2.0;
-            }
-            if (F.use_init) {
-                const float4 v = F.acc_buf[(size_t)i * npix + pix];
-                acc.l0 = v.x; acc.l1 = v.y; acc.l2 = v.z; acc.t = v.w;
-            } else {
-                acc.l0 = acc.l1 = acc.l2 = 0.f;
-                acc.t = 1.0f;
-            }
-            Diag di = dg;
-            if (DIAG && i > 0) di.hit = 1;  // only the first sample's position is reported
-            if (!ui_pass && F.has_backdrop) {  // Exception::Backdrop hit: ColorBuf::from(Rgba)
-                const float a = F.backdrop[3];
-                cb_add(acc, F.backdrop[0] * a, F.backdrop[1] * a, F.backdrop[2] * a, 1.0f - a);
-            }
-            if (L.present) {
-                double o[3], d[3];
-                project_ndc_into_world(L.inv, px, py, o, d);
-                steps += trace_layer<VOL, LMODE, DIAG>(L, F.light_lut, o, d, !ui_pass, acc, di);
-            }
-            if (DIAG) {
-                if (i == 0) d0 = di;
-                else { d0.n_outer = di.n_outer; d0.n_inner = di.n_inner; d0.n_hits = di.n_hits; d0.n_light = di.n_light; }
-                dg.n_outer = di.n_outer; dg.n_inner = di.n_inner; dg.n_hits = di.n_hits; dg.n_light = di.n_light;
-            }
-            if (ui_pass) {
-                F.acc_buf[(size_t)i * npix + pix] = make_float4(acc.l0, acc.l1, acc.l2, acc.t);
-            } else {
-                if (!cb_opaque(acc)) {  // P::paint(NO_WORLD_TO_SHOW) replaces the accumulator
-                    acc.l0 = 0.f + (NO_WORLD_TO_SHOW * 1.0f) * 1.0f;
-                    acc.l1 = acc.l0;
-                    acc.l2 = acc.l0;
-                    acc.t = 1.0f * (1.0f - 1.0f);
-                }
-                s0 = s0 + acc.l0; s1 = s1 + acc.l1; s2 = s2 + acc.l2; st = st + acc.t;
-            }
-        }
-        if (DIAG) dg = d0;
-        if (!ui_pass) {
-            ColorBuf pixel;
-            if (aa) {  // ColorBuf::mean (raytracer_components.rs:97-102)
-                pixel.l0 = s0 / 4.0f; pixel.l1 = s1 / 4.0f; pixel.l2 = s2 / 4.0f; pixel.t = st / 4.0f;
-            } else {
-                pixel = acc;
-            }
-            // encoder: Camera::post_process_color(Rgba::from(buf)).to_srgb8()
-            float c[4];
-            cb_to_rgba(pixel, c);
-            const float ex = F.world.exposure;
-            float r = ps_mul(c[0], ex), g = ps_mul(c[1], ex), bl = ps_mul(c[2], ex);
-            const float m = F.world.opt.maximum_intensity;
-            if (isfinite(m)) {  // ToneMappingOperator::apply (graphics_options.rs:352-368)
-                if (F.world.opt.tone_mapping == 0) {
-                    r = r < 0.f ? 0.f : (r > m ? m : r);
-                    g = g < 0.f ? 0.f : (g > m ? m : g);
-                    bl = bl < 0.f ? 0.f : (bl > m ? m : bl);
+        if (run != 0u) {
+            // ============================ event phase ======================================
+            AIC_PROF(0, 1);
+            AIC_PROF(1, c_light + c_flush + c_enter + c_ray);
+            AIC_PROF(2, run == EV_FLUSH ? 1 : 0); AIC_PROF(3, run == EV_FLUSH ? c_flush : 0);
+            AIC_PROF(4, run == EV_LIGHT ? 1 : 0); AIC_PROF(5, run == EV_LIGHT ? c_light : 0);
+            AIC_PROF(6, run == EV_ENTER ? 1 : 0); AIC_PROF(7, run == EV_ENTER ? c_enter : 0);
+            AIC_PROF(8, run == EV_FINISH ? 1 : 0); AIC_PROF(9, run == EV_FINISH ? c_ray : 0);
+            // -- compositing a surface / span: trace_through_span + Surface::to_light + ColorBuf add --
+            // (for !VOL the surface's light must be known first, so LIGHT runs before FLUSH)
+            auto do_light = [&](float &i0, float &i1, float &i2, SurfDiag &sd) {
+                // illumination of the surface discovered by the step held in `cur` (surface.rs:113-206)
+                const int face = lvl_face(cur);
+                const bool inb = (cur.st & ST_IN_BLOCK) != 0;
+                const int ocx = inb ? saved.cx : cur.cx, ocy = inb ? saved.cy : cur.cy, ocz = inb ? saved.cz : cur.cz;
+                uint32_t nl = 0;
+                if (LMODE == 1) {
+                    int nx = 0, ny = 0, nz = 0;
+                    if (face == 1) nx = -1; else if (face == 2) ny = -1; else if (face == 3) nz = -1;
+                    else if (face == 4) nx = 1; else if (face == 5) ny = 1; else if (face == 6) nz = 1;
+                    const uint32_t tx = get_packed_light<DIAG>(L, ocx + nx, ocy + ny, ocz + nz, nl);
+                    i0 = lut[tx & 255u]; i1 = lut[(tx >> 8) & 255u]; i2 = lut[(tx >> 16) & 255u];
                 } else {
-                    float scale = ps_clamped(1.0f / (1.0f + luminance(r, g, bl) / m));
-                    r = ps_mul(r, scale); g = ps_mul(g, scale); bl = ps_mul(bl, scale);
+                    double ip[3];
+                    if (inb) {
+                        const double kd = (double)blk_res;
+                        double vp[3];
+                        intersection_point(cur, (ox - (double)ocx) * kd, (oy - (double)ocy) * kd, (oz - (double)ocz) * kd, dirx, diry, dirz, vp);
+                        const double as = 1.0 / kd;
+                        ip[0] = vp[0] * as + (double)ocx;  // surface.rs:406-407
+                        ip[1] = vp[1] * as + (double)ocy;
+                        ip[2] = vp[2] * as + (double)ocz;
+                    } else {
+                        intersection_point(cur, ox, oy, oz, dirx, diry, dirz, ip);
+                    }
+                    const int oc[3] = {ocx, ocy, ocz};
+                    float il[3];
+                    get_interpolated_light<DIAG>(L, lut, oc, ip, face, opt.lighting, il, nl);
+                    i0 = il[0]; i1 = il[1]; i2 = il[2];
+                }
+                if (DIAG) sd.nlight = nl;
+            };
+            if (run == EV_LIGHT && !VOL && LMODE != 0 && (ev & EV_LIGHT)) {
+                do_light(span_i0, span_i1, span_i2, span_d);
+                ev &= ~EV_LIGHT;
+            }
+            if (run == EV_FLUSH && (ev & EV_FLUSH) && (VOL || (ev & EV_LIGHT) == 0u)) {
+                float r, g, b, a, e0, e1, e2;
+                if (span_ref & 0x80000000u) {
+                    const DevBlock *tb = &L.blocks[span_ref & 0xffffu];
+                    const float4 col = *reinterpret_cast<const float4 *>(tb->color);
+                    r = col.x; g = col.y; b = col.z; a = col.w;
+                    e0 = tb->emission[0]; e1 = tb->emission[1]; e2 = tb->emission[2];
+                } else {
+                    const DevPaletteEntry *pe = &L.palette[span_ref];
+                    const float4 col = *reinterpret_cast<const float4 *>(pe->color);
+                    const float4 em = *reinterpret_cast<const float4 *>(pe->emission);
+                    r = col.x; g = col.y; b = col.z; a = col.w;
+                    e0 = em.x; e1 = em.y; e2 = em.z;
+                }
+                if (VOL) {
+                    // trace_through_span (sr.rs:720-740) + apply_transmittance (raytracer_components.rs:215-258)
+                    float thickness = (float)((span_exit - span_t) * t_abs);
+                    thickness = fmaxf(thickness, 0.0f);
+                    float coeff;
+                    if (thickness == 0.0f) {
+                        if (a == 1.0f) coeff = 1.0f;
+                        else { r = g = b = a = 0.f; coeff = 0.0f; }
+                    } else {
+                        const float unit_t = 1.0f - a;
+                        // powf(0, y>0) == 0 and powf(1, y) == 1 exactly: skip the general evaluation
+                        const float depth_t = unit_t == 0.0f ? 0.0f : (unit_t == 1.0f ? 1.0f : powf_exact(unit_t, thickness));
+                        a = zo_clamped(1.0f - depth_t);
+                        const float ec = (unit_t == 1.0f) ? thickness : (depth_t - 1.f) / (unit_t - 1.f);
+                        coeff = fmaxf(ec, 0.0f);
+                    }
+                    const float c = ps_clamped(coeff);
+                    e0 = ps_mul(e0, c); e1 = ps_mul(e1, c); e2 = ps_mul(e2, c);
+                }
+                // Surface::to_light (surface.rs:73-106)
+                if (opt.transparency == 2) {  // limit_alpha (graphics_options.rs:496-507)
+                    if (a > opt.threshold) a = 1.0f;
+                    else { r = g = b = a = 0.f; }
+                }
+                if (!(a == 0.f && e0 == 0.f && e1 == 0.f && e2 == 0.f)) {
+                    float o0 = ps_mul(ps_mul(r, span_i0), a) + e0;
+                    float o1 = ps_mul(ps_mul(g, span_i1), a) + e1;
+                    float o2 = ps_mul(ps_mul(b, span_i2), a) + e2;
+                    float tr = 1.0f - a;
+                    if (fog_on) {  // distance_fog (sr.rs:745-768)
+                        float sky[3];
+                        sky_of(L, dirx, diry, dirz, sky);
+                        const float fog_blend = opt.fog == 1 ? 1.0f : (opt.fog == 2 ? 0.5f : 0.0f);
+                        float rel = (float)span_t * t_view;
+                        rel = rel < 0.0f ? 0.0f : (rel > 1.0f ? 1.0f : rel);
+                        const float fog_exp = 1.0f - expf_exact(-1.6f * rel);
+                        const float fudged = fog_exp / 0.79810348f;
+                        const float sq = rel * rel;
+                        const float amount = zo_clamped(fudged * (1.0f - fog_blend) + (sq * sq) * fog_blend);
+                        const float comp = 1.0f - amount;
+                        o0 = ps_mul(o0, comp) + ps_mul(sky[0], amount);
+                        o1 = ps_mul(o1, comp) + ps_mul(sky[1], amount);
+                        o2 = ps_mul(o2, comp) + ps_mul(sky[2], amount);
+                        tr *= comp;
+                    }
+                    cb_add(acc, o0, o1, o2, tr);
+                    if (cb_opaque(acc)) cur.st |= ST_OPAQUE;
+                    if (DIAG) {
+                        dg.n_hits++;
+                        dg.n_light += span_d.nlight;
+                        if (!dg.hit) {
+                            dg.hit = 1;
+                            for (int a2 = 0; a2 < 3; a2++) { dg.cube[a2] = span_d.cube[a2]; dg.voxel[a2] = span_d.voxel[a2]; }
+                            dg.res = span_d.res; dg.face = span_d.face; dg.block = span_d.block; dg.t = span_t;
+                        }
+                    }
+                }
+                ev &= ~EV_FLUSH;
+            }
+            if (run == EV_LIGHT && VOL && LMODE != 0 && (ev & EV_LIGHT)) {
+                do_light(last_i0, last_i1, last_i2, last_d);
+                ev &= ~EV_LIGHT;
+            }
+            if (LMODE == 0) ev &= ~EV_LIGHT;
+            // -- entering a recursive block: RaycastStep::recursive_raycast (raycast.rs:458-476) --
+            if (run == EV_ENTER && (ev & EV_ENTER)) {
+                const DevBlock *tb = &L.blocks[blk_index];
+                blk_vlo = tb->vlo_packed;
+                blk_vsize = tb->vsize_packed;
+                blk_vox_off = tb->vox_off;
+                blk_pal_off = tb->pal_off;
+                blk_ninvis = tb->n_invisible;
+                const double kd = (double)blk_res;
+                const double sx_ = (ox - (double)cur.cx) * kd, sy_ = (oy - (double)cur.cy) * kd, sz_ = (oz - (double)cur.cz) * kd;
+                const uint32_t keep = cur.st & (ST_HAS_LAST | ST_BUFFERED | ST_OPAQUE | ST_TRACED);
+                saved = cur;
+                const int ilx = (int)(blk_vlo & 255u), ily = (int)((blk_vlo >> 8) & 255u), ilz = (int)((blk_vlo >> 16) & 255u);
+                const LvlLim ll = lvl_init(sx_, sy_, sz_, rd, true, ilx, ily, ilz, ilx + (int)(blk_vsize & 255u),
+                                           ily + (int)((blk_vsize >> 8) & 255u), ilz + (int)((blk_vsize >> 16) & 255u), true);
+                cur = ll.s;
+                lim = ll.lim;
+                cur.st |= keep | ST_IN_BLOCK;
+                ev &= ~EV_ENTER;
+            }
+            // -- finishing a ray: TracingState::finish + layer tail + (last sample) encode & store --
+            if (run == EV_FINISH && (ev & EV_FINISH)) {
+                if (cur.st & ST_TRACED) {
+                    // finish (sr.rs:658-693): the sky hit, then the optional cost visualisation
+                    if (include_sky) {
+                        float sky[3];
+                        sky_of(L, dirx, diry, dirz, sky);
+                        cb_add(acc, sky[0] * 1.0f, sky[1] * 1.0f, sky[2] * 1.0f, 0.0f);
+                    } else {
+                        cb_add(acc, 0.f, 0.f, 0.f, 1.0f);
+                    }
+                    if (opt.debug_pixel_cost) {  // accum.rs:228-234
+                        const float n = ps_clamped((float)count);
+                        const float red = ps_clamped(ps_mul(0.02f, n) * 1.0f);
+                        const float green = ps_clamped(ps_mul(0.002f, n) * 1.0f);
+                        float cur_rgba[4];
+                        cb_to_rgba(acc, cur_rgba);
+                        const float blue = ps_clamped(luminance(cur_rgba[0], cur_rgba[1], cur_rgba[2]) * 0.2f);
+                        acc.l0 = red; acc.l1 = green; acc.l2 = blue; acc.t = 0.0f;
+                    }
+                    total_steps += count;
+                    if (DIAG) px_steps += count;
+                }
+                const uint32_t x = pxy & 0xffffu, lrow = pxy >> 16;
+                const size_t pix = (size_t)lrow * F.width + x;
+                if (ui_pass) {
+                    F.acc_buf[(size_t)sample * npix + pix] = make_float4(acc.l0, acc.l1, acc.l2, acc.t);
+                } else {
+                    if (!cb_opaque(acc)) {  // renderer.rs:474-477: P::paint(NO_WORLD_TO_SHOW) replaces the accumulator
+                        acc.l0 = 0.f + (NO_WORLD_TO_SHOW * 1.0f) * 1.0f;
+                        acc.l1 = acc.l0;
+                        acc.l2 = acc.l0;
+                        acc.t = 1.0f * (1.0f - 1.0f);
+                    }
+                    s0 = s0 + acc.l0; s1 = s1 + acc.l1; s2 = s2 + acc.l2; st_sum = st_sum + acc.t;
+                }
+                sample++;
+                if (sample < n_samples) {
+                    ev = EV_NEWRAY;  // next antialiasing sample of the same pixel
+                } else {
+                    if (!ui_pass) {
+                        ColorBuf pixel;
+                        if (n_samples == 4) {  // ColorBuf::mean (raytracer_components.rs:97-102)
+                            pixel.l0 = s0 / 4.0f; pixel.l1 = s1 / 4.0f; pixel.l2 = s2 / 4.0f; pixel.t = st_sum / 4.0f;
+                        } else {
+                            pixel = acc;
+                        }
+                        // encoder: Camera::post_process_color(Rgba::from(buf)).to_srgb8()
+                        float c[4];
+                        cb_to_rgba(pixel, c);
+                        const float ex = F.exposure;
+                        float r = ps_mul(c[0], ex), g = ps_mul(c[1], ex), bl = ps_mul(c[2], ex);
+                        const float m = F.maximum_intensity;
+                        if (isfinite(m)) {  // ToneMappingOperator::apply (graphics_options.rs:352-368)
+                            if (F.tone_mapping == 0) {
+                                r = r < 0.f ? 0.f : (r > m ? m : r);
+                                g = g < 0.f ? 0.f : (g > m ? m : g);
+                                bl = bl < 0.f ? 0.f : (bl > m ? m : bl);
+                            } else {
+                                const float scale = ps_clamped(1.0f / (1.0f + luminance(r, g, bl) / m));
+                                r = ps_mul(r, scale); g = ps_mul(g, scale); bl = ps_mul(bl, scale);
+                            }
+                        }
+                        const uint32_t R = srgb8_channel(r, F.srgb_thr);
+                        const uint32_t G = srgb8_channel(g, F.srgb_thr);
+                        const uint32_t B = srgb8_channel(bl, F.srgb_thr);
+                        const uint32_t A = round_sat_u8(c[3] * 255.0f);
+                        F.out[pix] = R | (G << 8) | (B << 16) | (A << 24);
+                    }
+                    if (DIAG) {
+                        if (F.aux) {
+                            DevAux &a = F.aux[pix];
+                            a.hit = dg.hit & 1;
+                            for (int k = 0; k < 3; k++) { a.cube[k] = dg.cube[k]; a.voxel[k] = dg.voxel[k]; }
+                            a.resolution = dg.res; a.face = dg.face; a.block_index = dg.block;
+                            a.cubes_traced = px_steps_prev + px_steps; a.pad = 0; a.t_distance = dg.t;
+                        }
+                        tot_outer += dg.n_outer; tot_inner += dg.n_inner; tot_hits += dg.n_hits; tot_light += dg.n_light;
+                    }
+                    sample = 0;
+                    ev = EV_NEWRAY | 64u;  // 64: take a new pixel
                 }
             }
-            const uint32_t R = round_sat_u8(component_to_srgb(r) * 255.f);
-            const uint32_t G = round_sat_u8(component_to_srgb(g) * 255.f);
-            const uint32_t B = round_sat_u8(component_to_srgb(bl) * 255.f);
-            const uint32_t A = round_sat_u8(c[3] * 255.0f);
-            F.out[pix] = R | (G << 8) | (B << 16) | (A << 24);
+            // -- starting a ray: lane refill + Camera::project_ndc_into_world + Raycaster::within --
+            if (run == EV_FINISH) {
+                // wave-level refill (uniform control flow): hand the next unassigned pixels to the
+                // lanes that finished a pixel -- ballot + prefix popcount -- pulling a fresh tile
+                // from the global counter whenever the current one is used up.
+                bool want = (ev & (EV_NEWRAY | 64u)) == (EV_NEWRAY | 64u);
+                for (;;) {
+                    const unsigned long long need = __ballot(want);
+                    if (need == 0ull) break;
+                    if (next_idx >= 256u) {
+                        uint32_t t = 0;
+                        if (lane == (uint32_t)__ffsll((long long)need) - 1u) t = atomicAdd(&F.counters->tile_next, 1u);
+                        tile_cur = (uint32_t)__shfl((int)t, (int)(__ffsll((long long)need) - 1), 64);
+                        next_idx = 0;
+                    }
+                    if (tile_cur >= n_tiles) {  // image exhausted: these lanes are done
+                        if (want) ev = EV_DONE;
+                        tile_cur = 0xffffffffu;
+                        next_idx = 256;
+                        break;
+                    }
+                    const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                    const uint32_t avail = 256u - next_idx;
+                    if (want && rank < avail) {
+                        const uint32_t pidx = next_idx + rank;
+                        // pixel order inside a tile: four 8x8 quadrants, row-major inside each
+                        const uint32_t x = (tile_cur % F.tiles_x) * kTile + (pidx & 7u) + (((pidx >> 6) & 1u) << 3);
+                        const uint32_t lrow = (tile_cur / F.tiles_x) * kTile + ((pidx >> 3) & 7u) + (((pidx >> 7) & 1u) << 3);
+                        if (x < F.width && lrow < F.local_rows) {  // pixels of partial tiles outside the image are skipped
+                            pxy = x | (lrow << 16);
+                            want = false;
+                        }
+                    }
+                    const uint32_t n_need = (uint32_t)__popcll(need);
+                    next_idx += n_need < avail ? n_need : avail;
+                }
+            }
+            if (run == EV_FINISH && (ev & EV_NEWRAY) && ev != EV_DONE) {
+                bool have_pixel = true;
+                if (ev & 64u) {
+                    const uint32_t x = pxy & 0xffffu, lrow = pxy >> 16;
+                    s0 = s1 = s2 = st_sum = 0.f;
+                    if (DIAG) {
+                        dg.n_outer = dg.n_inner = dg.n_hits = dg.n_light = 0; dg.hit = 0; dg.res = dg.face = dg.block = 0; dg.t = 0.0;
+                        for (int a = 0; a < 3; a++) dg.cube[a] = dg.voxel[a] = 0;
+                        px_steps = 0; px_steps_prev = 0;
+                        if (F.use_init && F.aux) {  // continue the UI pre-pass's per-pixel record
+                            const DevAux &a = F.aux[(size_t)lrow * F.width + x];
+                            dg.hit = a.hit;
+                            for (int k = 0; k < 3; k++) { dg.cube[k] = a.cube[k]; dg.voxel[k] = a.voxel[k]; }
+                            dg.res = a.resolution; dg.face = a.face; dg.block = a.block_index; dg.t = a.t_distance;
+                            px_steps_prev = a.cubes_traced;
+                        }
+                    }
+                }
+                if (have_pixel) {
+                    const uint32_t x = pxy & 0xffffu, lrow = pxy >> 16;
+                    const size_t pix = (size_t)lrow * F.width + x;
+                    // global row of this local row under the strip partition
+                    const uint32_t y = (F.part + (lrow / F.strip_rows) * F.n_parts) * F.strip_rows + (lrow % F.strip_rows);
+                    const double x0 = fb_x_edge(F.width, x), x1 = fb_x_edge(F.width, x + 1);
+                    const double y0 = fb_y_edge(F.height, y), y1 = fb_y_edge(F.height, y + 1);
+                    double px, py;  // renderer.rs:428-433 sample points, else the patch centre
+                    if (n_samples == 4) {
+                        const double ux = (sample == 0) ? 1. / 8. : (sample == 1) ? 3. / 8. : (sample == 2) ? 5. / 8. : 7. / 8.;
+                        const double uy = (sample == 0) ? 5. / 8. : (sample == 1) ? 1. / 8. : (sample == 2) ? 7. / 8. : 3. / 8.;
+                        px = x0 + (x1 - x0) * ux;
+                        py = y0 + (y1 - y0) * uy;
+                    } else {
+                        px = (x0 + x1) / 2.0;
+                        py = (y0 + y1) / 2.0;
+                    }
+                    if (F.use_init) {
+                        const float4 v = F.acc_buf[(size_t)sample * npix + pix];
+                        acc.l0 = v.x; acc.l1 = v.y; acc.l2 = v.z; acc.t = v.w;
+                    } else {
+                        acc.l0 = acc.l1 = acc.l2 = 0.f;
+                        acc.t = 1.0f;
+                    }
+                    if (DIAG && sample > 0) dg.hit = dg.hit | 2;  // only the first sample's position is reported
+                    if (!ui_pass && F.has_backdrop) {  // Exception::Backdrop hit: ColorBuf::from(Rgba)
+                        const float a = F.backdrop[3];
+                        cb_add(acc, F.backdrop[0] * a, F.backdrop[1] * a, F.backdrop[2] * a, 1.0f - a);
+                    }
+                    count = 0;
+                    if (L.present) {
+                        double o[3], f[3];
+                        unproject(L.inv, px, py, 0.0, o);
+                        unproject(L.inv, px, py, 1.0, f);
+                        ox = o[0]; oy = o[1]; oz = o[2];
+                        dirx = f[0] - o[0]; diry = f[1] - o[1]; dirz = f[2] - o[2];
+                        t_abs = sqrt(dirx * dirx + diry * diry + dirz * dirz);  // sr.rs:146
+                        t_view = (float)(t_abs / opt.view_distance);             // sr.rs:149-151
+                        rd = raydir_init(dirx, diry, dirz);
+                        const LvlLim ll = lvl_init(ox, oy, oz, rd, true, olx, oly, olz, ohx, ohy, ohz, true);
+                        cur = ll.s;
+                        lim = ll.lim;
+                        cur.st |= ST_TRACED;
+                        if (cb_opaque(acc)) cur.st |= ST_OPAQUE;
+                        ev = 0u;
+                    } else {
+                        cur.st = FL_ENDED;
+                        ev = EV_FINISH;
+                    }
+                }
+            }
+            continue;
         }
-        if (DIAG && F.aux) {
-            DevAux &a = F.aux[pix];
-            a.hit = dg.hit;
-#pragma unroll
-            for (int k = 0; k < 3; k++) { a.cube[k] = dg.cube[k]; a.voxel[k] = dg.voxel[k]; }
-            a.resolution = dg.res; a.face = dg.face; a.block_index = dg.block;
-            a.cubes_traced = steps_prev + steps; a.pad = 0; a.t_distance = dg.t;
+
+        // ============================ stepping phase ======================================
+        AIC_PROF(10, 1);
+        AIC_PROF(11, n_step);
+        if (ev == 0u) {
+            // what this step yields: 0 nothing/invisible, 1 a visible surface, 2 a block to enter
+            int ts_kind = 0;
+            uint32_t ref = 0;
+            bool produced = true;   // false: no TraceStep came out of this trip (pre-entry step / level pop)
+            bool flush = false, need_light = false, enter = false;
+            if (VOL && (cur.st & ST_BUFFERED)) {
+                cur.st &= ~ST_BUFFERED;  // DepthStep::EnterBlock: counted, nothing to draw
+            } else {
+                // -- SurfaceIter::next (surface.rs:283-354): ONE dda event of the current level --
+                const bool inb = (cur.st & ST_IN_BLOCK) != 0;
+                const uint32_t fl = cur.st & 3u;
+                bool is_exit = false;
+                if (fl == FL_ENDED) {
+                    produced = false;
+                    if (inb) {  // current_block exhausted -> resume the outer raycaster
+                        const uint32_t keep = cur.st & (ST_HAS_LAST | ST_BUFFERED | ST_OPAQUE | ST_TRACED);
+                        cur = saved;
+                        cur.st = (cur.st & ~(ST_IN_BLOCK | ST_HAS_LAST | ST_BUFFERED | ST_OPAQUE | ST_TRACED)) | keep;
+                        lim.x = rd.sx > 0 ? ohx : olx - 1;
+                        lim.y = rd.sy > 0 ? ohy : oly - 1;
+                        lim.z = rd.sz > 0 ? ohz : olz - 1;
+                    } else {
+                        ev = EV_FINISH;  // ray finished
+                    }
+                } else {
+                    const uint32_t stepped_axis = (cur.st >> 5) & 3u;
+                    const bool stepped = (cur.st & 128u) != 0;
+                    if (stepped) {
+                        // the deferred State::step (raycast.rs:577-626)
+                        uint32_t face;
+                        if (stepped_axis == 0) { cur.last_t = cur.tx; cur.tx += rd.tdx; cur.cx += rd.sx; face = rd.sx > 0 ? 1u : 4u; }
+                        else if (stepped_axis == 1) { cur.last_t = cur.ty; cur.ty += rd.tdy; cur.cy += rd.sy; face = rd.sy > 0 ? 2u : 5u; }
+                        else { cur.last_t = cur.tz; cur.tz += rd.tdz; cur.cz += rd.sz; face = rd.sz > 0 ? 3u : 6u; }
+                        cur.st = (cur.st & ~(7u << 2) & ~128u) | (face << 2);
+                    }
+                    bool in_bounds;
+                    if (fl == FL_INBOUNDS) {
+                        // only the axis just stepped can have left the bounds
+                        const int c = stepped_axis == 0 ? cur.cx : (stepped_axis == 1 ? cur.cy : cur.cz);
+                        const int l = stepped_axis == 0 ? lim.x : (stepped_axis == 1 ? lim.y : lim.z);
+                        in_bounds = !(stepped && c == l);
+                        if (!in_bounds) {  // (InBounds, false, true): the include_exit step
+                            cur.st = (cur.st & ~3u) | FL_ENDED;
+                            is_exit = true;
+                        }
+                    } else {
+                        // Beginning: is_out_of_bounds_ahead (raycast.rs:711-728) against the level's bounds
+                        int lox, loy, loz, hix, hiy, hiz;
+                        if (inb) {
+                            lox = (int)(blk_vlo & 255u); loy = (int)((blk_vlo >> 8) & 255u); loz = (int)((blk_vlo >> 16) & 255u);
+                            hix = lox + (int)(blk_vsize & 255u); hiy = loy + (int)((blk_vsize >> 8) & 255u); hiz = loz + (int)((blk_vsize >> 16) & 255u);
+                        } else {
+                            lox = olx; loy = oly; loz = olz; hix = ohx; hiy = ohy; hiz = ohz;
+                        }
+                        bool oob_enter = false, oob_exit = false;
+                        {
+                            const bool low = cur.cx < lox, high = cur.cx >= hix;
+                            oob_enter |= rd.sx == 0 ? (low | high) : (rd.sx < 0 ? high : low);
+                            oob_exit |= rd.sx == 0 ? (low | high) : (rd.sx < 0 ? low : high);
+                        }
+                        {
+                            const bool low = cur.cy < loy, high = cur.cy >= hiy;
+                            oob_enter |= rd.sy == 0 ? (low | high) : (rd.sy < 0 ? high : low);
+                            oob_exit |= rd.sy == 0 ? (low | high) : (rd.sy < 0 ? low : high);
+                        }
+                        {
+                            const bool low = cur.cz < loz, high = cur.cz >= hiz;
+                            oob_enter |= rd.sz == 0 ? (low | high) : (rd.sz < 0 ? high : low);
+                            oob_exit |= rd.sz == 0 ? (low | high) : (rd.sz < 0 ? low : high);
+                        }
+                        in_bounds = !oob_enter && !oob_exit;
+                        if (!in_bounds) {
+                            produced = false;
+                            if (oob_enter && !oob_exit) {
+                                // not yet inside: take a silent step (raycast.rs:255-263)
+                                const int pick = pick_axis(cur.tx, cur.ty, cur.tz);
+                                const double tp = pick == 0 ? cur.tx : (pick == 1 ? cur.ty : cur.tz);
+                                const int c = pick == 0 ? cur.cx : (pick == 1 ? cur.cy : cur.cz);
+                                const int sgn = pick == 0 ? rd.sx : (pick == 1 ? rd.sy : rd.sz);
+                                if (!isfinite(tp) || (sgn > 0 && c == I32_MAX_) || (sgn < 0 && c == I32_MIN_)) cur.st = (cur.st & ~3u) | FL_ENDED;
+                                else cur.st = (cur.st & ~(3u << 5)) | ((uint32_t)pick << 5) | 128u;
+                            } else {
+                                cur.st = (cur.st & ~3u) | FL_ENDED;  // misses the bounds
+                            }
+                        }
+                    }
+                    if (in_bounds) {
+                        // (Beginning|InBounds, false, false): emit this cube, schedule the next step
+                        const int pick = pick_axis(cur.tx, cur.ty, cur.tz);
+                        const double tp = pick == 0 ? cur.tx : (pick == 1 ? cur.ty : cur.tz);
+                        if (!isfinite(tp)) {  // !valid_for_stepping (raycast.rs:245-249)
+                            cur.st = (cur.st & ~3u) | FL_ENDED;
+                            if (lvl_face(cur) != FACE_WITHIN) produced = false;
+                        } else {
+                            cur.st = (cur.st & ~3u & ~(3u << 5)) | FL_INBOUNDS | ((uint32_t)pick << 5) | 128u;
+                        }
+                        if (produced) {
+                            if (!inb) {
+                                // outer cube lookup
+                                const uint32_t idx = ((uint32_t)(cur.cx - olx) * osy + (uint32_t)(cur.cy - oly)) * osz + (uint32_t)(cur.cz - olz);
+                                const uint32_t bi = L.grid[idx];
+                                if (DIAG) dg.n_outer++;
+                                if ((int)bi != L.air_index) {
+                                    const uint32_t k = L.blocks[bi].kind;
+                                    if ((k & 255u) == 0u) {
+                                        if (!(k & 0x80000000u)) {  // a visible single-voxel block
+                                            ts_kind = 1;
+                                            ref = 0x80000000u | bi;
+                                        }
+                                    } else {
+                                        ts_kind = 2;
+                                        blk_res = k & 255u;
+                                        blk_index = bi;
+                                    }
+                                }
+                            } else {
+                                // voxel lookup
+                                const uint32_t vsy = (blk_vsize >> 8) & 255u, vsz = (blk_vsize >> 16) & 255u;
+                                const uint32_t vidx = ((uint32_t)(cur.cx - (int)(blk_vlo & 255u)) * vsy + (uint32_t)(cur.cy - (int)((blk_vlo >> 8) & 255u))) * vsz +
+                                                      (uint32_t)(cur.cz - (int)((blk_vlo >> 16) & 255u));
+                                const uint32_t code = L.voxels[(size_t)blk_vox_off + vidx];
+                                if (DIAG) dg.n_inner++;
+                                if (code >= blk_ninvis) {
+                                    ts_kind = 1;
+                                    ref = blk_pal_off + code;
+                                }
+                            }
+                        }
+                    }
+                }
+                if (produced) {
+                    // -- TraceStep -> DepthIter::next (surface.rs:453-491) / direct use --
+                    const bool has_last = (cur.st & ST_HAS_LAST) != 0;
+                    if (ts_kind == 1 || (VOL && has_last)) {
+                        // t of this step in outer units (surface.rs:385-386: inner t times 1/resolution)
+                        const double ts_t = (cur.st & ST_IN_BLOCK) ? cur.last_t * __hiloint2double((int)((1023u - (31u - (uint32_t)__clz((int)blk_res))) << 20), 0) : cur.last_t;
+                        if (VOL) {
+                            if (has_last) {
+                                span_ref = last_ref; span_i0 = last_i0; span_i1 = last_i1; span_i2 = last_i2; span_t = last_t;
+                                span_exit = ts_t;
+                                if (DIAG) span_d = last_d;
+                                flush = true;
+                                cur.st &= ~ST_HAS_LAST;
+                            }
+                            if (ts_kind == 1) {
+                                last_ref = ref; last_t = ts_t;
+                                last_i0 = last_i1 = last_i2 = 1.0f;
+                                cur.st |= ST_HAS_LAST;
+                                need_light = LMODE != 0;
+                            }
+                        } else {
+                            span_ref = ref; span_t = ts_t;
+                            span_i0 = span_i1 = span_i2 = 1.0f;
+                            flush = true;
+                            need_light = LMODE != 0;
+                        }
+                        if (DIAG && ts_kind == 1) {
+                            SurfDiag sd;
+                            sd.nlight = 0;
+                            if (cur.st & ST_IN_BLOCK) {
+                                sd.cube[0] = saved.cx; sd.cube[1] = saved.cy; sd.cube[2] = saved.cz;
+                                sd.voxel[0] = cur.cx; sd.voxel[1] = cur.cy; sd.voxel[2] = cur.cz;
+                                sd.res = (int)blk_res; sd.block = (int)blk_index;
+                            } else {
+                                sd.cube[0] = cur.cx; sd.cube[1] = cur.cy; sd.cube[2] = cur.cz;
+                                sd.voxel[0] = sd.voxel[1] = sd.voxel[2] = 0;
+                                sd.res = 1; sd.block = (int)(ref & 0xffffu);
+                            }
+                            sd.face = lvl_face(cur);
+                            if (VOL) last_d = sd; else span_d = sd;
+                        }
+                    }
+                    if (ts_kind == 2) {
+                        enter = true;
+                        if (VOL) cur.st |= ST_BUFFERED;
+                    }
+                }
+            }
+            if (produced) {
+                // ---- TracingState::count_step_should_stop (sr.rs:625-656) ----
+                count++;
+                if (count > 1000u || (cur.st & ST_OPAQUE)) ev = EV_FINISH;
+                else ev = (flush ? EV_FLUSH : 0u) | (need_light ? EV_LIGHT : 0u) | (enter ? EV_ENTER : 0u);
+            }
         }
     }
 
-    // RaytraceInfo sum (renderer.rs:555): wave reduction then one atomic per wave
-    unsigned long long s = steps;
+#ifdef AIC_PROFILE
+    if (lane == 0) for (int i = 0; i < 12; i++) atomicAdd(&F.counters->prof[i], (unsigned long long)prof[i]);
+#endif
+    // ---- RaytraceInfo sum (renderer.rs:555): wave reduction then one atomic per wave ----
+    unsigned long long s = total_steps;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0 && s) atomicAdd(&F.counters->cubes_traced, s);
     if (DIAG) {
-        unsigned long long v[4] = {active ? dg.n_outer : 0u, active ? dg.n_inner : 0u, active ? dg.n_hits : 0u, active ? dg.n_light : 0u};
+        unsigned long long v[4] = {tot_outer, tot_inner, tot_hits, tot_light};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
 #pragma unroll
@@ -1072,30 +1360,31 @@ __global__ void assemble_strips_kernel(const uint32_t *gathered, uint32_t *out, 
 __global__ void probe_raycast_kernel(const double *od, int use_bounds, const int *lohi, int include_exit, uint32_t max_steps,
                                      double *out_rec, uint32_t *n_out, int *ended) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double o[3] = {od[0], od[1], od[2]}, d[3] = {od[3], od[4], od[5]};
+    const double ox = od[0], oy = od[1], oz = od[2], dx = od[3], dy = od[4], dz = od[5];
     int lo[3] = {lohi[0], lohi[1], lohi[2]}, hi[3] = {lohi[3], lohi[4], lohi[5]};
     if (!use_bounds) {
         lo[0] = lo[1] = lo[2] = I32_MIN_ + 1;
         hi[0] = hi[1] = hi[2] = I32_MAX_ - 1;
     }
-    RayDir rd;
-    raydir_init(rd, d);
-    Dda s;
-    dda_init(s, o, rd, use_bounds != 0, lo, hi, include_exit != 0);
+    const RayDir rd = raydir_init(dx, dy, dz);
+    const LvlLim ll = lvl_init(ox, oy, oz, rd, use_bounds != 0, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], include_exit != 0);
+    Lvl s = ll.s;
+    const Lim lim = ll.lim;
     uint32_t n = 0;
     *ended = 0;
     while (n < max_steps) {
-        bool is_exit;
-        if (!dda_next(s, rd, lo, hi, &is_exit)) {
+        const NextResult nr = lvl_next(s, lim, rd, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]);
+        s = nr.s;
+        if (!nr.got) {
             *ended = 1;
             break;
         }
         double ip[3];
-        intersection_point(s, o, d, ip);
+        intersection_point(s, ox, oy, oz, dx, dy, dz, ip);
         double *r = out_rec + 8 * (size_t)n;
         // record: cube[3] as doubles, face, t, ip[3]
-        r[0] = (double)s.cube[0]; r[1] = (double)s.cube[1]; r[2] = (double)s.cube[2];
-        r[3] = (double)dda_face(s); r[4] = s.last_t; r[5] = ip[0]; r[6] = ip[1]; r[7] = ip[2];
+        r[0] = (double)s.cx; r[1] = (double)s.cy; r[2] = (double)s.cz;
+        r[3] = (double)lvl_face(s); r[4] = s.last_t; r[5] = ip[0]; r[6] = ip[1]; r[7] = ip[2];
         n++;
     }
     *n_out = n;
@@ -1106,9 +1395,13 @@ __global__ void probe_raycast_kernel(const double *od, int use_bounds, const int
 
 template <bool VOL, int LMODE, bool DIAG>
 static void launch_trace(const DevFrame &F, hipStream_t stream) {
+    // persistent waves: enough workgroups to fill the chip at the kernel's occupancy, never more
+    // waves than tiles (each wave pulls 16x16 tiles from counters->tile_next)
     const uint32_t n_tiles = F.tiles_x * F.tiles_y;
-    const uint32_t per = (n_tiles + 7u) / 8u;
-    const uint32_t grid = per * 8u;
+    const uint32_t resident_groups = F.n_cus * (uint32_t)AIC_MIN_WAVES;  // 4 waves per group, AIC_MIN_WAVES groups per CU
+    uint32_t grid = (n_tiles + 3u) / 4u;
+    if (grid > resident_groups) grid = resident_groups;
+    if (grid == 0) return;
     hipLaunchKernelGGL((trace_image_kernel<VOL, LMODE, DIAG>), dim3(grid), dim3(256), 0, stream, F);
 }
 
@@ -1126,9 +1419,8 @@ static void launch_trace_diag(const DevFrame &F, bool vol, int lmode, hipStream_
 }
 
 void launch_trace_image(const DevFrame &F, bool diag, hipStream_t stream) {
-    const DevLayer &L = F.pass == 1 ? F.ui : F.world;
-    const bool vol = L.opt.transparency == 1;
-    const int l = L.opt.lighting;
+    const bool vol = F.layer_transparency == 1;
+    const int l = F.layer_lighting;
     const int lmode = l == 0 ? 0 : (l == 1 ? 1 : 2);
     if (diag) launch_trace_diag<true>(F, vol, lmode, stream);
     else launch_trace_diag<false>(F, vol, lmode, stream);

@@ -68,6 +68,9 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="atrium", choices=["atrium", "s256", "small"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lighting", type=int, default=3, help="experiment: LightingOption (0 None,1 Flat,2 Coarse,3 Linear,4 Smoothstep); default Linear")
+    ap.add_argument("--fog", type=int, default=1, help="experiment: FogOption (0 None,1 Abrupt,...); default Abrupt")
+    ap.add_argument("--transparency", type=int, default=1, help="experiment: 0 Surface, 1 Volumetric; default Volumetric")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample duration")
     args = ap.parse_args()
 
@@ -102,6 +105,11 @@ def main() -> int:
     opts.bloom_intensity = 0.0
     opts.view_distance = view_distance
     opts.debug_info_text = False
+    if (args.lighting, args.fog, args.transparency) != (3, 1, 1):  # experiments only; the headline run uses the defaults
+        opts.lighting_display = H.LightingOption(H.LightingKind(args.lighting))
+        opts.fog = H.FogOption(args.fog)
+        opts.transparency = H.TransparencyOption(H.TransparencyKind(args.transparency))
+        label += f" [EXPERIMENT lighting={args.lighting} fog={args.fog} transparency={args.transparency}]"
     cams.graphics_options = opts
     cams.viewport = H.Viewport.with_scale(1.0, w, h)
     cams.world_space = space_from_flat(flat_space)
