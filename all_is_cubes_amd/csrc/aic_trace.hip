@@ -551,32 +551,44 @@ AIC_DEV void get_interpolated_light(const DevLayer &L, const float *__restrict__
     const uint32_t d1n = (uint32_t)v1n - (uint32_t)lo_1, d1f = (uint32_t)v1f - (uint32_t)lo_1;
     const uint32_t d2n = (uint32_t)v2n - (uint32_t)lo_2, d2f = (uint32_t)v2f - (uint32_t)lo_2;
 
-    auto texel = [&](int vn, bool okn, uint32_t dn, int v1, bool ok1, uint32_t d1, int v2, bool ok2, uint32_t d2) -> uint32_t {
-        if (!(okn && ok1 && ok2)) return L.block_sky[6];  // numerical overflow: BlockSky::mean (sr.rs:307-311)
-        if (DIAG) nlight++;
-        if ((dn < sz_n) & (d1 < sz_1) & (d2 < sz_2)) return L.light[dn * st_n + d1 * st_1 + d2 * st_2];
-        // outside the space: BlockSky::light_outside on the reassembled cube
-        int c[3];
-        c[0] = an == 0 ? vn : (a1 == 0 ? v1 : v2);
-        c[1] = an == 1 ? vn : (a1 == 1 ? v1 : v2);
-        c[2] = an == 2 ? vn : (a1 == 2 ? v1 : v2);
-        return light_outside(L, c[0], c[1], c[2]);
-    };
+    // One plane of four texels. The four light-grid loads are issued together (clamped index, no
+    // branch in front of them); the rare "outside the space" / "no cube" cases are patched afterwards.
     auto fetch2d = [&](double on, float res[4]) {
         bool okn = true;
         const int vn = fl(on, okn);
         const uint32_t dn = (uint32_t)vn - (uint32_t)lo_n;
-        const uint32_t near12 = texel(vn, okn, dn, v1n, ok1n, d1n, v2n, ok2n, d2n);
-        const uint32_t near1far2 = texel(vn, okn, dn, v1n, ok1n, d1n, v2f, ok2f, d2f);
-        const uint32_t near2far1 = texel(vn, okn, dn, v1f, ok1f, d1f, v2n, ok2n, d2n);
-        uint32_t far12 = texel(vn, okn, dn, v1f, ok1f, d1f, v2f, ok2f, d2f);
+        const bool in_n = dn < sz_n, in_1n = d1n < sz_1, in_1f = d1f < sz_1, in_2n = d2n < sz_2, in_2f = d2f < sz_2;
+        const uint32_t bn = dn * st_n, b1n = d1n * st_1, b1f = d1f * st_1, b2n = d2n * st_2, b2f = d2f * st_2;
+        const bool i00 = in_n & in_1n & in_2n, i01 = in_n & in_1n & in_2f, i10 = in_n & in_1f & in_2n, i11 = in_n & in_1f & in_2f;
+        uint32_t t00 = L.light[i00 ? bn + b1n + b2n : 0u];  // near12
+        uint32_t t01 = L.light[i01 ? bn + b1n + b2f : 0u];  // near1far2
+        uint32_t t10 = L.light[i10 ? bn + b1f + b2n : 0u];  // near2far1
+        uint32_t t11 = L.light[i11 ? bn + b1f + b2f : 0u];  // far12
+        const bool k00 = okn & ok1n & ok2n, k01 = okn & ok1n & ok2f, k10 = okn & ok1f & ok2n, k11 = okn & ok1f & ok2f;
+        if (DIAG) nlight += (k00 ? 1u : 0u) + (k01 ? 1u : 0u) + (k10 ? 1u : 0u) + (k11 ? 1u : 0u);
+        if (!(i00 & i01 & i10 & i11)) {
+            // outside the space: BlockSky::light_outside on the reassembled cube; numerical overflow
+            // (no containing cube): BlockSky::mean (sr.rs:307-311)
+            auto patch = [&](bool inb, bool ok, int v1, int v2, uint32_t t) -> uint32_t {
+                if (!ok) return L.block_sky[6];
+                if (inb) return t;
+                const int c0 = an == 0 ? vn : (a1 == 0 ? v1 : v2);
+                const int c1 = an == 1 ? vn : (a1 == 1 ? v1 : v2);
+                const int c2 = an == 2 ? vn : (a1 == 2 ? v1 : v2);
+                return light_outside(L, c0, c1, c2);
+            };
+            t00 = patch(i00, k00, v1n, v2n, t00);
+            t01 = patch(i01, k01, v1n, v2f, t01);
+            t10 = patch(i10, k10, v1f, v2n, t10);
+            t11 = patch(i11, k11, v1f, v2f, t11);
+        }
         // light-leak fix: both side texels invalid => far corner := near corner
-        if ((near1far2 >> 24) != 255u && (near2far1 >> 24) != 255u) far12 = near12;
+        if ((t01 >> 24) != 255u && (t10 >> 24) != 255u) t11 = t00;
         float a[4], b[4], c[4], d[4], ab[4], cd[4];
-        texel_value_ao(near12, lut, a);
-        texel_value_ao(near1far2, lut, b);
-        texel_value_ao(near2far1, lut, c);
-        texel_value_ao(far12, lut, d);
+        texel_value_ao(t00, lut, a);
+        texel_value_ao(t01, lut, b);
+        texel_value_ao(t10, lut, c);
+        texel_value_ao(t11, lut, d);
         mix4(a, b, m2, ab);
         mix4(c, d, m2, cd);
         mix4(ab, cd, m1, res);
@@ -672,7 +684,7 @@ AIC_DEV uint32_t srgb8_channel(float c, const float *__restrict__ thr) {
 }
 
 // lane event bits
-constexpr uint32_t EV_FLUSH = 1u, EV_LIGHT = 2u, EV_ENTER = 4u, EV_FINISH = 8u, EV_NEWRAY = 16u, EV_DONE = 32u;
+constexpr uint32_t EV_SHADE = 2u, EV_ENTER = 4u, EV_FINISH = 8u, EV_NEWRAY = 16u, EV_DONE = 32u;
 // lane state bits (st): 0-1 first_last | 2-4 last_face | 5-6 pick | 7 need_step | 8 include_exit (unused here)
 constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_BUFFERED = 1u << 11, ST_OPAQUE = 1u << 12, ST_TRACED = 1u << 13;
 
@@ -695,7 +707,13 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
     uint32_t tile_cur = 0xffffffffu;  // wave-uniform: tile the refill is drawing pixels from
     const DevLayer &L = F.layer;
     const DevOptions &opt = L.opt;
-    const float *__restrict__ lut = F.light_lut;
+    // the two 1 KiB decode tables live in LDS for the life of the persistent workgroup
+    __shared__ float s_lut[256];  // PackedLight scalar decode (light/data.rs:301-354)
+    __shared__ float s_thr[256];  // sRGB8 encode thresholds
+    s_lut[threadIdx.x] = F.light_lut[threadIdx.x];
+    s_thr[threadIdx.x] = F.srgb_thr[threadIdx.x];
+    __syncthreads();
+    const float *lut = s_lut;
     const bool ui_pass = F.pass == 1;
     const bool include_sky = !ui_pass;
     const bool fog_on = (opt.fog != 0) && include_sky;
@@ -722,14 +740,15 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
     uint32_t count = 0;
     double t_abs = 0.0;
     float t_view = 0.f;
-    // surfaces in flight: `last` = DepthIter.last_surface, `span` = the one being composited
-    uint32_t last_ref = 0, span_ref = 0;
-    float last_i0 = 1.f, last_i1 = 1.f, last_i2 = 1.f, span_i0 = 1.f, span_i1 = 1.f, span_i2 = 1.f;
-    double last_t = 0.0, span_t = 0.0, span_exit = 0.0;
-    SurfDiag last_d, span_d;
+    // DepthIter.last_surface, already shaded: its premultiplied light and transmittance
+    uint32_t shade_ref = 0;  // colour record of the surface waiting to be shaded (bit31: single-voxel block)
+    float pend0 = 0.f, pend1 = 0.f, pend2 = 0.f, pend_tr = 1.f;
+    SurfDiag pend_d;
+    double pend_t = 0.0;
+    bool pend_visible = false;
     if (DIAG) {
-        last_d.nlight = span_d.nlight = 0; last_d.res = last_d.face = last_d.block = span_d.res = span_d.face = span_d.block = 0;
-        for (int a = 0; a < 3; a++) last_d.cube[a] = last_d.voxel[a] = span_d.cube[a] = span_d.voxel[a] = 0;
+        pend_d.nlight = 0; pend_d.res = pend_d.face = pend_d.block = 0;
+        for (int a = 0; a < 3; a++) pend_d.cube[a] = pend_d.voxel[a] = 0;
     }
     // pixel bookkeeping
     uint32_t pxy = 0;           // this lane's pixel: x | (local row << 16)
@@ -755,23 +774,20 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
 
     for (;;) {
         // ---- wave scheduler: step, or run ONE kind of parked work for all lanes waiting on it ----
-        // Kinds: LIGHT, FLUSH, ENTER, RAY (finish the old ray and/or start a new one). A kind is run
+        // Kinds: SHADE (light + composite a surface), ENTER (a block), RAY (finish / start a ray). A kind is run
         // when enough lanes wait on it to fill the wave reasonably (AIC_T_BATCH), or when so few
         // lanes can still step (AIC_N_FEW) that waiting longer only idles the wave.
         const unsigned long long m_st = __ballot(ev == 0u);
-        // for !VOL a surface is lit before it is composited, so its FLUSH waits for its LIGHT
-        const unsigned long long b_light = __ballot((ev & EV_LIGHT) != 0u);
-        const unsigned long long b_flush = __ballot((ev & EV_FLUSH) != 0u && (VOL || (ev & EV_LIGHT) == 0u));
+        const unsigned long long b_shade = __ballot((ev & EV_SHADE) != 0u);
         const unsigned long long b_enter = __ballot((ev & EV_ENTER) != 0u);
         const unsigned long long b_ray = __ballot((ev & (EV_FINISH | EV_NEWRAY)) != 0u);
-        if ((m_st | b_light | b_flush | b_enter | b_ray) == 0ull) break;
+        if ((m_st | b_shade | b_enter | b_ray) == 0ull) break;
         const int n_step = __popcll(m_st);
-        const int c_light = __popcll(b_light), c_flush = __popcll(b_flush), c_enter = __popcll(b_enter), c_ray = __popcll(b_ray);
+        const int c_shade = __popcll(b_shade), c_enter = __popcll(b_enter), c_ray = __popcll(b_ray);
         uint32_t run = 0u;  // kind to run this trip (an EV_* bit), 0 = step
         {
-            int best = c_light;
-            uint32_t kind = EV_LIGHT;
-            if (c_flush > best) { best = c_flush; kind = EV_FLUSH; }
+            int best = c_shade;
+            uint32_t kind = EV_SHADE;
             if (c_enter > best) { best = c_enter; kind = EV_ENTER; }
             if (c_ray > best) { best = c_ray; kind = EV_FINISH; }
             if (best > 0 && (best >= AIC_T_BATCH || n_step <= AIC_N_FEW)) run = kind;
@@ -779,66 +795,80 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
         if (run != 0u) {
             // ============================ event phase ======================================
             AIC_PROF(0, 1);
-            AIC_PROF(1, c_light + c_flush + c_enter + c_ray);
-            AIC_PROF(2, run == EV_FLUSH ? 1 : 0); AIC_PROF(3, run == EV_FLUSH ? c_flush : 0);
-            AIC_PROF(4, run == EV_LIGHT ? 1 : 0); AIC_PROF(5, run == EV_LIGHT ? c_light : 0);
+            AIC_PROF(1, c_shade + c_enter + c_ray);
+            AIC_PROF(4, run == EV_SHADE ? 1 : 0); AIC_PROF(5, run == EV_SHADE ? c_shade : 0);
             AIC_PROF(6, run == EV_ENTER ? 1 : 0); AIC_PROF(7, run == EV_ENTER ? c_enter : 0);
             AIC_PROF(8, run == EV_FINISH ? 1 : 0); AIC_PROF(9, run == EV_FINISH ? c_ray : 0);
-            // -- compositing a surface / span: trace_through_span + Surface::to_light + ColorBuf add --
-            // (for !VOL the surface's light must be known first, so LIGHT runs before FLUSH)
-            auto do_light = [&](float &i0, float &i1, float &i2, SurfDiag &sd) {
-                // illumination of the surface discovered by the step held in `cur` (surface.rs:113-206)
-                const int face = lvl_face(cur);
+            // -- shading a discovered surface: compute_illumination + trace_through_span +
+            //    Surface::to_light (surface.rs:73-206; sr.rs:697-740). For Volumetric transparency the
+            //    span's exit distance is the t of the ray's NEXT TraceStep, which is already fixed when
+            //    the surface is discovered: it is the t_max of the deferred step. The contribution is
+            //    therefore computed here in full and merely *applied* by the stepping code when that
+            //    next step is counted (so the order count -> stop-check -> accumulate is kept). --
+            if (run == EV_SHADE && (ev & EV_SHADE)) {
                 const bool inb = (cur.st & ST_IN_BLOCK) != 0;
-                const int ocx = inb ? saved.cx : cur.cx, ocy = inb ? saved.cy : cur.cy, ocz = inb ? saved.cz : cur.cz;
+                const double as = inb ? __hiloint2double((int)((1023u - (31u - (uint32_t)__clz((int)blk_res))) << 20), 0) : 1.0;
+                const double t_enter = cur.last_t * as;  // surface.rs:385-386
+                // illumination (surface.rs:113-206)
+                float i0 = 1.0f, i1 = 1.0f, i2 = 1.0f;
                 uint32_t nl = 0;
-                if (LMODE == 1) {
-                    int nx = 0, ny = 0, nz = 0;
-                    if (face == 1) nx = -1; else if (face == 2) ny = -1; else if (face == 3) nz = -1;
-                    else if (face == 4) nx = 1; else if (face == 5) ny = 1; else if (face == 6) nz = 1;
-                    const uint32_t tx = get_packed_light<DIAG>(L, ocx + nx, ocy + ny, ocz + nz, nl);
-                    i0 = lut[tx & 255u]; i1 = lut[(tx >> 8) & 255u]; i2 = lut[(tx >> 16) & 255u];
-                } else {
-                    double ip[3];
-                    if (inb) {
-                        const double kd = (double)blk_res;
-                        double vp[3];
-                        intersection_point(cur, (ox - (double)ocx) * kd, (oy - (double)ocy) * kd, (oz - (double)ocz) * kd, dirx, diry, dirz, vp);
-                        const double as = 1.0 / kd;
-                        ip[0] = vp[0] * as + (double)ocx;  // surface.rs:406-407
-                        ip[1] = vp[1] * as + (double)ocy;
-                        ip[2] = vp[2] * as + (double)ocz;
+                if (LMODE != 0) {
+                    const int face = lvl_face(cur);
+                    const int ocx = inb ? saved.cx : cur.cx, ocy = inb ? saved.cy : cur.cy, ocz = inb ? saved.cz : cur.cz;
+                    if (LMODE == 1) {
+                        int nx = 0, ny = 0, nz = 0;
+                        if (face == 1) nx = -1; else if (face == 2) ny = -1; else if (face == 3) nz = -1;
+                        else if (face == 4) nx = 1; else if (face == 5) ny = 1; else if (face == 6) nz = 1;
+                        const uint32_t tx = get_packed_light<DIAG>(L, ocx + nx, ocy + ny, ocz + nz, nl);
+                        i0 = lut[tx & 255u]; i1 = lut[(tx >> 8) & 255u]; i2 = lut[(tx >> 16) & 255u];
                     } else {
-                        intersection_point(cur, ox, oy, oz, dirx, diry, dirz, ip);
+                        double ip[3];
+                        if (inb) {
+                            const double kd = (double)blk_res;
+                            double vp[3];
+                            intersection_point(cur, (ox - (double)ocx) * kd, (oy - (double)ocy) * kd, (oz - (double)ocz) * kd, dirx, diry, dirz, vp);
+                            ip[0] = vp[0] * as + (double)ocx;  // surface.rs:406-407
+                            ip[1] = vp[1] * as + (double)ocy;
+                            ip[2] = vp[2] * as + (double)ocz;
+                        } else {
+                            intersection_point(cur, ox, oy, oz, dirx, diry, dirz, ip);
+                        }
+                        const int oc[3] = {ocx, ocy, ocz};
+                        float il[3];
+                        get_interpolated_light<DIAG>(L, lut, oc, ip, face, opt.lighting, il, nl);
+                        i0 = il[0]; i1 = il[1]; i2 = il[2];
                     }
-                    const int oc[3] = {ocx, ocy, ocz};
-                    float il[3];
-                    get_interpolated_light<DIAG>(L, lut, oc, ip, face, opt.lighting, il, nl);
-                    i0 = il[0]; i1 = il[1]; i2 = il[2];
                 }
-                if (DIAG) sd.nlight = nl;
-            };
-            if (run == EV_LIGHT && !VOL && LMODE != 0 && (ev & EV_LIGHT)) {
-                do_light(span_i0, span_i1, span_i2, span_d);
-                ev &= ~EV_LIGHT;
-            }
-            if (run == EV_FLUSH && (ev & EV_FLUSH) && (VOL || (ev & EV_LIGHT) == 0u)) {
+                // colour record
                 float r, g, b, a, e0, e1, e2;
-                if (span_ref & 0x80000000u) {
-                    const DevBlock *tb = &L.blocks[span_ref & 0xffffu];
+                if (shade_ref & 0x80000000u) {
+                    const DevBlock *tb = &L.blocks[shade_ref & 0xffffu];
                     const float4 col = *reinterpret_cast<const float4 *>(tb->color);
                     r = col.x; g = col.y; b = col.z; a = col.w;
                     e0 = tb->emission[0]; e1 = tb->emission[1]; e2 = tb->emission[2];
                 } else {
-                    const DevPaletteEntry *pe = &L.palette[span_ref];
+                    const DevPaletteEntry *pe = &L.palette[shade_ref];
                     const float4 col = *reinterpret_cast<const float4 *>(pe->color);
                     const float4 em = *reinterpret_cast<const float4 *>(pe->emission);
                     r = col.x; g = col.y; b = col.z; a = col.w;
                     e0 = em.x; e1 = em.y; e2 = em.z;
                 }
+                bool will_flush = true;
                 if (VOL) {
+                    // exit distance = t of the next TraceStep: the deferred step of this level, or -- if this
+                    // level cannot step any more -- of the enclosing cube grid; none => the span is never emitted
+                    double t_exit = 0.0;
+                    if ((cur.st & 3u) != FL_ENDED) {
+                        const uint32_t pk = (cur.st >> 5) & 3u;
+                        t_exit = (pk == 0 ? cur.tx : (pk == 1 ? cur.ty : cur.tz)) * as;
+                    } else if (inb && (saved.st & 3u) != FL_ENDED) {
+                        const uint32_t pk = (saved.st >> 5) & 3u;
+                        t_exit = pk == 0 ? saved.tx : (pk == 1 ? saved.ty : saved.tz);
+                    } else {
+                        will_flush = false;
+                    }
                     // trace_through_span (sr.rs:720-740) + apply_transmittance (raytracer_components.rs:215-258)
-                    float thickness = (float)((span_exit - span_t) * t_abs);
+                    float thickness = (float)((t_exit - t_enter) * t_abs);
                     thickness = fmaxf(thickness, 0.0f);
                     float coeff;
                     if (thickness == 0.0f) {
@@ -860,16 +890,18 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
                     if (a > opt.threshold) a = 1.0f;
                     else { r = g = b = a = 0.f; }
                 }
-                if (!(a == 0.f && e0 == 0.f && e1 == 0.f && e2 == 0.f)) {
-                    float o0 = ps_mul(ps_mul(r, span_i0), a) + e0;
-                    float o1 = ps_mul(ps_mul(g, span_i1), a) + e1;
-                    float o2 = ps_mul(ps_mul(b, span_i2), a) + e2;
-                    float tr = 1.0f - a;
+                float o0 = 0.f, o1 = 0.f, o2 = 0.f, tr = 1.0f;
+                const bool visible = !(a == 0.f && e0 == 0.f && e1 == 0.f && e2 == 0.f);
+                if (visible) {
+                    o0 = ps_mul(ps_mul(r, i0), a) + e0;
+                    o1 = ps_mul(ps_mul(g, i1), a) + e1;
+                    o2 = ps_mul(ps_mul(b, i2), a) + e2;
+                    tr = 1.0f - a;
                     if (fog_on) {  // distance_fog (sr.rs:745-768)
                         float sky[3];
                         sky_of(L, dirx, diry, dirz, sky);
                         const float fog_blend = opt.fog == 1 ? 1.0f : (opt.fog == 2 ? 0.5f : 0.0f);
-                        float rel = (float)span_t * t_view;
+                        float rel = (float)t_enter * t_view;
                         rel = rel < 0.0f ? 0.0f : (rel > 1.0f ? 1.0f : rel);
                         const float fog_exp = 1.0f - expf_exact(-1.6f * rel);
                         const float fudged = fog_exp / 0.79810348f;
@@ -881,25 +913,43 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
                         o2 = ps_mul(o2, comp) + ps_mul(sky[2], amount);
                         tr *= comp;
                     }
-                    cb_add(acc, o0, o1, o2, tr);
+                }
+                SurfDiag sd;
+                if (DIAG) {
+                    sd.nlight = nl;
+                    if (inb) {
+                        sd.cube[0] = saved.cx; sd.cube[1] = saved.cy; sd.cube[2] = saved.cz;
+                        sd.voxel[0] = cur.cx; sd.voxel[1] = cur.cy; sd.voxel[2] = cur.cz;
+                        sd.res = (int)blk_res; sd.block = (int)blk_index;
+                    } else {
+                        sd.cube[0] = cur.cx; sd.cube[1] = cur.cy; sd.cube[2] = cur.cz;
+                        sd.voxel[0] = sd.voxel[1] = sd.voxel[2] = 0;
+                        sd.res = 1; sd.block = (int)(shade_ref & 0xffffu);
+                    }
+                    sd.face = lvl_face(cur);
+                }
+                if (VOL) {
+                    // DepthIter.last_surface: applied when the next TraceStep is counted
+                    if (will_flush) {
+                        pend0 = o0; pend1 = o1; pend2 = o2; pend_tr = tr;
+                        cur.st |= ST_HAS_LAST;
+                        if (DIAG) { pend_d = sd; pend_t = t_enter; pend_visible = visible; }
+                    }
+                } else if (visible) {
+                    cb_add(acc, o0, o1, o2, tr);  // trace_through_surface (sr.rs:697-717)
                     if (cb_opaque(acc)) cur.st |= ST_OPAQUE;
                     if (DIAG) {
                         dg.n_hits++;
-                        dg.n_light += span_d.nlight;
+                        dg.n_light += sd.nlight;
                         if (!dg.hit) {
                             dg.hit = 1;
-                            for (int a2 = 0; a2 < 3; a2++) { dg.cube[a2] = span_d.cube[a2]; dg.voxel[a2] = span_d.voxel[a2]; }
-                            dg.res = span_d.res; dg.face = span_d.face; dg.block = span_d.block; dg.t = span_t;
+                            for (int a2 = 0; a2 < 3; a2++) { dg.cube[a2] = sd.cube[a2]; dg.voxel[a2] = sd.voxel[a2]; }
+                            dg.res = sd.res; dg.face = sd.face; dg.block = sd.block; dg.t = t_enter;
                         }
                     }
                 }
-                ev &= ~EV_FLUSH;
+                ev &= ~EV_SHADE;
             }
-            if (run == EV_LIGHT && VOL && LMODE != 0 && (ev & EV_LIGHT)) {
-                do_light(last_i0, last_i1, last_i2, last_d);
-                ev &= ~EV_LIGHT;
-            }
-            if (LMODE == 0) ev &= ~EV_LIGHT;
             // -- entering a recursive block: RaycastStep::recursive_raycast (raycast.rs:458-476) --
             if (run == EV_ENTER && (ev & EV_ENTER)) {
                 const DevBlock *tb = &L.blocks[blk_index];
@@ -983,9 +1033,9 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
                                 r = ps_mul(r, scale); g = ps_mul(g, scale); bl = ps_mul(bl, scale);
                             }
                         }
-                        const uint32_t R = srgb8_channel(r, F.srgb_thr);
-                        const uint32_t G = srgb8_channel(g, F.srgb_thr);
-                        const uint32_t B = srgb8_channel(bl, F.srgb_thr);
+                        const uint32_t R = srgb8_channel(r, s_thr);
+                        const uint32_t G = srgb8_channel(g, s_thr);
+                        const uint32_t B = srgb8_channel(bl, s_thr);
                         const uint32_t A = round_sat_u8(c[3] * 255.0f);
                         F.out[pix] = R | (G << 8) | (B << 16) | (A << 24);
                     }
@@ -1120,7 +1170,6 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
             int ts_kind = 0;
             uint32_t ref = 0;
             bool produced = true;   // false: no TraceStep came out of this trip (pre-entry step / level pop)
-            bool flush = false, need_light = false, enter = false;
             if (VOL && (cur.st & ST_BUFFERED)) {
                 cur.st &= ~ST_BUFFERED;  // DepthStep::EnterBlock: counted, nothing to draw
             } else {
@@ -1246,59 +1295,37 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
                         }
                     }
                 }
-                if (produced) {
-                    // -- TraceStep -> DepthIter::next (surface.rs:453-491) / direct use --
-                    const bool has_last = (cur.st & ST_HAS_LAST) != 0;
-                    if (ts_kind == 1 || (VOL && has_last)) {
-                        // t of this step in outer units (surface.rs:385-386: inner t times 1/resolution)
-                        const double ts_t = (cur.st & ST_IN_BLOCK) ? cur.last_t * __hiloint2double((int)((1023u - (31u - (uint32_t)__clz((int)blk_res))) << 20), 0) : cur.last_t;
-                        if (VOL) {
-                            if (has_last) {
-                                span_ref = last_ref; span_i0 = last_i0; span_i1 = last_i1; span_i2 = last_i2; span_t = last_t;
-                                span_exit = ts_t;
-                                if (DIAG) span_d = last_d;
-                                flush = true;
-                                cur.st &= ~ST_HAS_LAST;
-                            }
-                            if (ts_kind == 1) {
-                                last_ref = ref; last_t = ts_t;
-                                last_i0 = last_i1 = last_i2 = 1.0f;
-                                cur.st |= ST_HAS_LAST;
-                                need_light = LMODE != 0;
-                            }
-                        } else {
-                            span_ref = ref; span_t = ts_t;
-                            span_i0 = span_i1 = span_i2 = 1.0f;
-                            flush = true;
-                            need_light = LMODE != 0;
-                        }
-                        if (DIAG && ts_kind == 1) {
-                            SurfDiag sd;
-                            sd.nlight = 0;
-                            if (cur.st & ST_IN_BLOCK) {
-                                sd.cube[0] = saved.cx; sd.cube[1] = saved.cy; sd.cube[2] = saved.cz;
-                                sd.voxel[0] = cur.cx; sd.voxel[1] = cur.cy; sd.voxel[2] = cur.cz;
-                                sd.res = (int)blk_res; sd.block = (int)blk_index;
-                            } else {
-                                sd.cube[0] = cur.cx; sd.cube[1] = cur.cy; sd.cube[2] = cur.cz;
-                                sd.voxel[0] = sd.voxel[1] = sd.voxel[2] = 0;
-                                sd.res = 1; sd.block = (int)(ref & 0xffffu);
-                            }
-                            sd.face = lvl_face(cur);
-                            if (VOL) last_d = sd; else span_d = sd;
-                        }
-                    }
-                    if (ts_kind == 2) {
-                        enter = true;
-                        if (VOL) cur.st |= ST_BUFFERED;
-                    }
-                }
             }
             if (produced) {
                 // ---- TracingState::count_step_should_stop (sr.rs:625-656) ----
                 count++;
-                if (count > 1000u || (cur.st & ST_OPAQUE)) ev = EV_FINISH;
-                else ev = (flush ? EV_FLUSH : 0u) | (need_light ? EV_LIGHT : 0u) | (enter ? EV_ENTER : 0u);
+                if (count > 1000u || (cur.st & ST_OPAQUE)) {
+                    ev = EV_FINISH;
+                } else {
+                    // ---- DepthIter::next (surface.rs:453-491): a pending surface's span ends at this step;
+                    // its contribution was computed when it was shaded, apply it now ----
+                    if (VOL && (cur.st & ST_HAS_LAST)) {
+                        cb_add(acc, pend0, pend1, pend2, pend_tr);
+                        if (cb_opaque(acc)) cur.st |= ST_OPAQUE;
+                        cur.st &= ~ST_HAS_LAST;
+                        if (DIAG && pend_visible) {
+                            dg.n_hits++;
+                            dg.n_light += pend_d.nlight;
+                            if (!dg.hit) {
+                                dg.hit = 1;
+                                for (int a2 = 0; a2 < 3; a2++) { dg.cube[a2] = pend_d.cube[a2]; dg.voxel[a2] = pend_d.voxel[a2]; }
+                                dg.res = pend_d.res; dg.face = pend_d.face; dg.block = pend_d.block; dg.t = pend_t;
+                            }
+                        }
+                    }
+                    if (ts_kind == 1) {
+                        shade_ref = ref;
+                        ev = EV_SHADE;
+                    } else if (ts_kind == 2) {
+                        if (VOL) cur.st |= ST_BUFFERED;  // the extra DepthStep::EnterBlock item
+                        ev = EV_ENTER;
+                    }
+                }
             }
         }
     }
