@@ -70,10 +70,11 @@ struct DevBuf {
 struct Layer {
     bool present = false;
     int32_t lo[3] = {0, 0, 0}, size[3] = {0, 0, 0};
-    DevBuf<uint16_t> grid;
+    DevBuf<uint16_t> pool;   // [0, n_cubes): cube grid; then the voxel volumes of the recursive blocks
+    DevBuf<uint32_t> cls;    // 2-bit block classes
+    std::vector<uint32_t> host_cls;
     DevBuf<uint32_t> light;
     DevBuf<DevBlock> blocks;
-    DevBuf<uint16_t> voxels;
     DevBuf<DevPaletteEntry> palette;
     std::vector<DevBlock> host_blocks;  // mirror of the block table (for replace/append)
     int32_t air_index = -1;
@@ -84,8 +85,8 @@ struct Layer {
     bool opt_set = false;
     size_t n_cubes() const { return (size_t)size[0] * (size_t)size[1] * (size_t)size[2]; }
     void release() {
-        grid.release(); light.release(); blocks.release(); voxels.release(); palette.release();
-        host_blocks.clear();
+        pool.release(); cls.release(); light.release(); blocks.release(); palette.release();
+        host_blocks.clear(); host_cls.clear();
         present = false;
     }
 };
@@ -147,6 +148,12 @@ int hip_fail(aic_ctx *c, const char *what, hipError_t e) {
 
 bool valid_layer(int l) { return l == AIC_LAYER_WORLD || l == AIC_LAYER_UI; }
 bool valid_resolution(int r) { return r >= 1 && r <= 128 && (r & (r - 1)) == 0; }
+
+inline uint32_t block_class(const DevBlock &b) { return (b.kind & 255u) ? 2u : ((b.kind & 0x80000000u) ? 0u : 1u); }
+inline void set_class(std::vector<uint32_t> &cls, uint32_t index, uint32_t c2) {
+    if (cls.size() <= index / 16u) cls.resize(index / 16u + 1u, 0u);
+    cls[index / 16u] = (cls[index / 16u] & ~(3u << ((index & 15u) * 2u))) | (c2 << ((index & 15u) * 2u));
+}
 
 inline bool invisible(const float *e) { return e[3] == 0.f && e[4] == 0.f && e[5] == 0.f && e[6] == 0.f; }
 
@@ -220,10 +227,11 @@ int convert_block(aic_ctx *c, const aic_block_desc &d, const uint16_t *voxels, c
 void fill_dev_layer(const aic_ctx *c, const Layer &l, const aic_camera &cam, DevLayer *d, uint32_t *flaws) {
     std::memset(d, 0, sizeof(*d));
     d->present = l.present ? 1 : 0;
-    d->grid = l.grid.p;
+    d->pool = l.pool.p;
+    d->cls = l.cls.p;
+    d->n_blocks = (uint32_t)l.host_blocks.size();
     d->light = l.light.p;
     d->blocks = l.blocks.p;
-    d->voxels = l.voxels.p;
     d->palette = l.palette.p;
     for (int a = 0; a < 3; a++) { d->lo[a] = l.lo[a]; d->size[a] = l.size[a]; }
     d->air_index = l.air_index;
@@ -354,6 +362,7 @@ int aic_upload_space(aic_ctx *c, int layer, const aic_space_desc *s) {
     const size_t n = (size_t)s->size[0] * (size_t)s->size[1] * (size_t)s->size[2];
     if (n && (!s->block_index || !s->light)) return fail(c, AIC_ERR_INVALID, "space has cubes but no block_index/light");
     if (s->n_blocks > 65536) return fail(c, AIC_ERR_INVALID, "more than 65536 blocks");
+    if (n + s->n_voxels > 0xfffffff0ull) return fail(c, AIC_ERR_INVALID, "space too large (cube grid + voxel pool must index with 32 bits)");
     if (s->n_blocks && !s->blocks) return fail(c, AIC_ERR_INVALID, "blocks is null");
 
     // block table + pools
@@ -371,7 +380,7 @@ int aic_upload_space(aic_ctx *c, int layer, const aic_space_desc *s) {
             return fail(c, AIC_ERR_INVALID, "block voxel/palette range exceeds the pools");
         if (vox.size() > 0xffffffffull || pal.size() > 0xffffffffull) return fail(c, AIC_ERR_INVALID, "pool too large");
         int rc = convert_block(c, d, s->voxels ? s->voxels + d.vox_off : nullptr, s->palette ? s->palette + 8 * (size_t)d.pal_off : nullptr,
-                               (uint32_t)vox.size(), (uint32_t)pal.size(), &blocks[i], &vox, &pal);
+                               (uint32_t)(n + vox.size()), (uint32_t)pal.size(), &blocks[i], &vox, &pal);
         if (rc != AIC_OK) return rc;
         if ((d.flags & AIC_BLOCK_AIR) && air_index < 0) air_index = (int32_t)i;
     }
@@ -380,22 +389,27 @@ int aic_upload_space(aic_ctx *c, int layer, const aic_space_desc *s) {
         if (s->block_index[i] >= s->n_blocks) return fail(c, AIC_ERR_INVALID, "cube block index out of range");
 
     hipError_t e;
-    if ((e = l.grid.ensure(n)) != hipSuccess) return hip_fail(c, "alloc grid", e);
+    std::vector<uint32_t> cls;
+    for (uint32_t i = 0; i < s->n_blocks; i++) set_class(cls, i, block_class(blocks[i]));
+    if (cls.empty()) cls.push_back(0u);
+    if ((e = l.pool.ensure(n + vox.size())) != hipSuccess) return hip_fail(c, "alloc pool", e);
+    if ((e = l.cls.ensure(cls.size())) != hipSuccess) return hip_fail(c, "alloc classes", e);
     if ((e = l.light.ensure(n)) != hipSuccess) return hip_fail(c, "alloc light", e);
     if ((e = l.blocks.ensure(blocks.size())) != hipSuccess) return hip_fail(c, "alloc blocks", e);
-    if ((e = l.voxels.ensure(vox.size())) != hipSuccess) return hip_fail(c, "alloc voxels", e);
     if ((e = l.palette.ensure(pal.size())) != hipSuccess) return hip_fail(c, "alloc palette", e);
     if (n) {
-        HIP_TRY(c, hipMemcpyAsync(l.grid.p, s->block_index, n * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(l.pool.p, s->block_index, n * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(l.light.p, s->light, n * 4, hipMemcpyHostToDevice, c->stream));
     }
     if (!blocks.empty()) HIP_TRY(c, hipMemcpyAsync(l.blocks.p, blocks.data(), blocks.size() * sizeof(DevBlock), hipMemcpyHostToDevice, c->stream));
-    if (!vox.empty()) HIP_TRY(c, hipMemcpyAsync(l.voxels.p, vox.data(), vox.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    if (!vox.empty()) HIP_TRY(c, hipMemcpyAsync(l.pool.p + n, vox.data(), vox.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(l.cls.p, cls.data(), cls.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     if (!pal.empty()) HIP_TRY(c, hipMemcpyAsync(l.palette.p, pal.data(), pal.size() * sizeof(DevPaletteEntry), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // host buffers may be released on return
 
     for (int a = 0; a < 3; a++) { l.lo[a] = s->lo[a]; l.size[a] = s->size[a]; }
     l.host_blocks.swap(blocks);
+    l.host_cls.swap(cls);
     l.air_index = air_index;
     l.sky_kind = s->sky_kind;
     std::memcpy(l.sky, s->sky, sizeof(l.sky));
@@ -428,7 +442,7 @@ int aic_update_cubes(aic_ctx *c, int layer, uint32_t n, const int32_t *xyz, cons
     HIP_TRY(c, hipMemcpyAsync(base, xyz, b_xyz, hipMemcpyHostToDevice, c->stream));
     if (block_index) HIP_TRY(c, hipMemcpyAsync(base + b_xyz, block_index, (size_t)n * 2, hipMemcpyHostToDevice, c->stream));
     if (light) HIP_TRY(c, hipMemcpyAsync(base + b_xyz + b_bi, light, b_lt, hipMemcpyHostToDevice, c->stream));
-    launch_scatter_cubes(l.grid.p, l.light.p, (const int32_t *)base, block_index ? (const uint16_t *)(base + b_xyz) : nullptr,
+    launch_scatter_cubes(l.pool.p, l.light.p, (const int32_t *)base, block_index ? (const uint16_t *)(base + b_xyz) : nullptr,
                          light ? (const uint32_t *)(base + b_xyz + b_bi) : nullptr, n, l.lo, l.size, c->stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -455,13 +469,14 @@ int aic_replace_block(aic_ctx *c, int layer, uint32_t index, const aic_block_des
     std::vector<uint16_t> vox;
     std::vector<DevPaletteEntry> pal;
     DevBlock db;
-    const uint32_t vox_off = (uint32_t)l.voxels.n, pal_off = (uint32_t)l.palette.n;
+    const uint32_t vox_off = (uint32_t)l.pool.n, pal_off = (uint32_t)l.palette.n;
     int rc = convert_block(c, *desc, voxels, palette, vox_off, pal_off, &db, &vox, &pal);
     if (rc != AIC_OK) return rc;
     hipError_t e;
     if (!vox.empty()) {
-        if ((e = l.voxels.ensure(vox_off + vox.size(), true, c->stream)) != hipSuccess) return hip_fail(c, "grow voxels", e);
-        HIP_TRY(c, hipMemcpyAsync(l.voxels.p + vox_off, vox.data(), vox.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+        if ((uint64_t)vox_off + vox.size() > 0xfffffff0ull) return fail(c, AIC_ERR_INVALID, "voxel pool too large");
+        if ((e = l.pool.ensure(vox_off + vox.size(), true, c->stream)) != hipSuccess) return hip_fail(c, "grow pool", e);
+        HIP_TRY(c, hipMemcpyAsync(l.pool.p + vox_off, vox.data(), vox.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
     }
     if (!pal.empty()) {
         if ((e = l.palette.ensure(pal_off + pal.size(), true, c->stream)) != hipSuccess) return hip_fail(c, "grow palette", e);
@@ -474,6 +489,9 @@ int aic_replace_block(aic_ctx *c, int layer, uint32_t index, const aic_block_des
         l.host_blocks[index] = db;
     }
     HIP_TRY(c, hipMemcpyAsync(l.blocks.p + index, &db, sizeof(db), hipMemcpyHostToDevice, c->stream));
+    set_class(l.host_cls, index, block_class(db));
+    if ((e = l.cls.ensure(l.host_cls.size(), true, c->stream)) != hipSuccess) return hip_fail(c, "grow classes", e);
+    HIP_TRY(c, hipMemcpyAsync(l.cls.p + index / 16u, &l.host_cls[index / 16u], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (desc->flags & AIC_BLOCK_AIR) {
         if (l.air_index < 0) l.air_index = (int32_t)index;

@@ -1,10 +1,16 @@
 // aic_device.h -- device-side data layout shared by the host ABI code and the kernels.
 //
 // HBM layout of one uploaded Space ("layer"):
-//   grid    : u16  [n cubes]  block index, Z-major (same linearisation as the reference's Vol)
+//   pool    : u16 pool. [0, n cubes): the cube grid = block index per cube, Z-major (same
+//             linearisation as the reference's Vol); then, per recursive block, a Z-major volume
+//             of *device voxel codes* (see below). One pool so that both DDA levels index memory
+//             the same way: pool[volume offset + (x*sy + y)*sz + z].
+//   cls     : 2-bit class per block index (invisible single voxel / visible single voxel /
+//             recursive), copied to LDS by the trace kernel so that classifying a cube costs no
+//             second global load.
 //   light   : u32  [n cubes]  PackedLight texel r | g<<8 | b<<16 | status<<24
 //   blocks  : DevBlock [n blocks], 64 B each (one cache line per block entry)
-//   voxels  : u16 pool; per block a Z-major volume of *device voxel codes*: the block's
+//   voxels  : (inside pool) per block a Z-major volume of *device voxel codes*: the block's
 //             palette is reordered at upload so invisible entries (alpha == 0 && emission == 0,
 //             surface.rs:395) come first; code < DevBlock.n_invisible means "invisible voxel"
 //             and needs no palette fetch.
@@ -23,7 +29,7 @@ struct DevBlock {
                           // bit 31 (single voxel only): the voxel is invisible (alpha == 0 && emission == 0)
     uint32_t vlo_packed;  // stored voxel volume lower corner  x | y<<8 | z<<16  (each 0..127)
     uint32_t vsize_packed;  // stored voxel volume size      x | y<<8 | z<<16  (each 1..128)
-    uint32_t vox_off;     // u16 units into the voxel pool
+    uint32_t vox_off;     // u16 units into DevLayer.pool (already past the cube grid)
     uint32_t pal_off;     // entries into the palette pool
     uint32_t n_invisible; // device voxel codes below this are invisible
     uint32_t pad[3];
@@ -50,13 +56,15 @@ struct DevOptions {
 };
 
 struct DevLayer {
-    const uint16_t *grid;
+    const uint16_t *pool;    // u16 pool: the cube grid (block indices) at offset 0, then every block's
+                             // voxel volume (device voxel codes); DevBlock.vox_off is an offset into it
+    const uint32_t *cls;     // 2 bits per block index: 0 invisible single voxel, 1 visible single voxel, 2 recursive
     const uint32_t *light;
     const DevBlock *blocks;
-    const uint16_t *voxels;
     const DevPaletteEntry *palette;
     int32_t lo[3];
     int32_t size[3];
+    uint32_t n_blocks;
     int32_t present;        // 0: no space uploaded for this layer
     int32_t air_index;      // block index flagged AIR, or -1
     int32_t sky_kind;
@@ -120,5 +128,6 @@ struct DevFrame {
 // Tile geometry: one wavefront traces an 8x8 pixel tile (coherent rays), a workgroup of 256
 // threads covers 16x16 pixels.
 constexpr int kTile = 16;
+constexpr int kClsWords = 4096;  // 65536 blocks x 2 bits
 
 }  // namespace aic

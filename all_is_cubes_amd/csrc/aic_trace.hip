@@ -126,7 +126,7 @@ struct LvlLim {
     Lim lim;
 };
 AIC_DEV LvlLim lvl_init(double ox, double oy, double oz, const RayDir rd, bool bounded, int lox, int loy,
-                        int loz, int hix, int hiy, int hiz, bool include_exit) {
+                        int loz, int hix, int hiy, int hiz, bool include_exit, double half_over_len) {
     LvlLim out;
     Lvl &s = out.s;
     Lim &lim = out.lim;
@@ -167,8 +167,8 @@ AIC_DEV LvlLim lvl_init(double ox, double oy, double oz, const RayDir rd, bool b
         if (rd.sy != 0) max_t = fmax(max_t, rely / rd.dy);
         if (rd.sz != 0) max_t = fmax(max_t, relz / rd.dz);
         if (max_t > 0.0) {  // last_t_distance == 0 at this point
-            const double len = sqrt(rd.dx * rd.dx + rd.dy * rd.dy + rd.dz * rd.dz);
-            double t_start = max_t - 0.5 / len;
+            // 0.5 / direction.length() (raycast.rs:669) is a per-ray constant, computed once by the caller
+            double t_start = max_t - half_over_len;
             if (!isfinite(t_start)) t_start = max_t;
             double ff[3] = {ox + rd.dx * t_start, oy + rd.dy * t_start, oz + rd.dz * t_start};
             if (!cube_containing(ff, cube)) return out;
@@ -369,7 +369,10 @@ AIC_DEV void cb_to_rgba(const ColorBuf &b, float out[4]) {
         return;
     }
     float alpha = 1.0f - b.t;
-    float c0 = b.l0 / alpha, c1 = b.l1 / alpha, c2 = b.l2 / alpha;
+    float c0 = b.l0, c1 = b.l1, c2 = b.l2;
+    if (__ballot(alpha != 1.0f) != 0ull) {  // x / 1.0f == x: fully opaque pixels (the usual case) need no division
+        c0 = b.l0 / alpha; c1 = b.l1 / alpha; c2 = b.l2 / alpha;
+    }
     bool ok = (c0 >= 0.f) & (c1 >= 0.f) & (c2 >= 0.f);  // false for negative or NaN
     out[0] = ok ? (c0 > 0.f ? c0 : 0.f) : 1.0f;
     out[1] = ok ? (c1 > 0.f ? c1 : 0.f) : 0.0f;
@@ -686,7 +689,8 @@ AIC_DEV uint32_t srgb8_channel(float c, const float *__restrict__ thr) {
 // lane event bits
 constexpr uint32_t EV_SHADE = 2u, EV_ENTER = 4u, EV_FINISH = 8u, EV_NEWRAY = 16u, EV_DONE = 32u;
 // lane state bits (st): 0-1 first_last | 2-4 last_face | 5-6 pick | 7 need_step | 8 include_exit (unused here)
-constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_BUFFERED = 1u << 11, ST_OPAQUE = 1u << 12, ST_TRACED = 1u << 13;
+constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_FRESH = 1u << 11, ST_OPAQUE = 1u << 12, ST_TRACED = 1u << 13,
+                   ST_OUTER_ALIVE = 1u << 21;  // bits 16-20: the suspended outer level's face + pick; 24-26: sky octant
 
 #ifndef AIC_MIN_WAVES
 #define AIC_MIN_WAVES 2
@@ -698,6 +702,16 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_BUFFERED = 
 #define AIC_N_FEW 8     // ... or once at most this many lanes can still step
 #endif
 
+// Runs Raycaster::next (raycast.rs:239-284) on a freshly initialised level until it yields its
+// first step or ends. Used by the ENTER / RAY events, so that the stepping loop only ever sees
+// levels that are already inside their bounds. On success the returned state is "emitted, step
+// scheduled" (fl = InBounds, pick + need_step set) with ABSOLUTE cube coordinates.
+AIC_DEV Lvl lvl_first(Lvl s, const Lim lim, const RayDir rd, int lox, int loy, int loz, int hix, int hiy, int hiz, bool *got) {
+    const NextResult nr = lvl_next(s, lim, rd, lox, loy, loz, hix, hiy, hiz);
+    *got = nr.got;
+    return nr.s;
+}
+
 template <bool VOL, int LMODE, bool DIAG>
 __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const DevFrame F) {
     // ---- persistent waves: each wave pulls 16x16-pixel tiles from a global counter until the
@@ -707,11 +721,16 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
     uint32_t tile_cur = 0xffffffffu;  // wave-uniform: tile the refill is drawing pixels from
     const DevLayer &L = F.layer;
     const DevOptions &opt = L.opt;
-    // the two 1 KiB decode tables live in LDS for the life of the persistent workgroup
-    __shared__ float s_lut[256];  // PackedLight scalar decode (light/data.rs:301-354)
-    __shared__ float s_thr[256];  // sRGB8 encode thresholds
+    // small decode tables live in LDS for the life of the persistent workgroup
+    __shared__ float s_lut[256];     // PackedLight scalar decode (light/data.rs:301-354)
+    __shared__ float s_thr[256];     // sRGB8 encode thresholds
+    __shared__ uint32_t s_cls[kClsWords];  // 2 bits per block: 0 invisible single voxel, 1 visible single voxel, 2 recursive
     s_lut[threadIdx.x] = F.light_lut[threadIdx.x];
     s_thr[threadIdx.x] = F.srgb_thr[threadIdx.x];
+    {
+        const uint32_t n_words = (L.n_blocks + 15u) / 16u;
+        for (uint32_t i = threadIdx.x; i < n_words && i < (uint32_t)kClsWords; i += 256u) s_cls[i] = L.cls[i];
+    }
     __syncthreads();
     const float *lut = s_lut;
     const bool ui_pass = F.pass == 1;
@@ -721,24 +740,29 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
     const int n_samples = F.antialias ? 4 : 1;
 
     const int olx = L.lo[0], oly = L.lo[1], olz = L.lo[2];
-    const int ohx = olx + L.size[0], ohy = oly + L.size[1], ohz = olz + L.size[2];
-    const uint32_t osy = (uint32_t)L.size[1], osz = (uint32_t)L.size[2];
+    const int osx_i = L.size[0], osy_i = L.size[1], osz_i = L.size[2];
+    const uint32_t osy = (uint32_t)osy_i, osz = (uint32_t)osz_i;
+    const uint16_t *__restrict__ pool = L.pool;  // cube grid at offset 0, then every block's voxel volume
 
     // ---- per-lane ray state ----
-    double ox = 0, oy = 0, oz = 0;     // ray origin
-    RayDir rd;
+    double ox = 0, oy = 0, oz = 0;  // ray origin
+    RayDir rd;                      // direction (sanitised), t_delta, step signs
     rd.dx = rd.dy = rd.dz = 0.0; rd.tdx = rd.tdy = rd.tdz = 0.0; rd.sx = rd.sy = rd.sz = 0;
-    double dirx = 0, diry = 0, dirz = 0;  // un-sanitised direction (sky, length, intersection point)
-    Lvl cur, saved;
-    cur.tx = cur.ty = cur.tz = cur.last_t = 0.0; cur.cx = cur.cy = cur.cz = 0; cur.st = FL_ENDED;
-    saved = cur;
-    Lim lim;
-    lim.x = lim.y = lim.z = 0;
-    uint32_t blk_index = 0, blk_res = 1, blk_vlo = 0, blk_vsize = 0, blk_vox_off = 0, blk_pal_off = 0, blk_ninvis = 0;
+    // current DDA level: t_max, last t, cube coordinates RELATIVE to the level's lower corner,
+    // exit coordinate per axis, and the volume being indexed: pool offset and y/z extents
+    double tx = 0, ty = 0, tz = 0, last_t = 0;
+    int cx = 0, cy = 0, cz = 0, limx = 0, limy = 0, limz = 0;
+    uint32_t vol_off = 0, vsy = 1, vsz = 1;
+    // the suspended outer level while inside a block
+    double s_tx = 0, s_ty = 0, s_tz = 0, s_last = 0;
+    int s_cx = 0, s_cy = 0, s_cz = 0;
+    // st: bits 0-1 first_last | 2-4 last_face | 5-6 pick | 7 need_step | 9.. flags | 16-22 saved outer (face, pick) | 24-26 sky octant
+    uint32_t st = FL_ENDED;
+    uint32_t blk_index = 0, blk_res = 1, blk_vlo = 0, blk_pal_off = 0, blk_ninvis = 0;
     ColorBuf acc;
     acc.l0 = acc.l1 = acc.l2 = 0.f; acc.t = 1.0f;
     uint32_t count = 0;
-    double t_abs = 0.0;
+    double t_abs = 0.0, half_over_len = 0.0;
     float t_view = 0.f;
     // DepthIter.last_surface, already shaded: its premultiplied light and transmittance
     uint32_t shade_ref = 0;  // colour record of the surface waiting to be shaded (bit31: single-voxel block)
@@ -772,11 +796,28 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
 #endif
     uint32_t next_idx = 256;  // wave-uniform: next unassigned pixel of tile_cur (256 = tile exhausted)
 
+    // sky colour seen along this ray (Sky::sample, sky.rs:32-41); the octant was fixed at ray start
+    auto sky_now = [&](float out[3]) {
+        const int idx = (L.sky_kind != 0) ? (int)((st >> 24) & 7u) : 0;
+        out[0] = L.sky[idx][0]; out[1] = L.sky[idx][1]; out[2] = L.sky[idx][2];
+    };
+    // the level's state as an absolute-coordinate Lvl (for RaycastStep::intersection_point)
+    auto cur_abs = [&]() {
+        Lvl a;
+        a.tx = tx; a.ty = ty; a.tz = tz; a.last_t = last_t; a.st = st;
+        if (st & ST_IN_BLOCK) {
+            a.cx = cx + (int)(blk_vlo & 255u); a.cy = cy + (int)((blk_vlo >> 8) & 255u); a.cz = cz + (int)((blk_vlo >> 16) & 255u);
+        } else {
+            a.cx = cx + olx; a.cy = cy + oly; a.cz = cz + olz;
+        }
+        return a;
+    };
+
     for (;;) {
         // ---- wave scheduler: step, or run ONE kind of parked work for all lanes waiting on it ----
-        // Kinds: SHADE (light + composite a surface), ENTER (a block), RAY (finish / start a ray). A kind is run
-        // when enough lanes wait on it to fill the wave reasonably (AIC_T_BATCH), or when so few
-        // lanes can still step (AIC_N_FEW) that waiting longer only idles the wave.
+        // Kinds: SHADE (light + composite a surface), ENTER (a block), RAY (finish / start a ray). A
+        // kind is run when enough lanes wait on it to fill the wave reasonably (AIC_T_BATCH), or when
+        // so few lanes can still step (AIC_N_FEW) that waiting longer only idles the wave.
         const unsigned long long m_st = __ballot(ev == 0u);
         const unsigned long long b_shade = __ballot((ev & EV_SHADE) != 0u);
         const unsigned long long b_enter = __ballot((ev & EV_ENTER) != 0u);
@@ -806,32 +847,33 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
             //    therefore computed here in full and merely *applied* by the stepping code when that
             //    next step is counted (so the order count -> stop-check -> accumulate is kept). --
             if (run == EV_SHADE && (ev & EV_SHADE)) {
-                const bool inb = (cur.st & ST_IN_BLOCK) != 0;
+                const bool inb = (st & ST_IN_BLOCK) != 0;
                 const double as = inb ? __hiloint2double((int)((1023u - (31u - (uint32_t)__clz((int)blk_res))) << 20), 0) : 1.0;
-                const double t_enter = cur.last_t * as;  // surface.rs:385-386
+                const double t_enter = last_t * as;  // surface.rs:385-386
+                const Lvl ca = cur_abs();
+                const int ocx = (inb ? s_cx : cx) + olx, ocy = (inb ? s_cy : cy) + oly, ocz = (inb ? s_cz : cz) + olz;  // the Space cube
                 // illumination (surface.rs:113-206)
                 float i0 = 1.0f, i1 = 1.0f, i2 = 1.0f;
                 uint32_t nl = 0;
                 if (LMODE != 0) {
-                    const int face = lvl_face(cur);
-                    const int ocx = inb ? saved.cx : cur.cx, ocy = inb ? saved.cy : cur.cy, ocz = inb ? saved.cz : cur.cz;
+                    const int face = lvl_face(ca);
                     if (LMODE == 1) {
                         int nx = 0, ny = 0, nz = 0;
                         if (face == 1) nx = -1; else if (face == 2) ny = -1; else if (face == 3) nz = -1;
                         else if (face == 4) nx = 1; else if (face == 5) ny = 1; else if (face == 6) nz = 1;
-                        const uint32_t tx = get_packed_light<DIAG>(L, ocx + nx, ocy + ny, ocz + nz, nl);
-                        i0 = lut[tx & 255u]; i1 = lut[(tx >> 8) & 255u]; i2 = lut[(tx >> 16) & 255u];
+                        const uint32_t txl = get_packed_light<DIAG>(L, ocx + nx, ocy + ny, ocz + nz, nl);
+                        i0 = lut[txl & 255u]; i1 = lut[(txl >> 8) & 255u]; i2 = lut[(txl >> 16) & 255u];
                     } else {
                         double ip[3];
                         if (inb) {
                             const double kd = (double)blk_res;
                             double vp[3];
-                            intersection_point(cur, (ox - (double)ocx) * kd, (oy - (double)ocy) * kd, (oz - (double)ocz) * kd, dirx, diry, dirz, vp);
+                            intersection_point(ca, (ox - (double)ocx) * kd, (oy - (double)ocy) * kd, (oz - (double)ocz) * kd, rd.dx, rd.dy, rd.dz, vp);
                             ip[0] = vp[0] * as + (double)ocx;  // surface.rs:406-407
                             ip[1] = vp[1] * as + (double)ocy;
                             ip[2] = vp[2] * as + (double)ocz;
                         } else {
-                            intersection_point(cur, ox, oy, oz, dirx, diry, dirz, ip);
+                            intersection_point(ca, ox, oy, oz, rd.dx, rd.dy, rd.dz, ip);
                         }
                         const int oc[3] = {ocx, ocy, ocz};
                         float il[3];
@@ -858,12 +900,12 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
                     // exit distance = t of the next TraceStep: the deferred step of this level, or -- if this
                     // level cannot step any more -- of the enclosing cube grid; none => the span is never emitted
                     double t_exit = 0.0;
-                    if ((cur.st & 3u) != FL_ENDED) {
-                        const uint32_t pk = (cur.st >> 5) & 3u;
-                        t_exit = (pk == 0 ? cur.tx : (pk == 1 ? cur.ty : cur.tz)) * as;
-                    } else if (inb && (saved.st & 3u) != FL_ENDED) {
-                        const uint32_t pk = (saved.st >> 5) & 3u;
-                        t_exit = pk == 0 ? saved.tx : (pk == 1 ? saved.ty : saved.tz);
+                    if ((st & 3u) != FL_ENDED) {
+                        const uint32_t pk = (st >> 5) & 3u;
+                        t_exit = (pk == 0 ? tx : (pk == 1 ? ty : tz)) * as;
+                    } else if (inb && (st & ST_OUTER_ALIVE)) {
+                        const uint32_t pk = (st >> 19) & 3u;  // the suspended outer level's scheduled step
+                        t_exit = pk == 0 ? s_tx : (pk == 1 ? s_ty : s_tz);
                     } else {
                         will_flush = false;
                     }
@@ -899,14 +941,21 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
                     tr = 1.0f - a;
                     if (fog_on) {  // distance_fog (sr.rs:745-768)
                         float sky[3];
-                        sky_of(L, dirx, diry, dirz, sky);
+                        sky_now(sky);
                         const float fog_blend = opt.fog == 1 ? 1.0f : (opt.fog == 2 ? 0.5f : 0.0f);
                         float rel = (float)t_enter * t_view;
                         rel = rel < 0.0f ? 0.0f : (rel > 1.0f ? 1.0f : rel);
-                        const float fog_exp = 1.0f - expf_exact(-1.6f * rel);
-                        const float fudged = fog_exp / 0.79810348f;
                         const float sq = rel * rel;
-                        const float amount = zo_clamped(fudged * (1.0f - fog_blend) + (sq * sq) * fog_blend);
+                        float amount;
+                        if (opt.fog == 1) {
+                            // Abrupt: blend == 1, so the exponential term is (finite, >= 0) * 0.0 == +0.0 and
+                            // +0.0 + rel^4 * 1.0 == rel^4 exactly -- no exp needed
+                            amount = zo_clamped((sq * sq) * 1.0f);
+                        } else {
+                            const float fog_exp = 1.0f - expf_exact(-1.6f * rel);
+                            const float fudged = fog_exp / 0.79810348f;
+                            amount = zo_clamped(fudged * (1.0f - fog_blend) + (sq * sq) * fog_blend);
+                        }
                         const float comp = 1.0f - amount;
                         o0 = ps_mul(o0, comp) + ps_mul(sky[0], amount);
                         o1 = ps_mul(o1, comp) + ps_mul(sky[1], amount);
@@ -917,27 +966,26 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
                 SurfDiag sd;
                 if (DIAG) {
                     sd.nlight = nl;
+                    sd.cube[0] = ocx; sd.cube[1] = ocy; sd.cube[2] = ocz;
                     if (inb) {
-                        sd.cube[0] = saved.cx; sd.cube[1] = saved.cy; sd.cube[2] = saved.cz;
-                        sd.voxel[0] = cur.cx; sd.voxel[1] = cur.cy; sd.voxel[2] = cur.cz;
+                        sd.voxel[0] = ca.cx; sd.voxel[1] = ca.cy; sd.voxel[2] = ca.cz;
                         sd.res = (int)blk_res; sd.block = (int)blk_index;
                     } else {
-                        sd.cube[0] = cur.cx; sd.cube[1] = cur.cy; sd.cube[2] = cur.cz;
                         sd.voxel[0] = sd.voxel[1] = sd.voxel[2] = 0;
                         sd.res = 1; sd.block = (int)(shade_ref & 0xffffu);
                     }
-                    sd.face = lvl_face(cur);
+                    sd.face = lvl_face(ca);
                 }
                 if (VOL) {
                     // DepthIter.last_surface: applied when the next TraceStep is counted
                     if (will_flush) {
                         pend0 = o0; pend1 = o1; pend2 = o2; pend_tr = tr;
-                        cur.st |= ST_HAS_LAST;
+                        st |= ST_HAS_LAST;
                         if (DIAG) { pend_d = sd; pend_t = t_enter; pend_visible = visible; }
                     }
                 } else if (visible) {
                     cb_add(acc, o0, o1, o2, tr);  // trace_through_surface (sr.rs:697-717)
-                    if (cb_opaque(acc)) cur.st |= ST_OPAQUE;
+                    if (cb_opaque(acc)) st |= ST_OPAQUE;
                     if (DIAG) {
                         dg.n_hits++;
                         dg.n_light += sd.nlight;
@@ -950,33 +998,42 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
                 }
                 ev &= ~EV_SHADE;
             }
-            // -- entering a recursive block: RaycastStep::recursive_raycast (raycast.rs:458-476) --
+            // -- entering a recursive block: RaycastStep::recursive_raycast (raycast.rs:458-476),
+            //    advanced to its first in-bounds voxel (or to its end) --
             if (run == EV_ENTER && (ev & EV_ENTER)) {
                 const DevBlock *tb = &L.blocks[blk_index];
+                blk_res = tb->kind & 255u;
                 blk_vlo = tb->vlo_packed;
-                blk_vsize = tb->vsize_packed;
-                blk_vox_off = tb->vox_off;
+                const uint32_t vsize = tb->vsize_packed;
                 blk_pal_off = tb->pal_off;
                 blk_ninvis = tb->n_invisible;
                 const double kd = (double)blk_res;
-                const double sx_ = (ox - (double)cur.cx) * kd, sy_ = (oy - (double)cur.cy) * kd, sz_ = (oz - (double)cur.cz) * kd;
-                const uint32_t keep = cur.st & (ST_HAS_LAST | ST_BUFFERED | ST_OPAQUE | ST_TRACED);
-                saved = cur;
+                const int acx = cx + olx, acy = cy + oly, acz = cz + olz;
+                const double sx_ = (ox - (double)acx) * kd, sy_ = (oy - (double)acy) * kd, sz_ = (oz - (double)acz) * kd;
+                // suspend the outer level (it always has its next step scheduled: pick + face go to st[16..22])
+                s_tx = tx; s_ty = ty; s_tz = tz; s_last = last_t; s_cx = cx; s_cy = cy; s_cz = cz;
+                st = (st & ~((0x1fu << 16) | ST_OUTER_ALIVE)) | (((st >> 2) & 0x1fu) << 16) | (((st & 3u) == FL_INBOUNDS) ? ST_OUTER_ALIVE : 0u);
                 const int ilx = (int)(blk_vlo & 255u), ily = (int)((blk_vlo >> 8) & 255u), ilz = (int)((blk_vlo >> 16) & 255u);
-                const LvlLim ll = lvl_init(sx_, sy_, sz_, rd, true, ilx, ily, ilz, ilx + (int)(blk_vsize & 255u),
-                                           ily + (int)((blk_vsize >> 8) & 255u), ilz + (int)((blk_vsize >> 16) & 255u), true);
-                cur = ll.s;
-                lim = ll.lim;
-                cur.st |= keep | ST_IN_BLOCK;
+                const int isx = (int)(vsize & 255u), isy = (int)((vsize >> 8) & 255u), isz = (int)((vsize >> 16) & 255u);
+                const LvlLim ll = lvl_init(sx_, sy_, sz_, rd, true, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz, true, half_over_len);
+                bool got;
+                const Lvl f = lvl_first(ll.s, ll.lim, rd, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz, &got);
+                tx = f.tx; ty = f.ty; tz = f.tz; last_t = f.last_t;
+                cx = f.cx - ilx; cy = f.cy - ily; cz = f.cz - ilz;
+                limx = rd.sx > 0 ? isx : -1; limy = rd.sy > 0 ? isy : -1; limz = rd.sz > 0 ? isz : -1;
+                vol_off = tb->vox_off; vsy = (uint32_t)isy; vsz = (uint32_t)isz;
+                // level flags: the low 9 bits come from the raycaster; a produced first step still needs its lookup
+                st = (st & ~0x1ffu) | (f.st & 0xffu) | ST_IN_BLOCK | (got ? ST_FRESH : 0u);
+                if (!got) st = (st & ~3u) | FL_ENDED;
                 ev &= ~EV_ENTER;
             }
             // -- finishing a ray: TracingState::finish + layer tail + (last sample) encode & store --
             if (run == EV_FINISH && (ev & EV_FINISH)) {
-                if (cur.st & ST_TRACED) {
+                if (st & ST_TRACED) {
                     // finish (sr.rs:658-693): the sky hit, then the optional cost visualisation
                     if (include_sky) {
                         float sky[3];
-                        sky_of(L, dirx, diry, dirz, sky);
+                        sky_now(sky);
                         cb_add(acc, sky[0] * 1.0f, sky[1] * 1.0f, sky[2] * 1.0f, 0.0f);
                     } else {
                         cb_add(acc, 0.f, 0.f, 0.f, 1.0f);
@@ -1091,16 +1148,16 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
                 }
             }
             if (run == EV_FINISH && (ev & EV_NEWRAY) && ev != EV_DONE) {
-                bool have_pixel = true;
+                const uint32_t x = pxy & 0xffffu, lrow = pxy >> 16;
+                const size_t pix = (size_t)lrow * F.width + x;
                 if (ev & 64u) {
-                    const uint32_t x = pxy & 0xffffu, lrow = pxy >> 16;
                     s0 = s1 = s2 = st_sum = 0.f;
                     if (DIAG) {
                         dg.n_outer = dg.n_inner = dg.n_hits = dg.n_light = 0; dg.hit = 0; dg.res = dg.face = dg.block = 0; dg.t = 0.0;
                         for (int a = 0; a < 3; a++) dg.cube[a] = dg.voxel[a] = 0;
                         px_steps = 0; px_steps_prev = 0;
                         if (F.use_init && F.aux) {  // continue the UI pre-pass's per-pixel record
-                            const DevAux &a = F.aux[(size_t)lrow * F.width + x];
+                            const DevAux &a = F.aux[pix];
                             dg.hit = a.hit;
                             for (int k = 0; k < 3; k++) { dg.cube[k] = a.cube[k]; dg.voxel[k] = a.voxel[k]; }
                             dg.res = a.resolution; dg.face = a.face; dg.block = a.block_index; dg.t = a.t_distance;
@@ -1108,206 +1165,152 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
                         }
                     }
                 }
-                if (have_pixel) {
-                    const uint32_t x = pxy & 0xffffu, lrow = pxy >> 16;
-                    const size_t pix = (size_t)lrow * F.width + x;
-                    // global row of this local row under the strip partition
-                    const uint32_t y = (F.part + (lrow / F.strip_rows) * F.n_parts) * F.strip_rows + (lrow % F.strip_rows);
-                    const double x0 = fb_x_edge(F.width, x), x1 = fb_x_edge(F.width, x + 1);
-                    const double y0 = fb_y_edge(F.height, y), y1 = fb_y_edge(F.height, y + 1);
-                    double px, py;  // renderer.rs:428-433 sample points, else the patch centre
-                    if (n_samples == 4) {
-                        const double ux = (sample == 0) ? 1. / 8. : (sample == 1) ? 3. / 8. : (sample == 2) ? 5. / 8. : 7. / 8.;
-                        const double uy = (sample == 0) ? 5. / 8. : (sample == 1) ? 1. / 8. : (sample == 2) ? 7. / 8. : 3. / 8.;
-                        px = x0 + (x1 - x0) * ux;
-                        py = y0 + (y1 - y0) * uy;
-                    } else {
-                        px = (x0 + x1) / 2.0;
-                        py = (y0 + y1) / 2.0;
-                    }
-                    if (F.use_init) {
-                        const float4 v = F.acc_buf[(size_t)sample * npix + pix];
-                        acc.l0 = v.x; acc.l1 = v.y; acc.l2 = v.z; acc.t = v.w;
-                    } else {
-                        acc.l0 = acc.l1 = acc.l2 = 0.f;
-                        acc.t = 1.0f;
-                    }
-                    if (DIAG && sample > 0) dg.hit = dg.hit | 2;  // only the first sample's position is reported
-                    if (!ui_pass && F.has_backdrop) {  // Exception::Backdrop hit: ColorBuf::from(Rgba)
-                        const float a = F.backdrop[3];
-                        cb_add(acc, F.backdrop[0] * a, F.backdrop[1] * a, F.backdrop[2] * a, 1.0f - a);
-                    }
-                    count = 0;
-                    if (L.present) {
-                        double o[3], f[3];
-                        unproject(L.inv, px, py, 0.0, o);
-                        unproject(L.inv, px, py, 1.0, f);
-                        ox = o[0]; oy = o[1]; oz = o[2];
-                        dirx = f[0] - o[0]; diry = f[1] - o[1]; dirz = f[2] - o[2];
-                        t_abs = sqrt(dirx * dirx + diry * diry + dirz * dirz);  // sr.rs:146
-                        t_view = (float)(t_abs / opt.view_distance);             // sr.rs:149-151
-                        rd = raydir_init(dirx, diry, dirz);
-                        const LvlLim ll = lvl_init(ox, oy, oz, rd, true, olx, oly, olz, ohx, ohy, ohz, true);
-                        cur = ll.s;
-                        lim = ll.lim;
-                        cur.st |= ST_TRACED;
-                        if (cb_opaque(acc)) cur.st |= ST_OPAQUE;
-                        ev = 0u;
-                    } else {
-                        cur.st = FL_ENDED;
-                        ev = EV_FINISH;
-                    }
+                // global row of this local row under the strip partition
+                const uint32_t y = (F.part + (lrow / F.strip_rows) * F.n_parts) * F.strip_rows + (lrow % F.strip_rows);
+                const double x0 = fb_x_edge(F.width, x), x1 = fb_x_edge(F.width, x + 1);
+                const double y0 = fb_y_edge(F.height, y), y1 = fb_y_edge(F.height, y + 1);
+                double px, py;  // renderer.rs:428-433 sample points, else the patch centre
+                if (n_samples == 4) {
+                    const double ux = (sample == 0) ? 1. / 8. : (sample == 1) ? 3. / 8. : (sample == 2) ? 5. / 8. : 7. / 8.;
+                    const double uy = (sample == 0) ? 5. / 8. : (sample == 1) ? 1. / 8. : (sample == 2) ? 7. / 8. : 3. / 8.;
+                    px = x0 + (x1 - x0) * ux;
+                    py = y0 + (y1 - y0) * uy;
+                } else {
+                    px = (x0 + x1) / 2.0;
+                    py = (y0 + y1) / 2.0;
+                }
+                if (F.use_init) {
+                    const float4 v = F.acc_buf[(size_t)sample * npix + pix];
+                    acc.l0 = v.x; acc.l1 = v.y; acc.l2 = v.z; acc.t = v.w;
+                } else {
+                    acc.l0 = acc.l1 = acc.l2 = 0.f;
+                    acc.t = 1.0f;
+                }
+                if (DIAG && sample > 0) dg.hit = dg.hit | 2;  // only the first sample's position is reported
+                if (!ui_pass && F.has_backdrop) {  // Exception::Backdrop hit: ColorBuf::from(Rgba)
+                    const float a = F.backdrop[3];
+                    cb_add(acc, F.backdrop[0] * a, F.backdrop[1] * a, F.backdrop[2] * a, 1.0f - a);
+                }
+                count = 0;
+                st = FL_ENDED;
+                if (L.present) {
+                    double o[3], f[3];
+                    unproject(L.inv, px, py, 0.0, o);
+                    unproject(L.inv, px, py, 1.0, f);
+                    ox = o[0]; oy = o[1]; oz = o[2];
+                    const double dirx = f[0] - o[0], diry = f[1] - o[1], dirz = f[2] - o[2];
+                    t_abs = sqrt(dirx * dirx + diry * diry + dirz * dirz);  // sr.rs:146
+                    t_view = (float)(t_abs / opt.view_distance);             // sr.rs:149-151
+                    rd = raydir_init(dirx, diry, dirz);
+                    const uint32_t octant = ((dirx >= 0.0 ? 1u : 0u) << 2) + ((diry >= 0.0 ? 1u : 0u) << 1) + (dirz >= 0.0 ? 1u : 0u);
+                    const int ohx = olx + osx_i, ohy = oly + osy_i, ohz = olz + osz_i;
+                    // the sanitised direction equals the original unless it was zeroed, in which case no fast-forward happens
+                    half_over_len = 0.5 / t_abs;
+                    const LvlLim ll = lvl_init(ox, oy, oz, rd, true, olx, oly, olz, ohx, ohy, ohz, true, half_over_len);
+                    bool got;
+                    const Lvl fs = lvl_first(ll.s, ll.lim, rd, olx, oly, olz, ohx, ohy, ohz, &got);
+                    tx = fs.tx; ty = fs.ty; tz = fs.tz; last_t = fs.last_t;
+                    cx = fs.cx - olx; cy = fs.cy - oly; cz = fs.cz - olz;
+                    limx = rd.sx > 0 ? osx_i : -1; limy = rd.sy > 0 ? osy_i : -1; limz = rd.sz > 0 ? osz_i : -1;
+                    vol_off = 0; vsy = osy; vsz = osz;
+                    st = (fs.st & 0xffu) | ST_TRACED | (octant << 24) | (got ? ST_FRESH : 0u);
+                    if (!got) st = (st & ~3u) | FL_ENDED;
+                    if (cb_opaque(acc)) st |= ST_OPAQUE;
+                    ev = 0u;
+                } else {
+                    ev = EV_FINISH;
                 }
             }
             continue;
         }
 
         // ============================ stepping phase ======================================
+        // One Amanatides-Woo step of the lane's current level -- the cube grid or a block's voxel
+        // volume: same registers, same code, one 2-byte lookup in the shared pool -- written as
+        // straight-line predicated code (SurfaceIter::next + Raycaster::next + State::step).
         AIC_PROF(10, 1);
         AIC_PROF(11, n_step);
         if (ev == 0u) {
-            // what this step yields: 0 nothing/invisible, 1 a visible surface, 2 a block to enter
-            int ts_kind = 0;
-            uint32_t ref = 0;
-            bool produced = true;   // false: no TraceStep came out of this trip (pre-entry step / level pop)
-            if (VOL && (cur.st & ST_BUFFERED)) {
-                cur.st &= ~ST_BUFFERED;  // DepthStep::EnterBlock: counted, nothing to draw
-            } else {
-                // -- SurfaceIter::next (surface.rs:283-354): ONE dda event of the current level --
-                const bool inb = (cur.st & ST_IN_BLOCK) != 0;
-                const uint32_t fl = cur.st & 3u;
-                bool is_exit = false;
-                if (fl == FL_ENDED) {
-                    produced = false;
-                    if (inb) {  // current_block exhausted -> resume the outer raycaster
-                        const uint32_t keep = cur.st & (ST_HAS_LAST | ST_BUFFERED | ST_OPAQUE | ST_TRACED);
-                        cur = saved;
-                        cur.st = (cur.st & ~(ST_IN_BLOCK | ST_HAS_LAST | ST_BUFFERED | ST_OPAQUE | ST_TRACED)) | keep;
-                        lim.x = rd.sx > 0 ? ohx : olx - 1;
-                        lim.y = rd.sy > 0 ? ohy : oly - 1;
-                        lim.z = rd.sz > 0 ? ohz : olz - 1;
-                    } else {
-                        ev = EV_FINISH;  // ray finished
-                    }
+            const bool inb = (st & ST_IN_BLOCK) != 0;
+            const bool fresh = (st & ST_FRESH) != 0;       // first cube of a level: already emitted by the event
+            const bool alive = (st & 3u) == FL_INBOUNDS;
+            const bool stepped = alive && !fresh;          // a scheduled step exists (need_step is implied)
+            // -- the deferred State::step (raycast.rs:577-626) along `pick` --
+            const uint32_t axis = (st >> 5) & 3u;
+            const bool m0 = stepped && axis == 0u, m1 = stepped && axis == 1u, m2 = stepped && axis == 2u;
+            const double t_old = axis == 0u ? tx : (axis == 1u ? ty : tz);
+            last_t = stepped ? t_old : last_t;
+            tx = tx + (m0 ? rd.tdx : 0.0);  // t_max values are never -0.0, so adding +0.0 is the identity
+            ty = ty + (m1 ? rd.tdy : 0.0);
+            tz = tz + (m2 ? rd.tdz : 0.0);
+            cx += m0 ? rd.sx : 0;
+            cy += m1 ? rd.sy : 0;
+            cz += m2 ? rd.sz : 0;
+            {
+                const int sgn = axis == 0u ? rd.sx : (axis == 1u ? rd.sy : rd.sz);
+                const uint32_t face = (sgn > 0 ? 1u : 4u) + axis;  // FACE_TABLE
+                st = stepped ? ((st & ~(7u << 2)) | (face << 2)) : st;
+            }
+            // -- left the bounds? only the axis just stepped can have (raycast.rs:265-274) --
+            const int c_ax = axis == 0u ? cx : (axis == 1u ? cy : cz);
+            const int l_ax = axis == 0u ? limx : (axis == 1u ? limy : limz);
+            const bool is_exit = stepped && c_ax == l_ax;
+            // -- schedule the next step: pick + valid_for_stepping (raycast.rs:563-596) --
+            const bool c01 = tx < ty, c02 = tx < tz, c12 = ty < tz;
+            const uint32_t pick = c01 ? (c02 ? 0u : 2u) : (c12 ? 1u : 2u);
+            const double t_pick = pick == 0u ? tx : (pick == 1u ? ty : tz);
+            const bool valid = isfinite(t_pick);
+            const bool in_step = stepped && !is_exit;      // stepped into an in-bounds cube
+            // a cube is produced by a fresh level, or by a step that stays in bounds and can go on stepping
+            const bool lookup = fresh || (in_step && valid);
+            const bool level_over = is_exit || (in_step && !valid) || (!alive && !fresh) || (fresh && !alive);
+            st = (in_step && valid) ? ((st & ~(3u << 5)) | (pick << 5)) : st;
+            st &= ~ST_FRESH;
+            // -- the lookup: one u16 from the pool, for whichever level this is --
+            uint32_t ts_kind = 0u, ref = 0u;  // TraceStep: 0 Invisible, 1 EnterSurface, 2 EnterBlock
+            if (lookup) {
+                const uint32_t code = pool[(size_t)vol_off + (uint32_t)(((uint32_t)cx * vsy + (uint32_t)cy) * vsz + (uint32_t)cz)];
+                // voxel: visible iff its (re-ordered) palette code is past the invisible ones
+                const bool vox_surf = code >= blk_ninvis;
+                // cube: class of the block from the LDS table
+                const uint32_t cls = (s_cls[code >> 4] >> ((code & 15u) << 1)) & 3u;
+                ts_kind = inb ? (vox_surf ? 1u : 0u) : cls;
+                ref = inb ? (blk_pal_off + code) : (0x80000000u | code);
+                blk_index = (!inb && cls == 2u) ? code : blk_index;
+                if (DIAG) { if (inb) dg.n_inner++; else dg.n_outer++; }
+            }
+            const bool produced = lookup || is_exit;  // the include_exit step is an Invisible TraceStep
+            // -- the level is finished: resume the cube grid, or the ray is complete --
+            bool ray_over = false;
+            if (level_over) {
+                if (ts_kind != 0u) {
+                    // (degenerate rays only) the surface / block just produced still needs this level's
+                    // state for its event: end the level now, leave it on the next trip
+                    st = (st & ~3u) | FL_ENDED;
+                } else if (inb) {
+                    tx = s_tx; ty = s_ty; tz = s_tz; last_t = s_last; cx = s_cx; cy = s_cy; cz = s_cz;
+                    limx = rd.sx > 0 ? osx_i : -1; limy = rd.sy > 0 ? osy_i : -1; limz = rd.sz > 0 ? osz_i : -1;
+                    vol_off = 0; vsy = osy; vsz = osz;
+                    // outer level: face + pick from st[16..20]; InBounds with its step scheduled if it was alive
+                    const uint32_t ofl = (st & ST_OUTER_ALIVE) ? (FL_INBOUNDS | 128u) : FL_ENDED;
+                    st = (st & ~(0x1ffu | ST_IN_BLOCK)) | ofl | (((st >> 16) & 0x1fu) << 2);
                 } else {
-                    const uint32_t stepped_axis = (cur.st >> 5) & 3u;
-                    const bool stepped = (cur.st & 128u) != 0;
-                    if (stepped) {
-                        // the deferred State::step (raycast.rs:577-626)
-                        uint32_t face;
-                        if (stepped_axis == 0) { cur.last_t = cur.tx; cur.tx += rd.tdx; cur.cx += rd.sx; face = rd.sx > 0 ? 1u : 4u; }
-                        else if (stepped_axis == 1) { cur.last_t = cur.ty; cur.ty += rd.tdy; cur.cy += rd.sy; face = rd.sy > 0 ? 2u : 5u; }
-                        else { cur.last_t = cur.tz; cur.tz += rd.tdz; cur.cz += rd.sz; face = rd.sz > 0 ? 3u : 6u; }
-                        cur.st = (cur.st & ~(7u << 2) & ~128u) | (face << 2);
-                    }
-                    bool in_bounds;
-                    if (fl == FL_INBOUNDS) {
-                        // only the axis just stepped can have left the bounds
-                        const int c = stepped_axis == 0 ? cur.cx : (stepped_axis == 1 ? cur.cy : cur.cz);
-                        const int l = stepped_axis == 0 ? lim.x : (stepped_axis == 1 ? lim.y : lim.z);
-                        in_bounds = !(stepped && c == l);
-                        if (!in_bounds) {  // (InBounds, false, true): the include_exit step
-                            cur.st = (cur.st & ~3u) | FL_ENDED;
-                            is_exit = true;
-                        }
-                    } else {
-                        // Beginning: is_out_of_bounds_ahead (raycast.rs:711-728) against the level's bounds
-                        int lox, loy, loz, hix, hiy, hiz;
-                        if (inb) {
-                            lox = (int)(blk_vlo & 255u); loy = (int)((blk_vlo >> 8) & 255u); loz = (int)((blk_vlo >> 16) & 255u);
-                            hix = lox + (int)(blk_vsize & 255u); hiy = loy + (int)((blk_vsize >> 8) & 255u); hiz = loz + (int)((blk_vsize >> 16) & 255u);
-                        } else {
-                            lox = olx; loy = oly; loz = olz; hix = ohx; hiy = ohy; hiz = ohz;
-                        }
-                        bool oob_enter = false, oob_exit = false;
-                        {
-                            const bool low = cur.cx < lox, high = cur.cx >= hix;
-                            oob_enter |= rd.sx == 0 ? (low | high) : (rd.sx < 0 ? high : low);
-                            oob_exit |= rd.sx == 0 ? (low | high) : (rd.sx < 0 ? low : high);
-                        }
-                        {
-                            const bool low = cur.cy < loy, high = cur.cy >= hiy;
-                            oob_enter |= rd.sy == 0 ? (low | high) : (rd.sy < 0 ? high : low);
-                            oob_exit |= rd.sy == 0 ? (low | high) : (rd.sy < 0 ? low : high);
-                        }
-                        {
-                            const bool low = cur.cz < loz, high = cur.cz >= hiz;
-                            oob_enter |= rd.sz == 0 ? (low | high) : (rd.sz < 0 ? high : low);
-                            oob_exit |= rd.sz == 0 ? (low | high) : (rd.sz < 0 ? low : high);
-                        }
-                        in_bounds = !oob_enter && !oob_exit;
-                        if (!in_bounds) {
-                            produced = false;
-                            if (oob_enter && !oob_exit) {
-                                // not yet inside: take a silent step (raycast.rs:255-263)
-                                const int pick = pick_axis(cur.tx, cur.ty, cur.tz);
-                                const double tp = pick == 0 ? cur.tx : (pick == 1 ? cur.ty : cur.tz);
-                                const int c = pick == 0 ? cur.cx : (pick == 1 ? cur.cy : cur.cz);
-                                const int sgn = pick == 0 ? rd.sx : (pick == 1 ? rd.sy : rd.sz);
-                                if (!isfinite(tp) || (sgn > 0 && c == I32_MAX_) || (sgn < 0 && c == I32_MIN_)) cur.st = (cur.st & ~3u) | FL_ENDED;
-                                else cur.st = (cur.st & ~(3u << 5)) | ((uint32_t)pick << 5) | 128u;
-                            } else {
-                                cur.st = (cur.st & ~3u) | FL_ENDED;  // misses the bounds
-                            }
-                        }
-                    }
-                    if (in_bounds) {
-                        // (Beginning|InBounds, false, false): emit this cube, schedule the next step
-                        const int pick = pick_axis(cur.tx, cur.ty, cur.tz);
-                        const double tp = pick == 0 ? cur.tx : (pick == 1 ? cur.ty : cur.tz);
-                        if (!isfinite(tp)) {  // !valid_for_stepping (raycast.rs:245-249)
-                            cur.st = (cur.st & ~3u) | FL_ENDED;
-                            if (lvl_face(cur) != FACE_WITHIN) produced = false;
-                        } else {
-                            cur.st = (cur.st & ~3u & ~(3u << 5)) | FL_INBOUNDS | ((uint32_t)pick << 5) | 128u;
-                        }
-                        if (produced) {
-                            if (!inb) {
-                                // outer cube lookup
-                                const uint32_t idx = ((uint32_t)(cur.cx - olx) * osy + (uint32_t)(cur.cy - oly)) * osz + (uint32_t)(cur.cz - olz);
-                                const uint32_t bi = L.grid[idx];
-                                if (DIAG) dg.n_outer++;
-                                if ((int)bi != L.air_index) {
-                                    const uint32_t k = L.blocks[bi].kind;
-                                    if ((k & 255u) == 0u) {
-                                        if (!(k & 0x80000000u)) {  // a visible single-voxel block
-                                            ts_kind = 1;
-                                            ref = 0x80000000u | bi;
-                                        }
-                                    } else {
-                                        ts_kind = 2;
-                                        blk_res = k & 255u;
-                                        blk_index = bi;
-                                    }
-                                }
-                            } else {
-                                // voxel lookup
-                                const uint32_t vsy = (blk_vsize >> 8) & 255u, vsz = (blk_vsize >> 16) & 255u;
-                                const uint32_t vidx = ((uint32_t)(cur.cx - (int)(blk_vlo & 255u)) * vsy + (uint32_t)(cur.cy - (int)((blk_vlo >> 8) & 255u))) * vsz +
-                                                      (uint32_t)(cur.cz - (int)((blk_vlo >> 16) & 255u));
-                                const uint32_t code = L.voxels[(size_t)blk_vox_off + vidx];
-                                if (DIAG) dg.n_inner++;
-                                if (code >= blk_ninvis) {
-                                    ts_kind = 1;
-                                    ref = blk_pal_off + code;
-                                }
-                            }
-                        }
-                    }
+                    ray_over = true;
+                    st = (st & ~3u) | FL_ENDED;
                 }
             }
             if (produced) {
                 // ---- TracingState::count_step_should_stop (sr.rs:625-656) ----
                 count++;
-                if (count > 1000u || (cur.st & ST_OPAQUE)) {
+                if (count > 1000u || (st & ST_OPAQUE)) {
                     ev = EV_FINISH;
                 } else {
                     // ---- DepthIter::next (surface.rs:453-491): a pending surface's span ends at this step;
                     // its contribution was computed when it was shaded, apply it now ----
-                    if (VOL && (cur.st & ST_HAS_LAST)) {
+                    if (VOL && (st & ST_HAS_LAST)) {
                         cb_add(acc, pend0, pend1, pend2, pend_tr);
-                        if (cb_opaque(acc)) cur.st |= ST_OPAQUE;
-                        cur.st &= ~ST_HAS_LAST;
+                        if (cb_opaque(acc)) st |= ST_OPAQUE;
+                        st &= ~ST_HAS_LAST;
                         if (DIAG && pend_visible) {
                             dg.n_hits++;
                             dg.n_light += pend_d.nlight;
@@ -1318,14 +1321,22 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
                             }
                         }
                     }
-                    if (ts_kind == 1) {
+                    if (ts_kind == 1u) {
                         shade_ref = ref;
                         ev = EV_SHADE;
-                    } else if (ts_kind == 2) {
-                        if (VOL) cur.st |= ST_BUFFERED;  // the extra DepthStep::EnterBlock item
+                    } else if (ts_kind == 2u) {
                         ev = EV_ENTER;
+                        if (VOL) {
+                            // DepthIter emits a second, buffered item for EnterBlock (surface.rs:478-488): count it too
+                            count++;
+                            if (count > 1000u || (st & ST_OPAQUE)) ev = EV_FINISH;
+                        }
+                    } else if (ray_over) {
+                        ev = EV_FINISH;
                     }
                 }
+            } else if (ray_over) {
+                ev = EV_FINISH;
             }
         }
     }
@@ -1394,7 +1405,8 @@ __global__ void probe_raycast_kernel(const double *od, int use_bounds, const int
         hi[0] = hi[1] = hi[2] = I32_MAX_ - 1;
     }
     const RayDir rd = raydir_init(dx, dy, dz);
-    const LvlLim ll = lvl_init(ox, oy, oz, rd, use_bounds != 0, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], include_exit != 0);
+    const LvlLim ll = lvl_init(ox, oy, oz, rd, use_bounds != 0, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], include_exit != 0,
+                               0.5 / sqrt(rd.dx * rd.dx + rd.dy * rd.dy + rd.dz * rd.dz));
     Lvl s = ll.s;
     const Lim lim = ll.lim;
     uint32_t n = 0;

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/<tag>/ (written by tools/measure.sh) into profiles/<tag>_*.
+
+  python tools/summarize_profile.py r01
+
+Outputs: profiles/<tag>_kernel_stats_<workload>.csv (rocprofv3 --kernel-trace --stats summary),
+profiles/<tag>_pmc_<workload>.json (per-launch means of every collected counter for the trace
+kernel, plus the derived HBM traffic that bench.py reports as roofline.traffic), and the bench
+JSON lines."""
+import csv, glob, json, os, shutil, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+src = os.path.join(root, "gpurun_out", tag)
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def find(d, suffix):
+    hits = glob.glob(os.path.join(src, d, "**", "*" + suffix), recursive=True)
+    return hits[0] if hits else None
+
+
+for wl in ("atrium", "s256"):
+    p = find(f"stats_{wl}", "kernel_stats.csv")
+    if p:
+        shutil.copy(p, os.path.join(dst, f"{tag}_kernel_stats_{wl}.csv"))
+    pmc = {}
+    for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq1", "pmc_sq2"):
+        p = find(f"{d}_{wl}", "counter_collection.csv")
+        if not p:
+            continue
+        acc = {}
+        with open(p) as f:
+            for row in csv.DictReader(f):
+                if "trace_image_kernel" not in row.get("Kernel_Name", ""):
+                    continue
+                acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+        for k, v in acc.items():
+            pmc[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+    if pmc:
+        out = {"workload": wl, "kernel": "trace_image_kernel", "counters": pmc}
+        if "FETCH_SIZE" in pmc:
+            # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB. MI355X_MICROARCH.md (HBM section):
+            # on gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide streaming reads ->
+            # doubled here as the guide prescribes (an upper bound for our narrow gathers);
+            # WRITE_SIZE is uncalibrated and taken as reported.
+            fetch = pmc["FETCH_SIZE"]["mean_per_launch"] * 1024.0
+            write = pmc.get("WRITE_SIZE", {"mean_per_launch": 0.0})["mean_per_launch"] * 1024.0
+            out["hbm_traffic_bytes_per_launch"] = 2.0 * fetch + write
+            out["fetch_bytes_raw"] = fetch
+            out["write_bytes_raw"] = write
+        if "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc:
+            h, m = pmc["TCC_HIT_sum"]["mean_per_launch"], pmc["TCC_MISS_sum"]["mean_per_launch"]
+            out["l2_hit_rate"] = h / (h + m) if h + m else None
+        with open(os.path.join(dst, f"{tag}_pmc_{wl}.json"), "w") as f:
+            json.dump(out, f, indent=1, sort_keys=True)
+    b = os.path.join(src, f"bench_{wl}.json")
+    if os.path.exists(b):
+        lines = [l for l in open(b).read().splitlines() if l.startswith("{")]
+        if lines:
+            with open(os.path.join(dst, f"{tag}_bench_{wl}.json"), "w") as f:
+                f.write(lines[-1] + "\n")
+print(sorted(os.listdir(dst)))
