@@ -245,6 +245,29 @@ def main() -> int:
     return 0
 
 
+def usable_cpus():
+    """Threads the CPU baseline may actually run on: the scheduler affinity mask capped by the
+    container's cgroup CPU quota (oversubscribing a quota only adds throttling)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = f"affinity {n} of {os.cpu_count()} logical CPUs"
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            q = max(1, int(int(quota) / int(period)))
+            note += f", cgroup cpu.max quota {q}"
+            n = min(n, q)
+    except OSError:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                note += f", cgroup cfs quota {max(1, q // per)}"
+                n = min(n, max(1, q // per))
+        except OSError:
+            pass
+    return n, note
+
+
 def cpu_baseline(flat_space, opts, w, h, eye, target, view_distance, target_seconds: float) -> dict:
     """The CPU oracle (a restatement of the reference algorithm -- the reference itself is Rust and
     cannot be built here) timed on this host's cores over a bounded sample of the same workload:
@@ -253,7 +276,7 @@ def cpu_baseline(flat_space, opts, w, h, eye, target, view_distance, target_seco
     the GPU number; not the optimisation target."""
     import oracle
 
-    threads = os.cpu_count() or 1
+    threads, cpu_note = usable_cpus()
     sp = oracle.Space(flat_space)
     oo = oracle.make_options(fog=int(opts.fog), transparency=int(opts.transparency.kind), lighting=int(opts.lighting_display.kind),
                              view_distance=view_distance)
@@ -278,7 +301,7 @@ def cpu_baseline(flat_space, opts, w, h, eye, target, view_distance, target_seco
         "cores": threads,
         "kind": "port",
         "sample": f"{frames} whole {w}x{h} frames of the same workload in {dt:.1f} s wall (median {1e3 * float(np.median(per_frame)):.1f} ms/frame), "
-                  f"oracle/aic_oracle.cpp row-parallel on {threads} threads",
+                  f"oracle/aic_oracle.cpp row-parallel on {threads} threads ({cpu_note})",
         "frames_per_s": round(frames / dt, 4),
     }
 
