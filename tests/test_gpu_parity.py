@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle
-from all_is_cubes_amd import abi
+from all_is_cubes_amd import abi, flat
 from tests import scenes
 from tests.test_oracle_goldens import COMMON_VIEWPORT, camera_for, diff_to, neighbourhood_diff
 
@@ -389,3 +389,78 @@ def test_multi_part_gather_on_one_gpu(ctx, synth_space):
     torch.cuda.synchronize()
     assert (out.cpu() == full).all()
     assert (D.assemble_strips_torch(gathered, h, w, strip).cpu() == full).all()
+
+
+# --- sparse blocks (long runs of invisible voxels), partial stored volumes, 16-bit palettes ----
+def _sparse_block(res, seed, vlo=(0, 0, 0), vsize=None, n_pal=5):
+    rng = np.random.default_rng(seed)
+    vsize = vsize or (res, res, res)
+    pal = np.zeros((n_pal, 8), np.float32)
+    pal[0] = flat.evoxel((0, 0, 0, 0))                  # invisible
+    pal[1] = flat.evoxel((0, 0, 0, 0))                  # a second, distinct-index invisible entry
+    for i in range(2, n_pal):
+        a = 1.0 if i % 2 else 0.4
+        pal[i] = flat.evoxel((*rng.uniform(0.1, 0.9, 3), a), emission=(0.0, 0.05 * (i % 3), 0.0))
+    vox = rng.integers(0, 2, vsize).astype(np.uint16)   # mostly the two invisible entries...
+    pts = rng.integers(0, np.array(vsize), (max(3, res * res // 6), 3))
+    vox[pts[:, 0], pts[:, 1], pts[:, 2]] = rng.integers(2, n_pal, len(pts))  # ...with a few visible voxels
+    return flat.voxel_block(res, vox, pal, vlo=vlo)
+
+
+def _sparse_space(extra_blocks=()):
+    sp = flat.FlatSpace((-3, 0, -3), (6, 5, 6))
+    sp.set_sky_uniform((0.6, 0.7, 0.9))
+    blocks = [_sparse_block(32, 1), _sparse_block(16, 2, vlo=(3, 0, 5), vsize=(9, 16, 7)), _sparse_block(8, 3), *extra_blocks]
+    ids = [sp.add_block(b) for b in blocks]
+    rng = np.random.default_rng(9)
+    for x in range(-3, 3):
+        for y in range(0, 5):
+            for z in range(-3, 3):
+                if rng.random() < 0.6:
+                    sp.set((x, y, z), ids[int(rng.integers(0, len(ids)))])
+    return sp
+
+
+@pytest.mark.parametrize("transparency", [0, 1])
+def test_sparse_blocks_match_oracle(ctx, transparency):
+    sp = _sparse_space()
+    opt = oracle.make_options(transparency=transparency)
+    w, h = 128, 96
+    eye = (0.3, 2.6, 7.5)
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, (0, 2.2, 0)), eye)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+    got = ctx.render(ctx.make_frame(w, h, world_inv=inv), want_aux=True)
+    ref = oracle.render(oracle.Space(sp), opt, oracle.make_camera(inv, w, h), want_aux=True)
+    assert_parity(got, ref)
+    assert int(ref["info"]["n_inner"]) > 20 * w * h  # rays really cross long empty runs
+
+
+def test_block_with_16bit_palette(ctx):
+    sp = _sparse_space()
+    opt = oracle.make_options()
+    w, h = 96, 64
+    eye = (0.3, 2.6, 7.5)
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, (0, 2.2, 0)), eye)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+    # a block whose palette needs more than 13 bits arrives as an incremental update
+    rng = np.random.default_rng(21)
+    n_pal = 9000
+    pal = np.zeros((n_pal, 8), np.float32)
+    pal[1:, 0:3] = rng.uniform(0.05, 0.95, (n_pal - 1, 3))
+    pal[1:, 3] = 1.0
+    vox = np.zeros((32, 32, 32), np.uint16)
+    sel = rng.random((32, 32, 32)) < 0.3
+    vox[sel] = rng.integers(1, n_pal, int(sel.sum()))
+    vox[0, 0, 0] = n_pal - 1
+    big = flat.voxel_block(32, vox, pal)
+    ctx.replace_block(abi.LAYER_WORLD, 1, big)
+    sp.blocks[1] = big
+    inc = ctx.render(ctx.make_frame(w, h, world_inv=inv), want_aux=True)
+    ref = oracle.render(oracle.Space(sp), opt, oracle.make_camera(inv, w, h), want_aux=True)
+    assert_parity(inc, ref)
+    ctx.upload_space(abi.LAYER_WORLD, sp)  # and as a full snapshot
+    assert_parity(ctx.render(ctx.make_frame(w, h, world_inv=inv), want_aux=True), ref)
