@@ -21,7 +21,8 @@
 namespace aic {
 void launch_trace_image(const DevFrame &F, bool diag, hipStream_t stream);
 void launch_scatter_cubes(uint16_t *grid, uint32_t *light, const int32_t *xyz, const uint16_t *bi, const uint32_t *lt,
-                          uint32_t n, const int lo[3], const int size[3], hipStream_t stream);
+                          uint32_t n, const int lo[3], const int size[3], const uint32_t *cls, hipStream_t stream);
+void launch_tag_cubes(uint16_t *grid, size_t n, const uint32_t *cls, int from_tagged, int to_tagged, hipStream_t stream);
 void launch_assemble_strips(const uint32_t *gathered, uint32_t *out, uint32_t w, uint32_t h, uint32_t strip_rows,
                             uint32_t n_parts, uint32_t max_rows, hipStream_t stream);
 void launch_probe_raycast(const double *od, int use_bounds, const int *lohi, int include_exit, uint32_t max_steps,
@@ -83,6 +84,7 @@ struct Layer {
     uint32_t block_sky[7] = {};
     aic_options opt;
     bool opt_set = false;
+    bool cls_in_code = false;  // cube-grid entries carry the block class in bits 14-15 (aic_device.h)
     size_t n_cubes() const { return (size_t)size[0] * (size_t)size[1] * (size_t)size[2]; }
     void release() {
         pool.release(); cls.release(); light.release(); blocks.release(); palette.release();
@@ -254,6 +256,7 @@ void fill_dev_layer(const aic_ctx *c, const Layer &l, const aic_camera &cam, Dev
     d->opt.view_distance = o.view_distance;
     std::memcpy(d->inv, cam.inverse_projection_view, sizeof(d->inv));
     d->exposure = cam.exposure;
+    d->cls_in_code = l.cls_in_code ? 1u : 0u;
     (void)c;
 }
 
@@ -404,6 +407,8 @@ int aic_upload_space(aic_ctx *c, int layer, const aic_space_desc *s) {
     if (!blocks.empty()) HIP_TRY(c, hipMemcpyAsync(l.blocks.p, blocks.data(), blocks.size() * sizeof(DevBlock), hipMemcpyHostToDevice, c->stream));
     if (!vox.empty()) HIP_TRY(c, hipMemcpyAsync(l.pool.p + n, vox.data(), vox.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(l.cls.p, cls.data(), cls.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    const bool cls_in_code = s->n_blocks <= kCubeIndexMask + 1u;
+    if (cls_in_code) launch_tag_cubes(l.pool.p, n, l.cls.p, 0, 1, c->stream);
     if (!pal.empty()) HIP_TRY(c, hipMemcpyAsync(l.palette.p, pal.data(), pal.size() * sizeof(DevPaletteEntry), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // host buffers may be released on return
 
@@ -416,6 +421,7 @@ int aic_upload_space(aic_ctx *c, int layer, const aic_space_desc *s) {
     for (int f = 0; f < 7; f++)
         l.block_sky[f] = (uint32_t)s->block_sky[f][0] | ((uint32_t)s->block_sky[f][1] << 8) | ((uint32_t)s->block_sky[f][2] << 16) |
                          ((uint32_t)s->block_sky[f][3] << 24);
+    l.cls_in_code = cls_in_code;
     l.present = true;
     return AIC_OK;
 }
@@ -443,7 +449,7 @@ int aic_update_cubes(aic_ctx *c, int layer, uint32_t n, const int32_t *xyz, cons
     if (block_index) HIP_TRY(c, hipMemcpyAsync(base + b_xyz, block_index, (size_t)n * 2, hipMemcpyHostToDevice, c->stream));
     if (light) HIP_TRY(c, hipMemcpyAsync(base + b_xyz + b_bi, light, b_lt, hipMemcpyHostToDevice, c->stream));
     launch_scatter_cubes(l.pool.p, l.light.p, (const int32_t *)base, block_index ? (const uint16_t *)(base + b_xyz) : nullptr,
-                         light ? (const uint32_t *)(base + b_xyz + b_bi) : nullptr, n, l.lo, l.size, c->stream);
+                         light ? (const uint32_t *)(base + b_xyz + b_bi) : nullptr, n, l.lo, l.size, l.cls_in_code ? l.cls.p : nullptr, c->stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return AIC_OK;
@@ -482,16 +488,29 @@ int aic_replace_block(aic_ctx *c, int layer, uint32_t index, const aic_block_des
         if ((e = l.palette.ensure(pal_off + pal.size(), true, c->stream)) != hipSuccess) return hip_fail(c, "grow palette", e);
         HIP_TRY(c, hipMemcpyAsync(l.palette.p + pal_off, pal.data(), pal.size() * sizeof(DevPaletteEntry), hipMemcpyHostToDevice, c->stream));
     }
+    bool class_changed = false;
     if (index == l.host_blocks.size()) {
         l.host_blocks.push_back(db);
         if ((e = l.blocks.ensure(l.host_blocks.size(), true, c->stream)) != hipSuccess) return hip_fail(c, "grow blocks", e);
     } else {
+        class_changed = block_class(l.host_blocks[index]) != block_class(db);
         l.host_blocks[index] = db;
     }
     HIP_TRY(c, hipMemcpyAsync(l.blocks.p + index, &db, sizeof(db), hipMemcpyHostToDevice, c->stream));
     set_class(l.host_cls, index, block_class(db));
     if ((e = l.cls.ensure(l.host_cls.size(), true, c->stream)) != hipSuccess) return hip_fail(c, "grow classes", e);
     HIP_TRY(c, hipMemcpyAsync(l.cls.p + index / 16u, &l.host_cls[index / 16u], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    if (l.cls_in_code) {
+        // the cube grid carries class bits: drop them if the table outgrew 14-bit indices, refresh
+        // them if an existing block changed class (cubes already holding this index must follow)
+        if (l.host_blocks.size() > kCubeIndexMask + 1u) {
+            launch_tag_cubes(l.pool.p, l.n_cubes(), l.cls.p, 1, 0, c->stream);
+            l.cls_in_code = false;
+        } else if (class_changed) {
+            launch_tag_cubes(l.pool.p, l.n_cubes(), l.cls.p, 1, 1, c->stream);
+        }
+        HIP_TRY(c, hipGetLastError());
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (desc->flags & AIC_BLOCK_AIR) {
         if (l.air_index < 0) l.air_index = (int32_t)index;
@@ -624,8 +643,8 @@ int aic_render(aic_ctx *c, const aic_frame_desc *f, void *out_rgba8, int out_is_
             info->n_hits = hc.n_hits;
             info->n_light = hc.n_light;
 #ifdef AIC_PROFILE
-            { static const char *names[12] = {"ev_phases","ev_lanes","flush_ph","flush_ln","light_ph","light_ln","enter_ph","enter_ln","finish_ph","finish_ln","step_iters","step_lanes"};
-              for (int i = 0; i < 12; i++) std::fprintf(stderr, "PROF %s %llu\n", names[i], hc.prof[i]); }
+            { static const char *names[16] = {"ev_phases","ev_lanes","-","-","shade_ph","shade_ln","enter_ph","enter_ln","ray_ph","ray_ln","step_iters","step_lanes","cyc_step","cyc_shade","cyc_enter","cyc_ray"};
+              for (int i = 0; i < 16; i++) std::fprintf(stderr, "PROF %s %llu\n", names[i], hc.prof[i]); }
 #endif
         }
         c->aux_records = want_aux ? npix : 0;

@@ -73,8 +73,15 @@ struct DevLayer {
     DevOptions opt;
     double inv[16];         // camera inverse_projection_view
     float exposure;
-    int32_t pad;
+    uint32_t cls_in_code;   // cube-grid entries carry their block's class in the top two bits (below)
 };
+
+// Cube-grid entries of the pool when DevLayer.cls_in_code != 0 (block table of at most 16384 entries):
+//   bits 0-13 block index, bits 14-15 the block's class (0 invisible single voxel, 1 visible single
+//   voxel, 2 recursive) -- so the trace kernel classifies a cube with no second lookup.
+// Larger block tables store the plain 16-bit index and the kernel consults the class table in LDS.
+static constexpr uint32_t kCubeClassShift = 14u;
+static constexpr uint32_t kCubeIndexMask = (1u << kCubeClassShift) - 1u;
 
 struct DevCounters {
     unsigned long long cubes_traced;

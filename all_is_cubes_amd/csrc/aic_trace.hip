@@ -699,6 +699,9 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_FRESH = 1u 
 #define AIC_T_BATCH 32  // run a kind of parked work once this many lanes wait on it
 #endif
 #ifndef AIC_N_FEW
+#ifndef AIC_STEP_REPS
+#define AIC_STEP_REPS 4  // DDA steps per scheduler trip
+#endif
 #define AIC_N_FEW 8     // ... or once at most this many lanes can still step
 #endif
 
@@ -742,7 +745,17 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
     const int olx = L.lo[0], oly = L.lo[1], olz = L.lo[2];
     const int osx_i = L.size[0], osy_i = L.size[1], osz_i = L.size[2];
     const uint32_t osy = (uint32_t)osy_i, osz = (uint32_t)osz_i;
-    const uint16_t *__restrict__ pool = L.pool;  // cube grid at offset 0, then every block's voxel volume
+    // cube grid at offset 0, then every block's voxel volume. The pointer is laundered through an
+    // s_mov so that it is a computed SGPR pair rather than a re-loadable kernel argument: under SGPR
+    // pressure the compiler would otherwise re-fetch it (s_load + wait) in front of every lookup.
+    typedef const __attribute__((address_space(1))) uint16_t *GlobalU16Ptr;
+    GlobalU16Ptr pool;
+    {
+        unsigned long long bits = (unsigned long long)L.pool;
+        asm volatile("s_mov_b64 %0, %1" : "=s"(bits) : "s"(bits));
+        pool = (GlobalU16Ptr)bits;
+    }
+    const bool cls_in_code = L.cls_in_code != 0u;
 
     // ---- per-lane ray state ----
     double ox = 0, oy = 0, oz = 0;  // ray origin
@@ -789,10 +802,13 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
 
     uint32_t ev = EV_NEWRAY | 64u;  // every lane starts by taking a pixel
 #ifdef AIC_PROFILE
-    uint32_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t prof_tm = (uint32_t)__builtin_readcyclecounter();
 #define AIC_PROF(i, v) prof[i] += (uint32_t)(v)
+#define AIC_TICK(i) { const uint32_t now_ = (uint32_t)__builtin_readcyclecounter(); prof[i] += now_ - prof_tm; prof_tm = now_; }
 #else
 #define AIC_PROF(i, v)
+#define AIC_TICK(i)
 #endif
     uint32_t next_idx = 256;  // wave-uniform: next unassigned pixel of tile_cur (256 = tile exhausted)
 
@@ -1221,6 +1237,7 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
                     ev = EV_FINISH;
                 }
             }
+            if (run == EV_SHADE) { AIC_TICK(13) } else if (run == EV_ENTER) { AIC_TICK(14) } else { AIC_TICK(15) }
             continue;
         }
 
@@ -1228,8 +1245,11 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
         // One Amanatides-Woo step of the lane's current level -- the cube grid or a block's voxel
         // volume: same registers, same code, one 2-byte lookup in the shared pool -- written as
         // straight-line predicated code (SurfaceIter::next + Raycaster::next + State::step).
+#pragma unroll 1
+        for (int rep = 0; rep < AIC_STEP_REPS; rep++) {
+        if (rep > 0 && __ballot(ev == 0u) == 0ull) break;
         AIC_PROF(10, 1);
-        AIC_PROF(11, n_step);
+        AIC_PROF(11, __popcll(__ballot(ev == 0u)));
         if (ev == 0u) {
             const bool inb = (st & ST_IN_BLOCK) != 0;
             const bool fresh = (st & ST_FRESH) != 0;       // first cube of a level: already emitted by the event
@@ -1269,11 +1289,14 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
             // -- the lookup: one u16 from the pool, for whichever level this is --
             uint32_t ts_kind = 0u, ref = 0u;  // TraceStep: 0 Invisible, 1 EnterSurface, 2 EnterBlock
             if (lookup) {
-                const uint32_t code = pool[(size_t)vol_off + (uint32_t)(((uint32_t)cx * vsy + (uint32_t)cy) * vsz + (uint32_t)cz)];
+                const uint32_t raw = pool[(size_t)vol_off + (uint32_t)(((uint32_t)cx * vsy + (uint32_t)cy) * vsz + (uint32_t)cz)];
                 // voxel: visible iff its (re-ordered) palette code is past the invisible ones
-                const bool vox_surf = code >= blk_ninvis;
-                // cube: class of the block from the LDS table
-                const uint32_t cls = (s_cls[code >> 4] >> ((code & 15u) << 1)) & 3u;
+                const bool vox_surf = raw >= blk_ninvis;
+                // cube: class of the block, carried in the top bits of the grid entry when the block
+                // table is small enough (aic_device.h), else from the LDS table
+                uint32_t cls, code = raw;
+                if (cls_in_code) { cls = raw >> kCubeClassShift; code = inb ? raw : (raw & kCubeIndexMask); }
+                else cls = (s_cls[raw >> 4] >> ((raw & 15u) << 1)) & 3u;
                 ts_kind = inb ? (vox_surf ? 1u : 0u) : cls;
                 ref = inb ? (blk_pal_off + code) : (0x80000000u | code);
                 blk_index = (!inb && cls == 2u) ? code : blk_index;
@@ -1339,10 +1362,12 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
                 ev = EV_FINISH;
             }
         }
+        }
+        AIC_TICK(12);
     }
 
 #ifdef AIC_PROFILE
-    if (lane == 0) for (int i = 0; i < 12; i++) atomicAdd(&F.counters->prof[i], (unsigned long long)prof[i]);
+    if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(&F.counters->prof[i], (unsigned long long)prof[i]);
 #endif
     // ---- RaytraceInfo sum (renderer.rs:555): wave reduction then one atomic per wave ----
     unsigned long long s = total_steps;
@@ -1370,7 +1395,8 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
 
 // aic_update_cubes: scatter of SpaceChange::{CubeBlock,CubeLight} (updating.rs:146-166)
 __global__ void scatter_cubes_kernel(uint16_t *grid, uint32_t *light, const int32_t *xyz, const uint16_t *bi,
-                                     const uint32_t *lt, uint32_t n, int lx, int ly, int lz, int sx, int sy, int sz) {
+                                     const uint32_t *lt, uint32_t n, int lx, int ly, int lz, int sx, int sy, int sz,
+                                     const uint32_t *cls) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t dx = (uint32_t)xyz[3 * i + 0] - (uint32_t)lx;
@@ -1378,8 +1404,22 @@ __global__ void scatter_cubes_kernel(uint16_t *grid, uint32_t *light, const int3
     uint32_t dz = (uint32_t)xyz[3 * i + 2] - (uint32_t)lz;
     if ((dx >= (uint32_t)sx) | (dy >= (uint32_t)sy) | (dz >= (uint32_t)sz)) return;
     size_t idx = ((size_t)dx * sy + dy) * sz + dz;
-    if (bi) grid[idx] = bi[i];
+    if (bi) {
+        uint32_t b = bi[i];
+        if (cls) b |= ((cls[b >> 4] >> ((b & 15u) << 1)) & 3u) << kCubeClassShift;  // cls != null: tagged grid
+        grid[idx] = (uint16_t)b;
+    }
     if (lt) light[idx] = lt[i];
+}
+
+// (re)writes the class bits of every cube-grid entry from the class table (aic_device.h)
+__global__ void tag_cubes_kernel(uint16_t *grid, size_t n, const uint32_t *cls, int from_tagged, int to_tagged) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t b = grid[i];
+    if (from_tagged) b &= kCubeIndexMask;
+    if (to_tagged) b |= ((cls[b >> 4] >> ((b & 15u) << 1)) & 3u) << kCubeClassShift;
+    grid[i] = (uint16_t)b;
 }
 
 // aic_assemble_strips: [n_parts][max_rows][w] compacted strips -> [h][w]
@@ -1465,11 +1505,16 @@ void launch_trace_image(const DevFrame &F, bool diag, hipStream_t stream) {
     else launch_trace_diag<false>(F, vol, lmode, stream);
 }
 
+void launch_tag_cubes(uint16_t *grid, size_t n, const uint32_t *cls, int from_tagged, int to_tagged, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(tag_cubes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, grid, n, cls, from_tagged, to_tagged);
+}
+
 void launch_scatter_cubes(uint16_t *grid, uint32_t *light, const int32_t *xyz, const uint16_t *bi, const uint32_t *lt,
-                          uint32_t n, const int lo[3], const int size[3], hipStream_t stream) {
+                          uint32_t n, const int lo[3], const int size[3], const uint32_t *cls, hipStream_t stream) {
     if (!n) return;
     hipLaunchKernelGGL(scatter_cubes_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, grid, light, xyz, bi, lt, n, lo[0],
-                       lo[1], lo[2], size[0], size[1], size[2]);
+                       lo[1], lo[2], size[0], size[1], size[2], cls);
 }
 
 void launch_assemble_strips(const uint32_t *gathered, uint32_t *out, uint32_t w, uint32_t h, uint32_t strip_rows,

@@ -464,3 +464,31 @@ def test_block_with_16bit_palette(ctx):
     assert_parity(inc, ref)
     ctx.upload_space(abi.LAYER_WORLD, sp)  # and as a full snapshot
     assert_parity(ctx.render(ctx.make_frame(w, h, world_inv=inv), want_aux=True), ref)
+
+
+def test_replace_block_changes_class_of_placed_cubes(ctx):
+    """SpaceChange::BlockEvaluation that turns an atom into a recursive block (and into an invisible
+    one): every cube already holding that index must be re-classified (updating.rs:139-153)."""
+    sp = flat.FlatSpace((0, 0, 0), (5, 4, 5))
+    sp.set_sky_uniform((0.5, 0.6, 0.8))
+    a = sp.add_block(flat.atom((0.8, 0.2, 0.2, 1.0)))
+    b = sp.add_block(flat.atom((0.2, 0.8, 0.2, 1.0)))
+    rng = np.random.default_rng(5)
+    for x in range(5):
+        for z in range(5):
+            sp.set((x, 0, z), a if (x + z) % 2 else b)
+            if rng.random() < 0.4:
+                sp.set((x, 1 + int(rng.integers(0, 3)), z), a)
+    opt = oracle.make_options()
+    w, h = 96, 72
+    eye = (2.5, 3.2, 7.0)
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, (2.5, 1.0, 2.5)), eye)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+    for replacement in (_sparse_block(8, 11), flat.atom((0.0, 0.0, 0.0, 0.0)), flat.atom((0.1, 0.1, 0.9, 0.5)), scenes.synthetic_blocks(4, 1, seed=3)[0]):
+        ctx.replace_block(abi.LAYER_WORLD, a, replacement)
+        sp.blocks[a] = replacement
+        got = ctx.render(ctx.make_frame(w, h, world_inv=inv), want_aux=True)
+        ref = oracle.render(oracle.Space(sp), opt, oracle.make_camera(inv, w, h), want_aux=True)
+        assert_parity(got, ref)
