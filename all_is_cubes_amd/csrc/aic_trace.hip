@@ -699,10 +699,10 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_FRESH = 1u 
 #define AIC_T_BATCH 32  // run a kind of parked work once this many lanes wait on it
 #endif
 #ifndef AIC_N_FEW
+#define AIC_N_FEW 32    // ... or once at most this many lanes can still step
+#endif
 #ifndef AIC_STEP_REPS
 #define AIC_STEP_REPS 4  // DDA steps per scheduler trip
-#endif
-#define AIC_N_FEW 8     // ... or once at most this many lanes can still step
 #endif
 
 // Runs Raycaster::next (raycast.rs:239-284) on a freshly initialised level until it yields its
