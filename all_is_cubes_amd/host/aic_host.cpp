@@ -332,6 +332,7 @@ Evoxels Evoxels::air() {
 void SpaceRendererTodo::receive(const SpaceChange &c) {  // updating.rs:201-219
     switch (c.kind) {
         case SpaceChangeKind::EveryBlock: everything = true; break;
+        case SpaceChangeKind::EveryLight: every_light = true; break;
         case SpaceChangeKind::CubeBlock:
         case SpaceChangeKind::CubeLight: cubes.insert({c.cube[0], c.cube[1], c.cube[2]}); break;
         case SpaceChangeKind::BlockIndex:
@@ -393,6 +394,10 @@ void Space::load_contents(const uint16_t *block_index, const uint8_t *light) {
     }
     if (light) std::memcpy((void *)light_.data(), light, n * 4);
     notify(SpaceChange{SpaceChangeKind::EveryBlock, {0, 0, 0}, 0});
+}
+void Space::load_light(const uint8_t *light) {
+    std::memcpy((void *)light_.data(), light, contents_.size() * 4);
+    notify(SpaceChange{SpaceChangeKind::EveryLight, {0, 0, 0}, 0});
 }
 uint16_t Space::get_block_index(int32_t x, int32_t y, int32_t z) const { return contents_[index(x, y, z)]; }
 PackedLight Space::get_light(int32_t x, int32_t y, int32_t z) const { return light_[index(x, y, z)]; }
@@ -516,6 +521,10 @@ bool HipRtRenderer::sync_space(int layer, const std::shared_ptr<Space> &space, c
             }
             check(aic_replace_block(ctx_, layer, bi, &bd, e.indices.data(), pal.data()), "aic_replace_block");
         }
+        changed = true;
+    }
+    if (todo.every_light) {  // one H2D copy of the light volume instead of a scatter (BASELINE config 5)
+        check(aic_update_light_volume(ctx_, layer, reinterpret_cast<const uint8_t *>(space->light().data())), "aic_update_light_volume");
         changed = true;
     }
     if (!todo.cubes.empty()) {

@@ -182,7 +182,9 @@ struct Evoxels {
     static Evoxels air();
 };
 
-enum class SpaceChangeKind { EveryBlock, CubeBlock, CubeLight, BlockIndex, BlockEvaluation };
+// EveryLight is this mirror's coalesced form of a burst of CubeLight notifications: what a light-propagation
+// step that touched most of the space sends (the reference emits one CubeLight per cube, space.rs light updater).
+enum class SpaceChangeKind { EveryBlock, CubeBlock, CubeLight, BlockIndex, BlockEvaluation, EveryLight };
 struct SpaceChange {
     SpaceChangeKind kind;
     int32_t cube[3];
@@ -191,10 +193,11 @@ struct SpaceChange {
 // What UpdatingSpaceRaytracer accumulates between updates (updating.rs:180-219).
 struct SpaceRendererTodo {
     bool everything = true;
+    bool every_light = false;
     std::set<uint32_t> blocks;
     std::set<std::array<int32_t, 3>> cubes;
     void receive(const SpaceChange &c);
-    void clear() { everything = false; blocks.clear(); cubes.clear(); }
+    void clear() { everything = false; every_light = false; blocks.clear(); cubes.clear(); }
 };
 
 class Space {
@@ -212,6 +215,7 @@ class Space {
     void set_light(int32_t x, int32_t y, int32_t z, PackedLight l);    // emits CubeLight
     void fill_all(uint32_t block_index);                               // emits EveryBlock
     void load_contents(const uint16_t *block_index, const uint8_t *light);  // emits EveryBlock
+    void load_light(const uint8_t *light);                                  // emits EveryLight
     uint16_t get_block_index(int32_t x, int32_t y, int32_t z) const;
     PackedLight get_light(int32_t x, int32_t y, int32_t z) const;
     const std::vector<uint16_t> &contents() const { return contents_; }

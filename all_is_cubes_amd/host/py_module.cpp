@@ -167,6 +167,10 @@ PYBIND11_MODULE(_host, m) {
             }
             s.load_contents(bi.data(), lp);
         }, py::arg("block_index"), py::arg("light") = py::none())
+        .def("load_light", [](Space &s, py::array_t<uint8_t, py::array::c_style | py::array::forcecast> la) {
+            if ((size_t)la.size() != s.contents().size() * 4) throw std::invalid_argument("light size mismatch");
+            s.load_light(la.data());
+        }, py::arg("light"))
         .def("bounds", [](const Space &s) { const GridAab &b = s.bounds(); return py::make_tuple(std::array<int32_t, 3>{b.lo[0], b.lo[1], b.lo[2]}, std::array<int32_t, 3>{b.hi[0], b.hi[1], b.hi[2]}); });
 
     py::class_<UiViewState>(m, "UiViewState")

@@ -45,6 +45,13 @@ def build_workload(name: str):
         eye, target = (0.5, 9.91, 10.0), (0.5, 8.0, -20.0)  # atrium spawn eye (content atrium/mod.rs:98-102)
         view_distance = 200.0
         label = "atrium-like 19x35x51 R16, 1920x1080, GraphicsOptions::default() minus bloom"
+    elif name == "orbit":
+        # BASELINE.json configs[4]: 1080p 60-frame camera orbit with a per-frame light re-upload
+        space = scenes.atrium_like_space()
+        size = (1920, 1080)
+        eye, target = (0.5, 9.91, 10.0), (0.5, 8.0, 0.0)
+        view_distance = 200.0
+        label = "atrium-like 19x35x51 R16, 1920x1080, 60-frame orbit, light volume re-uploaded + camera moved every frame"
     elif name == "s256":
         space = scenes.synthetic_space(n=256, resolution=32, n_blocks=64, seed=1)
         size = (3840, 2160)
@@ -67,7 +74,7 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="atrium", choices=["atrium", "s256", "small"])
+    ap.add_argument("--workload", default="atrium", choices=["atrium", "s256", "small", "orbit"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lighting", type=int, default=3, help="experiment: LightingOption (0 None,1 Flat,2 Coarse,3 Linear,4 Smoothstep); default Linear")
     ap.add_argument("--fog", type=int, default=1, help="experiment: FogOption (0 None,1 Abrupt,...); default Abrupt")
@@ -125,8 +132,27 @@ def main() -> int:
     rays_per_frame = w * h * (4 if opts.antialiasing == H.AntialiasingOption.Always else 1)
 
     kernel_ms = []
+    orbit = None
+    if args.workload == "orbit":
+        # 60 key frames: the eye circles the atrium's axis, the light field breathes (status bytes kept)
+        base = flat_space.light.copy()
+        lights, views = [], []
+        for k in range(60):
+            a = 2.0 * np.pi * k / 60.0
+            gain = 0.85 + 0.15 * np.sin(a)
+            lk = base.copy()
+            lk[..., 0:3] = np.clip(np.round(base[..., 0:3].astype(np.float32) + 10.0 * np.log2(gain)), 0, 255).astype(np.uint8) * (base[..., 0:3] > 0)
+            lights.append(np.ascontiguousarray(lk.reshape(-1, 4)))
+            views.append(H.look_at_y_up((0.5 + 7.0 * np.sin(a), eye[1], 7.0 * np.cos(a)), target))
+        orbit = {"k": 0, "lights": lights, "views": views}
 
     def step() -> None:
+        if orbit is not None:
+            k = orbit["k"] % 60
+            orbit["k"] += 1
+            cams.world_space.load_light(orbit["lights"][k])   # SpaceChange burst -> aic_update_light_volume
+            cams.world_view_transform = orbit["views"][k]
+            renderer.update()
         info = renderer.draw_rows_to_device(local_buf.data_ptr(), strip, world, rank)
         kernel_ms.append(info.kernel_ms)
         if world > 1:
@@ -181,7 +207,7 @@ def main() -> int:
     # committed per-launch figure for this workload is reported (null when none is on file
     # or when the image is partitioned differently from the profiled single-GPU launch).
     traffic, traffic_src = None, None
-    if world == 1 and (args.lighting, args.fog, args.transparency) == (3, 1, 1):
+    if world == 1 and (args.lighting, args.fog, args.transparency) == (3, 1, 1) and args.workload != "orbit":
         cands = sorted(glob.glob(os.path.join(str(ROOT), "profiles", f"r*_pmc_{args.workload}.json")))
         if cands:
             with open(cands[-1]) as f:

@@ -308,4 +308,15 @@ def atrium_like_space(seed: int = 7) -> flat.FlatSpace:
     grid[arches] = rec[arches]
     grid[:, sy - 1, :] = np.where((X[:, 0, :] + Z[:, 0, :]) % 3 == 0, a, stone)  # skylights
     sp.block_index[...] = grid
+    # an evaluated-looking light field (the template is lit by its skylights): brighter towards the
+    # roof, smooth elsewhere; cubes holding a block are STATUS_OPAQUE with no light of their own,
+    # which is what exercises the ambient-occlusion weights and the light-leak rule of
+    # get_interpolated_light (sr.rs:248-359)
+    nonair = grid != a
+    lv = (100 + 60 * (Y / sy) + 20 * np.sin(X * 0.4) * np.cos(Z * 0.3)).clip(1, 200).astype(np.uint8)
+    sp.light[..., 0] = lv
+    sp.light[..., 1] = lv
+    sp.light[..., 2] = np.minimum(lv.astype(np.int64) + 4, 255).astype(np.uint8)
+    sp.light[..., 3] = np.where(nonair, flat.STATUS_OPAQUE, flat.STATUS_VISIBLE)
+    sp.light[nonair, 0:3] = 0
     return sp

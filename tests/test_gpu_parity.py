@@ -4,6 +4,8 @@ against the CPU oracle on the same seeded inputs, and against the reference's go
 Bar: bit-exact for integer results (hit cube / voxel / face / block index, step counts,
 f64 t-distances); RGBA8 within +-1 LSB (f32 colour math goes through powf/exp whose last bit
 is libm-dependent; the reference itself tolerates 1-2 levels: cases/src/lib.rs:347,1233)."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -489,6 +491,50 @@ def test_replace_block_changes_class_of_placed_cubes(ctx):
     for replacement in (_sparse_block(8, 11), flat.atom((0.0, 0.0, 0.0, 0.0)), flat.atom((0.1, 0.1, 0.9, 0.5)), scenes.synthetic_blocks(4, 1, seed=3)[0]):
         ctx.replace_block(abi.LAYER_WORLD, a, replacement)
         sp.blocks[a] = replacement
+        got = ctx.render(ctx.make_frame(w, h, world_inv=inv), want_aux=True)
+        ref = oracle.render(oracle.Space(sp), opt, oracle.make_camera(inv, w, h), want_aux=True)
+        assert_parity(got, ref)
+
+
+# --- the reference's own ASCII golden frames (raytracer/text.rs:195-341), from the device ---------
+def _gpu_print_space(ctx, sp, direction=(1.0, 1.0, 1.0)):
+    """PrintSpace (text.rs:147-182) with the device as the tracer: CharacterBuf shows the first hit
+    block's character, ' ' for a ray that entered the space and hit nothing, '.' for one that never
+    entered it -- all three are in the per-pixel aux record (first hit, step count)."""
+    eye = oracle.eye_for_look_at(sp.lo, sp.hi, direction)
+    center = (np.array(sp.lo, float) + np.array(sp.hi, float)) / 2.0
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, 1.0, oracle.look_at_y_up(eye, center), eye)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.set_options(abi.LAYER_WORLD, abi.make_options())
+    aux = ctx.render(ctx.make_frame(80, 40, world_inv=inv), want_aux=True)["aux"]
+    lines = []
+    for row in aux:
+        lines.append("".join(sp.blocks[int(p["block_index"])].name[0] if p["hit"] == 1 else (" " if p["cubes_traced"] > 0 else ".") for p in row))
+    return "\n".join(lines) + "\n"
+
+
+def test_reference_ascii_frames_from_device(ctx):
+    golden = Path(__file__).parent / "golden"
+    assert _gpu_print_space(ctx, scenes.print_space_test_space()) == (golden / "ascii_print_space.txt").read_text()
+    assert _gpu_print_space(ctx, scenes.partial_voxels_space()) == (golden / "ascii_partial_voxels.txt").read_text()
+
+
+# --- BASELINE config 5 in miniature: orbiting camera, light volume re-uploaded every frame -------
+def test_orbit_with_light_reupload_matches_oracle(ctx):
+    sp = scenes.atrium_like_space()
+    opt = oracle.make_options()
+    w, h = 96, 54
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+    base = sp.light.copy()
+    for k in range(4):
+        a = 2.0 * np.pi * k / 4.0
+        sp.light[..., 0:3] = np.clip(base[..., 0:3].astype(np.int32) + int(round(8 * np.sin(a))), 0, 255).astype(np.uint8) * (base[..., 0:3] > 0)
+        ctx.update_light_volume(abi.LAYER_WORLD, sp.light)
+        eye = (0.5 + 7.0 * np.sin(a), 9.91, 7.0 * np.cos(a))
+        _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, (0.5, 8.0, 0.0)), eye)
         got = ctx.render(ctx.make_frame(w, h, world_inv=inv), want_aux=True)
         ref = oracle.render(oracle.Space(sp), opt, oracle.make_camera(inv, w, h), want_aux=True)
         assert_parity(got, ref)
