@@ -57,3 +57,50 @@ def assemble_strips_torch(gathered: torch.Tensor, height: int, width: int, strip
     part = strip % world
     lrow = (strip // world) * strip_rows + (y % strip_rows)
     return gathered[part, lrow]
+
+
+class StripGatherPipeline:
+    """The per-frame exchange step, `depth` frames deep: while frame i's strips travel to rank 0,
+    frame i+1 is already being traced. A ring of `depth` slots, each a local strip buffer
+    [max_rows, width, 4] (every rank) and a gather target [world, max_rows, width, 4] (rank 0):
+
+        buf = pipe.local[slot]            # render this rank's strips into it
+        pipe.submit(slot)                 # asynchronous gather of the slot to rank 0
+        ...
+        g = pipe.retire(slot)             # before the slot is reused: wait for its gather;
+                                          # rank 0 gets the gathered strips back (de-interleave them)
+
+    The renderer writes on its own HIP stream, so `retire` waits on the host, not just on torch's
+    current stream: a slot handed back is really free. Buffers are allocated once."""
+
+    def __init__(self, height: int, width: int, strip_rows: int, device, depth: int = 2, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.height, self.width, self.strip_rows, self.depth = height, width, strip_rows, depth
+        self.max_rows = max_partition_rows(height, strip_rows, self.world)
+        self.local = [torch.zeros((self.max_rows, width, 4), dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.gathered = [torch.empty((self.world, self.max_rows, width, 4), dtype=torch.uint8, device=device) if self.rank == 0 else None
+                         for _ in range(depth)]
+        self.work = [None] * depth
+        self.order: List[int] = []  # slots with a gather in flight, oldest first
+
+    def submit(self, slot: int) -> None:
+        assert self.work[slot] is None, "slot still in flight: retire it first"
+        gl = list(self.gathered[slot].unbind(0)) if self.rank == 0 else None
+        self.work[slot] = dist.gather(self.local[slot], gather_list=gl, dst=0, group=self.group, async_op=True)
+        self.order.append(slot)
+
+    def retire(self, slot: int) -> Optional[torch.Tensor]:
+        w = self.work[slot]
+        if w is None:
+            return None
+        w.wait()
+        if self.local[slot].is_cuda:
+            torch.cuda.current_stream(self.local[slot].device).synchronize()
+        self.work[slot] = None
+        self.order.remove(slot)
+        return self.gathered[slot]
+
+    def oldest(self) -> Optional[int]:
+        return self.order[0] if self.order else None

@@ -618,4 +618,6 @@ void HipRtRenderer::assemble_strips(const void *gathered_device, void *out_devic
           "aic_assemble_strips");
 }
 
+void HipRtRenderer::synchronize() { check(aic_synchronize(ctx_), "aic_synchronize"); }
+
 }  // namespace aic::host

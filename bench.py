@@ -76,6 +76,8 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="atrium", choices=["atrium", "s256", "small", "orbit"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="N > 1: check the assembled frame against a single-rank trace")
+    ap.add_argument("--no-pipeline", action="store_true", help="N > 1: gather each frame before tracing the next")
     ap.add_argument("--lighting", type=int, default=3, help="experiment: LightingOption (0 None,1 Flat,2 Coarse,3 Linear,4 Smoothstep); default Linear")
     ap.add_argument("--fog", type=int, default=1, help="experiment: FogOption (0 None,1 Abrupt,...); default Abrupt")
     ap.add_argument("--transparency", type=int, default=1, help="experiment: 0 Surface, 1 Volumetric; default Volumetric")
@@ -98,12 +100,19 @@ def main() -> int:
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists in the product)")
+    # (test hook: AIC_BENCH_ONE_GPU=1 maps every rank to GPU 0, to exercise the N > 1 path on a 1-GPU box)
+    if os.environ.get("AIC_BENCH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    one_gpu_test = os.environ.get("AIC_BENCH_ONE_GPU") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu_test:  # RCCL refuses two ranks on one device: the test hook gathers through host memory
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     flat_space, (w, h), eye, target, view_distance, label = build_workload(args.workload)
 
@@ -127,9 +136,12 @@ def main() -> int:
 
     strip = D.STRIP_ROWS
     local_rows = renderer.partition_rows(strip, world, rank)
-    local_buf = torch.empty((max(local_rows, 1), w, 4), dtype=torch.uint8, device=dev)
-    frame_buf = torch.empty((h, w, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
     rays_per_frame = w * h * (4 if opts.antialiasing == H.AntialiasingOption.Always else 1)
+    # N > 1: a two-deep ring of strip buffers so that frame i's RCCL gather overlaps frame i+1's trace
+    pipe = D.StripGatherPipeline(h, w, strip, "cpu" if one_gpu_test else dev, depth=1 if args.no_pipeline else 2) if world > 1 else None
+    local_buf = torch.empty((max(local_rows, 1), w, 4), dtype=torch.uint8, device=dev) if (pipe is None or one_gpu_test) else None
+    stage_buf = torch.empty((world, pipe.max_rows, w, 4), dtype=torch.uint8, device=dev) if (one_gpu_test and pipe is not None and rank == 0) else None
+    frame_buf = torch.empty((h, w, 4), dtype=torch.uint8, device=dev) if (rank == 0 and world > 1) else None
 
     kernel_ms = []
     orbit = None
@@ -146,6 +158,17 @@ def main() -> int:
             views.append(H.look_at_y_up((0.5 + 7.0 * np.sin(a), eye[1], 7.0 * np.cos(a)), target))
         orbit = {"k": 0, "lights": lights, "views": views}
 
+    frame_no = [0]
+
+    def finish(slot) -> None:  # a gathered frame leaves the ring: de-interleave it on rank 0
+        g = pipe.retire(slot)
+        if rank == 0 and g is not None:
+            if one_gpu_test:
+                stage_buf.copy_(g)
+                torch.cuda.synchronize()
+                g = stage_buf
+            renderer.assemble_strips(g.data_ptr(), frame_buf.data_ptr(), strip, world)
+
     def step() -> None:
         if orbit is not None:
             k = orbit["k"] % 60
@@ -153,14 +176,27 @@ def main() -> int:
             cams.world_space.load_light(orbit["lights"][k])   # SpaceChange burst -> aic_update_light_volume
             cams.world_view_transform = orbit["views"][k]
             renderer.update()
-        info = renderer.draw_rows_to_device(local_buf.data_ptr(), strip, world, rank)
+        if pipe is None:
+            info = renderer.draw_rows_to_device(local_buf.data_ptr(), strip, world, rank)
+            kernel_ms.append(info.kernel_ms)
+            return
+        slot = frame_no[0] % pipe.depth
+        frame_no[0] += 1
+        finish(slot)
+        target_buf = local_buf if one_gpu_test else pipe.local[slot]
+        info = renderer.draw_rows_to_device(target_buf.data_ptr(), strip, world, rank)
         kernel_ms.append(info.kernel_ms)
-        if world > 1:
-            gathered = D.gather_strips(local_buf[:local_rows], h, w, strip)
-            if rank == 0:
-                renderer.assemble_strips(gathered.data_ptr(), frame_buf.data_ptr(), strip, world)
+        if one_gpu_test:
+            pipe.local[slot][:local_rows].copy_(local_buf[:local_rows])
+        pipe.submit(slot)
+
+    def drain() -> None:  # every frame issued so far is gathered and assembled
+        while pipe is not None and pipe.oldest() is not None:
+            finish(pipe.oldest())
 
     def fence() -> None:
+        drain()
+        renderer.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -174,15 +210,28 @@ def main() -> int:
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu_test else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     mean_kernel_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
 
     # --- untimed extras: algorithmic-byte counters, read-back rate ------------------------------
-    info = renderer.draw_rows_to_device(local_buf.data_ptr(), strip, world, rank, True)
-    counts = torch.tensor([info.cubes_traced, info.n_outer, info.n_inner, info.n_hits, info.n_light], dtype=torch.int64, device=dev)
+    if args.verify and world > 1:
+        # the assembled frame of the last step must equal the same frame traced by one rank alone
+        if rank == 0:
+            whole = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
+            renderer.draw_rows_to_device(whole.data_ptr(), strip, 1, 0)
+            renderer.synchronize()
+            same = bool((whole == frame_buf).all().item())
+            print(f"verify: assembled {world}-rank frame == single-rank frame: {same}", file=sys.stderr, flush=True)
+            if not same:
+                raise SystemExit("multi-rank frame differs from the single-rank frame")
+        dist.barrier()
+    cbuf = local_buf if (pipe is None or one_gpu_test) else pipe.local[0]
+    info = renderer.draw_rows_to_device(cbuf.data_ptr(), strip, world, rank, True)
+    counts = torch.tensor([info.cubes_traced, info.n_outer, info.n_inner, info.n_hits, info.n_light], dtype=torch.int64,
+                          device="cpu" if one_gpu_test else dev)
     if world > 1:
         dist.all_reduce(counts)
     cubes_traced, n_outer, n_inner, n_hits, n_light = (int(v) for v in counts.tolist())

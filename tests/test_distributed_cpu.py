@@ -77,3 +77,48 @@ def test_partition_matches_abi_helper():
         for p in range(n):
             part = abi.Partition(strip, n, p, 0)
             assert lib.aic_partition_rows(h, ctypes.byref(part)) == len(D.partition_rows(h, strip, n, p))
+
+
+def _pipeline_worker(rank, world, port, h, w, strip, frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def frame_image(f):  # what a full frame f looks like: every pixel names its frame and position
+            y, x = np.mgrid[0:h, 0:w]
+            return np.stack([(x + 3 * f) % 256, (y * 7 + f) % 256, (x ^ y) % 256, np.full_like(x, f)], -1).astype(np.uint8)
+
+        pipe = D.StripGatherPipeline(h, w, strip, "cpu", depth=2)
+        rows = D.partition_rows(h, strip, world, rank)
+        done, ok = [], True
+
+        def finish(slot):
+            g = pipe.retire(slot)
+            if rank == 0 and g is not None:
+                done.append(D.assemble_strips_torch(g, h, w, strip).numpy().copy())
+
+        for f in range(frames):
+            slot = f % pipe.depth
+            finish(slot)                                        # frame f-2 leaves the ring
+            pipe.local[slot][: len(rows)] = torch.from_numpy(frame_image(f)[rows])  # "render" this rank's strips
+            pipe.submit(slot)
+        while pipe.oldest() is not None:
+            finish(pipe.oldest())
+        if rank == 0:
+            ok = len(done) == frames and all((done[f] == frame_image(f)).all() for f in range(frames))
+            q.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_pipelined_gather_keeps_frames_in_order():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, 2, port, 70, 24, 16, 5, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
