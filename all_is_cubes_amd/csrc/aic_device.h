@@ -121,6 +121,7 @@ struct DevFrame {
     uint32_t strip_rows, n_parts, part;
     uint32_t local_rows;     // rows this launch renders
     uint32_t tiles_x, tiles_y;  // tile grid over (width, local_rows)
+    uint32_t tile;              // tile edge in pixels: 8 (default) or 16
     uint32_t n_cus;          // compute units of the device (sizes the persistent grid)
     int32_t pass;            // 0: final pass (world layer + encode); 1: UI pre-pass
     int32_t use_init;        // final pass: start each sample from acc_buf (written by the UI pre-pass)

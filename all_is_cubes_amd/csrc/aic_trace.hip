@@ -810,7 +810,8 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
 #define AIC_PROF(i, v)
 #define AIC_TICK(i)
 #endif
-    uint32_t next_idx = 256;  // wave-uniform: next unassigned pixel of tile_cur (256 = tile exhausted)
+    const uint32_t tile_px = F.tile * F.tile;  // pixels per tile: 256 or 64
+    uint32_t next_idx = tile_px;  // wave-uniform: next unassigned pixel of tile_cur (tile_px = tile exhausted)
 
     // sky colour seen along this ray (Sky::sample, sky.rs:32-41); the octant was fixed at ray start
     auto sky_now = [&](float out[3]) {
@@ -1135,7 +1136,7 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
                 for (;;) {
                     const unsigned long long need = __ballot(want);
                     if (need == 0ull) break;
-                    if (next_idx >= 256u) {
+                    if (next_idx >= tile_px) {
                         uint32_t t = 0;
                         if (lane == (uint32_t)__ffsll((long long)need) - 1u) t = atomicAdd(&F.counters->tile_next, 1u);
                         tile_cur = (uint32_t)__shfl((int)t, (int)(__ffsll((long long)need) - 1), 64);
@@ -1144,16 +1145,16 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
                     if (tile_cur >= n_tiles) {  // image exhausted: these lanes are done
                         if (want) ev = EV_DONE;
                         tile_cur = 0xffffffffu;
-                        next_idx = 256;
+                        next_idx = tile_px;
                         break;
                     }
                     const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                    const uint32_t avail = 256u - next_idx;
+                    const uint32_t avail = tile_px - next_idx;
                     if (want && rank < avail) {
                         const uint32_t pidx = next_idx + rank;
                         // pixel order inside a tile: four 8x8 quadrants, row-major inside each
-                        const uint32_t x = (tile_cur % F.tiles_x) * kTile + (pidx & 7u) + (((pidx >> 6) & 1u) << 3);
-                        const uint32_t lrow = (tile_cur / F.tiles_x) * kTile + ((pidx >> 3) & 7u) + (((pidx >> 7) & 1u) << 3);
+                        const uint32_t x = (tile_cur % F.tiles_x) * F.tile + (pidx & 7u) + (((pidx >> 6) & 1u) << 3);
+                        const uint32_t lrow = (tile_cur / F.tiles_x) * F.tile + ((pidx >> 3) & 7u) + (((pidx >> 7) & 1u) << 3);
                         if (x < F.width && lrow < F.local_rows) {  // pixels of partial tiles outside the image are skipped
                             pxy = x | (lrow << 16);
                             want = false;
