@@ -650,7 +650,7 @@ int aic_render(aic_ctx *c, const aic_frame_desc *f, void *out_rgba8, int out_is_
             info->n_hits = hc.n_hits;
             info->n_light = hc.n_light;
 #ifdef AIC_PROFILE
-            { static const char *names[16] = {"ev_phases","ev_lanes","-","-","shade_ph","shade_ln","enter_ph","enter_ln","ray_ph","ray_ln","step_iters","step_lanes","cyc_step","cyc_shade","cyc_enter","cyc_ray"};
+            { static const char *names[16] = {"ev_phases","ev_lanes","cyc_until_dry","cyc_lifetime","shade_ph","shade_ln","enter_ph","enter_ln","ray_ph","ray_ln","step_iters","step_lanes","cyc_step","cyc_shade","cyc_enter","cyc_ray"};
               for (int i = 0; i < 16; i++) std::fprintf(stderr, "PROF %s %llu\n", names[i], hc.prof[i]); }
 #endif
         }

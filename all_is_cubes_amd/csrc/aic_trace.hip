@@ -804,6 +804,7 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
 #ifdef AIC_PROFILE
     uint32_t prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t prof_tm = (uint32_t)__builtin_readcyclecounter();
+    const uint32_t prof_t0 = prof_tm;
 #define AIC_PROF(i, v) prof[i] += (uint32_t)(v)
 #define AIC_TICK(i) { const uint32_t now_ = (uint32_t)__builtin_readcyclecounter(); prof[i] += now_ - prof_tm; prof_tm = now_; }
 #else
@@ -1143,6 +1144,9 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
                         next_idx = 0;
                     }
                     if (tile_cur >= n_tiles) {  // image exhausted: these lanes are done
+#ifdef AIC_PROFILE
+                        if (prof[2] == 0u) prof[2] = (uint32_t)__builtin_readcyclecounter() - prof_t0;  // wave saw the queue run dry
+#endif
                         if (want) ev = EV_DONE;
                         tile_cur = 0xffffffffu;
                         next_idx = tile_px;
@@ -1368,6 +1372,7 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
     }
 
 #ifdef AIC_PROFILE
+    prof[3] = (uint32_t)__builtin_readcyclecounter() - prof_t0;  // wave lifetime
     if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(&F.counters->prof[i], (unsigned long long)prof[i]);
 #endif
     // ---- RaytraceInfo sum (renderer.rs:555): wave reduction then one atomic per wave ----
