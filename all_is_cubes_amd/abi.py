@@ -18,6 +18,7 @@ LIB_PATH = _PKG / "libaic_hip.so"
 AIC_OK = 0
 ERR_NAMES = {1: "AIC_ERR_INVALID", 2: "AIC_ERR_NO_DEVICE", 3: "AIC_ERR_OOM", 4: "AIC_ERR_DEVICE", 5: "AIC_ERR_UNSUPPORTED"}
 LAYER_WORLD, LAYER_UI = 0, 1
+MAX_IN_FLIGHT = 2  # AIC_MAX_IN_FLIGHT
 FLAW_UNSUPPORTED, FLAW_NO_BLOOM = 1, 2
 FRAME_COUNTERS, FRAME_AUX = 1, 2
 
@@ -25,7 +26,7 @@ FRAME_COUNTERS, FRAME_AUX = 1, 2
 ABI_SYMBOLS = [
     "aic_abi_version", "aic_create", "aic_destroy", "aic_last_error", "aic_device_name", "aic_upload_space",
     "aic_clear_space", "aic_update_cubes", "aic_update_light_volume", "aic_replace_block", "aic_set_options",
-    "aic_render", "aic_partition_rows", "aic_assemble_strips", "aic_read_aux", "aic_synchronize", "aic_stream",
+    "aic_render", "aic_render_submit", "aic_render_wait", "aic_partition_rows", "aic_assemble_strips", "aic_read_aux", "aic_synchronize", "aic_stream",
     "aic_probe_raycast", "aic_probe_light_lut",
 ]
 
@@ -110,6 +111,8 @@ def load() -> C.CDLL:
         lib.aic_replace_block.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(BlockDesc), C.c_void_p, C.c_void_p]
         lib.aic_set_options.argtypes = [C.c_void_p, C.c_int, C.POINTER(Options)]
         lib.aic_render.argtypes = [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.c_int, C.POINTER(FrameInfo)]
+        lib.aic_render_submit.argtypes = [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.c_uint32]
+        lib.aic_render_wait.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(FrameInfo)]
         lib.aic_assemble_strips.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.aic_read_aux.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         lib.aic_synchronize.argtypes = [C.c_void_p]
@@ -329,6 +332,15 @@ class Context:
         """Leaves the RGBA8 rows in HBM at `device_ptr` (e.g. a torch tensor's data_ptr())."""
         info = FrameInfo()
         self._check(self._lib.aic_render(self._h, C.byref(frame), C.c_void_p(device_ptr), 1, C.byref(info)))
+        return info
+
+    def render_submit(self, frame: FrameDesc, device_ptr: int, slot: int) -> None:
+        """Queues a frame on `slot` (0..MAX_IN_FLIGHT-1); returns without waiting (aic_render_submit)."""
+        self._check(self._lib.aic_render_submit(self._h, C.byref(frame), C.c_void_p(device_ptr), int(slot)))
+
+    def render_wait(self, slot: int) -> FrameInfo:
+        info = FrameInfo()
+        self._check(self._lib.aic_render_wait(self._h, int(slot), C.byref(info)))
         return info
 
     def assemble_strips(self, gathered_ptr: int, out_ptr: int, width: int, height: int, strip_rows: int, n_parts: int) -> None:

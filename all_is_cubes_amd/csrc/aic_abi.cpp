@@ -122,6 +122,18 @@ struct aic_ctx {
     DevBuf<float4> acc;        // UI pre-pass accumulators
     DevBuf<unsigned char> staging;  // scratch for scatter updates / probes
     uint64_t aux_records = 0;
+    // frames in flight: slot 0 runs on `stream` (and serves the synchronous aic_render), slot 1 on a
+    // second stream so that a submitted frame's trace can start while the previous one drains
+    struct FrameSlot {
+        hipStream_t stream = nullptr;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        DevBuf<DevCounters> counters;
+        DevBuf<float4> acc;  // UI pre-pass accumulators
+        bool busy = false;
+        uint32_t flaws = 0, local_rows = 0;
+        size_t npix = 0;
+        std::chrono::steady_clock::time_point t_begin;
+    } slots[AIC_MAX_IN_FLIGHT];
     std::string err;
     char devname[256] = {0};
     uint32_t n_cus = 256;
@@ -147,6 +159,13 @@ int hip_fail(aic_ctx *c, const char *what, hipError_t e) {
         hipError_t e_ = (expr);                               \
         if (e_ != hipSuccess) return hip_fail(ctx, #expr, e_); \
     } while (0)
+
+// Every scene mutation waits for the frames in flight: they read the buffers it is about to change.
+int quiesce(aic_ctx *c) {
+    for (uint32_t i = 0; i < AIC_MAX_IN_FLIGHT; i++)
+        if (c->slots[i].busy) HIP_TRY(c, hipStreamSynchronize(c->slots[i].stream));
+    return AIC_OK;
+}
 
 bool valid_layer(int l) { return l == AIC_LAYER_WORLD || l == AIC_LAYER_UI; }
 bool valid_resolution(int r) { return r >= 1 && r <= 128 && (r & (r - 1)) == 0; }
@@ -293,6 +312,12 @@ aic_ctx *aic_create(int device_id, int *status) {
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) std::snprintf(c->devname, sizeof(c->devname), "%s (%s)", prop.name, prop.gcnArchName);
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&c->ev0) == hipSuccess &&
               hipEventCreate(&c->ev1) == hipSuccess;
+    for (uint32_t i = 0; ok && i < AIC_MAX_IN_FLIGHT; i++) {
+        aic_ctx::FrameSlot &fs = c->slots[i];
+        if (i == 0) fs.stream = c->stream;
+        else ok = hipStreamCreateWithFlags(&fs.stream, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreate(&fs.ev0) == hipSuccess && hipEventCreate(&fs.ev1) == hipSuccess && fs.counters.ensure(1) == hipSuccess;
+    }
     // PackedLight decode table: PACKED_LIGHT_SCALAR_LOOKUP_TABLE is *defined* as
     // exp2f((v - 144) / 10) with 0 -> 0 (light/data.rs:239-249, 301-354); correctly rounded.
     float lut[256];
@@ -340,6 +365,14 @@ void aic_destroy(aic_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (uint32_t i = 0; i < AIC_MAX_IN_FLIGHT; i++) {
+        aic_ctx::FrameSlot &fs = c->slots[i];
+        if (fs.stream) (void)hipStreamSynchronize(fs.stream);
+        fs.counters.release(); fs.acc.release();
+        if (fs.ev0) (void)hipEventDestroy(fs.ev0);
+        if (fs.ev1) (void)hipEventDestroy(fs.ev1);
+        if (i > 0 && fs.stream) (void)hipStreamDestroy(fs.stream);
+    }
     for (auto &l : c->layers) l.release();
     c->lut.release(); c->srgb_thr.release(); c->counters.release(); c->out.release(); c->aux.release(); c->acc.release(); c->staging.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -359,6 +392,7 @@ int aic_device_name(const aic_ctx *c, char *buf, uint32_t buf_len) {
 int aic_upload_space(aic_ctx *c, int layer, const aic_space_desc *s) {
     if (!c || !s || !valid_layer(layer)) return fail(c, AIC_ERR_INVALID, "aic_upload_space: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
+    { int qrc = quiesce(c); if (qrc != AIC_OK) return qrc; }
     for (int a = 0; a < 3; a++)
         if (s->size[a] < 0 || (int64_t)s->lo[a] + s->size[a] > 2147483647LL) return fail(c, AIC_ERR_INVALID, "space bounds out of range");
     Layer &l = c->layers[layer];
@@ -428,6 +462,7 @@ int aic_upload_space(aic_ctx *c, int layer, const aic_space_desc *s) {
 
 int aic_clear_space(aic_ctx *c, int layer) {
     if (!c || !valid_layer(layer)) return fail(c, AIC_ERR_INVALID, "aic_clear_space: bad argument");
+    { int qrc = quiesce(c); if (qrc != AIC_OK) return qrc; }
     c->layers[layer].present = false;
     return AIC_OK;
 }
@@ -438,6 +473,7 @@ int aic_update_cubes(aic_ctx *c, int layer, uint32_t n, const int32_t *xyz, cons
     if (!l.present) return fail(c, AIC_ERR_INVALID, "aic_update_cubes: no space uploaded for this layer");
     if (!n) return AIC_OK;
     HIP_TRY(c, hipSetDevice(c->device));
+    { int qrc = quiesce(c); if (qrc != AIC_OK) return qrc; }
     if (block_index)
         for (uint32_t i = 0; i < n; i++)
             if (block_index[i] >= l.host_blocks.size()) return fail(c, AIC_ERR_INVALID, "cube block index out of range");
@@ -460,6 +496,7 @@ int aic_update_light_volume(aic_ctx *c, int layer, const uint8_t *light) {
     Layer &l = c->layers[layer];
     if (!l.present) return fail(c, AIC_ERR_INVALID, "aic_update_light_volume: no space uploaded for this layer");
     HIP_TRY(c, hipSetDevice(c->device));
+    { int qrc = quiesce(c); if (qrc != AIC_OK) return qrc; }
     HIP_TRY(c, hipMemcpyAsync(l.light.p, light, l.n_cubes() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return AIC_OK;
@@ -471,6 +508,7 @@ int aic_replace_block(aic_ctx *c, int layer, uint32_t index, const aic_block_des
     if (!l.present) return fail(c, AIC_ERR_INVALID, "aic_replace_block: no space uploaded for this layer");
     if (index > l.host_blocks.size() || index >= 65536) return fail(c, AIC_ERR_INVALID, "aic_replace_block: index out of range");
     HIP_TRY(c, hipSetDevice(c->device));
+    { int qrc = quiesce(c); if (qrc != AIC_OK) return qrc; }
     // new data is appended to the pools (the old ranges become garbage until the next full upload)
     std::vector<uint16_t> vox;
     std::vector<DevPaletteEntry> pal;
@@ -544,10 +582,12 @@ uint32_t aic_partition_rows(uint32_t height, const aic_partition *p) {
     return rows;
 }
 
-int aic_render(aic_ctx *c, const aic_frame_desc *f, void *out_rgba8, int out_is_device, aic_frame_info *info) {
-    if (!c || !f) return fail(c, AIC_ERR_INVALID, "aic_render: bad argument");
-    const auto t_begin = std::chrono::steady_clock::now();
-    HIP_TRY(c, hipSetDevice(c->device));
+namespace {
+
+// Queues one frame on a slot's stream: counters reset, optional UI pre-pass, the trace. No waiting.
+int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint32_t slot, bool allow_aux) {
+    aic_ctx::FrameSlot &fs = c->slots[slot];
+    fs.t_begin = std::chrono::steady_clock::now();
     aic_partition part = f->partition;
     if (part.n_parts <= 1 || part.strip_rows == 0) {
         part.n_parts = 1;
@@ -557,8 +597,7 @@ int aic_render(aic_ctx *c, const aic_frame_desc *f, void *out_rgba8, int out_is_
     if (part.part >= part.n_parts) return fail(c, AIC_ERR_INVALID, "aic_render: partition.part >= n_parts");
     const uint32_t local_rows = aic_partition_rows(f->height, &part);
     const size_t npix = (size_t)f->width * local_rows;
-    if (info) std::memset(info, 0, sizeof(*info));
-    if (npix && !out_rgba8) return fail(c, AIC_ERR_INVALID, "aic_render: output buffer is null");
+    if (npix && !out_device) return fail(c, AIC_ERR_INVALID, "aic_render: output buffer is null");
     if (f->width > 65535u || local_rows > 65535u) return fail(c, AIC_ERR_INVALID, "aic_render: frame dimensions above 65535 are not supported");
 
     uint32_t flaws = 0;
@@ -596,75 +635,117 @@ int aic_render(aic_ctx *c, const aic_frame_desc *f, void *out_rgba8, int out_is_
     F.light_lut = c->lut.p;
     F.n_cus = c->n_cus;
     F.srgb_thr = c->srgb_thr.p;
-    F.counters = c->counters.p;
+    F.counters = fs.counters.p;
 
-    const bool want_aux = (f->flags & AIC_FRAME_AUX) != 0;
+    const bool want_aux = allow_aux && (f->flags & AIC_FRAME_AUX) != 0;
     const bool diag = want_aux || (f->flags & AIC_FRAME_COUNTERS) != 0;
+    fs.flaws = flaws;
+    fs.local_rows = local_rows;
+    fs.npix = npix;
+    if (allow_aux) c->aux_records = 0;
+    if (!npix) return AIC_OK;
+    hipError_t e;
+    F.out = out_device;
+    if (want_aux) {
+        if ((e = c->aux.ensure(npix)) != hipSuccess) return hip_fail(c, "alloc aux", e);
+        F.aux = c->aux.p;
+    }
+    HIP_TRY(c, hipMemsetAsync(fs.counters.p, 0, sizeof(DevCounters), fs.stream));
+    const bool ui = hl[1].present != 0;
+    if (ui) {
+        const size_t samples = F.antialias ? 4 : 1;
+        if ((e = fs.acc.ensure(samples * npix)) != hipSuccess) return hip_fail(c, "alloc accumulators", e);
+        F.acc_buf = fs.acc.p;
+    }
+    HIP_TRY(c, hipEventRecord(fs.ev0, fs.stream));
+    if (ui) {
+        F.pass = 1;
+        F.use_init = 0;
+        F.layer = hl[1];
+        F.layer_transparency = hl[1].opt.transparency;
+        F.layer_lighting = hl[1].opt.lighting;
+        launch_trace_image(F, diag, fs.stream);
+        HIP_TRY(c, hipMemsetAsync(&fs.counters.p->tile_next, 0, sizeof(uint32_t), fs.stream));
+        F.use_init = 1;
+    }
+    F.pass = 0;
+    F.layer = hl[0];
+    F.layer_transparency = hl[0].opt.transparency;
+    F.layer_lighting = hl[0].opt.lighting;
+    launch_trace_image(F, diag, fs.stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(fs.ev1, fs.stream));
+    fs.busy = true;
+    if (want_aux) c->aux_records = npix;
+    return AIC_OK;
+}
+
+// Waits for a slot's frame and reports it.
+int wait_frame(aic_ctx *c, uint32_t slot, aic_frame_info *info) {
+    aic_ctx::FrameSlot &fs = c->slots[slot];
+    if (info) std::memset(info, 0, sizeof(*info));
     float kernel_ms = 0.f;
-    if (npix) {
-        hipError_t e;
-        if (out_is_device) F.out = (uint32_t *)out_rgba8;
-        else {
-            if ((e = c->out.ensure(npix)) != hipSuccess) return hip_fail(c, "alloc output", e);
-            F.out = c->out.p;
-        }
-        if (want_aux) {
-            if ((e = c->aux.ensure(npix)) != hipSuccess) return hip_fail(c, "alloc aux", e);
-            F.aux = c->aux.p;
-        }
-        HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(DevCounters), c->stream));
-        const bool ui = hl[1].present != 0;
-        if (ui) {
-            const size_t samples = F.antialias ? 4 : 1;
-            if ((e = c->acc.ensure(samples * npix)) != hipSuccess) return hip_fail(c, "alloc accumulators", e);
-            F.acc_buf = c->acc.p;
-        }
-        HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-        if (ui) {
-            F.pass = 1;
-            F.use_init = 0;
-            F.layer = hl[1];
-            F.layer_transparency = hl[1].opt.transparency;
-            F.layer_lighting = hl[1].opt.lighting;
-            HIP_TRY(c, hipMemsetAsync(&c->counters.p->tile_next, 0, sizeof(uint32_t), c->stream));
-            launch_trace_image(F, diag, c->stream);
-            F.use_init = 1;
-        }
-        F.pass = 0;
-        F.layer = hl[0];
-        F.layer_transparency = hl[0].opt.transparency;
-        F.layer_lighting = hl[0].opt.lighting;
-        HIP_TRY(c, hipMemsetAsync(&c->counters.p->tile_next, 0, sizeof(uint32_t), c->stream));
-        launch_trace_image(F, diag, c->stream);
-        HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-        if (!out_is_device) HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->out.p, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    if (fs.busy) {
         DevCounters hc;
-        HIP_TRY(c, hipMemcpyAsync(&hc, c->counters.p, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipEventElapsedTime(&kernel_ms, c->ev0, c->ev1));
+        HIP_TRY(c, hipMemcpyAsync(&hc, fs.counters.p, sizeof(hc), hipMemcpyDeviceToHost, fs.stream));
+        HIP_TRY(c, hipStreamSynchronize(fs.stream));
+        fs.busy = false;
+        HIP_TRY(c, hipEventElapsedTime(&kernel_ms, fs.ev0, fs.ev1));
         if (info) {
             info->cubes_traced = hc.cubes_traced;
             info->n_outer = hc.n_outer;
             info->n_inner = hc.n_inner;
             info->n_hits = hc.n_hits;
             info->n_light = hc.n_light;
-#ifdef AIC_PROFILE
-            { static const char *names[16] = {"ev_phases","ev_lanes","cyc_until_dry","cyc_lifetime","shade_ph","shade_ln","enter_ph","enter_ln","ray_ph","ray_ln","step_iters","step_lanes","cyc_step","cyc_shade","cyc_enter","cyc_ray"};
-              for (int i = 0; i < 16; i++) std::fprintf(stderr, "PROF %s %llu\n", names[i], hc.prof[i]); }
-#endif
         }
-        c->aux_records = want_aux ? npix : 0;
-    } else {
-        c->aux_records = 0;
+#ifdef AIC_PROFILE
+        { static const char *names[16] = {"ev_phases","ev_lanes","cyc_until_dry","cyc_lifetime","shade_ph","shade_ln","enter_ph","enter_ln","ray_ph","ray_ln","step_iters","step_lanes","cyc_step","cyc_shade","cyc_enter","cyc_ray"};
+          for (int i = 0; i < 16; i++) std::fprintf(stderr, "PROF %s %llu\n", names[i], hc.prof[i]); }
+#endif
     }
     if (info) {
         info->kernel_ms = kernel_ms;
-        info->rows_rendered = local_rows;
-        info->flaws = flaws;
-        info->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        info->rows_rendered = fs.local_rows;
+        info->flaws = fs.flaws;
+        info->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - fs.t_begin).count();
     }
     return AIC_OK;
+}
+
+}  // namespace
+
+int aic_render(aic_ctx *c, const aic_frame_desc *f, void *out_rgba8, int out_is_device, aic_frame_info *info) {
+    if (!c || !f) return fail(c, AIC_ERR_INVALID, "aic_render: bad argument");
+    if (info) std::memset(info, 0, sizeof(*info));
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->slots[0].busy) return fail(c, AIC_ERR_INVALID, "aic_render: a submitted frame still occupies slot 0 (aic_render_wait it first)");
+    uint32_t *target = (uint32_t *)out_rgba8;
+    if (!out_is_device && out_rgba8) {
+        aic_partition part = f->partition;
+        if (part.n_parts <= 1 || part.strip_rows == 0) { part.n_parts = 1; part.part = 0; part.strip_rows = f->height ? f->height : 1; }
+        const size_t npix = (size_t)f->width * (part.part < part.n_parts ? aic_partition_rows(f->height, &part) : 0);
+        hipError_t e;
+        if (npix && (e = c->out.ensure(npix)) != hipSuccess) return hip_fail(c, "alloc output", e);
+        target = c->out.p;
+    }
+    int rc = submit_frame(c, f, target, 0, true);
+    if (rc != AIC_OK) return rc;
+    if (!out_is_device && c->slots[0].npix)
+        HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->out.p, c->slots[0].npix * 4, hipMemcpyDeviceToHost, c->slots[0].stream));
+    return wait_frame(c, 0, info);
+}
+
+int aic_render_submit(aic_ctx *c, const aic_frame_desc *f, void *out_device, uint32_t slot) {
+    if (!c || !f || slot >= AIC_MAX_IN_FLIGHT) return fail(c, AIC_ERR_INVALID, "aic_render_submit: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->slots[slot].busy) return fail(c, AIC_ERR_INVALID, "aic_render_submit: slot busy (aic_render_wait it first)");
+    return submit_frame(c, f, (uint32_t *)out_device, slot, false);
+}
+
+int aic_render_wait(aic_ctx *c, uint32_t slot, aic_frame_info *info) {
+    if (!c || slot >= AIC_MAX_IN_FLIGHT) return fail(c, AIC_ERR_INVALID, "aic_render_wait: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return wait_frame(c, slot, info);
 }
 
 int aic_assemble_strips(aic_ctx *c, const void *gathered_device, void *out_device, uint32_t width, uint32_t height,
@@ -695,6 +776,7 @@ int aic_synchronize(aic_ctx *c) {
     if (!c) return AIC_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (uint32_t i = 1; i < AIC_MAX_IN_FLIGHT; i++) HIP_TRY(c, hipStreamSynchronize(c->slots[i].stream));
     return AIC_OK;
 }
 

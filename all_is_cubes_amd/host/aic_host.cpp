@@ -618,6 +618,17 @@ void HipRtRenderer::assemble_strips(const void *gathered_device, void *out_devic
           "aic_assemble_strips");
 }
 
+void HipRtRenderer::submit_rows_to_device(void *device_out, uint32_t strip_rows, uint32_t n_parts, uint32_t part, uint32_t slot) {
+    aic_frame_desc f = make_frame();
+    f.partition = aic_partition{strip_rows, n_parts, part, 0};
+    check(aic_render_submit(ctx_, &f, device_out, slot), "aic_render_submit");
+}
+ImageInfo HipRtRenderer::wait_rows(uint32_t slot) {
+    aic_frame_info fi;
+    check(aic_render_wait(ctx_, slot, &fi), "aic_render_wait");
+    const Viewport vp = world_camera_.viewport();
+    return to_info(fi, vp.framebuffer_width, vp.framebuffer_height);
+}
 void HipRtRenderer::synchronize() { check(aic_synchronize(ctx_), "aic_synchronize"); }
 
 }  // namespace aic::host

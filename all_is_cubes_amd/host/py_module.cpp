@@ -219,6 +219,10 @@ PYBIND11_MODULE(_host, m) {
             return r.draw_rows_to_device(reinterpret_cast<void *>(ptr), strip_rows, n_parts, part, counters);
         }, py::arg("device_ptr"), py::arg("strip_rows"), py::arg("n_parts"), py::arg("part"), py::arg("counters") = false)
         .def("partition_rows", &HipRtRenderer::partition_rows)
+        .def("submit_rows_to_device", [](HipRtRenderer &r, uintptr_t ptr, uint32_t strip_rows, uint32_t n_parts, uint32_t part, uint32_t slot) {
+            r.submit_rows_to_device(reinterpret_cast<void *>(ptr), strip_rows, n_parts, part, slot);
+        }, py::arg("device_ptr"), py::arg("strip_rows"), py::arg("n_parts"), py::arg("part"), py::arg("slot"))
+        .def("wait_rows", [](HipRtRenderer &r, uint32_t slot) { py::gil_scoped_release rel; return r.wait_rows(slot); }, py::arg("slot"))
         .def("synchronize", [](HipRtRenderer &r) { py::gil_scoped_release rel; r.synchronize(); })
         .def("assemble_strips", [](HipRtRenderer &r, uintptr_t gathered, uintptr_t out, uint32_t strip_rows, uint32_t n_parts) {
             r.assemble_strips(reinterpret_cast<const void *>(gathered), reinterpret_cast<void *>(out), strip_rows, n_parts);

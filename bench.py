@@ -137,9 +137,14 @@ def main() -> int:
     strip = D.STRIP_ROWS
     local_rows = renderer.partition_rows(strip, world, rank)
     rays_per_frame = w * h * (4 if opts.antialiasing == H.AntialiasingOption.Always else 1)
-    # N > 1: a two-deep ring of strip buffers so that frame i's RCCL gather overlaps frame i+1's trace
-    pipe = D.StripGatherPipeline(h, w, strip, "cpu" if one_gpu_test else dev, depth=1 if args.no_pipeline else 2) if world > 1 else None
-    local_buf = torch.empty((max(local_rows, 1), w, 4), dtype=torch.uint8, device=dev) if (pipe is None or one_gpu_test) else None
+    # Frames are streamed: two traces in flight on the device (frame i+1 starts filling the GPU while
+    # frame i's last rays finish) and, for N > 1, frame i-2's RCCL gather running under them.
+    # --no-pipeline: one frame at a time, gathered before the next is traced.
+    streamed = not args.no_pipeline
+    ring = 3 if streamed else 1
+    pipe = D.StripGatherPipeline(h, w, strip, "cpu" if one_gpu_test else dev, depth=ring) if world > 1 else None
+    n_local = 2 if streamed else 1
+    local_bufs = [torch.empty((max(local_rows, 1), w, 4), dtype=torch.uint8, device=dev) for _ in range(n_local)] if (pipe is None or one_gpu_test) else None
     stage_buf = torch.empty((world, pipe.max_rows, w, 4), dtype=torch.uint8, device=dev) if (one_gpu_test and pipe is not None and rank == 0) else None
     frame_buf = torch.empty((h, w, 4), dtype=torch.uint8, device=dev) if (rank == 0 and world > 1) else None
 
@@ -159,6 +164,7 @@ def main() -> int:
         orbit = {"k": 0, "lights": lights, "views": views}
 
     frame_no = [0]
+    traced = []  # frames whose trace is in flight: (frame number, render slot)
 
     def finish(slot) -> None:  # a gathered frame leaves the ring: de-interleave it on rank 0
         g = pipe.retire(slot)
@@ -169,28 +175,47 @@ def main() -> int:
                 g = stage_buf
             renderer.assemble_strips(g.data_ptr(), frame_buf.data_ptr(), strip, world)
 
+    def render_target(i):
+        if pipe is not None and not one_gpu_test:
+            return pipe.local[i % ring]
+        return local_bufs[i % n_local]
+
+    def complete_oldest() -> None:  # the oldest traced frame: wait for it, hand its strips to the gather
+        i, rslot = traced.pop(0)
+        info = renderer.wait_rows(rslot)
+        kernel_ms.append(info.kernel_ms)
+        if pipe is not None:
+            if one_gpu_test:
+                pipe.local[i % ring][:local_rows].copy_(local_bufs[i % n_local][:local_rows])
+            pipe.submit(i % ring)
+
     def step() -> None:
+        i = frame_no[0]
+        frame_no[0] += 1
         if orbit is not None:
-            k = orbit["k"] % 60
-            orbit["k"] += 1
+            k = i % 60
             cams.world_space.load_light(orbit["lights"][k])   # SpaceChange burst -> aic_update_light_volume
             cams.world_view_transform = orbit["views"][k]
-            renderer.update()
-        if pipe is None:
-            info = renderer.draw_rows_to_device(local_buf.data_ptr(), strip, world, rank)
+            renderer.update()                                  # (waits for the frames in flight: they read the light volume)
+        if not streamed:
+            info = renderer.draw_rows_to_device(render_target(i).data_ptr(), strip, world, rank)
             kernel_ms.append(info.kernel_ms)
+            if pipe is not None:
+                finish(0)
+                if one_gpu_test:
+                    pipe.local[0][:local_rows].copy_(local_bufs[0][:local_rows])
+                pipe.submit(0)
             return
-        slot = frame_no[0] % pipe.depth
-        frame_no[0] += 1
-        finish(slot)
-        target_buf = local_buf if one_gpu_test else pipe.local[slot]
-        info = renderer.draw_rows_to_device(target_buf.data_ptr(), strip, world, rank)
-        kernel_ms.append(info.kernel_ms)
-        if one_gpu_test:
-            pipe.local[slot][:local_rows].copy_(local_buf[:local_rows])
-        pipe.submit(slot)
+        if len(traced) == 2:
+            complete_oldest()
+        if pipe is not None:
+            finish(i % ring)  # the gather that last used this ring slot (frame i-3)
+        renderer.submit_rows_to_device(render_target(i).data_ptr(), strip, world, rank, i % 2)
+        traced.append((i, i % 2))
 
-    def drain() -> None:  # every frame issued so far is gathered and assembled
+    def drain() -> None:  # every frame issued so far is traced, gathered and assembled
+        while traced:
+            complete_oldest()
         while pipe is not None and pipe.oldest() is not None:
             finish(pipe.oldest())
 
@@ -228,7 +253,7 @@ def main() -> int:
             if not same:
                 raise SystemExit("multi-rank frame differs from the single-rank frame")
         dist.barrier()
-    cbuf = local_buf if (pipe is None or one_gpu_test) else pipe.local[0]
+    cbuf = render_target(0)
     info = renderer.draw_rows_to_device(cbuf.data_ptr(), strip, world, rank, True)
     counts = torch.tensor([info.cubes_traced, info.n_outer, info.n_inner, info.n_hits, info.n_light], dtype=torch.int64,
                           device="cpu" if one_gpu_test else dev)

@@ -191,6 +191,16 @@ int aic_set_options(aic_ctx *ctx, int layer, const aic_options *options);
  * as sRGB RGBA8 row-major (headless.rs:52-67). `out_is_device` != 0: out_rgba8 is a device
  * pointer on the context's device (no read-back; used for the RCCL gather). */
 int aic_render(aic_ctx *ctx, const aic_frame_desc *frame, void *out_rgba8, int out_is_device, aic_frame_info *info);
+/* Streaming pair for frame sequences (the reference's recording loop renders frame after frame,
+ * all-is-cubes-desktop/src/record.rs:97-113): aic_render_submit queues a frame on slot
+ * 0..AIC_MAX_IN_FLIGHT-1 and returns at once; aic_render_wait blocks until that slot's frame is in
+ * `out_device` and reports it. With two frames in flight the next frame's trace starts filling the
+ * GPU while the previous frame's last rays finish. out_device must be a device pointer; the
+ * AIC_FRAME_AUX flag is ignored here (use aic_render). Scene updates wait for every frame in
+ * flight before touching device memory. */
+#define AIC_MAX_IN_FLIGHT 2u
+int aic_render_submit(aic_ctx *ctx, const aic_frame_desc *frame, void *out_device, uint32_t slot);
+int aic_render_wait(aic_ctx *ctx, uint32_t slot, aic_frame_info *info);
 /* number of rows / first rows a partition selects (host-side helper for buffer sizing) */
 uint32_t aic_partition_rows(uint32_t height, const aic_partition *partition);
 /* scatter compacted strips gathered from n_parts contexts back into a full frame, on device:

@@ -538,3 +538,48 @@ def test_orbit_with_light_reupload_matches_oracle(ctx):
         got = ctx.render(ctx.make_frame(w, h, world_inv=inv), want_aux=True)
         ref = oracle.render(oracle.Space(sp), opt, oracle.make_camera(inv, w, h), want_aux=True)
         assert_parity(got, ref)
+
+
+# --- streaming pair: two frames in flight equal two synchronous frames ---------------------------
+def test_two_frames_in_flight_equal_synchronous_frames(ctx):
+    import torch
+
+    sp = scenes.synthetic_space(n=20, resolution=8, n_blocks=6, seed=4, light="field")
+    w, h = 160, 96
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.set_options(abi.LAYER_WORLD, abi.make_options())
+    frames = []
+    for k in range(5):
+        eye = (10.5 + 6.0 * np.sin(k), 18.5, 30.0 - 2.0 * k)
+        _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, (10, 6, 10)), eye)
+        frames.append(ctx.make_frame(w, h, world_inv=inv))
+    sync = [ctx.render(f)["rgba8"].copy() for f in frames]
+    sync_steps = [ctx.render(f)["info"].cubes_traced for f in frames]
+    bufs = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    got, steps, in_flight = [], [], []
+
+    def complete():
+        k, slot = in_flight.pop(0)
+        info = ctx.render_wait(slot)
+        got.append((k, bufs[slot].cpu().numpy().copy()))
+        steps.append(info.cubes_traced)
+
+    for k, f in enumerate(frames):
+        if len(in_flight) == abi.MAX_IN_FLIGHT:
+            complete()
+        ctx.render_submit(f, bufs[k % 2].data_ptr(), k % 2)
+        in_flight.append((k, k % 2))
+    with pytest.raises(abi.AicError):  # both slots are taken
+        ctx.render_submit(frames[0], bufs[0].data_ptr(), in_flight[0][1])
+    while in_flight:
+        complete()
+    assert [k for k, _ in got] == list(range(5))
+    for (k, img), ref in zip(got, sync):
+        assert (img == ref).all(), f"frame {k}"
+    assert steps == sync_steps
+    # a scene update while a frame is in flight waits for it instead of racing it
+    ctx.render_submit(frames[0], bufs[0].data_ptr(), 0)
+    ctx.update_cubes(abi.LAYER_WORLD, np.array([[10, 12, 10]], np.int32), np.array([1], np.uint16))
+    ctx.render_wait(0)
+    assert (bufs[0].cpu().numpy() == sync[0]).all()
