@@ -22,6 +22,7 @@ namespace aic {
 void launch_trace_image(const DevFrame &F, bool diag, hipStream_t stream);
 void launch_scatter_cubes(uint16_t *grid, uint32_t *light, const int32_t *xyz, const uint16_t *bi, const uint32_t *lt,
                           uint32_t n, const int lo[3], const int size[3], const uint32_t *cls, hipStream_t stream);
+void launch_order_tiles(const uint32_t *cost, uint32_t *order, uint32_t n_tiles, hipStream_t stream);
 void launch_tag_cubes(uint16_t *grid, size_t n, const uint32_t *cls, int from_tagged, int to_tagged, hipStream_t stream);
 void launch_assemble_strips(const uint32_t *gathered, uint32_t *out, uint32_t w, uint32_t h, uint32_t strip_rows,
                             uint32_t n_parts, uint32_t max_rows, hipStream_t stream);
@@ -129,6 +130,10 @@ struct aic_ctx {
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         DevBuf<DevCounters> counters;
         DevBuf<float4> acc;  // UI pre-pass accumulators
+        // cost feedback: the longest ray of every tile of the slot's last frame, and the tile order made from it
+        DevBuf<uint32_t> tile_cost, tile_order;
+        uint32_t cost_sig[4] = {0, 0, 0, 0};  // width, local rows, partition of the frame tile_cost describes
+        double cost_cam[16] = {0};            // ... and its world camera
         bool busy = false;
         uint32_t flaws = 0, local_rows = 0;
         size_t npix = 0;
@@ -368,7 +373,7 @@ void aic_destroy(aic_ctx *c) {
     for (uint32_t i = 0; i < AIC_MAX_IN_FLIGHT; i++) {
         aic_ctx::FrameSlot &fs = c->slots[i];
         if (fs.stream) (void)hipStreamSynchronize(fs.stream);
-        fs.counters.release(); fs.acc.release();
+        fs.counters.release(); fs.acc.release(); fs.tile_cost.release(); fs.tile_order.release();
         if (fs.ev0) (void)hipEventDestroy(fs.ev0);
         if (fs.ev1) (void)hipEventDestroy(fs.ev1);
         if (i > 0 && fs.stream) (void)hipStreamDestroy(fs.stream);
@@ -584,6 +589,30 @@ uint32_t aic_partition_rows(uint32_t height, const aic_partition *p) {
 
 namespace {
 
+// Do two cameras see nearly the same picture? Compares the rays through three NDC points.
+bool cameras_close(const double a[16], const double b[16]) {
+    auto unproject = [](const double m[16], double x, double y, double z, double out[3]) {  // euclid row-vector convention
+        const double w = x * m[3] + y * m[7] + z * m[11] + m[15];
+        for (int k = 0; k < 3; k++) out[k] = (x * m[k] + y * m[4 + k] + z * m[8 + k] + m[12 + k]) / w;
+    };
+    static const double pts[3][2] = {{0.0, 0.0}, {1.0, 1.0}, {-1.0, -1.0}};
+    for (const auto &p : pts) {
+        double na[3], fa[3], nb[3], fb[3];
+        unproject(a, p[0], p[1], 0.0, na); unproject(a, p[0], p[1], 1.0, fa);
+        unproject(b, p[0], p[1], 0.0, nb); unproject(b, p[0], p[1], 1.0, fb);
+        double da[3], db[3], la = 0, lb = 0, dot = 0, move = 0;
+        for (int k = 0; k < 3; k++) {
+            da[k] = fa[k] - na[k]; db[k] = fb[k] - nb[k];
+            la += da[k] * da[k]; lb += db[k] * db[k]; dot += da[k] * db[k];
+            move += (na[k] - nb[k]) * (na[k] - nb[k]);
+        }
+        if (!(la > 0) || !(lb > 0)) return false;
+        if (!(dot / std::sqrt(la * lb) >= 0.99985)) return false;  // cos(1 degree)
+        if (!(move <= 0.0625)) return false;
+    }
+    return true;
+}
+
 // Queues one frame on a slot's stream: counters reset, optional UI pre-pass, the trace. No waiting.
 int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint32_t slot, bool allow_aux) {
     aic_ctx::FrameSlot &fs = c->slots[slot];
@@ -631,6 +660,10 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         F.tile = (forced == 8 || forced == 16) ? (uint32_t)forced : 8u;
         F.tiles_x = (f->width + F.tile - 1) / F.tile;
         F.tiles_y = (local_rows + F.tile - 1) / F.tile;
+        static const int macro_env = [] { const char *e = std::getenv("AIC_MACRO"); return e ? std::atoi(e) : 0; }();
+        F.macro = (macro_env == 1 || macro_env == 2 || macro_env == 4 || macro_env == 8 || macro_env == 16) ? (uint32_t)macro_env : 2u;
+        F.macros_x = (F.tiles_x + F.macro - 1) / F.macro;
+        F.macros_y = (F.tiles_y + F.macro - 1) / F.macro;
     }
     F.light_lut = c->lut.p;
     F.n_cus = c->n_cus;
@@ -651,6 +684,31 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         F.aux = c->aux.p;
     }
     HIP_TRY(c, hipMemsetAsync(fs.counters.p, 0, sizeof(DevCounters), fs.stream));
+    {
+        // tile order for this frame from the cost the slot's previous frame recorded, if that frame
+        // had the same shape (else index order); then the cost array is cleared for this frame's record
+        static const bool feedback = [] { const char *e = std::getenv("AIC_TILE_FEEDBACK"); return !e || std::atoi(e) != 0; }();
+        const uint32_t n_tiles = F.macros_x * F.macros_y;  // the feedback works on macro tiles
+        if (feedback && n_tiles) {
+            const uint32_t sig[4] = {f->width, local_rows, (part.n_parts << 16) | part.part, (part.strip_rows << 8) | (F.macro << 4) | (F.tile >> 3)};
+            bool same = std::memcmp(sig, fs.cost_sig, sizeof(sig)) == 0 && fs.tile_cost.n >= n_tiles;
+            if (same) {
+                // the record only predicts this frame if the camera has barely moved since: the view rays
+                // through the centre and two corners within a degree, the eye within a quarter cube.
+                // (A stale order is worse than none.)
+                same = cameras_close(f->world.inverse_projection_view, fs.cost_cam);
+            }
+            if ((e = fs.tile_cost.ensure(n_tiles)) != hipSuccess || (e = fs.tile_order.ensure(n_tiles)) != hipSuccess) return hip_fail(c, "alloc tile feedback", e);
+            if (same) {
+                launch_order_tiles(fs.tile_cost.p, fs.tile_order.p, n_tiles, fs.stream);
+                F.tile_order = fs.tile_order.p;
+            }
+            HIP_TRY(c, hipMemsetAsync(fs.tile_cost.p, 0, (size_t)n_tiles * sizeof(uint32_t), fs.stream));
+            F.tile_cost = fs.tile_cost.p;
+            std::memcpy(fs.cost_sig, sig, sizeof(sig));
+            std::memcpy(fs.cost_cam, f->world.inverse_projection_view, sizeof(fs.cost_cam));
+        }
+    }
     const bool ui = hl[1].present != 0;
     if (ui) {
         const size_t samples = F.antialias ? 4 : 1;
@@ -664,7 +722,13 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         F.layer = hl[1];
         F.layer_transparency = hl[1].opt.transparency;
         F.layer_lighting = hl[1].opt.lighting;
+        const uint32_t *order_keep = F.tile_order;
+        uint32_t *cost_keep = F.tile_cost;
+        F.tile_order = nullptr;  // the feedback describes the world pass
+        F.tile_cost = nullptr;
         launch_trace_image(F, diag, fs.stream);
+        F.tile_order = order_keep;
+        F.tile_cost = cost_keep;
         HIP_TRY(c, hipMemsetAsync(&fs.counters.p->tile_next, 0, sizeof(uint32_t), fs.stream));
         F.use_init = 1;
     }
@@ -699,8 +763,14 @@ int wait_frame(aic_ctx *c, uint32_t slot, aic_frame_info *info) {
             info->n_light = hc.n_light;
         }
 #ifdef AIC_PROFILE
-        { static const char *names[16] = {"ev_phases","ev_lanes","cyc_until_dry","cyc_lifetime","shade_ph","shade_ln","enter_ph","enter_ln","ray_ph","ray_ln","step_iters","step_lanes","cyc_step","cyc_shade","cyc_enter","cyc_ray"};
-          for (int i = 0; i < 16; i++) std::fprintf(stderr, "PROF %s %llu\n", names[i], hc.prof[i]); }
+        { static const char *names[16] = {"max_lifetime","max_until_dry","cyc_until_dry","cyc_lifetime","shade_ph","shade_ln","enter_ph","enter_ln","ray_ph","ray_ln","step_iters","step_lanes","cyc_step","cyc_shade","cyc_enter","cyc_ray"};
+          for (int i = 0; i < 16; i++) std::fprintf(stderr, "PROF %s %llu\n", names[i], hc.prof[i]);
+          if (const char *path = std::getenv("AIC_WAVE_PROF")) {
+              if (FILE *fp = std::fopen(path, "w")) {
+                  for (int w = 0; w < 2048; w++) std::fprintf(fp, "%u %u %u %u\n", hc.wave_prof[w][0], hc.wave_prof[w][1], hc.wave_prof[w][2], hc.wave_prof[w][3]);
+                  std::fclose(fp);
+              }
+          } }
 #endif
     }
     if (info) {

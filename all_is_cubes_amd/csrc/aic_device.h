@@ -92,6 +92,9 @@ struct DevCounters {
     unsigned long long prof[16];  // AIC_PROFILE builds only
     uint32_t tile_next;           // dynamic tile dispenser of the persistent trace kernel
     uint32_t pad;
+#ifdef AIC_PROFILE
+    uint32_t wave_prof[2048][4];  // per wave: start, first saw the queue dry, end (cycle counter), pixels taken
+#endif
 };
 
 struct DevAux {  // == aic_pixel_aux
@@ -122,6 +125,8 @@ struct DevFrame {
     uint32_t local_rows;     // rows this launch renders
     uint32_t tiles_x, tiles_y;  // tile grid over (width, local_rows)
     uint32_t tile;              // tile edge in pixels: 8 (default) or 16
+    uint32_t macro;             // tiles are handed out macro x macro at a time (a power of two): neighbours stay together
+    uint32_t macros_x, macros_y;  // macro-tile grid; tile_order / tile_cost are indexed by macro tile
     uint32_t n_cus;          // compute units of the device (sizes the persistent grid)
     int32_t pass;            // 0: final pass (world layer + encode); 1: UI pre-pass
     int32_t use_init;        // final pass: start each sample from acc_buf (written by the UI pre-pass)
@@ -129,6 +134,10 @@ struct DevFrame {
     uint32_t *out;           // [local_rows][width] RGBA8
     DevAux *aux;             // [local_rows][width] or null
     DevCounters *counters;
+    // cost feedback (aic_trace.hip order_tiles_kernel): tile_order[k] = k-th macro tile to hand out, longest
+    // rays of the previous frame first (null: index order); tile_cost[macro tile] receives this frame's longest ray
+    const uint32_t *tile_order;
+    uint32_t *tile_cost;
     const float *light_lut;  // 256 floats
     const float *srgb_thr;   // 256 floats: srgb_thr[k] = smallest linear value whose sRGB8 encoding is >= k
 };

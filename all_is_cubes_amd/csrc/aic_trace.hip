@@ -720,8 +720,7 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
     // ---- persistent waves: each wave pulls 16x16-pixel tiles from a global counter until the
     // image is exhausted, so cheap (sky) and expensive (geometry) tiles balance dynamically ----
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n_tiles = F.tiles_x * F.tiles_y;
-    uint32_t tile_cur = 0xffffffffu;  // wave-uniform: tile the refill is drawing pixels from
+    uint32_t tile_x0 = 0, tile_y0 = 0;  // wave-uniform: pixel origin of the tile the refill is drawing from
     const DevLayer &L = F.layer;
     const DevOptions &opt = L.opt;
     // small decode tables live in LDS for the life of the persistent workgroup
@@ -812,6 +811,8 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
 #define AIC_TICK(i)
 #endif
     const uint32_t tile_px = F.tile * F.tile;  // pixels per tile: 256 or 64
+    const uint32_t macro_shift = (uint32_t)__ffs((int)F.macro) - 1u;
+    const uint32_t n_virtual = (F.macros_x * F.macros_y) << (macro_shift * 2u);  // work items incl. the macro tiles' overhang
     uint32_t next_idx = tile_px;  // wave-uniform: next unassigned pixel of tile_cur (tile_px = tile exhausted)
 
     // sky colour seen along this ray (Sky::sample, sky.rs:32-41); the octant was fixed at ray start
@@ -849,7 +850,13 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
             uint32_t kind = EV_SHADE;
             if (c_enter > best) { best = c_enter; kind = EV_ENTER; }
             if (c_ray > best) { best = c_ray; kind = EV_FINISH; }
-            if (best > 0 && (best >= AIC_T_BATCH || n_step <= AIC_N_FEW)) run = kind;
+            // thresholds scale with the lanes still alive, so that a wave that is running out of rays
+            // (the frame's tail) keeps batching instead of running every event for a lane or two
+            const int alive = n_step + c_shade + c_enter + c_ray;
+            const int half = alive >> 1;
+            const int t_batch = half < AIC_T_BATCH ? (half > 0 ? half : 1) : AIC_T_BATCH;
+            const int n_few = half < AIC_N_FEW ? half : AIC_N_FEW;
+            if (best > 0 && (best >= t_batch || n_step <= n_few)) run = kind;
         }
         if (run != 0u) {
             // ============================ event phase ======================================
@@ -1069,6 +1076,13 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
                     if (DIAG) px_steps += count;
                 }
                 const uint32_t x = pxy & 0xffffu, lrow = pxy >> 16;
+                if (F.tile_cost && count > 48u) {
+                    // longest ray of the macro tile so far. Only rays long enough to matter for the frame's
+                    // tail are recorded (the rest leave their tile at cost 0: handed out last, in index
+                    // order), and the plain read filters out almost every atomic.
+                    uint32_t *tc = &F.tile_cost[(lrow / (F.tile << macro_shift)) * F.macros_x + x / (F.tile << macro_shift)];
+                    if (count > *tc) atomicMax(tc, count);
+                }
                 const size_t pix = (size_t)lrow * F.width + x;
                 if (ui_pass) {
                     F.acc_buf[(size_t)sample * npix + pix] = make_float4(acc.l0, acc.l1, acc.l2, acc.t);
@@ -1138,27 +1152,40 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
                     const unsigned long long need = __ballot(want);
                     if (need == 0ull) break;
                     if (next_idx >= tile_px) {
+                        // next work item: tiles are numbered macro tile by macro tile (macro x macro tiles
+                        // each, row-major inside), and the macro tiles are taken in `tile_order` -- the
+                        // previous frame's costliest first -- so that long rays start early while
+                        // neighbouring tiles still run together and share their cache lines
                         uint32_t t = 0;
-                        if (lane == (uint32_t)__ffsll((long long)need) - 1u) t = atomicAdd(&F.counters->tile_next, 1u);
-                        tile_cur = (uint32_t)__shfl((int)t, (int)(__ffsll((long long)need) - 1), 64);
-                        next_idx = 0;
-                    }
-                    if (tile_cur >= n_tiles) {  // image exhausted: these lanes are done
+                        const int leader = __ffsll((long long)need) - 1;
+                        if ((int)lane == leader) t = atomicAdd(&F.counters->tile_next, 1u);
+                        t = (uint32_t)__shfl((int)t, leader, 64);
+                        if (t >= n_virtual) {  // image exhausted: these lanes are done
 #ifdef AIC_PROFILE
-                        if (prof[2] == 0u) prof[2] = (uint32_t)__builtin_readcyclecounter() - prof_t0;  // wave saw the queue run dry
+                            if (prof[2] == 0u) prof[2] = (uint32_t)__builtin_readcyclecounter() - prof_t0;  // wave saw the queue run dry
 #endif
-                        if (want) ev = EV_DONE;
-                        tile_cur = 0xffffffffu;
-                        next_idx = tile_px;
-                        break;
+                            if (want) ev = EV_DONE;
+                            next_idx = tile_px;
+                            break;
+                        }
+                        const uint32_t m_shift = macro_shift * 2u;
+                        uint32_t mt = t >> m_shift;
+                        const uint32_t inner = t & ((1u << m_shift) - 1u);
+                        if (F.tile_order) mt = F.tile_order[mt];
+                        const uint32_t tx = ((mt % F.macros_x) << macro_shift) + (inner & ((1u << macro_shift) - 1u));
+                        const uint32_t ty = ((mt / F.macros_x) << macro_shift) + (inner >> macro_shift);
+                        tile_x0 = tx * F.tile;
+                        tile_y0 = ty * F.tile;
+                        if (tile_x0 >= F.width || tile_y0 >= F.local_rows) continue;  // a macro tile's overhang past the image edge
+                        next_idx = 0;
                     }
                     const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
                     const uint32_t avail = tile_px - next_idx;
                     if (want && rank < avail) {
                         const uint32_t pidx = next_idx + rank;
                         // pixel order inside a tile: four 8x8 quadrants, row-major inside each
-                        const uint32_t x = (tile_cur % F.tiles_x) * F.tile + (pidx & 7u) + (((pidx >> 6) & 1u) << 3);
-                        const uint32_t lrow = (tile_cur / F.tiles_x) * F.tile + ((pidx >> 3) & 7u) + (((pidx >> 7) & 1u) << 3);
+                        const uint32_t x = tile_x0 + (pidx & 7u) + (((pidx >> 6) & 1u) << 3);
+                        const uint32_t lrow = tile_y0 + ((pidx >> 3) & 7u) + (((pidx >> 7) & 1u) << 3);
                         if (x < F.width && lrow < F.local_rows) {  // pixels of partial tiles outside the image are skipped
                             pxy = x | (lrow << 16);
                             want = false;
@@ -1373,6 +1400,19 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
 
 #ifdef AIC_PROFILE
     prof[3] = (uint32_t)__builtin_readcyclecounter() - prof_t0;  // wave lifetime
+    if (lane == 0) {
+        const uint32_t wid = blockIdx.x * 4u + (threadIdx.x >> 6);
+        if (wid < 2048u) {
+            F.counters->wave_prof[wid][0] = prof_t0;
+            F.counters->wave_prof[wid][1] = prof_t0 + prof[2];
+            F.counters->wave_prof[wid][2] = prof_t0 + prof[3];
+            F.counters->wave_prof[wid][3] = prof[9];
+        }
+        atomicMax(&F.counters->prof[0], (unsigned long long)prof[3]);
+        atomicMax(&F.counters->prof[1], (unsigned long long)prof[2]);
+        // coarse histogram of wave lifetimes in units of 1/8 of 4M cycles -> packed into n_light... (profile builds only)
+    }
+    prof[0] = 0; prof[1] = 0;
     if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(&F.counters->prof[i], (unsigned long long)prof[i]);
 #endif
     // ---- RaytraceInfo sum (renderer.rs:555): wave reduction then one atomic per wave ----
@@ -1426,6 +1466,40 @@ __global__ void tag_cubes_kernel(uint16_t *grid, size_t n, const uint32_t *cls, 
     if (from_tagged) b &= kCubeIndexMask;
     if (to_tagged) b |= ((cls[b >> 4] >> ((b & 15u) << 1)) & 3u) << kCubeClassShift;
     grid[i] = (uint16_t)b;
+}
+
+// Orders the tiles of the next frame by the cost the previous frame measured for them (its longest
+// ray, in steps), costliest first: the rays most likely to be long start early instead of landing
+// in the frame's tail, where a wave with two live lanes still pays a whole event phase for each.
+// One workgroup: histogram over 1024 cost buckets, prefix sum, scatter. Order inside a bucket is
+// whatever the atomics give -- every pixel is traced exactly once either way.
+__global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n_tiles) {
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t scan[1024];
+    const uint32_t tid = threadIdx.x;
+    hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t t = tid; t < n_tiles; t += 1024u) {
+        const uint32_t c = cost[t];
+        atomicAdd(&hist[1023u - (c < 1023u ? c : 1023u)], 1u);
+    }
+    __syncthreads();
+    // exclusive prefix sum (Hillis-Steele over 1024 entries)
+    scan[tid] = hist[tid];
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        const uint32_t v = tid >= off ? scan[tid - off] : 0u;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    hist[tid] = scan[tid] - hist[tid];  // start of each bucket
+    __syncthreads();
+    for (uint32_t t = tid; t < n_tiles; t += 1024u) {
+        const uint32_t c = cost[t];
+        const uint32_t pos = atomicAdd(&hist[1023u - (c < 1023u ? c : 1023u)], 1u);
+        order[pos] = t;
+    }
 }
 
 // aic_assemble_strips: [n_parts][max_rows][w] compacted strips -> [h][w]
@@ -1521,6 +1595,11 @@ void launch_scatter_cubes(uint16_t *grid, uint32_t *light, const int32_t *xyz, c
     if (!n) return;
     hipLaunchKernelGGL(scatter_cubes_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, grid, light, xyz, bi, lt, n, lo[0],
                        lo[1], lo[2], size[0], size[1], size[2], cls);
+}
+
+void launch_order_tiles(const uint32_t *cost, uint32_t *order, uint32_t n_tiles, hipStream_t stream) {
+    if (!n_tiles) return;
+    hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n_tiles);
 }
 
 void launch_assemble_strips(const uint32_t *gathered, uint32_t *out, uint32_t w, uint32_t h, uint32_t strip_rows,
