@@ -77,6 +77,7 @@ def main() -> int:
     ap.add_argument("--workload", default="atrium", choices=["atrium", "s256", "small", "orbit"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="N > 1: check the assembled frame against a single-rank trace")
+    ap.add_argument("--in-flight", type=int, default=0, help="frames traced concurrently (1..4); default 2 at N = 1, 4 at N > 1")
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: gather each frame before tracing the next")
     ap.add_argument("--lighting", type=int, default=3, help="experiment: LightingOption (0 None,1 Flat,2 Coarse,3 Linear,4 Smoothstep); default Linear")
     ap.add_argument("--fog", type=int, default=1, help="experiment: FogOption (0 None,1 Abrupt,...); default Abrupt")
@@ -141,9 +142,10 @@ def main() -> int:
     # frame i's last rays finish) and, for N > 1, frame i-2's RCCL gather running under them.
     # --no-pipeline: one frame at a time, gathered before the next is traced.
     streamed = not args.no_pipeline
-    ring = 3 if streamed else 1
+    depth = max(1, min(4, args.in_flight if args.in_flight > 0 else (2 if world == 1 else 4)))  # traces in flight (AIC_MAX_IN_FLIGHT = 4)
+    ring = depth + 1 if streamed else 1
     pipe = D.StripGatherPipeline(h, w, strip, "cpu" if one_gpu_test else dev, depth=ring) if world > 1 else None
-    n_local = 2 if streamed else 1
+    n_local = depth if streamed else 1
     local_bufs = [torch.empty((max(local_rows, 1), w, 4), dtype=torch.uint8, device=dev) for _ in range(n_local)] if (pipe is None or one_gpu_test) else None
     stage_buf = torch.empty((world, pipe.max_rows, w, 4), dtype=torch.uint8, device=dev) if (one_gpu_test and pipe is not None and rank == 0) else None
     frame_buf = torch.empty((h, w, 4), dtype=torch.uint8, device=dev) if (rank == 0 and world > 1) else None
@@ -206,12 +208,12 @@ def main() -> int:
                     pipe.local[0][:local_rows].copy_(local_bufs[0][:local_rows])
                 pipe.submit(0)
             return
-        if len(traced) == 2:
+        if len(traced) == depth:
             complete_oldest()
         if pipe is not None:
             finish(i % ring)  # the gather that last used this ring slot (frame i-3)
-        renderer.submit_rows_to_device(render_target(i).data_ptr(), strip, world, rank, i % 2)
-        traced.append((i, i % 2))
+        renderer.submit_rows_to_device(render_target(i).data_ptr(), strip, world, rank, i % depth)
+        traced.append((i, i % depth))
 
     def drain() -> None:  # every frame issued so far is traced, gathered and assembled
         while traced:

@@ -194,11 +194,11 @@ int aic_render(aic_ctx *ctx, const aic_frame_desc *frame, void *out_rgba8, int o
 /* Streaming pair for frame sequences (the reference's recording loop renders frame after frame,
  * all-is-cubes-desktop/src/record.rs:97-113): aic_render_submit queues a frame on slot
  * 0..AIC_MAX_IN_FLIGHT-1 and returns at once; aic_render_wait blocks until that slot's frame is in
- * `out_device` and reports it. With two frames in flight the next frame's trace starts filling the
+ * `out_device` and reports it. With several frames in flight the next frame's trace starts filling the
  * GPU while the previous frame's last rays finish. out_device must be a device pointer; the
  * AIC_FRAME_AUX flag is ignored here (use aic_render). Scene updates wait for every frame in
  * flight before touching device memory. */
-#define AIC_MAX_IN_FLIGHT 2u
+#define AIC_MAX_IN_FLIGHT 4u
 int aic_render_submit(aic_ctx *ctx, const aic_frame_desc *frame, void *out_device, uint32_t slot);
 int aic_render_wait(aic_ctx *ctx, uint32_t slot, aic_frame_info *info);
 /* number of rows / first rows a partition selects (host-side helper for buffer sizing) */
