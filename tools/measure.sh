@@ -14,8 +14,10 @@ python bench.py --workload s256 --steps 10 --warmup 2 --cpu-seconds 6 > "$O/benc
 BENCH="python bench.py --steps 20 --warmup 3 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_atrium" -- $BENCH > "$O/stats_atrium.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_s256" -- $BENCH --workload s256 --steps 5 --warmup 1 > "$O/stats_s256.log" 2>&1
+# counter passes trace one frame at a time (--no-pipeline): PMC values are device-wide over a kernel's
+# execution window, so overlapping frames would be counted into each other
 for W in atrium s256; do
-  X=""; [ $W = s256 ] && X="--workload s256"
+  X="--no-pipeline"; [ $W = s256 ] && X="--no-pipeline --workload s256"
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch_$W" -- $BENCH --steps 3 --warmup 1 $X > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write_$W" -- $BENCH --steps 3 --warmup 1 $X > /dev/null 2>&1
   rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_l2_$W" -- $BENCH --steps 3 --warmup 1 $X > /dev/null 2>&1

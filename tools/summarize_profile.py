@@ -18,7 +18,7 @@ os.makedirs(dst, exist_ok=True)
 
 def find(d, suffix):
     hits = glob.glob(os.path.join(src, d, "**", "*" + suffix), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None  # gpurun merges into the old directory: take the newest run
 
 
 for wl in ("atrium", "s256"):
