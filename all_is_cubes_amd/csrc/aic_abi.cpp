@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/aic_hip.h"
@@ -76,6 +77,7 @@ struct Layer {
     DevBuf<uint32_t> cls;    // 2-bit block classes
     std::vector<uint32_t> host_cls;
     DevBuf<uint32_t> light;
+    DevBuf<uint32_t> light_alt;  // the other half of the light double buffer (aic_update_light_volume)
     DevBuf<DevBlock> blocks;
     DevBuf<DevPaletteEntry> palette;
     std::vector<DevBlock> host_blocks;  // mirror of the block table (for replace/append)
@@ -88,7 +90,7 @@ struct Layer {
     bool cls_in_code = false;  // cube-grid entries carry the block class in bits 14-15 (aic_device.h)
     size_t n_cubes() const { return (size_t)size[0] * (size_t)size[1] * (size_t)size[2]; }
     void release() {
-        pool.release(); cls.release(); light.release(); blocks.release(); palette.release();
+        pool.release(); cls.release(); light.release(); light_alt.release(); blocks.release(); palette.release();
         host_blocks.clear(); host_cls.clear();
         present = false;
     }
@@ -113,6 +115,7 @@ aic_options default_options() {
 struct aic_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t upload_stream = nullptr;  // light-volume uploads run beside the frames in flight
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Layer layers[2];
     DevBuf<float> lut;
@@ -135,6 +138,7 @@ struct aic_ctx {
         uint32_t cost_sig[4] = {0, 0, 0, 0};  // width, local rows, partition of the frame tile_cost describes
         double cost_cam[16] = {0};            // ... and its world camera
         bool busy = false;
+        const void *light_used[2] = {nullptr, nullptr};  // per layer: the light buffer the slot's frame reads
         uint32_t flaws = 0, local_rows = 0;
         size_t npix = 0;
         std::chrono::steady_clock::time_point t_begin;
@@ -316,7 +320,7 @@ aic_ctx *aic_create(int device_id, int *status) {
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) std::snprintf(c->devname, sizeof(c->devname), "%s (%s)", prop.name, prop.gcnArchName);
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&c->ev0) == hipSuccess &&
-              hipEventCreate(&c->ev1) == hipSuccess;
+              hipEventCreate(&c->ev1) == hipSuccess && hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) == hipSuccess;
     for (uint32_t i = 0; ok && i < AIC_MAX_IN_FLIGHT; i++) {
         aic_ctx::FrameSlot &fs = c->slots[i];
         if (i == 0) fs.stream = c->stream;
@@ -382,6 +386,7 @@ void aic_destroy(aic_ctx *c) {
     c->lut.release(); c->srgb_thr.release(); c->counters.release(); c->out.release(); c->aux.release(); c->acc.release(); c->staging.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->upload_stream) (void)hipStreamDestroy(c->upload_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -501,9 +506,17 @@ int aic_update_light_volume(aic_ctx *c, int layer, const uint8_t *light) {
     Layer &l = c->layers[layer];
     if (!l.present) return fail(c, AIC_ERR_INVALID, "aic_update_light_volume: no space uploaded for this layer");
     HIP_TRY(c, hipSetDevice(c->device));
-    { int qrc = quiesce(c); if (qrc != AIC_OK) return qrc; }
-    HIP_TRY(c, hipMemcpyAsync(l.light.p, light, l.n_cubes() * 4, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // Double-buffered: the new volume goes into the buffer no frame in flight is reading, on its own
+    // stream, and becomes current for the frames submitted from now on -- a streaming loop that
+    // re-lights every frame (BASELINE config 5) keeps its frames overlapped.
+    const size_t n = l.n_cubes();
+    hipError_t e;
+    if ((e = l.light_alt.ensure(n)) != hipSuccess) return hip_fail(c, "alloc light (double buffer)", e);
+    for (uint32_t i = 0; i < AIC_MAX_IN_FLIGHT; i++)
+        if (c->slots[i].busy && c->slots[i].light_used[layer] == (const void *)l.light_alt.p) HIP_TRY(c, hipStreamSynchronize(c->slots[i].stream));
+    if (n) HIP_TRY(c, hipMemcpyAsync(l.light_alt.p, light, n * 4, hipMemcpyHostToDevice, c->upload_stream));
+    HIP_TRY(c, hipStreamSynchronize(c->upload_stream));
+    std::swap(l.light, l.light_alt);
     return AIC_OK;
 }
 
@@ -673,6 +686,8 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
     const bool want_aux = allow_aux && (f->flags & AIC_FRAME_AUX) != 0;
     const bool diag = want_aux || (f->flags & AIC_FRAME_COUNTERS) != 0;
     fs.flaws = flaws;
+    fs.light_used[0] = hl[0].light;
+    fs.light_used[1] = hl[1].light;
     fs.local_rows = local_rows;
     fs.npix = npix;
     if (allow_aux) c->aux_records = 0;

@@ -583,3 +583,36 @@ def test_two_frames_in_flight_equal_synchronous_frames(ctx):
     ctx.update_cubes(abi.LAYER_WORLD, np.array([[10, 12, 10]], np.int32), np.array([1], np.uint16))
     ctx.render_wait(0)
     assert (bufs[0].cpu().numpy() == sync[0]).all()
+
+
+def test_light_reupload_does_not_disturb_a_frame_in_flight(ctx):
+    """aic_update_light_volume is double-buffered: a frame submitted before it keeps the light it was
+    submitted with, the next frame sees the new volume."""
+    import torch
+
+    sp = scenes.atrium_like_space()
+    w, h = 192, 108
+    eye = (0.5, 9.91, 10.0)
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, (0.5, 8.0, -20.0)), eye)
+    fr = ctx.make_frame(w, h, world_inv=inv)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.set_options(abi.LAYER_WORLD, abi.make_options())
+    dark = sp.light.copy()
+    dark[..., 0:3] = np.clip(dark[..., 0:3].astype(np.int32) - 30, 0, 255).astype(np.uint8) * (sp.light[..., 0:3] > 0)
+    before = ctx.render(fr)["rgba8"].copy()
+    bufs = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    for rep in range(3):  # alternate volumes with frames in flight across the swap
+        ctx.render_submit(fr, bufs[0].data_ptr(), 0)           # reads the bright volume
+        ctx.update_light_volume(abi.LAYER_WORLD, dark)
+        ctx.render_submit(fr, bufs[1].data_ptr(), 1)           # reads the dark one
+        ctx.update_light_volume(abi.LAYER_WORLD, sp.light)
+        ctx.render_submit(fr, bufs[2].data_ptr(), 2)           # bright again (buffer of frame 0: must wait for it)
+        for s in range(3):
+            ctx.render_wait(s)
+        assert (bufs[0].cpu().numpy() == before).all()
+        assert (bufs[2].cpu().numpy() == before).all()
+        assert (bufs[1].cpu().numpy() != before).any()
+    ctx.update_light_volume(abi.LAYER_WORLD, dark)
+    ref = ctx.render(fr)["rgba8"]
+    assert (bufs[1].cpu().numpy() == ref).all()
