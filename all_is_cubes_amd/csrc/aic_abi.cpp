@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <initializer_list>
 #include <string>
 #include <utility>
 #include <vector>
@@ -144,6 +145,7 @@ struct aic_ctx {
         std::chrono::steady_clock::time_point t_begin;
     } slots[AIC_MAX_IN_FLIGHT];
     std::string err;
+    std::FILE *dump = nullptr;  // AIC_DUMP=path: every scene / options / frame argument is appended here
     char devname[256] = {0};
     uint32_t n_cus = 256;
 };
@@ -160,6 +162,24 @@ int fail(aic_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
     }
     return code;
 }
+// ---- call recorder: AIC_DUMP=<path> makes a context append every argument it is given --
+// scene snapshots, deltas, options, frame descriptors -- to <path>, verbatim, so that a scene produced by
+// the reference (which cannot be generated here) can be captured where the Rust shim runs and replayed
+// anywhere (all_is_cubes_amd/replay.py). Layout: "AICDUMP1", then records {u32 tag, u32 layer, u64 bytes, payload}.
+enum DumpTag : uint32_t { DUMP_UPLOAD = 1, DUMP_CLEAR = 2, DUMP_CUBES = 3, DUMP_LIGHT = 4, DUMP_BLOCK = 5, DUMP_OPTIONS = 6, DUMP_FRAME = 7 };
+struct DumpPart { const void *p; size_t n; };
+void dump_record(aic_ctx *c, uint32_t tag, uint32_t layer, std::initializer_list<DumpPart> parts) {
+    if (!c || !c->dump) return;
+    uint64_t total = 0;
+    for (const DumpPart &d : parts) total += d.p ? d.n : 0;
+    std::fwrite(&tag, 4, 1, c->dump);
+    std::fwrite(&layer, 4, 1, c->dump);
+    std::fwrite(&total, 8, 1, c->dump);
+    for (const DumpPart &d : parts)
+        if (d.p && d.n) std::fwrite(d.p, 1, d.n, c->dump);
+    std::fflush(c->dump);
+}
+
 int hip_fail(aic_ctx *c, const char *what, hipError_t e) {
     return fail(c, e == hipErrorOutOfMemory ? AIC_ERR_OOM : AIC_ERR_DEVICE, what, e);
 }
@@ -319,6 +339,14 @@ aic_ctx *aic_create(int device_id, int *status) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) std::snprintf(c->devname, sizeof(c->devname), "%s (%s)", prop.name, prop.gcnArchName);
+    if (const char *path = std::getenv("AIC_DUMP")) {
+        static int n_dumps = 0;  // one file per context: <path>, <path>.1, <path>.2 ...
+        std::string pth = path;
+        if (n_dumps > 0) pth += "." + std::to_string(n_dumps);
+        n_dumps++;
+        c->dump = std::fopen(pth.c_str(), "wb");
+        if (c->dump) std::fwrite("AICDUMP1", 1, 8, c->dump);
+    }
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&c->ev0) == hipSuccess &&
               hipEventCreate(&c->ev1) == hipSuccess && hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) == hipSuccess;
     for (uint32_t i = 0; ok && i < AIC_MAX_IN_FLIGHT; i++) {
@@ -386,6 +414,7 @@ void aic_destroy(aic_ctx *c) {
     c->lut.release(); c->srgb_thr.release(); c->counters.release(); c->out.release(); c->aux.release(); c->acc.release(); c->staging.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->dump) std::fclose(c->dump);
     if (c->upload_stream) (void)hipStreamDestroy(c->upload_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -467,6 +496,17 @@ int aic_upload_space(aic_ctx *c, int layer, const aic_space_desc *s) {
                          ((uint32_t)s->block_sky[f][3] << 24);
     l.cls_in_code = cls_in_code;
     l.present = true;
+    if (c->dump) {
+        struct { int32_t lo[3], size[3]; uint32_t n_blocks; int32_t sky_kind; uint64_t n_voxels, n_palette; float sky[8][3]; uint8_t block_sky[7][4]; } h;
+        std::memset(&h, 0, sizeof(h));
+        for (int a = 0; a < 3; a++) { h.lo[a] = s->lo[a]; h.size[a] = s->size[a]; }
+        h.n_blocks = s->n_blocks; h.sky_kind = s->sky_kind; h.n_voxels = s->n_voxels; h.n_palette = s->n_palette;
+        std::memcpy(h.sky, s->sky, sizeof(h.sky));
+        std::memcpy(h.block_sky, s->block_sky, sizeof(h.block_sky));
+        dump_record(c, DUMP_UPLOAD, (uint32_t)layer,
+                    {{&h, sizeof(h)}, {s->block_index, n * 2}, {s->light, n * 4}, {s->blocks, (size_t)s->n_blocks * sizeof(aic_block_desc)},
+                     {s->voxels, (size_t)s->n_voxels * 2}, {s->palette, (size_t)s->n_palette * 32}});
+    }
     return AIC_OK;
 }
 
@@ -474,6 +514,7 @@ int aic_clear_space(aic_ctx *c, int layer) {
     if (!c || !valid_layer(layer)) return fail(c, AIC_ERR_INVALID, "aic_clear_space: bad argument");
     { int qrc = quiesce(c); if (qrc != AIC_OK) return qrc; }
     c->layers[layer].present = false;
+    dump_record(c, DUMP_CLEAR, (uint32_t)layer, {});
     return AIC_OK;
 }
 
@@ -498,6 +539,10 @@ int aic_update_cubes(aic_ctx *c, int layer, uint32_t n, const int32_t *xyz, cons
                          light ? (const uint32_t *)(base + b_xyz + b_bi) : nullptr, n, l.lo, l.size, l.cls_in_code ? l.cls.p : nullptr, c->stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    {
+        const uint32_t h[4] = {n, block_index ? 1u : 0u, light ? 1u : 0u, 0u};
+        dump_record(c, DUMP_CUBES, (uint32_t)layer, {{h, sizeof(h)}, {xyz, (size_t)n * 12}, {block_index, (size_t)n * 2}, {light, (size_t)n * 4}});
+    }
     return AIC_OK;
 }
 
@@ -517,6 +562,10 @@ int aic_update_light_volume(aic_ctx *c, int layer, const uint8_t *light) {
     if (n) HIP_TRY(c, hipMemcpyAsync(l.light_alt.p, light, n * 4, hipMemcpyHostToDevice, c->upload_stream));
     HIP_TRY(c, hipStreamSynchronize(c->upload_stream));
     std::swap(l.light, l.light_alt);
+    {
+        const uint64_t h = n;
+        dump_record(c, DUMP_LIGHT, (uint32_t)layer, {{&h, sizeof(h)}, {light, n * 4}});
+    }
     return AIC_OK;
 }
 
@@ -573,6 +622,12 @@ int aic_replace_block(aic_ctx *c, int layer, uint32_t index, const aic_block_des
     } else if (l.air_index == (int32_t)index) {
         l.air_index = -1;
     }
+    {
+        const bool one = (desc->flags & AIC_BLOCK_ONE) != 0;
+        const uint64_t nvox = one ? 0 : (uint64_t)(desc->vsize[0] > 0 ? desc->vsize[0] : 0) * (uint64_t)(desc->vsize[1] > 0 ? desc->vsize[1] : 0) * (uint64_t)(desc->vsize[2] > 0 ? desc->vsize[2] : 0);
+        const uint64_t h[2] = {index, nvox};
+        dump_record(c, DUMP_BLOCK, (uint32_t)layer, {{h, sizeof(h)}, {desc, sizeof(*desc)}, {voxels, (size_t)nvox * 2}, {palette, (size_t)desc->pal_len * 32}});
+    }
     return AIC_OK;
 }
 
@@ -583,6 +638,7 @@ int aic_set_options(aic_ctx *c, int layer, const aic_options *o) {
         return fail(c, AIC_ERR_INVALID, "aic_set_options: enum or view_distance out of range");
     c->layers[layer].opt = *o;
     c->layers[layer].opt_set = true;
+    dump_record(c, DUMP_OPTIONS, (uint32_t)layer, {{o, sizeof(*o)}});
     return AIC_OK;
 }
 
@@ -640,6 +696,7 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
     const uint32_t local_rows = aic_partition_rows(f->height, &part);
     const size_t npix = (size_t)f->width * local_rows;
     if (npix && !out_device) return fail(c, AIC_ERR_INVALID, "aic_render: output buffer is null");
+    dump_record(c, DUMP_FRAME, slot, {{f, sizeof(*f)}});
     if (f->width > 65535u || local_rows > 65535u) return fail(c, AIC_ERR_INVALID, "aic_render: frame dimensions above 65535 are not supported");
 
     uint32_t flaws = 0;

@@ -194,6 +194,16 @@ class FlatSpace:
         )
 
 
+def pack_block(b: BlockDef):
+    """(descriptor, voxels, palette) of one block as `aic_replace_block` takes them (offsets unused)."""
+    d = np.zeros(1, BLOCK_DTYPE)
+    d["resolution"], d["vlo"], d["vsize"] = b.resolution, b.vlo, b.voxels.shape
+    d["pal_len"] = len(b.palette)
+    d["flags"] = (FLAG_ONE if b.is_one else 0) | (FLAG_AIR if b.is_air else 0)
+    d["name_char"] = ord(b.name[0]) if b.name else ord("#")
+    return d, np.ascontiguousarray(b.voxels, np.uint16).reshape(-1), np.ascontiguousarray(b.palette, np.float32)
+
+
 def voxel_block(
     resolution: int,
     voxel_palette_index: np.ndarray,
