@@ -616,3 +616,43 @@ def test_light_reupload_does_not_disturb_a_frame_in_flight(ctx):
     ctx.update_light_volume(abi.LAYER_WORLD, dark)
     ref = ctx.render(fr)["rgba8"]
     assert (bufs[1].cpu().numpy() == ref).all()
+
+
+# --- BASELINE's full sizes: sampled rows against the oracle + size-independent properties -------------
+@pytest.mark.parametrize("workload", ["atrium", "s256"])
+def test_full_size_workload_rows_and_properties(ctx, workload):
+    import bench
+
+    sp, (w, h), eye, target, vd, _ = bench.build_workload(workload)
+    opt = oracle.make_options(view_distance=vd)
+    _, _, inv = oracle.camera_matrices(90.0, vd, w / h, oracle.look_at_y_up(eye, target), eye)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+    fr = ctx.make_frame(w, h, world_inv=inv)
+    first = ctx.render(fr, want_aux=True)   # index tile order (no cost record yet)
+    again = ctx.render(fr, want_aux=True)   # costliest-first tile order from the first frame's record
+    # idempotence / schedule independence: the picture and every per-pixel record do not depend on tile order
+    assert (first["rgba8"] == again["rgba8"]).all()
+    assert first["info"].cubes_traced == again["info"].cubes_traced
+    for k in ("cubes_traced", "hit", "cube", "voxel", "face", "block_index"):
+        assert (first["aux"][k] == again["aux"][k]).all()
+    # rows sampled over the frame, whole rows, against the oracle: steps, first hits, f64 t, RGBA8
+    osp, cam = oracle.Space(sp), oracle.make_camera(inv, w, h)
+    for y in sorted({0, h // 7, h // 3, h // 2, (2 * h) // 3, h - 1}):
+        ref = oracle.render(osp, opt, cam, rows=(y, y + 1), want_aux=True)
+        ga, ra = again["aux"][y], ref["aux"][y]
+        assert (ga["cubes_traced"] == ra["cubes_traced"]).all(), f"row {y}: step counts"
+        for k in ("hit", "cube", "voxel", "resolution", "face", "block_index"):
+            assert (ga[k] == ra[k]).all(), f"row {y}: {k}"
+        hit = ra["hit"] == 1
+        assert (ga["t_distance"][hit].view(np.uint64) == ra["t_distance"][hit].view(np.uint64)).all(), f"row {y}: t bits"
+        assert np.abs(again["rgba8"][y].astype(np.int16) - ref["rgba8"][y].astype(np.int16)).max() <= RGBA_TOL
+    # partition: eight ranks' strips add up to the frame, pixels and step count alike
+    total = 0
+    for part in range(8):
+        got = ctx.render(ctx.make_frame(w, h, world_inv=inv, partition=(16, 8, part)))
+        rows = [y for y in range(h) if (y // 16) % 8 == part]
+        assert (got["rgba8"] == again["rgba8"][rows]).all()
+        total += got["info"].cubes_traced
+    assert total == again["info"].cubes_traced
