@@ -117,14 +117,11 @@ struct aic_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t upload_stream = nullptr;  // light-volume uploads run beside the frames in flight
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     Layer layers[2];
     DevBuf<float> lut;
     DevBuf<float> srgb_thr;
-    DevBuf<DevCounters> counters;
     DevBuf<uint32_t> out;      // internal RGBA8 target when the caller wants a host copy
     DevBuf<DevAux> aux;
-    DevBuf<float4> acc;        // UI pre-pass accumulators
     DevBuf<unsigned char> staging;  // scratch for scatter updates / probes
     uint64_t aux_records = 0;
     // frames in flight: slot 0 runs on `stream` (and serves the synchronous aic_render), slot 1 on a
@@ -347,8 +344,8 @@ aic_ctx *aic_create(int device_id, int *status) {
         c->dump = std::fopen(pth.c_str(), "wb");
         if (c->dump) std::fwrite("AICDUMP1", 1, 8, c->dump);
     }
-    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&c->ev0) == hipSuccess &&
-              hipEventCreate(&c->ev1) == hipSuccess && hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) == hipSuccess;
     for (uint32_t i = 0; ok && i < AIC_MAX_IN_FLIGHT; i++) {
         aic_ctx::FrameSlot &fs = c->slots[i];
         if (i == 0) fs.stream = c->stream;
@@ -387,7 +384,6 @@ aic_ctx *aic_create(int device_id, int *status) {
         }
         ok = ok && c->srgb_thr.ensure(256) == hipSuccess && hipMemcpy(c->srgb_thr.p, thr, sizeof(thr), hipMemcpyHostToDevice) == hipSuccess;
     }
-    ok = ok && c->counters.ensure(1) == hipSuccess;
     if (!ok) {
         *status = AIC_ERR_DEVICE;
         aic_destroy(c);
@@ -411,9 +407,7 @@ void aic_destroy(aic_ctx *c) {
         if (i > 0 && fs.stream) (void)hipStreamDestroy(fs.stream);
     }
     for (auto &l : c->layers) l.release();
-    c->lut.release(); c->srgb_thr.release(); c->counters.release(); c->out.release(); c->aux.release(); c->acc.release(); c->staging.release();
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    c->lut.release(); c->srgb_thr.release(); c->out.release(); c->aux.release(); c->staging.release();
     if (c->dump) std::fclose(c->dump);
     if (c->upload_stream) (void)hipStreamDestroy(c->upload_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
