@@ -656,3 +656,43 @@ def test_full_size_workload_rows_and_properties(ctx, workload):
         assert (got["rgba8"] == again["rgba8"][rows]).all()
         total += got["info"].cubes_traced
     assert total == again["info"].cubes_traced
+
+
+def test_block_table_past_14_bits_uses_the_class_table(ctx):
+    """More than 16384 blocks: cube-grid entries can no longer carry the class bits (aic_device.h), the
+    kernel classifies through the LDS table; growing past the limit by replace_block re-tags the grid."""
+    rng = np.random.default_rng(31)
+    sp = flat.FlatSpace((0, 0, 0), (12, 10, 12))
+    sp.set_sky_uniform((0.4, 0.5, 0.7))
+    sp.add_block(flat.air())
+    rec = [sp.add_block(b) for b in scenes.synthetic_blocks(8, 3, seed=5)]
+    n_atoms = 16384 - len(sp.blocks)  # exactly at the limit: still tagged
+    for i in range(n_atoms):
+        c = rng.uniform(0.05, 0.95, 3)
+        sp.add_block(flat.atom((float(c[0]), float(c[1]), float(c[2]), 1.0 if i % 5 else 0.5)))
+    assert len(sp.blocks) == 16384
+    grid = rng.integers(1, len(sp.blocks), sp.size).astype(np.uint16)
+    grid[rng.random(sp.size) < 0.75] = 0
+    grid[:, 0, :] = rng.integers(1, len(sp.blocks), (12, 12))
+    grid[3, 3, 3], grid[8, 2, 5] = rec[0], rec[2]
+    sp.block_index[...] = grid
+    opt = oracle.make_options()
+    w, h = 112, 80
+    eye = (6.0, 8.5, 17.0)
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, (6, 2, 6)), eye)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+    fr = ctx.make_frame(w, h, world_inv=inv)
+    assert_parity(ctx.render(fr, want_aux=True), oracle.render(oracle.Space(sp), opt, oracle.make_camera(inv, w, h), want_aux=True))
+    # one more block: index 16384 needs 15 bits
+    extra = scenes.synthetic_blocks(4, 1, seed=9)[0]
+    ctx.replace_block(abi.LAYER_WORLD, len(sp.blocks), extra)
+    idx = sp.add_block(extra)
+    ctx.update_cubes(abi.LAYER_WORLD, np.array([[5, 1, 9], [6, 4, 6]], np.int32), np.array([idx, idx], np.uint16))
+    sp.set((5, 1, 9), idx)
+    sp.set((6, 4, 6), idx)
+    ref = oracle.render(oracle.Space(sp), opt, oracle.make_camera(inv, w, h), want_aux=True)
+    assert_parity(ctx.render(fr, want_aux=True), ref)
+    ctx.upload_space(abi.LAYER_WORLD, sp)  # and as a fresh snapshot of 16385 blocks
+    assert_parity(ctx.render(fr, want_aux=True), ref)
