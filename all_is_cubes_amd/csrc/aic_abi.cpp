@@ -344,14 +344,16 @@ aic_ctx *aic_create(int device_id, int *status) {
         c->dump = std::fopen(pth.c_str(), "wb");
         if (c->dump) std::fwrite("AICDUMP1", 1, 8, c->dump);
     }
-    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     for (uint32_t i = 0; ok && i < AIC_MAX_IN_FLIGHT; i++) {
         aic_ctx::FrameSlot &fs = c->slots[i];
         if (i == 0) fs.stream = c->stream;
         else ok = hipStreamCreateWithFlags(&fs.stream, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipEventCreate(&fs.ev0) == hipSuccess && hipEventCreate(&fs.ev1) == hipSuccess && fs.counters.ensure(1) == hipSuccess;
     }
+    // created after the frame streams: HIP deals streams onto a few hardware queues in creation order
+    // (4 by default), and two frame slots sharing a queue would serialise their kernels
+    ok = ok && hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking) == hipSuccess;
     // PackedLight decode table: PACKED_LIGHT_SCALAR_LOOKUP_TABLE is *defined* as
     // exp2f((v - 144) / 10) with 0 -> 0 (light/data.rs:239-249, 301-354); correctly rounded.
     float lut[256];

@@ -701,6 +701,9 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_FRESH = 1u 
 #ifndef AIC_N_FEW
 #define AIC_N_FEW 32    // ... or once at most this many lanes can still step
 #endif
+#ifndef AIC_WG_THREADS
+#define AIC_WG_THREADS 256  // threads per persistent workgroup (a multiple of 64)
+#endif
 #ifndef AIC_STEP_REPS
 #define AIC_STEP_REPS 4  // DDA steps per scheduler trip
 #endif
@@ -716,7 +719,7 @@ AIC_DEV Lvl lvl_first(Lvl s, const Lim lim, const RayDir rd, int lox, int loy, i
 }
 
 template <bool VOL, int LMODE, bool DIAG>
-__global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const DevFrame F) {
+__global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_kernel(const DevFrame F) {
     // ---- persistent waves: each wave pulls 16x16-pixel tiles from a global counter until the
     // image is exhausted, so cheap (sky) and expensive (geometry) tiles balance dynamically ----
     const uint32_t lane = threadIdx.x & 63u;
@@ -727,11 +730,13 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
     __shared__ float s_lut[256];     // PackedLight scalar decode (light/data.rs:301-354)
     __shared__ float s_thr[256];     // sRGB8 encode thresholds
     __shared__ uint32_t s_cls[kClsWords];  // 2 bits per block: 0 invisible single voxel, 1 visible single voxel, 2 recursive
-    s_lut[threadIdx.x] = F.light_lut[threadIdx.x];
-    s_thr[threadIdx.x] = F.srgb_thr[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < 256u; i += (uint32_t)AIC_WG_THREADS) {
+        s_lut[i] = F.light_lut[i];
+        s_thr[i] = F.srgb_thr[i];
+    }
     {
         const uint32_t n_words = (L.n_blocks + 15u) / 16u;
-        for (uint32_t i = threadIdx.x; i < n_words && i < (uint32_t)kClsWords; i += 256u) s_cls[i] = L.cls[i];
+        for (uint32_t i = threadIdx.x; i < n_words && i < (uint32_t)kClsWords; i += (uint32_t)AIC_WG_THREADS) s_cls[i] = L.cls[i];
     }
     __syncthreads();
     const float *lut = s_lut;
@@ -1401,7 +1406,7 @@ __global__ __launch_bounds__(256, AIC_MIN_WAVES) void trace_image_kernel(const D
 #ifdef AIC_PROFILE
     prof[3] = (uint32_t)__builtin_readcyclecounter() - prof_t0;  // wave lifetime
     if (lane == 0) {
-        const uint32_t wid = blockIdx.x * 4u + (threadIdx.x >> 6);
+        const uint32_t wid = blockIdx.x * (uint32_t)(AIC_WG_THREADS / 64) + (threadIdx.x >> 6);
         if (wid < 2048u) {
             F.counters->wave_prof[wid][0] = prof_t0;
             F.counters->wave_prof[wid][1] = prof_t0 + prof[2];
@@ -1557,11 +1562,12 @@ static void launch_trace(const DevFrame &F, hipStream_t stream) {
     // persistent waves: enough workgroups to fill the chip at the kernel's occupancy, never more
     // waves than tiles (each wave pulls 16x16 tiles from counters->tile_next)
     const uint32_t n_tiles = F.tiles_x * F.tiles_y;
-    const uint32_t resident_groups = F.n_cus * (uint32_t)AIC_MIN_WAVES;  // 4 waves per group, AIC_MIN_WAVES groups per CU
-    uint32_t grid = (n_tiles + 3u) / 4u;
+    const uint32_t wg_waves = (uint32_t)AIC_WG_THREADS / 64u;
+    const uint32_t resident_groups = F.n_cus * 4u * (uint32_t)AIC_MIN_WAVES / wg_waves;  // 4 SIMDs per CU, AIC_MIN_WAVES waves on each
+    uint32_t grid = (n_tiles + wg_waves - 1u) / wg_waves;
     if (grid > resident_groups) grid = resident_groups;
     if (grid == 0) return;
-    hipLaunchKernelGGL((trace_image_kernel<VOL, LMODE, DIAG>), dim3(grid), dim3(256), 0, stream, F);
+    hipLaunchKernelGGL((trace_image_kernel<VOL, LMODE, DIAG>), dim3(grid), dim3(AIC_WG_THREADS), 0, stream, F);
 }
 
 template <bool DIAG>

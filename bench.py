@@ -27,6 +27,11 @@ import sys
 import time
 from pathlib import Path
 
+# HIP deals streams onto hardware queues in creation order, 4 by default; with four frame streams,
+# an upload stream, torch's and RCCL's own, two frame slots could end up sharing a queue and
+# serialise their kernels. Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
