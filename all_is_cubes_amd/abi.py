@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "aic_abi_version", "aic_create", "aic_destroy", "aic_last_error", "aic_device_name", "aic_upload_space",
     "aic_clear_space", "aic_update_cubes", "aic_update_light_volume", "aic_replace_block", "aic_set_options",
     "aic_render", "aic_render_submit", "aic_render_wait", "aic_partition_rows", "aic_assemble_strips", "aic_read_aux", "aic_synchronize", "aic_stream",
-    "aic_probe_raycast", "aic_probe_light_lut",
+    "aic_probe_raycast", "aic_probe_light_lut", "aic_probe_powf",
 ]
 
 
@@ -120,6 +120,7 @@ def load() -> C.CDLL:
         lib.aic_probe_raycast.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                           C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
         lib.aic_probe_light_lut.argtypes = [C.c_void_p, C.c_void_p]
+        lib.aic_probe_powf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         assert C.sizeof(BlockDesc) == 48
         _lib = lib
     return _lib
@@ -361,6 +362,13 @@ class Context:
         self._check(self._lib.aic_probe_raycast(self._h, o.ctypes.data, d.ctypes.data, int(bounds is not None), lo.ctypes.data,
                                                 hi.ctypes.data, int(include_exit), max_steps, out.ctypes.data, C.byref(n), C.byref(ended)))
         return out[: n.value], bool(ended.value)
+
+    def probe_powf(self, x, y) -> np.ndarray:
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.ascontiguousarray(y, np.float32)
+        out = np.zeros(x.shape, np.float32)
+        self._check(self._lib.aic_probe_powf(self._h, _ptr(x), _ptr(y), x.size, _ptr(out)))
+        return out
 
     def probe_light_lut(self) -> np.ndarray:
         out = np.zeros(256, np.float32)

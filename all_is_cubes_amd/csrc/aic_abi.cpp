@@ -24,6 +24,7 @@ namespace aic {
 void launch_trace_image(const DevFrame &F, bool diag, hipStream_t stream);
 void launch_scatter_cubes(uint16_t *grid, uint32_t *light, const int32_t *xyz, const uint16_t *bi, const uint32_t *lt,
                           uint32_t n, const int lo[3], const int size[3], const uint32_t *cls, hipStream_t stream);
+void launch_probe_powf(const float *x, const float *y, float *out, uint32_t n, hipStream_t stream);
 void launch_order_tiles(const uint32_t *cost, uint32_t *order, uint32_t n_tiles, hipStream_t stream);
 void launch_tag_cubes(uint16_t *grid, size_t n, const uint32_t *cls, int from_tagged, int to_tagged, hipStream_t stream);
 void launch_assemble_strips(const uint32_t *gathered, uint32_t *out, uint32_t w, uint32_t h, uint32_t strip_rows,
@@ -958,6 +959,22 @@ int aic_probe_raycast(aic_ctx *c, const double origin[3], const double direction
     }
     *n_out = n;
     *ended = en;
+    return AIC_OK;
+}
+
+int aic_probe_powf(aic_ctx *c, const float *x, const float *y, uint32_t n, float *out) {
+    if (!c || (n && (!x || !y || !out))) return fail(c, AIC_ERR_INVALID, "aic_probe_powf: bad argument");
+    if (!n) return AIC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipError_t e = c->staging.ensure((size_t)n * 12);
+    if (e != hipSuccess) return hip_fail(c, "alloc staging", e);
+    float *dx = (float *)c->staging.p, *dy = dx + n, *dout = dy + n;
+    HIP_TRY(c, hipMemcpyAsync(dx, x, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dy, y, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    launch_probe_powf(dx, dy, dout, n, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return AIC_OK;
 }
 

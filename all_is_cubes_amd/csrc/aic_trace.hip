@@ -348,6 +348,83 @@ AIC_DEV float ps_mul(float a, float b) {  // PositiveSign::mul: 0*inf => 0
 }
 // f32::powf / f32::exp evaluated in f64 and rounded once
 AIC_DEV float powf_exact(float x, float y) { return (float)pow((double)x, (double)y); }
+
+// f32::powf as the reference's libm computes it on x86-64 Linux. Rust's `f32::powf` is the C library's
+// powf; glibc's (sysdeps/ieee754/flt-32/e_powf.c, from ARM's optimized-routines; not under
+// /root/reference, restated from the published algorithm) is: log2(x) by a 16-entry table and a
+// degree-4 polynomial, y*log2(x), exp2 by a 32-entry table and a cubic, all in f64, rounded to f32
+// once. Table and coefficient values are the published __powf_log2_data / __exp2f_data. The
+// multiply-adds are fused, as in the FMA build glibc selects on every current x86-64 CPU.
+// Domain: 0 < x < 1 normal, y > 0 finite (everything apply_transmittance feeds it); the caller
+// falls back to powf_exact otherwise. ~40 instructions instead of ~270; pinned against the host's
+// powf on a million inputs (tests/test_gpu_encode.py).
+__device__ const double kPowLog2Tab[16][2] = {
+    {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2},
+    {0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2},  {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2},
+    {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2}, {0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3}, {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4},
+    {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5}, {0x1p+0, 0x0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4},  {0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3},
+    {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2},
+    {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},  {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2},
+};
+__device__ const unsigned long long kPowExp2Tab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull,
+};
+// s_pow: [0,32) the log2 table as (invc, logc) pairs, [32,64) the exp2 table bit patterns
+AIC_DEV void pow_tables_to_lds(double *s_pow, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t i = tid; i < 64u; i += nthreads)
+        s_pow[i] = i < 32u ? kPowLog2Tab[i >> 1][i & 1u] : __longlong_as_double((long long)kPowExp2Tab[i - 32u]);
+}
+AIC_DEV bool powf_table_domain(float x, float y) {  // 0 < x < 1 normal; y > 0 finite
+    const uint32_t ix = __float_as_uint(x), iy = __float_as_uint(y);
+    return ix >= 0x00800000u && ix < 0x3f800000u && iy > 0u && iy < 0x7f800000u;
+}
+AIC_DEV float powf_table(float x, float y, const double *s_pow) {
+    const uint32_t ix = __float_as_uint(x);
+    // log2_inline
+    const uint32_t tmp = ix - 0x3f330000u;
+    const uint32_t i = (tmp >> 19) & 15u;
+    const uint32_t top = tmp & 0xff800000u;
+    const uint32_t iz = ix - top;
+    const int k = (int)top >> 23;
+    const double invc = s_pow[2u * i], logc = s_pow[2u * i + 1u];
+    const double z = (double)__uint_as_float(iz);
+    const double r = fma(z, invc, -1.0);
+    const double y0 = logc + (double)k;
+    const double r2 = r * r;
+    double yy = fma(0x1.27616c9496e0bp-2, r, -0x1.71969a075c67ap-2);
+    const double pp = fma(0x1.ec70a6ca7baddp-2, r, -0x1.7154748bef6c8p-1);
+    const double r4 = r2 * r2;
+    double q = fma(0x1.71547652ab82bp+0, r, y0);
+    q = fma(pp, r2, q);
+    yy = fma(yy, r4, q);
+    const double ylogx = (double)y * yy;
+    // |y*log2(x)| >= 126: x < 1 and y > 0 make it negative -- underflow to 0 at <= -150, else the
+    // general path rounds into the subnormals by itself
+    if (ylogx <= -150.0) return 0.0f;
+    // exp2_inline
+    double kd = ylogx + 0x1.8p+47;
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd -= 0x1.8p+47;
+    const double rr = ylogx - kd;
+    unsigned long long t = (unsigned long long)__double_as_longlong(s_pow[32u + (uint32_t)(ki & 31u)]);
+    t += ki << 47;
+    const double sc = __longlong_as_double((long long)t);
+    const double zz = fma(0x1.c6af84b912394p-5, rr, 0x1.ebfce50fac4f3p-3);
+    const double rr2 = rr * rr;
+    double e = fma(0x1.62e42ff0c52d6p-1, rr, 1.0);
+    e = fma(zz, rr2, e);
+    e = e * sc;
+    return (float)e;
+}
 AIC_DEV float expf_exact(float x) { return (float)exp((double)x); }
 
 struct ColorBuf {  // raytracer_components.rs:20-39
@@ -730,6 +807,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
     __shared__ float s_lut[256];     // PackedLight scalar decode (light/data.rs:301-354)
     __shared__ float s_thr[256];     // sRGB8 encode thresholds
     __shared__ uint32_t s_cls[kClsWords];  // 2 bits per block: 0 invisible single voxel, 1 visible single voxel, 2 recursive
+    __shared__ double s_pow[64];     // powf tables (powf_table)
+    pow_tables_to_lds(s_pow, threadIdx.x, (uint32_t)AIC_WG_THREADS);
     for (uint32_t i = threadIdx.x; i < 256u; i += (uint32_t)AIC_WG_THREADS) {
         s_lut[i] = F.light_lut[i];
         s_thr[i] = F.srgb_thr[i];
@@ -949,7 +1028,11 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                     } else {
                         const float unit_t = 1.0f - a;
                         // powf(0, y>0) == 0 and powf(1, y) == 1 exactly: skip the general evaluation
-                        const float depth_t = unit_t == 0.0f ? 0.0f : (unit_t == 1.0f ? 1.0f : powf_exact(unit_t, thickness));
+                        float depth_t;
+                        if (unit_t == 0.0f) depth_t = 0.0f;
+                        else if (unit_t == 1.0f) depth_t = 1.0f;
+                        else if (powf_table_domain(unit_t, thickness)) depth_t = powf_table(unit_t, thickness, s_pow);
+                        else depth_t = powf_exact(unit_t, thickness);
                         a = zo_clamped(1.0f - depth_t);
                         const float ec = (unit_t == 1.0f) ? thickness : (depth_t - 1.f) / (unit_t - 1.f);
                         coeff = fmaxf(ec, 0.0f);
@@ -1554,6 +1637,16 @@ __global__ void probe_raycast_kernel(const double *od, int use_bounds, const int
     *n_out = n;
 }
 
+// aic_probe_powf: the device's powf (table path where its domain allows, as the trace kernel chooses)
+__global__ void probe_powf_kernel(const float *x, const float *y, float *out, uint32_t n) {
+    __shared__ double s_pow[64];
+    pow_tables_to_lds(s_pow, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = powf_table_domain(x[i], y[i]) ? powf_table(x[i], y[i], s_pow) : powf_exact(x[i], y[i]);
+}
+
 // ---------------------------------------------------------------------------------------
 // host-callable launchers (used by aic_abi.cpp)
 
@@ -1601,6 +1694,11 @@ void launch_scatter_cubes(uint16_t *grid, uint32_t *light, const int32_t *xyz, c
     if (!n) return;
     hipLaunchKernelGGL(scatter_cubes_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, grid, light, xyz, bi, lt, n, lo[0],
                        lo[1], lo[2], size[0], size[1], size[2], cls);
+}
+
+void launch_probe_powf(const float *x, const float *y, float *out, uint32_t n, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(probe_powf_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, x, y, out, n);
 }
 
 void launch_order_tiles(const uint32_t *cost, uint32_t *order, uint32_t n_tiles, hipStream_t stream) {

@@ -287,7 +287,7 @@ def main() -> int:
     # tools/summarize_profile.py). PMC collection cannot run inside the timed bench, so the
     # committed per-launch figure for this workload is reported (null when none is on file
     # or when the image is partitioned differently from the profiled single-GPU launch).
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu = None, None, None
     if world == 1 and (args.lighting, args.fog, args.transparency) == (3, 1, 1) and args.workload != "orbit":
         cands = sorted(glob.glob(os.path.join(str(ROOT), "profiles", f"r*_pmc_{args.workload}.json")))
         if cands:
@@ -296,6 +296,14 @@ def main() -> int:
             if pj.get("hbm_traffic_bytes_per_launch"):
                 traffic = round(pj["hbm_traffic_bytes_per_launch"] / (mean_kernel_ms * 1e-3) / 1e9, 3) if mean_kernel_ms > 0 else None
                 traffic_src = "profiles/" + os.path.basename(cands[-1]) + f" ({int(pj['hbm_traffic_bytes_per_launch'])} B/launch, GB/s at this run's kernel time)"
+            vi = pj.get("counters", {}).get("SQ_INSTS_VALU", {}).get("mean_per_launch")
+            if vi and elapsed > 0:
+                # what actually bounds the kernel: wave-level VALU instructions per frame against the chip's issue
+                # rate (1024 SIMDs, one wave64 VALU instruction per 4 cycles, 2.4 GHz nominal), at this run's frame rate
+                peak = 1024 * 2.4e9 / 4.0
+                rate = vi * args.steps / elapsed
+                valu = {"wave_insts_per_frame": int(vi), "issue_rate": round(rate / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-insts/s",
+                        "frac": round(rate / peak, 4), "note": "SQ_INSTS_VALU from the same PMC file; the binding resource (DESIGN.md 6)"}
 
     result = None
     if rank == 0:
@@ -339,6 +347,8 @@ def main() -> int:
             },
             "device": renderer.device_name(),
         }
+        if valu is not None:
+            result["valu_issue"] = valu
         if fps_with_readback is not None:
             result["fps_with_readback"] = round(fps_with_readback, 3)
         if world == 1 and not args.no_cpu_baseline:

@@ -227,6 +227,8 @@ typedef struct aic_rc_step {
 int aic_probe_raycast(aic_ctx *ctx, const double origin[3], const double direction[3], int use_bounds,
                       const int32_t lo[3], const int32_t hi[3], int include_exit, uint32_t max_steps,
                       aic_rc_step *out, uint32_t *n_out, int *ended);
+/* the device's f32::powf as apply_transmittance uses it (raytracer_components.rs:215-258): out[i] = x[i]^y[i] */
+int aic_probe_powf(aic_ctx *ctx, const float *x, const float *y, uint32_t n, float *out);
 /* the device's PackedLight decode table (light/data.rs:301-354) */
 int aic_probe_light_lut(aic_ctx *ctx, float out[256]);
 

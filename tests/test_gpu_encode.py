@@ -39,3 +39,40 @@ def test_srgb_encode_matches_reference_formula_densely():
     ref = oracle.render(oracle.Space(sp), oracle.unaltered_colors(), oracle.make_camera(inv, w, h))["rgba8"]
     assert (got == ref).all()
     assert len(np.unique(ref[..., 0])) > 200  # the ramp really exercised the encoder
+
+
+def _host_powf(x, y):
+    """f32::powf as the reference gets it: the C library's powf (Rust's std calls it)."""
+    import ctypes
+    import ctypes.util
+
+    libm = ctypes.CDLL(ctypes.util.find_library("m"))
+    libm.powf.restype = ctypes.c_float
+    libm.powf.argtypes = [ctypes.c_float, ctypes.c_float]
+    return np.array([libm.powf(float(a), float(b)) for a, b in zip(x, y)], np.float32)
+
+
+def test_device_powf_equals_libm_powf():
+    """apply_transmittance's powf (raytracer_components.rs:215-258) on the device -- glibc's table
+    algorithm restated (aic_trace.hip powf_table) -- against the host libm, bit for bit."""
+    rng = np.random.default_rng(11)
+    n = 400_000
+    x = np.concatenate([
+        rng.uniform(0.0, 1.0, n), 1.0 - 10.0 ** rng.uniform(-7.5, -0.3, n // 4), 10.0 ** rng.uniform(-38, 0, n // 4),
+        np.array([0.5, 0.25, 0.9999999, 1.1754944e-38, 0.99999994, 0.70710677, 0.70710683, 0.7, 0.3]),
+    ]).astype(np.float32)
+    y = np.concatenate([
+        10.0 ** rng.uniform(-6, 2.7, n), rng.uniform(0.0, 4.0, n // 4), 10.0 ** rng.uniform(-3, 3, n // 4),
+        np.array([1.0, 2.0, 1e-30, 3.4e38, 1e-45, 0.5, 0.5, 150.0, 126.5]),
+    ]).astype(np.float32)
+    keep = (x > 0) & (x < 1) & (y > 0)
+    x, y = x[keep], y[keep]
+    with abi.Context(0) as ctx:
+        got = ctx.probe_powf(x, y)
+        # outside the table's domain the kernel keeps the f64 evaluation: x >= 1, subnormal x, y = inf
+        xs = np.array([1.0, 1.5, 1e-40, 0.5, 2.0], np.float32)
+        ys = np.array([3.0, 2.5, 2.0, np.inf, 0.5], np.float32)
+        assert (ctx.probe_powf(xs, ys).view(np.uint32) == _host_powf(xs, ys).view(np.uint32)).all()
+    want = _host_powf(x, y)
+    bad = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
+    assert len(bad) == 0, f"{len(bad)} of {len(x)} differ, e.g. x={x[bad[:3]]} y={y[bad[:3]]} got={got[bad[:3]]} want={want[bad[:3]]}"
