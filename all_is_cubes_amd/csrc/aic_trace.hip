@@ -684,9 +684,13 @@ AIC_DEV void get_interpolated_light(const DevLayer &L, const float *__restrict__
         mix4(same, front, (float)height_in_cube, fin);
     }
     const float w = fmaxf(fin[3], 0.1f);
-    out[0] = fin[0] / w;
-    out[1] = fin[1] / w;
-    out[2] = fin[2] / w;
+    if (__ballot(w != 1.0f) == 0ull) {  // x / 1.0f == x: fully lit neighbourhoods (the usual case) need no division
+        out[0] = fin[0]; out[1] = fin[1]; out[2] = fin[2];
+    } else {
+        out[0] = fin[0] / w;
+        out[1] = fin[1] / w;
+        out[2] = fin[2] / w;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -767,7 +771,10 @@ AIC_DEV uint32_t srgb8_channel(float c, const float *__restrict__ thr) {
 constexpr uint32_t EV_SHADE = 2u, EV_ENTER = 4u, EV_FINISH = 8u, EV_NEWRAY = 16u, EV_DONE = 32u;
 // lane state bits (st): 0-1 first_last | 2-4 last_face | 5-6 pick | 7 need_step | 8 include_exit (unused here)
 constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_FRESH = 1u << 11, ST_OPAQUE = 1u << 12, ST_TRACED = 1u << 13,
-                   ST_OUTER_ALIVE = 1u << 21;  // bits 16-20: the suspended outer level's face + pick; 24-26: sky octant
+                   ST_OUTER_ALIVE = 1u << 21,  // bits 16-20: the suspended outer level's face + pick; 24-26: sky octant
+                   // bits 2-3 hold the axis last stepped along instead of a Face (the stepping loop records only
+                   // that; `materialize_face` turns it into the Face when an event needs one)
+                   ST_FACE_LAZY = 1u << 7;
 
 #ifndef AIC_MIN_WAVES
 #define AIC_MIN_WAVES 2
@@ -904,10 +911,17 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
         const int idx = (L.sky_kind != 0) ? (int)((st >> 24) & 7u) : 0;
         out[0] = L.sky[idx][0]; out[1] = L.sky[idx][1]; out[2] = L.sky[idx][2];
     };
+    // FACE_TABLE (raycast.rs:618-623) applied late: st with a real Face in bits 2-4
+    auto materialize_face = [&](uint32_t v) -> uint32_t {
+        if (!(v & ST_FACE_LAZY)) return v;
+        const uint32_t ax = (v >> 2) & 3u;
+        const int sgn = ax == 0u ? rd.sx : (ax == 1u ? rd.sy : rd.sz);
+        return (v & ~(0x1cu | ST_FACE_LAZY)) | (((sgn > 0 ? 1u : 4u) + ax) << 2);
+    };
     // the level's state as an absolute-coordinate Lvl (for RaycastStep::intersection_point)
     auto cur_abs = [&]() {
         Lvl a;
-        a.tx = tx; a.ty = ty; a.tz = tz; a.last_t = last_t; a.st = st;
+        a.tx = tx; a.ty = ty; a.tz = tz; a.last_t = last_t; a.st = materialize_face(st);
         if (st & ST_IN_BLOCK) {
             a.cx = cx + (int)(blk_vlo & 255u); a.cy = cy + (int)((blk_vlo >> 8) & 255u); a.cz = cz + (int)((blk_vlo >> 16) & 255u);
         } else {
@@ -1125,7 +1139,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                 const double sx_ = (ox - (double)acx) * kd, sy_ = (oy - (double)acy) * kd, sz_ = (oz - (double)acz) * kd;
                 // suspend the outer level (it always has its next step scheduled: pick + face go to st[16..22])
                 s_tx = tx; s_ty = ty; s_tz = tz; s_last = last_t; s_cx = cx; s_cy = cy; s_cz = cz;
-                st = (st & ~((0x1fu << 16) | ST_OUTER_ALIVE)) | (((st >> 2) & 0x1fu) << 16) | (((st & 3u) == FL_INBOUNDS) ? ST_OUTER_ALIVE : 0u);
+                st = (st & ~((0x1fu << 16) | ST_OUTER_ALIVE)) | (((materialize_face(st) >> 2) & 0x1fu) << 16) | (((st & 3u) == FL_INBOUNDS) ? ST_OUTER_ALIVE : 0u);
                 const int ilx = (int)(blk_vlo & 255u), ily = (int)((blk_vlo >> 8) & 255u), ilz = (int)((blk_vlo >> 16) & 255u);
                 const int isx = (int)(vsize & 255u), isy = (int)((vsize >> 8) & 255u), isz = (int)((vsize >> 16) & 255u);
                 const LvlLim ll = lvl_init(sx_, sy_, sz_, rd, true, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz, true, half_over_len);
@@ -1136,7 +1150,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                 limx = rd.sx > 0 ? isx : -1; limy = rd.sy > 0 ? isy : -1; limz = rd.sz > 0 ? isz : -1;
                 vol_off = tb->vox_off; vsy = (uint32_t)isy; vsz = (uint32_t)isz;
                 // level flags: the low 9 bits come from the raycaster; a produced first step still needs its lookup
-                st = (st & ~0x1ffu) | (f.st & 0xffu) | ST_IN_BLOCK | (got ? ST_FRESH : 0u);
+                st = (st & ~0x1ffu) | (f.st & 0x7fu) | ST_IN_BLOCK | (got ? ST_FRESH : 0u);
                 if (!got) st = (st & ~3u) | FL_ENDED;
                 ev &= ~EV_ENTER;
             }
@@ -1349,7 +1363,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                     cx = fs.cx - olx; cy = fs.cy - oly; cz = fs.cz - olz;
                     limx = rd.sx > 0 ? osx_i : -1; limy = rd.sy > 0 ? osy_i : -1; limz = rd.sz > 0 ? osz_i : -1;
                     vol_off = 0; vsy = osy; vsz = osz;
-                    st = (fs.st & 0xffu) | ST_TRACED | (octant << 24) | (got ? ST_FRESH : 0u);
+                    st = (fs.st & 0x7fu) | ST_TRACED | (octant << 24) | (got ? ST_FRESH : 0u);
                     if (!got) st = (st & ~3u) | FL_ENDED;
                     if (cb_opaque(acc)) st |= ST_OPAQUE;
                     ev = 0u;
@@ -1386,15 +1400,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
             cx += m0 ? rd.sx : 0;
             cy += m1 ? rd.sy : 0;
             cz += m2 ? rd.sz : 0;
-            {
-                const int sgn = axis == 0u ? rd.sx : (axis == 1u ? rd.sy : rd.sz);
-                const uint32_t face = (sgn > 0 ? 1u : 4u) + axis;  // FACE_TABLE
-                st = stepped ? ((st & ~(7u << 2)) | (face << 2)) : st;
-            }
-            // -- left the bounds? only the axis just stepped can have (raycast.rs:265-274) --
-            const int c_ax = axis == 0u ? cx : (axis == 1u ? cy : cz);
-            const int l_ax = axis == 0u ? limx : (axis == 1u ? limy : limz);
-            const bool is_exit = stepped && c_ax == l_ax;
+            // -- left the bounds? only the axis just stepped can have (raycast.rs:265-274); the other two
+            //    coordinates are inside, so they cannot equal their exit coordinate --
+            const bool is_exit = stepped && ((cx == limx) | (cy == limy) | (cz == limz));
             // -- schedule the next step: pick + valid_for_stepping (raycast.rs:563-596) --
             const bool c01 = tx < ty, c02 = tx < tz, c12 = ty < tz;
             const uint32_t pick = c01 ? (c02 ? 0u : 2u) : (c12 ? 1u : 2u);
@@ -1404,7 +1412,10 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
             // a cube is produced by a fresh level, or by a step that stays in bounds and can go on stepping
             const bool lookup = fresh || (in_step && valid);
             const bool level_over = is_exit || (in_step && !valid) || (!alive && !fresh) || (fresh && !alive);
-            st = (in_step && valid) ? ((st & ~(3u << 5)) | (pick << 5)) : st;
+            // one update for the face and the next pick: the Face of the cube just entered is FACE_TABLE of
+            // (axis, sign) and is only needed by events, so the axis is recorded and decoded there; the pick
+            // is meaningless when the level is over, which is harmless (nothing reads it then)
+            st = stepped ? ((st & ~0xfcu) | (axis << 2) | (pick << 5) | ST_FACE_LAZY) : st;
             st &= ~ST_FRESH;
             // -- the lookup: one u16 from the pool, for whichever level this is --
             uint32_t ts_kind = 0u, ref = 0u;  // TraceStep: 0 Invisible, 1 EnterSurface, 2 EnterBlock
@@ -1435,7 +1446,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                     limx = rd.sx > 0 ? osx_i : -1; limy = rd.sy > 0 ? osy_i : -1; limz = rd.sz > 0 ? osz_i : -1;
                     vol_off = 0; vsy = osy; vsz = osz;
                     // outer level: face + pick from st[16..20]; InBounds with its step scheduled if it was alive
-                    const uint32_t ofl = (st & ST_OUTER_ALIVE) ? (FL_INBOUNDS | 128u) : FL_ENDED;
+                    const uint32_t ofl = (st & ST_OUTER_ALIVE) ? FL_INBOUNDS : FL_ENDED;
                     st = (st & ~(0x1ffu | ST_IN_BLOCK)) | ofl | (((st >> 16) & 0x1fu) << 2);
                 } else {
                     ray_over = true;
