@@ -142,8 +142,8 @@ struct DevFrame {
     const float *srgb_thr;   // 256 floats: srgb_thr[k] = smallest linear value whose sRGB8 encoding is >= k
 };
 
-// Tile geometry: one wavefront traces an 8x8 pixel tile (coherent rays), a workgroup of 256
-// threads covers 16x16 pixels.
+// Largest work tile edge in pixels (DevFrame.tile is 8 by default, 16 with AIC_TILE=16); row strips of
+// the multi-GPU partition are a multiple of it.
 constexpr int kTile = 16;
 constexpr int kClsWords = 4096;  // 65536 blocks x 2 bits
 

@@ -9,17 +9,17 @@
 //   ColorBuf / apply_transmittance (all-is-cubes/src/raytracer_components.rs:20-258)
 //   Camera::project_ndc_into_world / post_process_color, Rgba::to_srgb8.
 //
-// Design (MI355X-first, not a translation of the reference's iterator stack):
-//  * one lane per pixel; a wave64 owns an 8x8 pixel tile so its rays stay coherent in the
-//    cube grid; workgroup = 4 waves = 16x16 pixels; workgroup ids are remapped so that each
-//    XCD (private L2) gets a contiguous band of tiles.
-//  * ONE traversal loop serves both DDA levels (outer cube grid and inner block voxels): a
-//    lane carries a single "current level" state and swaps the outer state out while it is
-//    inside a block. Every loop trip is exactly one Amanatides-Woo step, whatever level each
-//    lane is on, so a wave does not serialise "outer" and "inner" code paths.
+// Design (MI355X-first, not a translation of the reference's iterator stack; DESIGN.md 4):
+//  * persistent waves: the grid is what is resident at the kernel's occupancy (2 waves per SIMD);
+//    each wave pulls 8x8-pixel tiles (one wave-full) from a global counter, macro tile by macro
+//    tile, costliest macro tiles of the previous frame first, and refills idle lanes one by one.
+//  * every lane is a state machine. ONE predicated, straight-line Amanatides-Woo step serves both
+//    DDA levels (cube grid and a block's voxels share the lookup pool, the registers and the
+//    code); the expensive, divergent work -- shading a surface, entering a block, finishing /
+//    starting a ray -- is parked per lane as an event and run kind by kind when enough lanes wait.
 //  * DDA arithmetic is f64 in the reference's exact operation order (bit-exact hit
 //    cubes/voxels/faces/t); built with -ffp-contract=off. Colour arithmetic is f32 in the
-//    reference's order; powf/exp are evaluated in f64 and rounded once.
+//    reference's order; powf follows the C library's algorithm, exp is evaluated in f64.
 //  * no MFMA: the path is branchy integer/f64 traversal and gather loads, not a contraction.
 
 #include <hip/hip_runtime.h>
@@ -700,10 +700,10 @@ AIC_DEV void get_interpolated_light(const DevLayer &L, const float *__restrict__
 // RtScene::trace_patch / trace_ray_through_layers and the draw_rgba encoder
 // (renderer.rs:282-308, 424-478, 516-556). Execution model (CDNA4-first):
 //
-//  * A wave64 owns a 16x16-pixel tile (256 rays, x4 with antialiasing) and runs them through
-//    its 64 lanes as a persistent ray pool: a lane that finishes a ray is refilled with the
-//    next pixel of the tile (wave-level __ballot + prefix popcount), so lanes stay busy until
-//    the tile is exhausted instead of idling behind the longest ray of a fixed 8x8 packet.
+//  * A wave64 runs its pixels through its 64 lanes as a persistent ray pool: a lane that finishes
+//    a ray is refilled with the next pixel of the wave's current 8x8 tile, and a new tile is pulled
+//    from the frame's queue when that one is used up (wave-level __ballot + prefix popcount), so
+//    lanes stay busy instead of idling behind the longest ray of a fixed packet.
 //  * Every lane is a small state machine. The *stepping* state is a tight loop body: one
 //    Amanatides-Woo step of whichever DDA level the lane is on (outer cube grid or inner block
 //    voxels share the code and the registers), one 2-byte lookup, the step bookkeeping. Anything
@@ -804,7 +804,7 @@ AIC_DEV Lvl lvl_first(Lvl s, const Lim lim, const RayDir rd, int lox, int loy, i
 
 template <bool VOL, int LMODE, bool DIAG>
 __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_kernel(const DevFrame F) {
-    // ---- persistent waves: each wave pulls 16x16-pixel tiles from a global counter until the
+    // ---- persistent waves: each wave pulls 8x8-pixel tiles from a global counter until the
     // image is exhausted, so cheap (sky) and expensive (geometry) tiles balance dynamically ----
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t tile_x0 = 0, tile_y0 = 0;  // wave-uniform: pixel origin of the tile the refill is drawing from
@@ -1664,7 +1664,7 @@ __global__ void probe_powf_kernel(const float *x, const float *y, float *out, ui
 template <bool VOL, int LMODE, bool DIAG>
 static void launch_trace(const DevFrame &F, hipStream_t stream) {
     // persistent waves: enough workgroups to fill the chip at the kernel's occupancy, never more
-    // waves than tiles (each wave pulls 16x16 tiles from counters->tile_next)
+    // waves than tiles (each wave pulls 8x8-pixel tiles from counters->tile_next)
     const uint32_t n_tiles = F.tiles_x * F.tiles_y;
     const uint32_t wg_waves = (uint32_t)AIC_WG_THREADS / 64u;
     const uint32_t resident_groups = F.n_cus * 4u * (uint32_t)AIC_MIN_WAVES / wg_waves;  // 4 SIMDs per CU, AIC_MIN_WAVES waves on each

@@ -14,7 +14,7 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
-STRIP_ROWS = 16  # one workgroup-tile row (aic_device.h kTile)
+STRIP_ROWS = 16  # rows per strip: a multiple of the kernel's work tile (aic_device.h kTile)
 
 
 def partition_rows(height: int, strip_rows: int, n_parts: int, part: int) -> List[int]:
