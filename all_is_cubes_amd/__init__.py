@@ -50,4 +50,5 @@ def evoxels_from_blockdef(b):
     else:
         e = H.Evoxels.paletted(b.resolution, tuple(int(v) for v in b.vlo), b.voxels, b.palette)
     e.is_air = bool(b.is_air)
+    e.display_name = "" if b.name == "#" else b.name
     return e

@@ -711,7 +711,8 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
     std::memcpy(F.backdrop, f->backdrop, sizeof(F.backdrop));
     F.has_backdrop = !(f->backdrop[0] == 0.f && f->backdrop[1] == 0.f && f->backdrop[2] == 0.f && f->backdrop[3] == 0.f);
     // the encoder and the sampling pattern follow the WORLD camera's options (renderer.rs:283-291, 426)
-    F.antialias = hl[0].opt.antialiasing == 2 ? 1 : 0;
+    F.pixel_centers = (f->flags & AIC_FRAME_PIXEL_CENTERS) ? 1 : 0;
+    F.antialias = (hl[0].opt.antialiasing == 2 && !F.pixel_centers) ? 1 : 0;
     F.exposure = hl[0].exposure;
     F.maximum_intensity = hl[0].opt.maximum_intensity;
     F.tone_mapping = hl[0].opt.tone_mapping;

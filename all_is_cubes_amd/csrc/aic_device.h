@@ -130,6 +130,7 @@ struct DevFrame {
     uint32_t n_cus;          // compute units of the device (sizes the persistent grid)
     int32_t pass;            // 0: final pass (world layer + encode); 1: UI pre-pass
     int32_t use_init;        // final pass: start each sample from acc_buf (written by the UI pre-pass)
+    int32_t pixel_centers;   // AIC_FRAME_PIXEL_CENTERS
     float4 *acc_buf;         // [samples][local_rows][width] ColorBuf {light rgb, transmittance}
     uint32_t *out;           // [local_rows][width] RGBA8
     DevAux *aux;             // [local_rows][width] or null

@@ -1325,6 +1325,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                     const double uy = (sample == 0) ? 5. / 8. : (sample == 1) ? 1. / 8. : (sample == 2) ? 7. / 8. : 3. / 8.;
                     px = x0 + (x1 - x0) * ux;
                     py = y0 + (y1 - y0) * uy;
+                } else if (F.pixel_centers) {  // Viewport::normalize_fb_x / _y (viewport.rs:89-99): the text renderer's rays
+                    px = ((double)x + 0.5) / (double)F.width * 2.0 - 1.0;
+                    py = -(((double)y + 0.5) / (double)F.height * 2.0 - 1.0);
                 } else {
                     px = (x0 + x1) / 2.0;
                     py = (y0 + y1) / 2.0;

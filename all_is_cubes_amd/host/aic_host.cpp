@@ -600,6 +600,37 @@ Rendering HipRtRenderer::draw_rgba(const std::string &info_text) {  // renderer.
     return r;
 }
 
+std::string HipRtRenderer::draw_text(const std::string &line_ending) {
+    aic_frame_desc f = make_frame();
+    f.flags |= AIC_FRAME_AUX | AIC_FRAME_PIXEL_CENTERS;
+    const size_t n = (size_t)f.width * f.height;
+    std::vector<uint8_t> rgba(n * 4);
+    std::vector<aic_pixel_aux> aux(n);
+    aic_frame_info fi;
+    check(aic_render(ctx_, &f, rgba.data(), 0, &fi), "aic_render");
+    if (n) check(aic_read_aux(ctx_, aux.data(), n), "aic_read_aux");
+    const std::shared_ptr<Space> &space = layers_[AIC_LAYER_WORLD].space;
+    std::string out;
+    for (uint32_t y = 0; y < f.height; y++) {
+        for (uint32_t x = 0; x < f.width; x++) {
+            const aic_pixel_aux &a = aux[(size_t)y * f.width + x];
+            if (a.hit == 1) {
+                const std::string &name = (space && (size_t)a.block_index < space->n_blocks()) ? space->block((uint32_t)a.block_index).display_name : std::string();
+                if (name.empty()) out += '#';
+                else {  // first UTF-8 scalar (graphemes of more than one scalar are beyond this mirror)
+                    size_t len = 1;
+                    const unsigned char c0 = (unsigned char)name[0];
+                    if (c0 >= 0xf0) len = 4; else if (c0 >= 0xe0) len = 3; else if (c0 >= 0xc0) len = 2;
+                    out.append(name, 0, std::min(len, name.size()));
+                }
+            } else if (a.cubes_traced > 1000u) out += 'X';      // Exception::Incomplete (sr.rs:643-651)
+            else out += (a.cubes_traced > 0u ? ' ' : '.');       // EnteredSpace / Empty (text.rs:111-119)
+        }
+        out += line_ending;
+    }
+    return out;
+}
+
 uint32_t HipRtRenderer::partition_rows(uint32_t strip_rows, uint32_t n_parts, uint32_t part) const {
     aic_partition p{strip_rows, n_parts, part, 0};
     return aic_partition_rows(world_camera_.viewport().framebuffer_height, &p);

@@ -178,6 +178,7 @@ struct Evoxels {
     std::vector<Evoxel> palette;
     bool is_one = true;
     bool is_air = false;
+    std::string display_name;  // BlockAttributes::display_name: its first character is what text renderings show (text.rs:27-38)
     static Evoxels from_one(const Evoxel &v);
     static Evoxels air();
 };
@@ -296,6 +297,10 @@ class HipRtRenderer : public HeadlessRenderer {
     void update(const Cursor *cursor) override { (void)update_scene(cursor); }
     Rendering draw(const std::string &info_text) override { return draw_rgba(info_text); }
     Rendering draw_rgba(const std::string &info_text);
+    // SpaceRaytracer::<CharacterRtData>::to_text::<CharacterBuf> (sr.rs:367-472, text.rs:52-128): one ray through each
+    // pixel centre; the first block hit shows the first character of its display name ('#' if it has none), a ray that
+    // entered the space and hit nothing ' ', one that never entered it '.', one that ran out of steps 'X'
+    std::string draw_text(const std::string &line_ending = "\n");
     // multi-GPU extension: render the rows of one partition into a device buffer (no read-back)
     ImageInfo draw_rows_to_device(void *device_out, uint32_t strip_rows, uint32_t n_parts, uint32_t part, bool counters = false);
     uint32_t partition_rows(uint32_t strip_rows, uint32_t n_parts, uint32_t part) const;

@@ -146,7 +146,8 @@ PYBIND11_MODULE(_host, m) {
             }
             return e;
         })
-        .def_readwrite("resolution", &Evoxels::resolution).def_readwrite("is_air", &Evoxels::is_air).def_readwrite("is_one", &Evoxels::is_one);
+        .def_readwrite("resolution", &Evoxels::resolution).def_readwrite("is_air", &Evoxels::is_air).def_readwrite("is_one", &Evoxels::is_one)
+        .def_readwrite("display_name", &Evoxels::display_name);
 
     py::class_<Space, std::shared_ptr<Space>>(m, "Space")
         .def(py::init([](const std::array<int32_t, 3> &lo, const std::array<int32_t, 3> &size) {
@@ -213,6 +214,7 @@ PYBIND11_MODULE(_host, m) {
         }), py::arg("cameras"), py::arg("size_policy") = py::none(), py::arg("device_id") = -1)
         .def("update", [](HipRtRenderer &r, py::object cursor) { Cursor c; return r.update_scene(cursor.is_none() ? nullptr : &c); }, py::arg("cursor") = py::none())
         .def("draw", [](HipRtRenderer &r, const std::string &t) { py::gil_scoped_release rel; return r.draw(t); }, py::arg("info_text") = "")
+        .def("draw_text", [](HipRtRenderer &r, const std::string &le) { py::gil_scoped_release rel; return r.draw_text(le); }, py::arg("line_ending") = "\n")
         .def("draw_rgba", [](HipRtRenderer &r, const std::string &t) { py::gil_scoped_release rel; return r.draw_rgba(t); }, py::arg("info_text") = "")
         .def("draw_rows_to_device", [](HipRtRenderer &r, uintptr_t ptr, uint32_t strip_rows, uint32_t n_parts, uint32_t part, bool counters) {
             py::gil_scoped_release rel;

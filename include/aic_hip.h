@@ -124,6 +124,9 @@ typedef struct aic_frame_desc {
 
 #define AIC_FRAME_COUNTERS 1u /* also accumulate n_outer/n_inner/n_hits/n_light */
 #define AIC_FRAME_AUX 2u      /* also write the per-pixel aic_pixel_aux records */
+#define AIC_FRAME_PIXEL_CENTERS 4u /* one ray through each pixel centre, Viewport::normalize_fb_x/_y (viewport.rs:89-99),
+                                    * as the text renderer casts them (sr.rs:400-472); default: the image path's patch
+                                    * centres / antialiasing points (renderer.rs:424-451) */
 
 /* `RaytraceInfo` / `ImageInfo` (sr.rs:508-537; renderer.rs:617-647) + kernel timing. */
 typedef struct aic_frame_info {

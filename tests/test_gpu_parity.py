@@ -696,3 +696,42 @@ def test_block_table_past_14_bits_uses_the_class_table(ctx):
     assert_parity(ctx.render(fr, want_aux=True), ref)
     ctx.upload_space(abi.LAYER_WORLD, sp)  # and as a fresh snapshot of 16385 blocks
     assert_parity(ctx.render(fr, want_aux=True), ref)
+
+
+# --- to_text::<CharacterBuf> through the host mirror: pixel-centre rays (sr.rs:367-472) ---------------
+def test_draw_text_matches_reference_frames_and_oracle(ctx):
+    import all_is_cubes_amd as A
+    from all_is_cubes_amd import _host as H
+
+    golden = Path(__file__).parent / "golden"
+
+    def text_of(sp, eye, quat):
+        cams = H.StandardCameras()
+        cams.graphics_options = H.GraphicsOptions()
+        # PrintSpace: nominal 40x40 viewport, 80x40 framebuffer (text.rs:147-182)
+        vp = H.Viewport()
+        vp.nominal_width, vp.nominal_height, vp.framebuffer_width, vp.framebuffer_height = 40.0, 40.0, 80, 40
+        cams.viewport = vp
+        cams.world_space = A.space_from_flat(sp)
+        vt = H.ViewTransform()
+        vt.rotation = tuple(float(v) for v in quat)
+        vt.translation = tuple(float(v) for v in eye)
+        cams.world_view_transform = vt
+        r = H.HipRtRenderer(cams)
+        r.update()
+        return r.draw_text("\n")
+
+    for sp, name in ((scenes.print_space_test_space(), "ascii_print_space.txt"), (scenes.partial_voxels_space(), "ascii_partial_voxels.txt")):
+        eye = oracle.eye_for_look_at(sp.lo, sp.hi, (1.0, 1.0, 1.0))
+        center = (np.array(sp.lo, float) + np.array(sp.hi, float)) / 2.0
+        assert text_of(sp, eye, oracle.look_at_y_up(eye, center)) == (golden / name).read_text()
+    # a busier scene, against the oracle's CharacterBuf (same pixel-centre rays): every character equal
+    sp = scenes.synthetic_space(n=16, resolution=8, n_blocks=6, seed=21)
+    for i, b in enumerate(sp.blocks):
+        b.name = " " if b.is_air else "ABCDEFGHIJKLMNOP"[i % 16]
+    eye = (8.5, 14.5, 26.0)
+    q = oracle.look_at_y_up(eye, (8, 5, 8))
+    want = oracle.render_text(oracle.Space(sp), oracle.make_options(), camera_for(80, 40, eye, q, aspect=1.0))
+    got = text_of(sp, eye, q)
+    assert got == want
+    assert len(set(got) - set(" .\n")) >= 3
