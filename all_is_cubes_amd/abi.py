@@ -26,7 +26,7 @@ FRAME_COUNTERS, FRAME_AUX, FRAME_PIXEL_CENTERS = 1, 2, 4
 ABI_SYMBOLS = [
     "aic_abi_version", "aic_create", "aic_destroy", "aic_last_error", "aic_device_name", "aic_upload_space",
     "aic_clear_space", "aic_update_cubes", "aic_update_light_volume", "aic_replace_block", "aic_set_options",
-    "aic_render", "aic_render_submit", "aic_render_wait", "aic_partition_rows", "aic_assemble_strips", "aic_read_aux", "aic_synchronize", "aic_stream",
+    "aic_render", "aic_render_submit", "aic_render_wait", "aic_trace_patches", "aic_partition_rows", "aic_assemble_strips", "aic_read_aux", "aic_synchronize", "aic_stream",
     "aic_probe_raycast", "aic_probe_light_lut", "aic_probe_powf",
 ]
 
@@ -113,6 +113,7 @@ def load() -> C.CDLL:
         lib.aic_render.argtypes = [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.c_int, C.POINTER(FrameInfo)]
         lib.aic_render_submit.argtypes = [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.c_uint32]
         lib.aic_render_wait.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(FrameInfo)]
+        lib.aic_trace_patches.argtypes = [C.c_void_p, C.POINTER(FrameDesc), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FrameInfo)]
         lib.aic_assemble_strips.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.aic_read_aux.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         lib.aic_synchronize.argtypes = [C.c_void_p]
@@ -334,6 +335,15 @@ class Context:
         info = FrameInfo()
         self._check(self._lib.aic_render(self._h, C.byref(frame), C.c_void_p(device_ptr), 1, C.byref(info)))
         return info
+
+    def trace_patches(self, frame: FrameDesc, rects, want_aux: bool = False):
+        """RtScene::trace_patch for a batch of NDC rectangles [n,4] = (min.x, min.y, max.x, max.y)."""
+        r = np.ascontiguousarray(rects, np.float64).reshape(-1, 4)
+        out = np.zeros((len(r), 4), np.uint8)
+        aux = np.zeros(len(r), PIXEL_AUX_DTYPE) if want_aux else None
+        info = FrameInfo()
+        self._check(self._lib.aic_trace_patches(self._h, C.byref(frame), len(r), _ptr(r), _ptr(out), _ptr(aux), C.byref(info)))
+        return {"rgba8": out, "aux": aux, "info": info}
 
     def render_submit(self, frame: FrameDesc, device_ptr: int, slot: int) -> None:
         """Queues a frame on `slot` (0..MAX_IN_FLIGHT-1); returns without waiting (aic_render_submit)."""

@@ -680,7 +680,8 @@ bool cameras_close(const double a[16], const double b[16]) {
 }
 
 // Queues one frame on a slot's stream: counters reset, optional UI pre-pass, the trace. No waiting.
-int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint32_t slot, bool allow_aux) {
+int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint32_t slot, bool allow_aux, const double *patches = nullptr,
+                 uint32_t n_patches = 0) {
     aic_ctx::FrameSlot &fs = c->slots[slot];
     fs.t_begin = std::chrono::steady_clock::now();
     aic_partition part = f->partition;
@@ -693,7 +694,7 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
     const uint32_t local_rows = aic_partition_rows(f->height, &part);
     const size_t npix = (size_t)f->width * local_rows;
     if (npix && !out_device) return fail(c, AIC_ERR_INVALID, "aic_render: output buffer is null");
-    dump_record(c, DUMP_FRAME, slot, {{f, sizeof(*f)}});
+    if (!patches) dump_record(c, DUMP_FRAME, slot, {{f, sizeof(*f)}});
     if (f->width > 65535u || local_rows > 65535u) return fail(c, AIC_ERR_INVALID, "aic_render: frame dimensions above 65535 are not supported");
 
     uint32_t flaws = 0;
@@ -711,7 +712,9 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
     std::memcpy(F.backdrop, f->backdrop, sizeof(F.backdrop));
     F.has_backdrop = !(f->backdrop[0] == 0.f && f->backdrop[1] == 0.f && f->backdrop[2] == 0.f && f->backdrop[3] == 0.f);
     // the encoder and the sampling pattern follow the WORLD camera's options (renderer.rs:283-291, 426)
-    F.pixel_centers = (f->flags & AIC_FRAME_PIXEL_CENTERS) ? 1 : 0;
+    F.pixel_centers = (f->flags & AIC_FRAME_PIXEL_CENTERS) && !patches ? 1 : 0;
+    F.patches = patches;
+    F.n_patches = n_patches;
     F.antialias = (hl[0].opt.antialiasing == 2 && !F.pixel_centers) ? 1 : 0;
     F.exposure = hl[0].exposure;
     F.maximum_intensity = hl[0].opt.maximum_intensity;
@@ -759,7 +762,7 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         // had the same shape (else index order); then the cost array is cleared for this frame's record
         static const bool feedback = [] { const char *e = std::getenv("AIC_TILE_FEEDBACK"); return !e || std::atoi(e) != 0; }();
         const uint32_t n_tiles = F.macros_x * F.macros_y;  // the feedback works on macro tiles
-        if (feedback && n_tiles) {
+        if (feedback && n_tiles && !patches) {
             const uint32_t sig[4] = {f->width, local_rows, (part.n_parts << 16) | part.part, (part.strip_rows << 8) | (F.macro << 4) | (F.tile >> 3)};
             bool same = std::memcmp(sig, fs.cost_sig, sizeof(sig)) == 0 && fs.tile_cost.n >= n_tiles;
             if (same) {
@@ -873,6 +876,37 @@ int aic_render(aic_ctx *c, const aic_frame_desc *f, void *out_rgba8, int out_is_
     if (!out_is_device && c->slots[0].npix)
         HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->out.p, c->slots[0].npix * 4, hipMemcpyDeviceToHost, c->slots[0].stream));
     return wait_frame(c, 0, info);
+}
+
+int aic_trace_patches(aic_ctx *c, const aic_frame_desc *f, uint32_t n, const double *rects, void *out_rgba8, aic_pixel_aux *aux,
+                      aic_frame_info *info) {
+    if (!c || !f || (n && (!rects || !out_rgba8))) return fail(c, AIC_ERR_INVALID, "aic_trace_patches: bad argument");
+    if (info) std::memset(info, 0, sizeof(*info));
+    if (!n) return AIC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->slots[0].busy) return fail(c, AIC_ERR_INVALID, "aic_trace_patches: a submitted frame still occupies slot 0 (aic_render_wait it first)");
+    // the batch is laid out as an image of up to 2048 columns; pixel i of that image traces rects[i]
+    aic_frame_desc g = *f;
+    g.width = n < 2048u ? n : 2048u;
+    g.height = (n + g.width - 1u) / g.width;
+    if (g.height > 65535u) return fail(c, AIC_ERR_INVALID, "aic_trace_patches: more than 2048 x 65535 rectangles in one call");
+    g.partition = aic_partition{0, 1, 0, 0};
+    g.flags = (f->flags & AIC_FRAME_COUNTERS) | (aux ? AIC_FRAME_AUX : 0u);
+    const size_t npix = (size_t)g.width * g.height;
+    hipError_t e;
+    if ((e = c->out.ensure(npix)) != hipSuccess) return hip_fail(c, "alloc output", e);
+    if ((e = c->staging.ensure((size_t)n * 32)) != hipSuccess) return hip_fail(c, "alloc staging", e);
+    HIP_TRY(c, hipMemcpyAsync(c->staging.p, rects, (size_t)n * 32, hipMemcpyHostToDevice, c->slots[0].stream));
+    int rc = submit_frame(c, &g, c->out.p, 0, true, (const double *)c->staging.p, n);
+    if (rc != AIC_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->out.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->slots[0].stream));
+    rc = wait_frame(c, 0, info);
+    if (rc != AIC_OK) return rc;
+    if (aux) {
+        HIP_TRY(c, hipMemcpy(aux, c->aux.p, (size_t)n * sizeof(aic_pixel_aux), hipMemcpyDeviceToHost));
+    }
+    if (info) info->rows_rendered = n;
+    return AIC_OK;
 }
 
 int aic_render_submit(aic_ctx *c, const aic_frame_desc *f, void *out_device, uint32_t slot) {

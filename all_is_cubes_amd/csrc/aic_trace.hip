@@ -1288,7 +1288,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                         // pixel order inside a tile: four 8x8 quadrants, row-major inside each
                         const uint32_t x = tile_x0 + (pidx & 7u) + (((pidx >> 6) & 1u) << 3);
                         const uint32_t lrow = tile_y0 + ((pidx >> 3) & 7u) + (((pidx >> 7) & 1u) << 3);
-                        if (x < F.width && lrow < F.local_rows) {  // pixels of partial tiles outside the image are skipped
+                        if (x < F.width && lrow < F.local_rows && (!F.patches || lrow * F.width + x < F.n_patches)) {  // pixels of partial tiles outside the image are skipped
                             pxy = x | (lrow << 16);
                             want = false;
                         }
@@ -1317,8 +1317,14 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                 }
                 // global row of this local row under the strip partition
                 const uint32_t y = (F.part + (lrow / F.strip_rows) * F.n_parts) * F.strip_rows + (lrow % F.strip_rows);
-                const double x0 = fb_x_edge(F.width, x), x1 = fb_x_edge(F.width, x + 1);
-                const double y0 = fb_y_edge(F.height, y), y1 = fb_y_edge(F.height, y + 1);
+                double x0, x1, y0, y1;  // the pixel's NdcRect {min: (x0, y0), max: (x1, y1)} (renderer.rs:537-550)
+                if (F.patches) {
+                    const double *r = F.patches + 4u * pix;
+                    x0 = r[0]; y0 = r[1]; x1 = r[2]; y1 = r[3];
+                } else {
+                    x0 = fb_x_edge(F.width, x); x1 = fb_x_edge(F.width, x + 1);
+                    y0 = fb_y_edge(F.height, y); y1 = fb_y_edge(F.height, y + 1);
+                }
                 double px, py;  // renderer.rs:428-433 sample points, else the patch centre
                 if (n_samples == 4) {
                     const double ux = (sample == 0) ? 1. / 8. : (sample == 1) ? 3. / 8. : (sample == 2) ? 5. / 8. : 7. / 8.;

@@ -204,6 +204,14 @@ int aic_render(aic_ctx *ctx, const aic_frame_desc *frame, void *out_rgba8, int o
 #define AIC_MAX_IN_FLIGHT 4u
 int aic_render_submit(aic_ctx *ctx, const aic_frame_desc *frame, void *out_device, uint32_t slot);
 int aic_render_wait(aic_ctx *ctx, uint32_t slot, aic_frame_info *info);
+/* replaces: RtScene::trace_patch (renderer.rs:418-451) for a batch of pixel rectangles -- the call
+ * all-is-cubes-gpu's raytrace_to_texture makes for its incremental pixel batches
+ * (raytrace_to_texture.rs:603-633). rects = [n][4] {min.x, min.y, max.x, max.y} in normalized device
+ * coordinates; each is traced like one image pixel (its centre, or the four antialiasing points).
+ * out_rgba8 = [n] encoded pixels and aux (may be NULL) = [n] first-hit records, both host memory.
+ * Only the cameras, backdrop and flags of `frame` are used. */
+int aic_trace_patches(aic_ctx *ctx, const aic_frame_desc *frame, uint32_t n, const double *rects, void *out_rgba8,
+                      aic_pixel_aux *aux, aic_frame_info *info);
 /* number of rows / first rows a partition selects (host-side helper for buffer sizing) */
 uint32_t aic_partition_rows(uint32_t height, const aic_partition *partition);
 /* scatter compacted strips gathered from n_parts contexts back into a full frame, on device:

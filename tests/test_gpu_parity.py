@@ -735,3 +735,43 @@ def test_draw_text_matches_reference_frames_and_oracle(ctx):
     got = text_of(sp, eye, q)
     assert got == want
     assert len(set(got) - set(" .\n")) >= 3
+
+
+# --- RtScene::trace_patch for batches of rectangles (renderer.rs:418-451; raytrace_to_texture.rs:603-633) ---
+@pytest.mark.parametrize("aa", [0, 2])
+def test_trace_patches_equal_the_image_path(ctx, aa):
+    sp = scenes.synthetic_space(n=20, resolution=8, n_blocks=6, seed=4, light="field")
+    w, h = 96, 70
+    eye = (10.5, 18.5, 30.0)
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, (10, 6, 10)), eye)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.set_options(abi.LAYER_WORLD, abi.make_options(antialiasing=aa))
+    fr = ctx.make_frame(w, h, world_inv=inv, backdrop=(0.2, 0.1, 0.3, 0.4))
+    img = ctx.render(fr, want_aux=True)
+    # the rectangle of every pixel, as trace_scene_to_image_impl builds it (renderer.rs:537-550)
+    ex = np.arange(w + 1, dtype=np.float64) / np.float64(w) * 2.0 - 1.0
+    ey = -(np.arange(h + 1, dtype=np.float64) / np.float64(h) * 2.0 - 1.0)
+    X, Y = np.meshgrid(np.arange(w), np.arange(h))
+    rects = np.stack([ex[X], ey[Y], ex[X + 1], ey[Y + 1]], -1).reshape(-1, 4)
+    # in a scrambled order and in two batches, like incremental refinement would ask for them
+    order = np.random.default_rng(2).permutation(len(rects))
+    got_rgba = np.zeros((len(rects), 4), np.uint8)
+    got_aux = np.zeros(len(rects), img["aux"].dtype)
+    steps = 0
+    for part in (order[: len(order) // 3], order[len(order) // 3:]):
+        r = ctx.trace_patches(fr, rects[part], want_aux=True)
+        got_rgba[part], got_aux[part] = r["rgba8"], r["aux"]
+        steps += r["info"].cubes_traced
+    assert (got_rgba.reshape(h, w, 4) == img["rgba8"]).all()
+    for k in ("hit", "cube", "voxel", "face", "block_index", "cubes_traced"):
+        assert (got_aux[k].reshape((h, w) + got_aux[k].shape[1:]) == img["aux"][k]).all(), k
+    assert steps == img["info"].cubes_traced
+    # a coarser pass (2x2-pixel rectangles) equals the frame rendered at half size
+    if w % 2 == 0 and h % 2 == 0:
+        half = ctx.render(ctx.make_frame(w // 2, h // 2, world_inv=inv, backdrop=(0.2, 0.1, 0.3, 0.4)))
+        X2, Y2 = np.meshgrid(np.arange(w // 2), np.arange(h // 2))
+        ex2 = np.arange(w // 2 + 1, dtype=np.float64) / np.float64(w // 2) * 2.0 - 1.0
+        ey2 = -(np.arange(h // 2 + 1, dtype=np.float64) / np.float64(h // 2) * 2.0 - 1.0)
+        r2 = np.stack([ex2[X2], ey2[Y2], ex2[X2 + 1], ey2[Y2 + 1]], -1).reshape(-1, 4)
+        assert (ctx.trace_patches(fr, r2)["rgba8"].reshape(h // 2, w // 2, 4) == half["rgba8"]).all()
