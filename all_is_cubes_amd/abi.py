@@ -20,7 +20,7 @@ ERR_NAMES = {1: "AIC_ERR_INVALID", 2: "AIC_ERR_NO_DEVICE", 3: "AIC_ERR_OOM", 4: 
 LAYER_WORLD, LAYER_UI = 0, 1
 MAX_IN_FLIGHT = 4  # AIC_MAX_IN_FLIGHT
 FLAW_UNSUPPORTED, FLAW_NO_BLOOM = 1, 2
-FRAME_COUNTERS, FRAME_AUX, FRAME_PIXEL_CENTERS = 1, 2, 4
+FRAME_COUNTERS, FRAME_AUX, FRAME_PIXEL_CENTERS, FRAME_OUT_LINEAR, FRAME_OUT_COLORBUF = 1, 2, 4, 8, 16
 
 # every symbol include/aic_hip.h declares
 ABI_SYMBOLS = [
@@ -320,7 +320,8 @@ class Context:
         if counters:
             frame.flags |= FRAME_COUNTERS
         rows = int(self._lib.aic_partition_rows(frame.height, C.byref(frame.partition)))
-        out = np.zeros((rows, frame.width, 4), np.uint8)
+        floats = bool(frame.flags & (FRAME_OUT_LINEAR | FRAME_OUT_COLORBUF))  # 16-byte float pixels instead of RGBA8
+        out = np.zeros((rows, frame.width, 4), np.float32 if floats else np.uint8)
         info = FrameInfo()
         self._check(self._lib.aic_render(self._h, C.byref(frame), _ptr(out), 0, C.byref(info)))
         aux = None
@@ -339,7 +340,7 @@ class Context:
     def trace_patches(self, frame: FrameDesc, rects, want_aux: bool = False):
         """RtScene::trace_patch for a batch of NDC rectangles [n,4] = (min.x, min.y, max.x, max.y)."""
         r = np.ascontiguousarray(rects, np.float64).reshape(-1, 4)
-        out = np.zeros((len(r), 4), np.uint8)
+        out = np.zeros((len(r), 4), np.float32 if frame.flags & (FRAME_OUT_LINEAR | FRAME_OUT_COLORBUF) else np.uint8)
         aux = np.zeros(len(r), PIXEL_AUX_DTYPE) if want_aux else None
         info = FrameInfo()
         self._check(self._lib.aic_trace_patches(self._h, C.byref(frame), len(r), _ptr(r), _ptr(out), _ptr(aux), C.byref(info)))

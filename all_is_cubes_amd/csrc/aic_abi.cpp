@@ -713,6 +713,7 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
     F.has_backdrop = !(f->backdrop[0] == 0.f && f->backdrop[1] == 0.f && f->backdrop[2] == 0.f && f->backdrop[3] == 0.f);
     // the encoder and the sampling pattern follow the WORLD camera's options (renderer.rs:283-291, 426)
     F.pixel_centers = (f->flags & AIC_FRAME_PIXEL_CENTERS) && !patches ? 1 : 0;
+    F.out_mode = (f->flags & AIC_FRAME_OUT_LINEAR) ? 1 : ((f->flags & AIC_FRAME_OUT_COLORBUF) ? 2 : 0);
     F.patches = patches;
     F.n_patches = n_patches;
     F.antialias = (hl[0].opt.antialiasing == 2 && !F.pixel_centers) ? 1 : 0;
@@ -863,18 +864,19 @@ int aic_render(aic_ctx *c, const aic_frame_desc *f, void *out_rgba8, int out_is_
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->slots[0].busy) return fail(c, AIC_ERR_INVALID, "aic_render: a submitted frame still occupies slot 0 (aic_render_wait it first)");
     uint32_t *target = (uint32_t *)out_rgba8;
+    const size_t px_words = (f->flags & (AIC_FRAME_OUT_LINEAR | AIC_FRAME_OUT_COLORBUF)) ? 4 : 1;  // 16 or 4 bytes per pixel
     if (!out_is_device && out_rgba8) {
         aic_partition part = f->partition;
         if (part.n_parts <= 1 || part.strip_rows == 0) { part.n_parts = 1; part.part = 0; part.strip_rows = f->height ? f->height : 1; }
         const size_t npix = (size_t)f->width * (part.part < part.n_parts ? aic_partition_rows(f->height, &part) : 0);
         hipError_t e;
-        if (npix && (e = c->out.ensure(npix)) != hipSuccess) return hip_fail(c, "alloc output", e);
+        if (npix && (e = c->out.ensure(npix * px_words)) != hipSuccess) return hip_fail(c, "alloc output", e);
         target = c->out.p;
     }
     int rc = submit_frame(c, f, target, 0, true);
     if (rc != AIC_OK) return rc;
     if (!out_is_device && c->slots[0].npix)
-        HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->out.p, c->slots[0].npix * 4, hipMemcpyDeviceToHost, c->slots[0].stream));
+        HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->out.p, c->slots[0].npix * px_words * 4, hipMemcpyDeviceToHost, c->slots[0].stream));
     return wait_frame(c, 0, info);
 }
 
@@ -891,15 +893,16 @@ int aic_trace_patches(aic_ctx *c, const aic_frame_desc *f, uint32_t n, const dou
     g.height = (n + g.width - 1u) / g.width;
     if (g.height > 65535u) return fail(c, AIC_ERR_INVALID, "aic_trace_patches: more than 2048 x 65535 rectangles in one call");
     g.partition = aic_partition{0, 1, 0, 0};
-    g.flags = (f->flags & AIC_FRAME_COUNTERS) | (aux ? AIC_FRAME_AUX : 0u);
+    g.flags = (f->flags & (AIC_FRAME_COUNTERS | AIC_FRAME_OUT_LINEAR | AIC_FRAME_OUT_COLORBUF)) | (aux ? AIC_FRAME_AUX : 0u);
     const size_t npix = (size_t)g.width * g.height;
     hipError_t e;
-    if ((e = c->out.ensure(npix)) != hipSuccess) return hip_fail(c, "alloc output", e);
+    const size_t px_words = (f->flags & (AIC_FRAME_OUT_LINEAR | AIC_FRAME_OUT_COLORBUF)) ? 4 : 1;
+    if ((e = c->out.ensure(npix * px_words)) != hipSuccess) return hip_fail(c, "alloc output", e);
     if ((e = c->staging.ensure((size_t)n * 32)) != hipSuccess) return hip_fail(c, "alloc staging", e);
     HIP_TRY(c, hipMemcpyAsync(c->staging.p, rects, (size_t)n * 32, hipMemcpyHostToDevice, c->slots[0].stream));
     int rc = submit_frame(c, &g, c->out.p, 0, true, (const double *)c->staging.p, n);
     if (rc != AIC_OK) return rc;
-    HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->out.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->slots[0].stream));
+    HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->out.p, (size_t)n * px_words * 4, hipMemcpyDeviceToHost, c->slots[0].stream));
     rc = wait_frame(c, 0, info);
     if (rc != AIC_OK) return rc;
     if (aux) {

@@ -131,6 +131,7 @@ struct DevFrame {
     int32_t pass;            // 0: final pass (world layer + encode); 1: UI pre-pass
     int32_t use_init;        // final pass: start each sample from acc_buf (written by the UI pre-pass)
     int32_t pixel_centers;   // AIC_FRAME_PIXEL_CENTERS
+    int32_t out_mode;        // 0 sRGB RGBA8 (4 B/pixel); 1 linear Rgba f32x4; 2 ColorBuf f32x4 (16 B/pixel)
     const double *patches;   // aic_trace_patches: [n_patches][4] NDC rectangles replacing the pixel grid (pixel i = row-major index)
     uint32_t n_patches;
     float4 *acc_buf;         // [samples][local_rows][width] ColorBuf {light rgb, transmittance}

@@ -1211,6 +1211,10 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                         // encoder: Camera::post_process_color(Rgba::from(buf)).to_srgb8()
                         float c[4];
                         cb_to_rgba(pixel, c);
+                        if (F.out_mode != 0) {  // float outputs: the linear Rgba, or the ColorBuf as it is
+                            reinterpret_cast<float4 *>(F.out)[pix] =
+                                F.out_mode == 1 ? make_float4(c[0], c[1], c[2], c[3]) : make_float4(pixel.l0, pixel.l1, pixel.l2, pixel.t);
+                        } else {
                         const float ex = F.exposure;
                         float r = ps_mul(c[0], ex), g = ps_mul(c[1], ex), bl = ps_mul(c[2], ex);
                         const float m = F.maximum_intensity;
@@ -1229,6 +1233,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                         const uint32_t B = srgb8_channel(bl, s_thr);
                         const uint32_t A = round_sat_u8(c[3] * 255.0f);
                         F.out[pix] = R | (G << 8) | (B << 16) | (A << 24);
+                        }
                     }
                     if (DIAG) {
                         if (F.aux) {

@@ -124,6 +124,11 @@ typedef struct aic_frame_desc {
 
 #define AIC_FRAME_COUNTERS 1u /* also accumulate n_outer/n_inner/n_hits/n_light */
 #define AIC_FRAME_AUX 2u      /* also write the per-pixel aic_pixel_aux records */
+/* float output instead of sRGB RGBA8: the output buffer holds [rows][width] float[4] (16 bytes per pixel) */
+#define AIC_FRAME_OUT_LINEAR 8u    /* Rgba::from(ColorBuf) (raytracer_components.rs:141-163): linear r,g,b,a before exposure and
+                                    * tone mapping -- what a float framebuffer wants */
+#define AIC_FRAME_OUT_COLORBUF 16u /* the ColorBuf itself: premultiplied light r,g,b and transmittance
+                                    * (raytracer_components.rs:20-39; raytrace_to_texture.rs:638-655 reads exactly this) */
 #define AIC_FRAME_PIXEL_CENTERS 4u /* one ray through each pixel centre, Viewport::normalize_fb_x/_y (viewport.rs:89-99),
                                     * as the text renderer casts them (sr.rs:400-472); default: the image path's patch
                                     * centres / antialiasing points (renderer.rs:424-451) */

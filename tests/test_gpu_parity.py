@@ -775,3 +775,32 @@ def test_trace_patches_equal_the_image_path(ctx, aa):
         ey2 = -(np.arange(h // 2 + 1, dtype=np.float64) / np.float64(h // 2) * 2.0 - 1.0)
         r2 = np.stack([ex2[X2], ey2[Y2], ex2[X2 + 1], ey2[Y2 + 1]], -1).reshape(-1, 4)
         assert (ctx.trace_patches(fr, r2)["rgba8"].reshape(h // 2, w // 2, 4) == half["rgba8"]).all()
+
+
+# --- float outputs: the linear Rgba (bit-equal to the oracle's) and the ColorBuf itself --------------------
+@pytest.mark.parametrize("aa", [0, 2])
+def test_float_outputs(ctx, aa):
+    sp = scenes.synthetic_space(n=20, resolution=8, n_blocks=6, seed=4, light="field")
+    w, h = 112, 80
+    eye = (10.5, 18.5, 30.0)
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, (10, 6, 10)), eye)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.set_options(abi.LAYER_WORLD, abi.make_options(antialiasing=aa))
+    ref = oracle.render(oracle.Space(sp), oracle.make_options(antialiasing=aa), oracle.make_camera(inv, w, h), want_linear=True)
+    lin = ctx.render(ctx.make_frame(w, h, world_inv=inv, flags=abi.FRAME_OUT_LINEAR))["rgba8"]
+    assert lin.dtype == np.float32 and lin.shape == (h, w, 4)
+    assert (lin.view(np.uint32) == ref["linear"].view(np.uint32)).all(), "linear Rgba differs from the oracle's bit pattern"
+    cb = ctx.render(ctx.make_frame(w, h, world_inv=inv, flags=abi.FRAME_OUT_COLORBUF))["rgba8"]
+    # Rgba::from(ColorBuf) (raytracer_components.rs:141-163) applied on the host gives the linear image back
+    t = cb[..., 3]
+    alpha = np.float32(1.0) - t
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rgb = cb[..., 0:3] / alpha[..., None]
+    rgb = np.where(rgb > 0, rgb, np.float32(0.0))
+    back = np.concatenate([rgb, alpha[..., None]], -1).astype(np.float32)
+    back[t >= 1.0] = 0.0
+    assert (back.view(np.uint32) == lin.view(np.uint32)).all()
+    # and both agree with the encoded frame
+    img = ctx.render(ctx.make_frame(w, h, world_inv=inv))["rgba8"]
+    assert (img == ref["rgba8"]).all()
