@@ -915,8 +915,10 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
     auto materialize_face = [&](uint32_t v) -> uint32_t {
         if (!(v & ST_FACE_LAZY)) return v;
         const uint32_t ax = (v >> 2) & 3u;
-        const int sgn = ax == 0u ? rd.sx : (ax == 1u ? rd.sy : rd.sz);
-        return (v & ~(0x1cu | ST_FACE_LAZY)) | (((sgn > 0 ? 1u : 4u) + ax) << 2);
+        // the sign of the ray along a stepped axis is its sky-octant bit (bits 26/25/24 for x/y/z: direction >= 0,
+        // and a stepped axis has a non-zero direction) -- read from `v` itself, not from rd.s* by a dynamic index
+        const uint32_t positive = (v >> (26u - ax)) & 1u;
+        return (v & ~(0x1cu | ST_FACE_LAZY)) | (((positive ? 1u : 4u) + ax) << 2);
     };
     // the level's state as an absolute-coordinate Lvl (for RaycastStep::intersection_point)
     auto cur_abs = [&]() {
