@@ -273,6 +273,16 @@ def main() -> int:
     my_bytes = 2 * info.n_outer + 2 * info.n_inner + 32 * info.n_hits + 4 * info.n_light + 4 * w * local_rows
     achieved_gbs = (my_bytes / (mean_kernel_ms * 1e-3)) / 1e9 if mean_kernel_ms > 0 else 0.0
 
+    # one frame at a time (submit, wait, repeat): the latency figure next to the streamed frame period
+    one_at_a_time_ms = None
+    if world == 1 and streamed:
+        n_l = max(3, min(10, args.steps))
+        renderer.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_l):
+            renderer.draw_rows_to_device(render_target(0).data_ptr(), strip, world, rank)
+        one_at_a_time_ms = (time.perf_counter() - t1) / n_l * 1e3
+
     fps_with_readback = None
     if world == 1:
         n_rb = max(3, min(10, args.steps))
@@ -330,6 +340,7 @@ def main() -> int:
                 "rays_per_frame": rays_per_frame,
                 "partition": f"interleaved {strip}-row strips over {world} GPU(s), scene replicated, RCCL gather to rank 0",
                 "steps_per_ray": round(cubes_traced / rays_per_frame, 2),
+                "frames_in_flight": depth if streamed else 1,
             },
             "roofline": {
                 "bound": "hbm",
@@ -349,6 +360,8 @@ def main() -> int:
         }
         if valu is not None:
             result["valu_issue"] = valu
+        if one_at_a_time_ms is not None:
+            result["ms_per_frame_one_at_a_time"] = round(one_at_a_time_ms, 4)
         if fps_with_readback is not None:
             result["fps_with_readback"] = round(fps_with_readback, 3)
         if world == 1 and not args.no_cpu_baseline:
