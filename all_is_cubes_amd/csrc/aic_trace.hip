@@ -457,32 +457,7 @@ AIC_DEV void cb_to_rgba(const ColorBuf &b, float out[4]) {
     out[3] = (alpha > 0.f && alpha <= 1.f) ? alpha : (alpha == 0.f ? 0.f : 1.0f);
 }
 
-// apply_transmittance (raytracer_components.rs:215-258); colour rgb is untouched, returns alpha
-AIC_DEV void apply_transmittance(float alpha_in, float thickness, bool *transparent_all, float *alpha_out, float *coeff) {
-    thickness = fmaxf(thickness, 0.0f);
-    *transparent_all = false;
-    if (thickness == 0.0f) {
-        if (alpha_in == 1.0f) {
-            *alpha_out = alpha_in;
-            *coeff = 1.0f;
-        } else {
-            *transparent_all = true;  // Rgba::TRANSPARENT
-            *alpha_out = 0.0f;
-            *coeff = 0.0f;
-        }
-        return;
-    }
-    float unit_t = 1.0f - alpha_in;
-    float depth_t = powf_exact(unit_t, thickness);
-    *alpha_out = zo_clamped(1.0f - depth_t);
-    float ec = (unit_t == 1.0f) ? thickness : (depth_t - 1.f) / (unit_t - 1.f);
-    *coeff = fmaxf(ec, 0.0f);
-}
 
-AIC_DEV float component_to_srgb(float c) {  // color.rs:1038-1049
-    if (c <= 0.0031308f) return c * (323.f / 25.f);
-    return (211.f * powf_exact(c, 5.f / 12.f) - 11.f) / 200.f;
-}
 AIC_DEV uint32_t round_sat_u8(float x) {  // `(x).round() as u8`
     float r = roundf(x);
     if (!(r > 0.f)) return 0u;  // NaN, negatives, zero
@@ -550,20 +525,6 @@ AIC_DEV double smoothstep(double x) {  // surface.rs:516-520
     if (x < 0.0) x = 0.0;
     if (x > 1.0) x = 1.0;
     return 3. * (x * x) - 2. * (x * x * x);
-}
-
-// tangent frame of Face::rotation_from_nz (face.rs:395-404): images of +X and +Y
-AIC_DEV void face_frame(int face, int fx[3], int fy[3]) {
-    fx[0] = fx[1] = fx[2] = 0;
-    fy[0] = fy[1] = fy[2] = 0;
-    switch (face) {
-        case 1: fx[1] = 1; fy[2] = 1; break;    // NX: +Y, +Z
-        case 2: fx[2] = 1; fy[0] = 1; break;    // NY: +Z, +X
-        case 4: fx[1] = -1; fy[2] = 1; break;   // PX: -Y, +Z
-        case 5: fx[2] = 1; fy[0] = -1; break;   // PY: +Z, -X
-        case 6: fx[0] = 1; fy[1] = -1; break;   // PZ: +X, -Y
-        default: fx[0] = 1; fy[1] = 1; break;   // NZ and Within (IDENTITY): +X, +Y
-    }
 }
 
 // SpaceRaytracer::get_interpolated_light (sr.rs:248-359).
@@ -726,12 +687,6 @@ struct SurfDiag {  // DIAG only: identity of a pending surface
     uint32_t nlight;
     int cube[3], voxel[3], res, face, block;
 };
-
-AIC_DEV void sky_of(const DevLayer &L, double dx, double dy, double dz, float out[3]) {  // Sky::sample (sky.rs:32-41)
-    int idx = 0;
-    if (L.sky_kind != 0) idx = ((dx >= 0.0 ? 1 : 0) << 2) + ((dy >= 0.0 ? 1 : 0) << 1) + (dz >= 0.0 ? 1 : 0);
-    out[0] = L.sky[idx][0]; out[1] = L.sky[idx][1]; out[2] = L.sky[idx][2];
-}
 
 // camera (camera_struct.rs:238-257; euclid Transform3D::transform_point3d)
 AIC_DEV void unproject(const double *__restrict__ m, double x, double y, double z, double out[3]) {
