@@ -2,16 +2,21 @@
 """bench.py -- headline benchmark of the MI355X voxel raytracer.
 
 Metric (BASELINE.json): Mrays/s (+ frames/s) at 1920x1080. One "step" = one frame of the hot
-path over the scene already resident in HBM: camera upload, trace kernel, and -- for N > 1 --
-the RCCL gather of the row strips to rank 0 plus the de-interleave. The finished RGBA8 frame
-stays in HBM (the PCIe-inclusive rate is reported separately as `fps_with_readback`).
+path over the scene already resident in HBM: camera upload, (tile ordering,) trace kernel, and --
+for N > 1 -- the RCCL gather of the row strips to rank 0 plus the de-interleave. Frames are
+streamed the way a recording loop submits them: 2 traces in flight at N = 1 (4 at N > 1), a
+frame's gather running under the next frames' traces; every frame issued in the timed region is
+complete, gathered and assembled before the clock stops. `--no-pipeline` traces one frame at a
+time (also reported as `ms_per_frame_one_at_a_time`). The finished RGBA8 frames stay in HBM (the
+PCIe-inclusive rate is reported separately as `fps_with_readback`).
 
 Workload (config.workload), BASELINE.json configs[1]: 1920x1080 single-frame raytrace of the
 Atrium scene at block resolution 16. The reference's Atrium generator needs the un-vendored
 noise crate and the block-evaluation engine, so the stand-in is
-`atrium_like_space` (19x35x51 cubes, R16 recursive blocks, the Atrium spawn camera), with
-GraphicsOptions::default() minus bloom (Volumetric transparency, Linear lighting, Abrupt fog).
-`--workload s256` selects configs[2] (3840x2160 synthetic 256^3 Space, R32).
+`atrium_like_space` (19x35x51 cubes, R16 recursive blocks, a light field, the Atrium spawn
+camera), with GraphicsOptions::default() minus bloom (Volumetric transparency, Linear lighting,
+Abrupt fog). `--workload s256` selects configs[2] (3840x2160 synthetic 256^3 Space, R32),
+`--workload orbit` configs[4] (60-frame orbit, light volume re-uploaded every frame).
 
 Launch: `python bench.py --gpus 1 --steps K --warmup W`, or for N > 1
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`.
