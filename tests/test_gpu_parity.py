@@ -806,3 +806,41 @@ def test_float_outputs(ctx, aa):
     # and both agree with the encoded frame
     img = ctx.render(ctx.make_frame(w, h, world_inv=inv))["rgba8"]
     assert (img == ref["rgba8"]).all()
+
+
+# --- degenerate inputs: empty spaces, one-cube spaces, blocks with empty stored volumes, R128 blocks ----
+def test_degenerate_spaces_and_blocks(ctx):
+    w, h = 64, 48
+    eye = (0.5, 0.6, 3.0)
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, (0.5, 0.5, 0.5)), eye)
+    opt = oracle.make_options()
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+    cases = []
+    # a Space with no cubes at all (SpaceRaytracer::new_empty-like): every ray misses
+    cases.append(flat.FlatSpace((0, 0, 0), (0, 0, 0)))
+    flatpl = flat.FlatSpace((3, -2, 1), (4, 0, 4))  # zero-thickness bounds
+    cases.append(flatpl)
+    # one cube holding a block whose stored voxel volume is empty (everything reads as AIR)
+    sp = flat.FlatSpace((0, 0, 0), (1, 1, 1))
+    sp.set_sky_uniform((0.3, 0.4, 0.5))
+    pal = np.stack([flat.evoxel((0, 0, 0, 0)), flat.evoxel((1, 0, 0, 1))])
+    sp.set((0, 0, 0), sp.add_block(flat.voxel_block(8, np.zeros((0, 0, 0), np.uint16), pal, vlo=(2, 2, 2))))
+    cases.append(sp)
+    # one cube at the largest resolution, a thin shell of voxels
+    sp = flat.FlatSpace((0, 0, 0), (1, 1, 1))
+    sp.set_sky_uniform((0.3, 0.4, 0.5))
+    vox = np.zeros((128, 128, 128), np.uint16)
+    vox[5:120, 64, 5:120] = 1
+    vox[64, 5:120, 5:120] = 1
+    sp.set((0, 0, 0), sp.add_block(flat.voxel_block(128, vox, pal)))
+    cases.append(sp)
+    for s in cases:
+        for b in s.blocks:
+            b.name = b.name or "#"
+        ctx.upload_space(abi.LAYER_WORLD, s)
+        got = ctx.render(ctx.make_frame(w, h, world_inv=inv), want_aux=True)
+        ref = oracle.render(oracle.Space(s), opt, oracle.make_camera(inv, w, h), want_aux=True)
+        assert_parity(got, ref)
+        fast = ctx.render(ctx.make_frame(w, h, world_inv=inv))
+        assert (fast["rgba8"] == got["rgba8"]).all()
