@@ -724,12 +724,13 @@ AIC_DEV uint32_t srgb8_channel(float c, const float *__restrict__ thr) {
 
 // lane event bits
 constexpr uint32_t EV_SHADE = 2u, EV_ENTER = 4u, EV_FINISH = 8u, EV_NEWRAY = 16u, EV_DONE = 32u;
-// lane state bits (st): 0-1 first_last | 2-4 last_face | 5-6 pick | 7 need_step | 8 include_exit (unused here)
-constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_FRESH = 1u << 11, ST_OPAQUE = 1u << 12, ST_TRACED = 1u << 13,
-                   ST_OUTER_ALIVE = 1u << 21,  // bits 16-20: the suspended outer level's face + pick; 24-26: sky octant
-                   // bits 2-3 hold the axis last stepped along instead of a Face (the stepping loop records only
-                   // that; `materialize_face` turns it into the Face when an event needs one)
-                   ST_FACE_LAZY = 1u << 7;
+// lane state bits (st):
+//   0      ST_DEAD       the current level's Raycaster has ended: it cannot step any further
+//   9-13   flags below
+//   16-18  the suspended outer level's Face while inside a block; 21 ST_OUTER_ALIVE: that level can go on stepping
+//   24-26  sign bits of the ray direction (x: 26, y: 25, z: 24; set = component >= 0) = the sky octant
+constexpr uint32_t ST_DEAD = 1u, ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_FRESH = 1u << 11,
+                   ST_OPAQUE = 1u << 12, ST_TRACED = 1u << 13, ST_OUTER_ALIVE = 1u << 21;
 
 #ifndef AIC_MIN_WAVES
 #define AIC_MIN_WAVES 2
@@ -757,7 +758,23 @@ AIC_DEV Lvl lvl_first(Lvl s, const Lim lim, const RayDir rd, int lox, int loy, i
     return nr.s;
 }
 
-template <bool VOL, int LMODE, bool DIAG>
+// How a DDA level is held in registers by the image kernel (both levels -- the cube grid and a block's
+// voxel volume -- use the same registers and the same stepping code):
+//   t[3]   t_max, exactly the reference's (raycast.rs:99-121)
+//   td[3]  t_delta = 1/|d|, a per-ray constant shared by both levels (a sub-ray keeps its direction)
+//   r[3]   steps the ray can still take along each axis before it leaves the level's bounds: for a
+//          coordinate c relative to the level's lower corner, r = size - c going up, c + 1 going down
+//          (direction sign = the octant bit). Stepping decrements it; r == 0 <=> the include_exit step.
+//          The coordinate is recovered when an event needs it: c = size - r or r - 1.
+//   boff   BYTE offset of the current cube's / voxel's u16 in the pool; ss[3] the signed byte strides.
+//          Stepping adds ss[axis]: no index arithmetic in the loop, and the lookup is a
+//          scalar-base + 32-bit-offset load (the pool is at most 4 GiB: aic_upload_space checks).
+//   thr    a looked-up code >= thr is a visible surface (voxels: the block's first visible palette code;
+//          cubes with class bits: 0x4000, i.e. class >= 1)
+// The axis to step along is recomputed from t[] at the start of a trip (three f64 compares) instead of being
+// carried in the state: it is a pure function of t[], which nothing modifies between trips.
+
+template <bool VOL, int LMODE, bool DIAG, bool BIG>
 __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_kernel(const DevFrame F) {
     // ---- persistent waves: each wave pulls 8x8-pixel tiles from a global counter until the
     // image is exhausted, so cheap (sky) and expensive (geometry) tiles balance dynamically ----
@@ -768,16 +785,11 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
     // small decode tables live in LDS for the life of the persistent workgroup
     __shared__ float s_lut[256];     // PackedLight scalar decode (light/data.rs:301-354)
     __shared__ float s_thr[256];     // sRGB8 encode thresholds
-    __shared__ uint32_t s_cls[kClsWords];  // 2 bits per block: 0 invisible single voxel, 1 visible single voxel, 2 recursive
     __shared__ double s_pow[64];     // powf tables (powf_table)
     pow_tables_to_lds(s_pow, threadIdx.x, (uint32_t)AIC_WG_THREADS);
     for (uint32_t i = threadIdx.x; i < 256u; i += (uint32_t)AIC_WG_THREADS) {
         s_lut[i] = F.light_lut[i];
         s_thr[i] = F.srgb_thr[i];
-    }
-    {
-        const uint32_t n_words = (L.n_blocks + 15u) / 16u;
-        for (uint32_t i = threadIdx.x; i < n_words && i < (uint32_t)kClsWords; i += (uint32_t)AIC_WG_THREADS) s_cls[i] = L.cls[i];
     }
     __syncthreads();
     const float *lut = s_lut;
@@ -789,42 +801,39 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
 
     const int olx = L.lo[0], oly = L.lo[1], olz = L.lo[2];
     const int osx_i = L.size[0], osy_i = L.size[1], osz_i = L.size[2];
-    const uint32_t osy = (uint32_t)osy_i, osz = (uint32_t)osz_i;
+    const int ostx = 2 * osy_i * osz_i, osty = 2 * osz_i;  // byte strides of the cube grid (z: 2)
     // cube grid at offset 0, then every block's voxel volume. The pointer is laundered through an
     // s_mov so that it is a computed SGPR pair rather than a re-loadable kernel argument: under SGPR
     // pressure the compiler would otherwise re-fetch it (s_load + wait) in front of every lookup.
-    typedef const __attribute__((address_space(1))) uint16_t *GlobalU16Ptr;
-    GlobalU16Ptr pool;
-    {
-        unsigned long long bits = (unsigned long long)L.pool;
-        asm volatile("s_mov_b64 %0, %1" : "=s"(bits) : "s"(bits));
-        pool = (GlobalU16Ptr)bits;
-    }
-    const bool cls_in_code = L.cls_in_code != 0u;
+    unsigned long long pool_bits = (unsigned long long)L.pool;
+    asm volatile("s_mov_b64 %0, %1" : "=s"(pool_bits) : "s"(pool_bits));
+    // BIG: block tables past 16384 entries -- plain 16-bit indices in the grid, classes from L.cls
+    const uint32_t idx_mask = BIG ? 0xffffu : kCubeIndexMask;
+    const uint32_t outer_thr = BIG ? 0x10000u : (1u << kCubeClassShift);
 
-    // ---- per-lane ray state ----
-    double ox = 0, oy = 0, oz = 0;  // ray origin
-    RayDir rd;                      // direction (sanitised), t_delta, step signs
-    rd.dx = rd.dy = rd.dz = 0.0; rd.tdx = rd.tdy = rd.tdz = 0.0; rd.sx = rd.sy = rd.sz = 0;
-    // current DDA level: t_max, last t, cube coordinates RELATIVE to the level's lower corner,
-    // exit coordinate per axis, and the volume being indexed: pool offset and y/z extents
-    double tx = 0, ty = 0, tz = 0, last_t = 0;
-    int cx = 0, cy = 0, cz = 0, limx = 0, limy = 0, limz = 0;
-    uint32_t vol_off = 0, vsy = 1, vsz = 1;
-    // the suspended outer level while inside a block
-    double s_tx = 0, s_ty = 0, s_tz = 0, s_last = 0;
-    int s_cx = 0, s_cy = 0, s_cz = 0;
-    // st: bits 0-1 first_last | 2-4 last_face | 5-6 pick | 7 need_step | 9.. flags | 16-22 saved outer (face, pick) | 24-26 sky octant
-    uint32_t st = FL_ENDED;
-    uint32_t blk_index = 0, blk_res = 1, blk_vlo = 0, blk_pal_off = 0, blk_ninvis = 0;
+    // ---- per-lane state, hot: lives in registers across the stepping loop ----
+    double tx = 0, ty = 0, tz = 0, last_t = 0;   // t_max of the current level, t of the step that entered the current cube
+    double tdx = 0, tdy = 0, tdz = 0;            // t_delta
+    uint32_t rx = 1, ry = 1, rz = 1;             // steps left before leaving the bounds, per axis
+    uint32_t boff = 0;                           // byte offset of the current cube / voxel in the pool
+    int ssx = 0, ssy = 0, ssz = 0;               // signed byte strides of the current level
+    uint32_t thr = outer_thr;                    // codes >= thr are visible surfaces
+    uint32_t raw = 0;                            // the code looked up last (read by the event it raised)
+    uint32_t lax = 8u;                           // axis last stepped along (0..2), or 8 | Face set by an event (FACE_TABLE applied late)
+    uint32_t st = ST_DEAD;
+    uint32_t count = 0;
     ColorBuf acc;
     acc.l0 = acc.l1 = acc.l2 = 0.f; acc.t = 1.0f;
-    uint32_t count = 0;
+    // DepthIter.last_surface, already shaded: its premultiplied light and transmittance
+    float pend0 = 0.f, pend1 = 0.f, pend2 = 0.f, pend_tr = 1.f;
+    // ---- per-lane state, cold: only events touch it ----
+    double ox = 0, oy = 0, oz = 0;               // ray origin
+    double dx = 0, dy = 0, dz = 0;               // ray direction (sanitised: Parameters::new, raycast.rs:749-771)
+    double s_tx = 0, s_ty = 0, s_tz = 0, s_last = 0;  // the suspended outer level while inside a block
+    uint32_t s_rx = 1, s_ry = 1, s_rz = 1, s_boff = 0;
+    uint32_t blk_index = 0, blk_res = 1, blk_vlo = 0, blk_vsz = 0, blk_pal_off = 0;
     double t_abs = 0.0, half_over_len = 0.0;
     float t_view = 0.f;
-    // DepthIter.last_surface, already shaded: its premultiplied light and transmittance
-    uint32_t shade_ref = 0;  // colour record of the surface waiting to be shaded (bit31: single-voxel block)
-    float pend0 = 0.f, pend1 = 0.f, pend2 = 0.f, pend_tr = 1.f;
     SurfDiag pend_d;
     double pend_t = 0.0;
     bool pend_visible = false;
@@ -866,26 +875,23 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
         const int idx = (L.sky_kind != 0) ? (int)((st >> 24) & 7u) : 0;
         out[0] = L.sky[idx][0]; out[1] = L.sky[idx][1]; out[2] = L.sky[idx][2];
     };
-    // FACE_TABLE (raycast.rs:618-623) applied late: st with a real Face in bits 2-4
-    auto materialize_face = [&](uint32_t v) -> uint32_t {
-        if (!(v & ST_FACE_LAZY)) return v;
-        const uint32_t ax = (v >> 2) & 3u;
-        // the sign of the ray along a stepped axis is its sky-octant bit (bits 26/25/24 for x/y/z: direction >= 0,
-        // and a stepped axis has a non-zero direction) -- read from `v` itself, not from rd.s* by a dynamic index
-        const uint32_t positive = (v >> (26u - ax)) & 1u;
-        return (v & ~(0x1cu | ST_FACE_LAZY)) | (((positive ? 1u : 4u) + ax) << 2);
+    // FACE_TABLE (raycast.rs:618-623) applied late: the Face of the cube the level is in
+    auto face_now = [&]() -> uint32_t {
+        if (lax & 8u) return lax & 7u;
+        // the sign of the ray along a stepped axis is its octant bit (a stepped axis has a non-zero direction)
+        const uint32_t positive = (st >> (26u - lax)) & 1u;
+        return (positive ? 1u : 4u) + lax;
     };
-    // the level's state as an absolute-coordinate Lvl (for RaycastStep::intersection_point)
-    auto cur_abs = [&]() {
-        Lvl a;
-        a.tx = tx; a.ty = ty; a.tz = tz; a.last_t = last_t; a.st = materialize_face(st);
-        if (st & ST_IN_BLOCK) {
-            a.cx = cx + (int)(blk_vlo & 255u); a.cy = cy + (int)((blk_vlo >> 8) & 255u); a.cz = cz + (int)((blk_vlo >> 16) & 255u);
-        } else {
-            a.cx = cx + olx; a.cy = cy + oly; a.cz = cz + olz;
-        }
-        return a;
+    // per-ray constants of the Raycaster, rebuilt from the stored direction when an event needs them
+    auto make_rd = [&]() {
+        RayDir r;
+        r.dx = dx; r.dy = dy; r.dz = dz;
+        r.tdx = tdx; r.tdy = tdy; r.tdz = tdz;
+        r.sx = signum_101(dx); r.sy = signum_101(dy); r.sz = signum_101(dz);
+        return r;
     };
+    // coordinate (relative to the level's lower corner) from the steps left along an axis
+    auto coord = [](uint32_t positive, int size, uint32_t r) -> int { return positive ? size - (int)r : (int)r - 1; };
 
     for (;;) {
         // ---- wave scheduler: step, or run ONE kind of parked work for all lanes waiting on it ----
@@ -920,18 +926,31 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
             AIC_PROF(4, run == EV_SHADE ? 1 : 0); AIC_PROF(5, run == EV_SHADE ? c_shade : 0);
             AIC_PROF(6, run == EV_ENTER ? 1 : 0); AIC_PROF(7, run == EV_ENTER ? c_enter : 0);
             AIC_PROF(8, run == EV_FINISH ? 1 : 0); AIC_PROF(9, run == EV_FINISH ? c_ray : 0);
+            const uint32_t posx = (st >> 26) & 1u, posy = (st >> 25) & 1u, posz = (st >> 24) & 1u;
             // -- shading a discovered surface: compute_illumination + trace_through_span +
             //    Surface::to_light (surface.rs:73-206; sr.rs:697-740). For Volumetric transparency the
             //    span's exit distance is the t of the ray's NEXT TraceStep, which is already fixed when
-            //    the surface is discovered: it is the t_max of the deferred step. The contribution is
-            //    therefore computed here in full and merely *applied* by the stepping code when that
-            //    next step is counted (so the order count -> stop-check -> accumulate is kept). --
+            //    the surface is discovered: it is the t_max of the step the level takes next. The
+            //    contribution is therefore computed here in full and merely *applied* by the stepping code
+            //    when that next step is counted (so the order count -> stop-check -> accumulate is kept). --
             if (run == EV_SHADE && (ev & EV_SHADE)) {
                 const bool inb = (st & ST_IN_BLOCK) != 0;
                 const double as = inb ? __hiloint2double((int)((1023u - (31u - (uint32_t)__clz((int)blk_res))) << 20), 0) : 1.0;
                 const double t_enter = last_t * as;  // surface.rs:385-386
-                const Lvl ca = cur_abs();
-                const int ocx = (inb ? s_cx : cx) + olx, ocy = (inb ? s_cy : cy) + oly, ocz = (inb ? s_cz : cz) + olz;  // the Space cube
+                // the Space cube, and the current level's cube in absolute coordinates
+                const int ocx = coord(posx, osx_i, inb ? s_rx : rx) + olx, ocy = coord(posy, osy_i, inb ? s_ry : ry) + oly,
+                          ocz = coord(posz, osz_i, inb ? s_rz : rz) + olz;
+                Lvl ca;
+                ca.tx = tx; ca.ty = ty; ca.tz = tz; ca.last_t = last_t; ca.st = face_now() << 2;
+                if (inb) {
+                    ca.cx = coord(posx, (int)(blk_vsz & 255u), rx) + (int)(blk_vlo & 255u);
+                    ca.cy = coord(posy, (int)((blk_vsz >> 8) & 255u), ry) + (int)((blk_vlo >> 8) & 255u);
+                    ca.cz = coord(posz, (int)((blk_vsz >> 16) & 255u), rz) + (int)((blk_vlo >> 16) & 255u);
+                } else {
+                    ca.cx = ocx; ca.cy = ocy; ca.cz = ocz;
+                }
+                // colour record of the surface: the block's single voxel, or the voxel's palette entry
+                const uint32_t shade_ref = inb ? (blk_pal_off + raw) : (0x80000000u | (raw & idx_mask));
                 // illumination (surface.rs:113-206)
                 float i0 = 1.0f, i1 = 1.0f, i2 = 1.0f;
                 uint32_t nl = 0;
@@ -948,12 +967,12 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                         if (inb) {
                             const double kd = (double)blk_res;
                             double vp[3];
-                            intersection_point(ca, (ox - (double)ocx) * kd, (oy - (double)ocy) * kd, (oz - (double)ocz) * kd, rd.dx, rd.dy, rd.dz, vp);
+                            intersection_point(ca, (ox - (double)ocx) * kd, (oy - (double)ocy) * kd, (oz - (double)ocz) * kd, dx, dy, dz, vp);
                             ip[0] = vp[0] * as + (double)ocx;  // surface.rs:406-407
                             ip[1] = vp[1] * as + (double)ocy;
                             ip[2] = vp[2] * as + (double)ocz;
                         } else {
-                            intersection_point(ca, ox, oy, oz, rd.dx, rd.dy, rd.dz, ip);
+                            intersection_point(ca, ox, oy, oz, dx, dy, dz, ip);
                         }
                         const int oc[3] = {ocx, ocy, ocz};
                         float il[3];
@@ -977,14 +996,14 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                 }
                 bool will_flush = true;
                 if (VOL) {
-                    // exit distance = t of the next TraceStep: the deferred step of this level, or -- if this
+                    // exit distance = t of the next TraceStep: the next step of this level, or -- if this
                     // level cannot step any more -- of the enclosing cube grid; none => the span is never emitted
                     double t_exit = 0.0;
-                    if ((st & 3u) != FL_ENDED) {
-                        const uint32_t pk = (st >> 5) & 3u;
+                    if (!(st & ST_DEAD)) {
+                        const int pk = pick_axis(tx, ty, tz);
                         t_exit = (pk == 0 ? tx : (pk == 1 ? ty : tz)) * as;
                     } else if (inb && (st & ST_OUTER_ALIVE)) {
-                        const uint32_t pk = (st >> 19) & 3u;  // the suspended outer level's scheduled step
+                        const int pk = pick_axis(s_tx, s_ty, s_tz);  // the suspended outer level's next step
                         t_exit = pk == 0 ? s_tx : (pk == 1 ? s_ty : s_tz);
                     } else {
                         will_flush = false;
@@ -1085,30 +1104,38 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
             // -- entering a recursive block: RaycastStep::recursive_raycast (raycast.rs:458-476),
             //    advanced to its first in-bounds voxel (or to its end) --
             if (run == EV_ENTER && (ev & EV_ENTER)) {
+                blk_index = raw & idx_mask;
                 const DevBlock *tb = &L.blocks[blk_index];
                 blk_res = tb->kind & 255u;
                 blk_vlo = tb->vlo_packed;
-                const uint32_t vsize = tb->vsize_packed;
+                blk_vsz = tb->vsize_packed;
                 blk_pal_off = tb->pal_off;
-                blk_ninvis = tb->n_invisible;
+                const uint32_t n_invisible = tb->n_invisible;
+                const uint32_t vox_off = tb->vox_off;
                 const double kd = (double)blk_res;
-                const int acx = cx + olx, acy = cy + oly, acz = cz + olz;
+                const int acx = coord(posx, osx_i, rx) + olx, acy = coord(posy, osy_i, ry) + oly, acz = coord(posz, osz_i, rz) + olz;
                 const double sx_ = (ox - (double)acx) * kd, sy_ = (oy - (double)acy) * kd, sz_ = (oz - (double)acz) * kd;
-                // suspend the outer level (it always has its next step scheduled: pick + face go to st[16..22])
-                s_tx = tx; s_ty = ty; s_tz = tz; s_last = last_t; s_cx = cx; s_cy = cy; s_cz = cz;
-                st = (st & ~((0x1fu << 16) | ST_OUTER_ALIVE)) | (((materialize_face(st) >> 2) & 0x1fu) << 16) | (((st & 3u) == FL_INBOUNDS) ? ST_OUTER_ALIVE : 0u);
+                // suspend the outer level; its Face goes to st[16..18]
+                s_tx = tx; s_ty = ty; s_tz = tz; s_last = last_t; s_rx = rx; s_ry = ry; s_rz = rz; s_boff = boff;
+                st = (st & ~((7u << 16) | ST_OUTER_ALIVE)) | (face_now() << 16) | ((st & ST_DEAD) ? 0u : ST_OUTER_ALIVE);
                 const int ilx = (int)(blk_vlo & 255u), ily = (int)((blk_vlo >> 8) & 255u), ilz = (int)((blk_vlo >> 16) & 255u);
-                const int isx = (int)(vsize & 255u), isy = (int)((vsize >> 8) & 255u), isz = (int)((vsize >> 16) & 255u);
+                const int isx = (int)(blk_vsz & 255u), isy = (int)((blk_vsz >> 8) & 255u), isz = (int)((blk_vsz >> 16) & 255u);
+                const RayDir rd = make_rd();
                 const LvlLim ll = lvl_init(sx_, sy_, sz_, rd, true, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz, true, half_over_len);
                 bool got;
                 const Lvl f = lvl_first(ll.s, ll.lim, rd, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz, &got);
                 tx = f.tx; ty = f.ty; tz = f.tz; last_t = f.last_t;
-                cx = f.cx - ilx; cy = f.cy - ily; cz = f.cz - ilz;
-                limx = rd.sx > 0 ? isx : -1; limy = rd.sy > 0 ? isy : -1; limz = rd.sz > 0 ? isz : -1;
-                vol_off = tb->vox_off; vsy = (uint32_t)isy; vsz = (uint32_t)isz;
-                // level flags: the low 9 bits come from the raycaster; a produced first step still needs its lookup
-                st = (st & ~0x1ffu) | (f.st & 0x7fu) | ST_IN_BLOCK | (got ? ST_FRESH : 0u);
-                if (!got) st = (st & ~3u) | FL_ENDED;
+                const int vcx = f.cx - ilx, vcy = f.cy - ily, vcz = f.cz - ilz;
+                rx = posx ? (uint32_t)(isx - vcx) : (uint32_t)(vcx + 1);
+                ry = posy ? (uint32_t)(isy - vcy) : (uint32_t)(vcy + 1);
+                rz = posz ? (uint32_t)(isz - vcz) : (uint32_t)(vcz + 1);
+                boff = 2u * (vox_off + (uint32_t)(((uint32_t)vcx * (uint32_t)isy + (uint32_t)vcy) * (uint32_t)isz + (uint32_t)vcz));
+                ssx = posx ? 2 * isy * isz : -2 * isy * isz; ssy = posy ? 2 * isz : -2 * isz; ssz = posz ? 2 : -2;
+                thr = n_invisible;
+                // a produced first voxel still needs its lookup (FRESH); a level that produced nothing, or ended with it, is DEAD
+                const bool dead = !got || lvl_fl(f) != FL_INBOUNDS;
+                lax = 8u | ((f.st >> 2) & 7u);
+                st = (st & ~(ST_DEAD | ST_FRESH)) | ST_IN_BLOCK | (got ? ST_FRESH : 0u) | (dead ? ST_DEAD : 0u);
                 ev &= ~EV_ENTER;
             }
             // -- finishing a ray: TracingState::finish + layer tail + (last sample) encode & store --
@@ -1236,10 +1263,10 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                         uint32_t mt = t >> m_shift;
                         const uint32_t inner = t & ((1u << m_shift) - 1u);
                         if (F.tile_order) mt = F.tile_order[mt];
-                        const uint32_t tx = ((mt % F.macros_x) << macro_shift) + (inner & ((1u << macro_shift) - 1u));
-                        const uint32_t ty = ((mt / F.macros_x) << macro_shift) + (inner >> macro_shift);
-                        tile_x0 = tx * F.tile;
-                        tile_y0 = ty * F.tile;
+                        const uint32_t tx_ = ((mt % F.macros_x) << macro_shift) + (inner & ((1u << macro_shift) - 1u));
+                        const uint32_t ty_ = ((mt / F.macros_x) << macro_shift) + (inner >> macro_shift);
+                        tile_x0 = tx_ * F.tile;
+                        tile_y0 = ty_ * F.tile;
                         if (tile_x0 >= F.width || tile_y0 >= F.local_rows) continue;  // a macro tile's overhang past the image edge
                         next_idx = 0;
                     }
@@ -1313,7 +1340,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                     cb_add(acc, F.backdrop[0] * a, F.backdrop[1] * a, F.backdrop[2] * a, 1.0f - a);
                 }
                 count = 0;
-                st = FL_ENDED;
+                st = ST_DEAD;
                 if (L.present) {
                     double o[3], f[3];
                     unproject(L.inv, px, py, 0.0, o);
@@ -1322,8 +1349,11 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                     const double dirx = f[0] - o[0], diry = f[1] - o[1], dirz = f[2] - o[2];
                     t_abs = sqrt(dirx * dirx + diry * diry + dirz * dirz);  // sr.rs:146
                     t_view = (float)(t_abs / opt.view_distance);             // sr.rs:149-151
-                    rd = raydir_init(dirx, diry, dirz);
-                    const uint32_t octant = ((dirx >= 0.0 ? 1u : 0u) << 2) + ((diry >= 0.0 ? 1u : 0u) << 1) + (dirz >= 0.0 ? 1u : 0u);
+                    const RayDir rd = raydir_init(dirx, diry, dirz);
+                    dx = rd.dx; dy = rd.dy; dz = rd.dz;
+                    tdx = rd.tdx; tdy = rd.tdy; tdz = rd.tdz;
+                    const uint32_t qx = dirx >= 0.0 ? 1u : 0u, qy = diry >= 0.0 ? 1u : 0u, qz = dirz >= 0.0 ? 1u : 0u;
+                    const uint32_t octant = (qx << 2) + (qy << 1) + qz;
                     const int ohx = olx + osx_i, ohy = oly + osy_i, ohz = olz + osz_i;
                     // the sanitised direction equals the original unless it was zeroed, in which case no fast-forward happens
                     half_over_len = 0.5 / t_abs;
@@ -1331,11 +1361,16 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                     bool got;
                     const Lvl fs = lvl_first(ll.s, ll.lim, rd, olx, oly, olz, ohx, ohy, ohz, &got);
                     tx = fs.tx; ty = fs.ty; tz = fs.tz; last_t = fs.last_t;
-                    cx = fs.cx - olx; cy = fs.cy - oly; cz = fs.cz - olz;
-                    limx = rd.sx > 0 ? osx_i : -1; limy = rd.sy > 0 ? osy_i : -1; limz = rd.sz > 0 ? osz_i : -1;
-                    vol_off = 0; vsy = osy; vsz = osz;
-                    st = (fs.st & 0x7fu) | ST_TRACED | (octant << 24) | (got ? ST_FRESH : 0u);
-                    if (!got) st = (st & ~3u) | FL_ENDED;
+                    const int ccx = fs.cx - olx, ccy = fs.cy - oly, ccz = fs.cz - olz;
+                    rx = qx ? (uint32_t)(osx_i - ccx) : (uint32_t)(ccx + 1);
+                    ry = qy ? (uint32_t)(osy_i - ccy) : (uint32_t)(ccy + 1);
+                    rz = qz ? (uint32_t)(osz_i - ccz) : (uint32_t)(ccz + 1);
+                    boff = 2u * (uint32_t)(((uint32_t)ccx * (uint32_t)osy_i + (uint32_t)ccy) * (uint32_t)osz_i + (uint32_t)ccz);
+                    ssx = qx ? ostx : -ostx; ssy = qy ? osty : -osty; ssz = qz ? 2 : -2;
+                    thr = outer_thr;
+                    const bool dead = !got || lvl_fl(fs) != FL_INBOUNDS;
+                    lax = 8u | ((fs.st >> 2) & 7u);
+                    st = ST_TRACED | (octant << 24) | (got ? ST_FRESH : 0u) | (dead ? ST_DEAD : 0u);
                     if (cb_opaque(acc)) st |= ST_OPAQUE;
                     ev = 0u;
                 } else {
@@ -1348,121 +1383,179 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
 
         // ============================ stepping phase ======================================
         // One Amanatides-Woo step of the lane's current level -- the cube grid or a block's voxel
-        // volume: same registers, same code, one 2-byte lookup in the shared pool -- written as
-        // straight-line predicated code (SurfaceIter::next + Raycaster::next + State::step).
+        // volume: same registers, same code, one 2-byte lookup in the shared pool
+        // (SurfaceIter::next + Raycaster::next + State::step).
+        //
+        // The trip is branch-free at the source level: every decision is a wave mask (SGPR pair, SALU
+        // logic), and the per-lane state is updated IN PLACE by short exec-masked instruction runs
+        // written as inline assembly. (Left to the compiler, the divergent branches of this loop turn
+        // into chains of Flow blocks with ~150 register copies per trip; measured in profiles/.)
 #pragma unroll 1
         for (int rep = 0; rep < AIC_STEP_REPS; rep++) {
-        if (rep > 0 && __ballot(ev == 0u) == 0ull) break;
+        const unsigned long long m_act = __builtin_amdgcn_ballot_w64(ev == 0u);
+        if (rep > 0 && m_act == 0ull) break;
         AIC_PROF(10, 1);
-        AIC_PROF(11, __popcll(__ballot(ev == 0u)));
-        if (ev == 0u) {
+        AIC_PROF(11, __popcll(m_act));
+        {
+            const bool act = ev == 0u;
             const bool inb = (st & ST_IN_BLOCK) != 0;
-            const bool fresh = (st & ST_FRESH) != 0;       // first cube of a level: already emitted by the event
-            const bool alive = (st & 3u) == FL_INBOUNDS;
-            const bool stepped = alive && !fresh;          // a scheduled step exists (need_step is implied)
-            // -- the deferred State::step (raycast.rs:577-626) along `pick` --
-            const uint32_t axis = (st >> 5) & 3u;
-            const bool m0 = stepped && axis == 0u, m1 = stepped && axis == 1u, m2 = stepped && axis == 2u;
-            const double t_old = axis == 0u ? tx : (axis == 1u ? ty : tz);
-            last_t = stepped ? t_old : last_t;
-            tx = tx + (m0 ? rd.tdx : 0.0);  // t_max values are never -0.0, so adding +0.0 is the identity
-            ty = ty + (m1 ? rd.tdy : 0.0);
-            tz = tz + (m2 ? rd.tdz : 0.0);
-            cx += m0 ? rd.sx : 0;
-            cy += m1 ? rd.sy : 0;
-            cz += m2 ? rd.sz : 0;
-            // -- left the bounds? only the axis just stepped can have (raycast.rs:265-274); the other two
-            //    coordinates are inside, so they cannot equal their exit coordinate --
-            const bool is_exit = stepped && ((cx == limx) | (cy == limy) | (cz == limz));
-            // -- schedule the next step: pick + valid_for_stepping (raycast.rs:563-596) --
-            const bool c01 = tx < ty, c02 = tx < tz, c12 = ty < tz;
-            const uint32_t pick = c01 ? (c02 ? 0u : 2u) : (c12 ? 1u : 2u);
-            const double t_pick = pick == 0u ? tx : (pick == 1u ? ty : tz);
-            const bool valid = isfinite(t_pick);
+            const bool fresh = act && (st & ST_FRESH) != 0;     // first cube of a level: already emitted by the event
+            const bool dead = act && (st & ST_DEAD) != 0;
+            const bool stepped = act && (st & (ST_FRESH | ST_DEAD)) == 0u;  // the level takes its next step
+            // -- State::step (raycast.rs:577-626) along the axis of the smallest t_max (strict <, ties to the
+            //    later axis: raycast.rs:584-596): X iff tx<ty && tx<tz, Y iff !(tx<ty) && ty<tz, else Z.
+            //    One exec-masked run per axis: last_t = t; t += t_delta; steps_left -= 1; offset += stride. --
+            {
+                const unsigned long long m_step = __builtin_amdgcn_ballot_w64(stepped);
+                unsigned long long sv, mx, mz;
+                asm volatile(
+                    "v_cmp_lt_f64 %[mx], %[tx], %[ty]\n\t"
+                    "v_cmp_lt_f64 %[mz], %[tx], %[tz]\n\t"
+                    "v_cmp_lt_f64 vcc, %[ty], %[tz]\n\t"
+                    "s_mov_b64 %[sv], exec\n\t"
+                    "s_andn2_b64 vcc, vcc, %[mx]\n\t"
+                    "s_and_b64 %[mx], %[mx], %[mz]\n\t"
+                    "s_and_b64 vcc, vcc, %[m]\n\t"
+                    "s_and_b64 %[mx], %[mx], %[m]\n\t"
+                    "s_or_b64 %[mz], %[mx], vcc\n\t"
+                    "s_andn2_b64 %[mz], %[m], %[mz]\n\t"
+                    "s_mov_b64 exec, %[mx]\n\t"
+                    "v_mov_b64 %[lt], %[tx]\n\t"
+                    "v_add_f64 %[tx], %[tx], %[tdx]\n\t"
+                    "v_add_u32 %[rx], -1, %[rx]\n\t"
+                    "v_add_u32 %[bo], %[bo], %[ssx]\n\t"
+                    "v_mov_b32 %[lax], 0\n\t"
+                    "s_mov_b64 exec, vcc\n\t"
+                    "v_mov_b64 %[lt], %[ty]\n\t"
+                    "v_add_f64 %[ty], %[ty], %[tdy]\n\t"
+                    "v_add_u32 %[ry], -1, %[ry]\n\t"
+                    "v_add_u32 %[bo], %[bo], %[ssy]\n\t"
+                    "v_mov_b32 %[lax], 1\n\t"
+                    "s_mov_b64 exec, %[mz]\n\t"
+                    "v_mov_b64 %[lt], %[tz]\n\t"
+                    "v_add_f64 %[tz], %[tz], %[tdz]\n\t"
+                    "v_add_u32 %[rz], -1, %[rz]\n\t"
+                    "v_add_u32 %[bo], %[bo], %[ssz]\n\t"
+                    "v_mov_b32 %[lax], 2\n\t"
+                    "s_mov_b64 exec, %[sv]\n\t"
+                    : [tx] "+v"(tx), [ty] "+v"(ty), [tz] "+v"(tz), [lt] "+v"(last_t), [rx] "+v"(rx), [ry] "+v"(ry), [rz] "+v"(rz),
+                      [bo] "+v"(boff), [lax] "+v"(lax), [sv] "=&s"(sv), [mx] "=&s"(mx), [mz] "=&s"(mz)
+                    : [tdx] "v"(tdx), [tdy] "v"(tdy), [tdz] "v"(tdz), [ssx] "v"(ssx), [ssy] "v"(ssy), [ssz] "v"(ssz), [m] "s"(m_step)
+                    : "vcc");
+            }
+            // -- left the bounds? (raycast.rs:265-274) only the axis just stepped can have run out of steps --
+            const bool is_exit = stepped && (min(rx, min(ry, rz)) == 0u);
+            // -- can the level step again? valid_for_stepping (raycast.rs:563-570): the smallest t_max is finite.
+            //    t_max values are non-negative and NaN-free, so their order is the order of their bit patterns
+            //    and the smallest one is finite iff the smallest high word is below the infinity pattern --
+            const uint32_t hmin = min((uint32_t)__double2hiint(tx), min((uint32_t)__double2hiint(ty), (uint32_t)__double2hiint(tz)));
+            const bool valid = hmin < 0x7ff00000u;
             const bool in_step = stepped && !is_exit;      // stepped into an in-bounds cube
             // a cube is produced by a fresh level, or by a step that stays in bounds and can go on stepping
             const bool lookup = fresh || (in_step && valid);
-            const bool level_over = is_exit || (in_step && !valid) || (!alive && !fresh) || (fresh && !alive);
-            // one update for the face and the next pick: the Face of the cube just entered is FACE_TABLE of
-            // (axis, sign) and is only needed by events, so the axis is recorded and decoded there; the pick
-            // is meaningless when the level is over, which is harmless (nothing reads it then)
-            st = stepped ? ((st & ~0xfcu) | (axis << 2) | (pick << 5) | ST_FACE_LAZY) : st;
-            st &= ~ST_FRESH;
-            // -- the lookup: one u16 from the pool, for whichever level this is --
-            uint32_t ts_kind = 0u, ref = 0u;  // TraceStep: 0 Invisible, 1 EnterSurface, 2 EnterBlock
-            if (lookup) {
-                const uint32_t raw = pool[(size_t)vol_off + (uint32_t)(((uint32_t)cx * vsy + (uint32_t)cy) * vsz + (uint32_t)cz)];
-                // voxel: visible iff its (re-ordered) palette code is past the invisible ones
-                const bool vox_surf = raw >= blk_ninvis;
-                // cube: class of the block, carried in the top bits of the grid entry when the block
-                // table is small enough (aic_device.h), else from the LDS table
-                uint32_t cls, code = raw;
-                if (cls_in_code) { cls = raw >> kCubeClassShift; code = inb ? raw : (raw & kCubeIndexMask); }
-                else cls = (s_cls[raw >> 4] >> ((raw & 15u) << 1)) & 3u;
-                ts_kind = inb ? (vox_surf ? 1u : 0u) : cls;
-                ref = inb ? (blk_pal_off + code) : (0x80000000u | code);
-                blk_index = (!inb && cls == 2u) ? code : blk_index;
-                if (DIAG) { if (inb) dg.n_inner++; else dg.n_outer++; }
+            const bool level_over = is_exit || (in_step && !valid) || dead;
+            // -- the lookup: one u16 from the pool, for whichever level this is (scalar base + 32-bit byte offset) --
+            {
+                const unsigned long long m_lookup = __builtin_amdgcn_ballot_w64(lookup);
+                unsigned long long sv;
+                asm volatile(
+                    "s_mov_b64 %[sv], exec\n\t"
+                    "s_mov_b64 exec, %[m]\n\t"
+                    "global_load_ushort %[raw], %[bo], %[pool]\n\t"
+                    "s_mov_b64 exec, %[sv]\n\t"
+                    : [raw] "+v"(raw), [sv] "=&s"(sv)
+                    : [bo] "v"(boff), [pool] "s"(pool_bits), [m] "s"(m_lookup)
+                    : "memory");
             }
+            st &= ~ST_FRESH;  // (harmless for lanes that are not stepping: FRESH is only ever set together with ev = 0)
+            if (DIAG) { if (lookup) { if (inb) dg.n_inner++; else dg.n_outer++; } }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw));
+            // TraceStep of a looked-up code: voxel -- visible iff its (re-ordered) palette code is past the invisible
+            // ones; cube -- the class of its block rides in the top two bits of the grid entry (aic_device.h)
+            bool is_block, is_surface;
+            if (BIG) {
+                // block tables past 16384 entries: plain 16-bit indices, classes from the table in global memory
+                uint32_t cls = 0u;
+                if (lookup && !inb) cls = (L.cls[raw >> 4] >> ((raw & 15u) << 1)) & 3u;
+                is_block = cls == 2u;
+                is_surface = lookup && (inb ? raw >= thr : cls == 1u);
+            } else {
+                is_block = lookup && !inb && raw >= (2u << kCubeClassShift);
+                is_surface = lookup && !is_block && raw >= thr;
+            }
+            const bool something = is_block || is_surface;
             const bool produced = lookup || is_exit;  // the include_exit step is an Invisible TraceStep
             // -- the level is finished: resume the cube grid, or the ray is complete --
-            bool ray_over = false;
-            if (level_over) {
-                if (ts_kind != 0u) {
-                    // (degenerate rays only) the surface / block just produced still needs this level's
-                    // state for its event: end the level now, leave it on the next trip
-                    st = (st & ~3u) | FL_ENDED;
-                } else if (inb) {
-                    tx = s_tx; ty = s_ty; tz = s_tz; last_t = s_last; cx = s_cx; cy = s_cy; cz = s_cz;
-                    limx = rd.sx > 0 ? osx_i : -1; limy = rd.sy > 0 ? osy_i : -1; limz = rd.sz > 0 ? osz_i : -1;
-                    vol_off = 0; vsy = osy; vsz = osz;
-                    // outer level: face + pick from st[16..20]; InBounds with its step scheduled if it was alive
-                    const uint32_t ofl = (st & ST_OUTER_ALIVE) ? FL_INBOUNDS : FL_ENDED;
-                    st = (st & ~(0x1ffu | ST_IN_BLOCK)) | ofl | (((st >> 16) & 0x1fu) << 2);
-                } else {
-                    ray_over = true;
-                    st = (st & ~3u) | FL_ENDED;
-                }
+            // (degenerate rays only) a surface / block produced by a level that is over still needs this level's
+            // state for its event: end the level now, leave it on the next trip
+            const bool defer = level_over && something;
+            const bool leave = level_over && !something && inb;
+            const bool ray_over = level_over && !something && !inb;
+            st |= (defer || ray_over) ? ST_DEAD : 0u;
+            const unsigned long long m_leave = __builtin_amdgcn_ballot_w64(leave);
+            if (m_leave != 0ull) {
+                unsigned long long sv;
+                asm volatile(
+                    "s_mov_b64 %[sv], exec\n\t"
+                    "s_mov_b64 exec, %[m]\n\t"
+                    "v_mov_b64 %[tx], %[stx]\n\t"
+                    "v_mov_b64 %[ty], %[sty]\n\t"
+                    "v_mov_b64 %[tz], %[stz]\n\t"
+                    "v_mov_b64 %[lt], %[slt]\n\t"
+                    "v_mov_b32 %[rx], %[srx]\n\t"
+                    "v_mov_b32 %[ry], %[sry]\n\t"
+                    "v_mov_b32 %[rz], %[srz]\n\t"
+                    "v_mov_b32 %[bo], %[sbo]\n\t"
+                    "s_mov_b64 exec, %[sv]\n\t"
+                    : [tx] "+v"(tx), [ty] "+v"(ty), [tz] "+v"(tz), [lt] "+v"(last_t), [rx] "+v"(rx), [ry] "+v"(ry), [rz] "+v"(rz),
+                      [bo] "+v"(boff), [sv] "=&s"(sv)
+                    : [stx] "v"(s_tx), [sty] "v"(s_ty), [stz] "v"(s_tz), [slt] "v"(s_last), [srx] "v"(s_rx), [sry] "v"(s_ry),
+                      [srz] "v"(s_rz), [sbo] "v"(s_boff), [m] "s"(m_leave));
+                ssx = leave ? ((st & (1u << 26)) ? ostx : -ostx) : ssx;
+                ssy = leave ? ((st & (1u << 25)) ? osty : -osty) : ssy;
+                ssz = leave ? ((st & (1u << 24)) ? 2 : -2) : ssz;
+                thr = leave ? outer_thr : thr;
+                // outer level: its Face from st[16..18]; it goes on stepping if it was alive
+                lax = leave ? (8u | ((st >> 16) & 7u)) : lax;
+                st = leave ? ((st & ~(ST_IN_BLOCK | ST_DEAD)) | ((st & ST_OUTER_ALIVE) ? 0u : ST_DEAD)) : st;
             }
-            if (produced) {
-                // ---- TracingState::count_step_should_stop (sr.rs:625-656) ----
-                count++;
-                if (count > 1000u || (st & ST_OPAQUE)) {
-                    ev = EV_FINISH;
-                } else {
-                    // ---- DepthIter::next (surface.rs:453-491): a pending surface's span ends at this step;
-                    // its contribution was computed when it was shaded, apply it now ----
-                    if (VOL && (st & ST_HAS_LAST)) {
-                        cb_add(acc, pend0, pend1, pend2, pend_tr);
-                        if (cb_opaque(acc)) st |= ST_OPAQUE;
-                        st &= ~ST_HAS_LAST;
-                        if (DIAG && pend_visible) {
-                            dg.n_hits++;
-                            dg.n_light += pend_d.nlight;
-                            if (!dg.hit) {
-                                dg.hit = 1;
-                                for (int a2 = 0; a2 < 3; a2++) { dg.cube[a2] = pend_d.cube[a2]; dg.voxel[a2] = pend_d.voxel[a2]; }
-                                dg.res = pend_d.res; dg.face = pend_d.face; dg.block = pend_d.block; dg.t = pend_t;
-                            }
+            // ---- TracingState::count_step_should_stop (sr.rs:625-656) ----
+            count += produced ? 1u : 0u;
+            const bool stop = produced && (count > 1000u || (st & ST_OPAQUE) != 0u);
+            const bool go_on = produced && !stop;
+            // ---- DepthIter::next (surface.rs:453-491): a pending surface's span ends at this step;
+            // its contribution was computed when it was shaded, apply it now ----
+            if (VOL) {
+                const bool apply = go_on && (st & ST_HAS_LAST) != 0u;
+                if (__builtin_amdgcn_ballot_w64(apply) != 0ull) {
+                    acc.l0 = apply ? acc.l0 + pend0 * acc.t : acc.l0;
+                    acc.l1 = apply ? acc.l1 + pend1 * acc.t : acc.l1;
+                    acc.l2 = apply ? acc.l2 + pend2 * acc.t : acc.l2;
+                    acc.t = apply ? acc.t * pend_tr : acc.t;
+                    st = apply ? ((st & ~ST_HAS_LAST) | (cb_opaque(acc) ? ST_OPAQUE : 0u)) : st;
+                    if (DIAG && apply && pend_visible) {
+                        dg.n_hits++;
+                        dg.n_light += pend_d.nlight;
+                        if (!dg.hit) {
+                            dg.hit = 1;
+                            for (int a2 = 0; a2 < 3; a2++) { dg.cube[a2] = pend_d.cube[a2]; dg.voxel[a2] = pend_d.voxel[a2]; }
+                            dg.res = pend_d.res; dg.face = pend_d.face; dg.block = pend_d.block; dg.t = pend_t;
                         }
                     }
-                    if (ts_kind == 1u) {
-                        shade_ref = ref;
-                        ev = EV_SHADE;
-                    } else if (ts_kind == 2u) {
-                        ev = EV_ENTER;
-                        if (VOL) {
-                            // DepthIter emits a second, buffered item for EnterBlock (surface.rs:478-488): count it too
-                            count++;
-                            if (count > 1000u || (st & ST_OPAQUE)) ev = EV_FINISH;
-                        }
-                    } else if (ray_over) {
-                        ev = EV_FINISH;
-                    }
                 }
-            } else if (ray_over) {
-                ev = EV_FINISH;
             }
+            // DepthIter emits a second, buffered item for EnterBlock (surface.rs:478-488): count it too
+            bool stop2 = false;
+            if (VOL) {
+                const bool second = go_on && is_block;
+                count += second ? 1u : 0u;
+                stop2 = second && (count > 1000u || (st & ST_OPAQUE) != 0u);
+            }
+            uint32_t nev = 0u;
+            nev = (go_on && is_surface) ? EV_SHADE : nev;
+            nev = (go_on && is_block) ? EV_ENTER : nev;
+            nev = (stop || stop2 || ray_over) ? EV_FINISH : nev;
+            ev = act ? nev : ev;
         }
         }
         AIC_TICK(12);
@@ -1480,7 +1573,6 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
         }
         atomicMax(&F.counters->prof[0], (unsigned long long)prof[3]);
         atomicMax(&F.counters->prof[1], (unsigned long long)prof[2]);
-        // coarse histogram of wave lifetimes in units of 1/8 of 4M cycles -> packed into n_light... (profile builds only)
     }
     prof[0] = 0; prof[1] = 0;
     if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(&F.counters->prof[i], (unsigned long long)prof[i]);
@@ -1632,7 +1724,7 @@ __global__ void probe_powf_kernel(const float *x, const float *y, float *out, ui
 // ---------------------------------------------------------------------------------------
 // host-callable launchers (used by aic_abi.cpp)
 
-template <bool VOL, int LMODE, bool DIAG>
+template <bool VOL, int LMODE, bool DIAG, bool BIG>
 static void launch_trace(const DevFrame &F, hipStream_t stream) {
     // persistent waves: enough workgroups to fill the chip at the kernel's occupancy, never more
     // waves than tiles (each wave pulls 8x8-pixel tiles from counters->tile_next)
@@ -1642,19 +1734,19 @@ static void launch_trace(const DevFrame &F, hipStream_t stream) {
     uint32_t grid = (n_tiles + wg_waves - 1u) / wg_waves;
     if (grid > resident_groups) grid = resident_groups;
     if (grid == 0) return;
-    hipLaunchKernelGGL((trace_image_kernel<VOL, LMODE, DIAG>), dim3(grid), dim3(AIC_WG_THREADS), 0, stream, F);
+    hipLaunchKernelGGL((trace_image_kernel<VOL, LMODE, DIAG, BIG>), dim3(grid), dim3(AIC_WG_THREADS), 0, stream, F);
 }
 
-template <bool DIAG>
+template <bool DIAG, bool BIG>
 static void launch_trace_diag(const DevFrame &F, bool vol, int lmode, hipStream_t stream) {
     if (vol) {
-        if (lmode == 0) launch_trace<true, 0, DIAG>(F, stream);
-        else if (lmode == 1) launch_trace<true, 1, DIAG>(F, stream);
-        else launch_trace<true, 2, DIAG>(F, stream);
+        if (lmode == 0) launch_trace<true, 0, DIAG, BIG>(F, stream);
+        else if (lmode == 1) launch_trace<true, 1, DIAG, BIG>(F, stream);
+        else launch_trace<true, 2, DIAG, BIG>(F, stream);
     } else {
-        if (lmode == 0) launch_trace<false, 0, DIAG>(F, stream);
-        else if (lmode == 1) launch_trace<false, 1, DIAG>(F, stream);
-        else launch_trace<false, 2, DIAG>(F, stream);
+        if (lmode == 0) launch_trace<false, 0, DIAG, BIG>(F, stream);
+        else if (lmode == 1) launch_trace<false, 1, DIAG, BIG>(F, stream);
+        else launch_trace<false, 2, DIAG, BIG>(F, stream);
     }
 }
 
@@ -1662,8 +1754,14 @@ void launch_trace_image(const DevFrame &F, bool diag, hipStream_t stream) {
     const bool vol = F.layer_transparency == 1;
     const int l = F.layer_lighting;
     const int lmode = l == 0 ? 0 : (l == 1 ? 1 : 2);
-    if (diag) launch_trace_diag<true>(F, vol, lmode, stream);
-    else launch_trace_diag<false>(F, vol, lmode, stream);
+    const bool big = F.layer.cls_in_code == 0u;  // block table past 16384 entries: untagged cube grid
+    if (diag) {
+        if (big) launch_trace_diag<true, true>(F, vol, lmode, stream);
+        else launch_trace_diag<true, false>(F, vol, lmode, stream);
+    } else {
+        if (big) launch_trace_diag<false, true>(F, vol, lmode, stream);
+        else launch_trace_diag<false, false>(F, vol, lmode, stream);
+    }
 }
 
 void launch_tag_cubes(uint16_t *grid, size_t n, const uint32_t *cls, int from_tagged, int to_tagged, hipStream_t stream) {
