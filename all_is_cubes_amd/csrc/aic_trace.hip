@@ -733,7 +733,7 @@ constexpr uint32_t ST_DEAD = 1u, ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, 
                    ST_OPAQUE = 1u << 12, ST_TRACED = 1u << 13, ST_OUTER_ALIVE = 1u << 21;
 
 #ifndef AIC_MIN_WAVES
-#define AIC_MIN_WAVES 2
+#define AIC_MIN_WAVES 4  // waves per SIMD the production variants are built for (128 VGPRs; cold lane state lives in LDS)
 #endif
 #ifndef AIC_T_BATCH
 #define AIC_T_BATCH 32  // run a kind of parked work once this many lanes wait on it
@@ -775,7 +775,7 @@ AIC_DEV Lvl lvl_first(Lvl s, const Lim lim, const RayDir rd, int lox, int loy, i
 // carried in the state: it is a pure function of t[], which nothing modifies between trips.
 
 template <bool VOL, int LMODE, bool DIAG, bool BIG>
-__global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_kernel(const DevFrame F) {
+__global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trace_image_kernel(const DevFrame F) {
     // ---- persistent waves: each wave pulls 8x8-pixel tiles from a global counter until the
     // image is exhausted, so cheap (sky) and expensive (geometry) tiles balance dynamically ----
     const uint32_t lane = threadIdx.x & 63u;
@@ -826,14 +826,24 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
     acc.l0 = acc.l1 = acc.l2 = 0.f; acc.t = 1.0f;
     // DepthIter.last_surface, already shaded: its premultiplied light and transmittance
     float pend0 = 0.f, pend1 = 0.f, pend2 = 0.f, pend_tr = 1.f;
-    // ---- per-lane state, cold: only events touch it ----
-    double ox = 0, oy = 0, oz = 0;               // ray origin
-    double dx = 0, dy = 0, dz = 0;               // ray direction (sanitised: Parameters::new, raycast.rs:749-771)
-    double s_tx = 0, s_ty = 0, s_tz = 0, s_last = 0;  // the suspended outer level while inside a block
-    uint32_t s_rx = 1, s_ry = 1, s_rz = 1, s_boff = 0;
-    uint32_t blk_index = 0, blk_res = 1, blk_vlo = 0, blk_vsz = 0, blk_pal_off = 0;
-    double t_abs = 0.0, half_over_len = 0.0;
-    float t_view = 0.f;
+    // the block the lane is inside: palette offset; log2(resolution) << 24 | stored-volume lower corner; stored-volume size
+    uint32_t blk_pal_off = 0, blk_geo = 0, blk_vsz = 0;
+    // ---- per-lane state, cold: only events touch it, so it lives in LDS (one column per thread: conflict-free
+    //      ds_read/ds_write), not in registers -- that is what lets the kernel run at 3-4 waves per SIMD ----
+    enum { C_OX, C_OY, C_OZ, C_DX, C_DY, C_DZ,      // ray origin, direction (sanitised: Parameters::new, raycast.rs:749-771)
+           C_STX, C_STY, C_STZ, C_SLAST,            // the suspended outer level while inside a block: t_max, last t
+           C_TABS, C_HOLEN, N_C64 };                // |direction| (sr.rs:146); 0.5 / |direction| (raycast.rs:669)
+    enum { K_SRX, K_SRY, K_SRZ, K_SBOFF,            // the suspended outer level: steps left, byte offset
+           K_BLK, K_TVIEW, K_PXY, K_STEPS,          // block index; |direction| / view distance; pixel x | row << 16; step sum
+           K_S0, K_S1, K_S2, K_ST, N_C32 };         // ColorBuf::mean accumulators (antialiasing)
+    __shared__ double c64[N_C64][AIC_WG_THREADS];
+    __shared__ uint32_t c32[N_C32][AIC_WG_THREADS];
+    const uint32_t tid = threadIdx.x;
+    // LDS byte addresses of this thread's columns (the low half of a generic LDS pointer is the LDS offset)
+    const uint32_t lds64 = (uint32_t)(uintptr_t)&c64[0][tid], lds32 = (uint32_t)(uintptr_t)&c32[0][tid];
+    c32[K_STEPS][tid] = 0u;
+    c32[K_BLK][tid] = 0u;
+    c32[K_PXY][tid] = 0u;
     SurfDiag pend_d;
     double pend_t = 0.0;
     bool pend_visible = false;
@@ -841,17 +851,13 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
         pend_d.nlight = 0; pend_d.res = pend_d.face = pend_d.block = 0;
         for (int a = 0; a < 3; a++) pend_d.cube[a] = pend_d.voxel[a] = 0;
     }
-    // pixel bookkeeping
-    uint32_t pxy = 0;           // this lane's pixel: x | (local row << 16)
-    int sample = 0;             // antialiasing sample being traced
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, st_sum = 0.f;  // ColorBuf::mean accumulators
+    // pixel bookkeeping: in LDS (K_PXY, K_S*); the antialiasing sample being traced rides in st bits 14-15
     uint32_t px_steps = 0, px_steps_prev = 0;          // DIAG: steps of this pixel
     Diag dg;
     if (DIAG) {
         dg.n_outer = dg.n_inner = dg.n_hits = dg.n_light = 0; dg.hit = 0; dg.res = dg.face = dg.block = 0; dg.t = 0.0;
         for (int a = 0; a < 3; a++) dg.cube[a] = dg.voxel[a] = 0;
     }
-    unsigned long long total_steps = 0;
     uint32_t tot_outer = 0, tot_inner = 0, tot_hits = 0, tot_light = 0;
 
     uint32_t ev = EV_NEWRAY | 64u;  // every lane starts by taking a pixel
@@ -883,7 +889,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
         return (positive ? 1u : 4u) + lax;
     };
     // per-ray constants of the Raycaster, rebuilt from the stored direction when an event needs them
-    auto make_rd = [&]() {
+    auto make_rd = [&](double dx, double dy, double dz) {
         RayDir r;
         r.dx = dx; r.dy = dy; r.dz = dz;
         r.tdx = tdx; r.tdy = tdy; r.tdz = tdz;
@@ -935,8 +941,10 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
             //    when that next step is counted (so the order count -> stop-check -> accumulate is kept). --
             if (run == EV_SHADE && (ev & EV_SHADE)) {
                 const bool inb = (st & ST_IN_BLOCK) != 0;
-                const double as = inb ? __hiloint2double((int)((1023u - (31u - (uint32_t)__clz((int)blk_res))) << 20), 0) : 1.0;
+                const uint32_t blk_res = 1u << (blk_geo >> 24), blk_vlo = blk_geo & 0xffffffu;
+                const double as = inb ? __hiloint2double((int)((1023u - (blk_geo >> 24)) << 20), 0) : 1.0;  // 1 / resolution
                 const double t_enter = last_t * as;  // surface.rs:385-386
+                const uint32_t s_rx = c32[K_SRX][tid], s_ry = c32[K_SRY][tid], s_rz = c32[K_SRZ][tid];
                 // the Space cube, and the current level's cube in absolute coordinates
                 const int ocx = coord(posx, osx_i, inb ? s_rx : rx) + olx, ocy = coord(posy, osy_i, inb ? s_ry : ry) + oly,
                           ocz = coord(posz, osz_i, inb ? s_rz : rz) + olz;
@@ -964,6 +972,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                         i0 = lut[txl & 255u]; i1 = lut[(txl >> 8) & 255u]; i2 = lut[(txl >> 16) & 255u];
                     } else {
                         double ip[3];
+                        const double ox = c64[C_OX][tid], oy = c64[C_OY][tid], oz = c64[C_OZ][tid];
+                        const double dx = c64[C_DX][tid], dy = c64[C_DY][tid], dz = c64[C_DZ][tid];
                         if (inb) {
                             const double kd = (double)blk_res;
                             double vp[3];
@@ -1003,13 +1013,14 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                         const int pk = pick_axis(tx, ty, tz);
                         t_exit = (pk == 0 ? tx : (pk == 1 ? ty : tz)) * as;
                     } else if (inb && (st & ST_OUTER_ALIVE)) {
+                        const double s_tx = c64[C_STX][tid], s_ty = c64[C_STY][tid], s_tz = c64[C_STZ][tid];
                         const int pk = pick_axis(s_tx, s_ty, s_tz);  // the suspended outer level's next step
                         t_exit = pk == 0 ? s_tx : (pk == 1 ? s_ty : s_tz);
                     } else {
                         will_flush = false;
                     }
                     // trace_through_span (sr.rs:720-740) + apply_transmittance (raytracer_components.rs:215-258)
-                    float thickness = (float)((t_exit - t_enter) * t_abs);
+                    float thickness = (float)((t_exit - t_enter) * c64[C_TABS][tid]);
                     thickness = fmaxf(thickness, 0.0f);
                     float coeff;
                     if (thickness == 0.0f) {
@@ -1046,7 +1057,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                         float sky[3];
                         sky_now(sky);
                         const float fog_blend = opt.fog == 1 ? 1.0f : (opt.fog == 2 ? 0.5f : 0.0f);
-                        float rel = (float)t_enter * t_view;
+                        float rel = (float)t_enter * __uint_as_float(c32[K_TVIEW][tid]);
                         rel = rel < 0.0f ? 0.0f : (rel > 1.0f ? 1.0f : rel);
                         const float sq = rel * rel;
                         float amount;
@@ -1072,7 +1083,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                     sd.cube[0] = ocx; sd.cube[1] = ocy; sd.cube[2] = ocz;
                     if (inb) {
                         sd.voxel[0] = ca.cx; sd.voxel[1] = ca.cy; sd.voxel[2] = ca.cz;
-                        sd.res = (int)blk_res; sd.block = (int)blk_index;
+                        sd.res = (int)blk_res; sd.block = (int)c32[K_BLK][tid];
                     } else {
                         sd.voxel[0] = sd.voxel[1] = sd.voxel[2] = 0;
                         sd.res = 1; sd.block = (int)(shade_ref & 0xffffu);
@@ -1104,24 +1115,28 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
             // -- entering a recursive block: RaycastStep::recursive_raycast (raycast.rs:458-476),
             //    advanced to its first in-bounds voxel (or to its end) --
             if (run == EV_ENTER && (ev & EV_ENTER)) {
-                blk_index = raw & idx_mask;
+                const uint32_t blk_index = raw & idx_mask;
+                c32[K_BLK][tid] = blk_index;
                 const DevBlock *tb = &L.blocks[blk_index];
-                blk_res = tb->kind & 255u;
-                blk_vlo = tb->vlo_packed;
+                const uint32_t blk_res = tb->kind & 255u;
+                const uint32_t blk_vlo = tb->vlo_packed;
+                blk_geo = ((31u - (uint32_t)__clz((int)blk_res)) << 24) | blk_vlo;
                 blk_vsz = tb->vsize_packed;
                 blk_pal_off = tb->pal_off;
+                const double ox = c64[C_OX][tid], oy = c64[C_OY][tid], oz = c64[C_OZ][tid];
                 const uint32_t n_invisible = tb->n_invisible;
                 const uint32_t vox_off = tb->vox_off;
                 const double kd = (double)blk_res;
                 const int acx = coord(posx, osx_i, rx) + olx, acy = coord(posy, osy_i, ry) + oly, acz = coord(posz, osz_i, rz) + olz;
                 const double sx_ = (ox - (double)acx) * kd, sy_ = (oy - (double)acy) * kd, sz_ = (oz - (double)acz) * kd;
                 // suspend the outer level; its Face goes to st[16..18]
-                s_tx = tx; s_ty = ty; s_tz = tz; s_last = last_t; s_rx = rx; s_ry = ry; s_rz = rz; s_boff = boff;
+                c64[C_STX][tid] = tx; c64[C_STY][tid] = ty; c64[C_STZ][tid] = tz; c64[C_SLAST][tid] = last_t;
+                c32[K_SRX][tid] = rx; c32[K_SRY][tid] = ry; c32[K_SRZ][tid] = rz; c32[K_SBOFF][tid] = boff;
                 st = (st & ~((7u << 16) | ST_OUTER_ALIVE)) | (face_now() << 16) | ((st & ST_DEAD) ? 0u : ST_OUTER_ALIVE);
                 const int ilx = (int)(blk_vlo & 255u), ily = (int)((blk_vlo >> 8) & 255u), ilz = (int)((blk_vlo >> 16) & 255u);
                 const int isx = (int)(blk_vsz & 255u), isy = (int)((blk_vsz >> 8) & 255u), isz = (int)((blk_vsz >> 16) & 255u);
-                const RayDir rd = make_rd();
-                const LvlLim ll = lvl_init(sx_, sy_, sz_, rd, true, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz, true, half_over_len);
+                const RayDir rd = make_rd(c64[C_DX][tid], c64[C_DY][tid], c64[C_DZ][tid]);
+                const LvlLim ll = lvl_init(sx_, sy_, sz_, rd, true, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz, true, c64[C_HOLEN][tid]);
                 bool got;
                 const Lvl f = lvl_first(ll.s, ll.lim, rd, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz, &got);
                 tx = f.tx; ty = f.ty; tz = f.tz; last_t = f.last_t;
@@ -1139,6 +1154,12 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                 ev &= ~EV_ENTER;
             }
             // -- finishing a ray: TracingState::finish + layer tail + (last sample) encode & store --
+            uint32_t pxy = 0;
+            int sample = 0;
+            if (run == EV_FINISH) {
+                pxy = c32[K_PXY][tid];
+                sample = (int)((st >> 14) & 3u);
+            }
             if (run == EV_FINISH && (ev & EV_FINISH)) {
                 if (st & ST_TRACED) {
                     // finish (sr.rs:658-693): the sky hit, then the optional cost visualisation
@@ -1158,7 +1179,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                         const float blue = ps_clamped(luminance(cur_rgba[0], cur_rgba[1], cur_rgba[2]) * 0.2f);
                         acc.l0 = red; acc.l1 = green; acc.l2 = blue; acc.t = 0.0f;
                     }
-                    total_steps += count;
+                    c32[K_STEPS][tid] += count;
                     if (DIAG) px_steps += count;
                 }
                 const uint32_t x = pxy & 0xffffu, lrow = pxy >> 16;
@@ -1179,7 +1200,12 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                         acc.l2 = acc.l0;
                         acc.t = 1.0f * (1.0f - 1.0f);
                     }
-                    s0 = s0 + acc.l0; s1 = s1 + acc.l1; s2 = s2 + acc.l2; st_sum = st_sum + acc.t;
+                    if (n_samples == 4) {
+                        c32[K_S0][tid] = __float_as_uint(__uint_as_float(c32[K_S0][tid]) + acc.l0);
+                        c32[K_S1][tid] = __float_as_uint(__uint_as_float(c32[K_S1][tid]) + acc.l1);
+                        c32[K_S2][tid] = __float_as_uint(__uint_as_float(c32[K_S2][tid]) + acc.l2);
+                        c32[K_ST][tid] = __float_as_uint(__uint_as_float(c32[K_ST][tid]) + acc.t);
+                    }
                 }
                 sample++;
                 if (sample < n_samples) {
@@ -1188,7 +1214,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                     if (!ui_pass) {
                         ColorBuf pixel;
                         if (n_samples == 4) {  // ColorBuf::mean (raytracer_components.rs:97-102)
-                            pixel.l0 = s0 / 4.0f; pixel.l1 = s1 / 4.0f; pixel.l2 = s2 / 4.0f; pixel.t = st_sum / 4.0f;
+                            pixel.l0 = __uint_as_float(c32[K_S0][tid]) / 4.0f; pixel.l1 = __uint_as_float(c32[K_S1][tid]) / 4.0f;
+                            pixel.l2 = __uint_as_float(c32[K_S2][tid]) / 4.0f; pixel.t = __uint_as_float(c32[K_ST][tid]) / 4.0f;
                         } else {
                             pixel = acc;
                         }
@@ -1290,7 +1317,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                 const uint32_t x = pxy & 0xffffu, lrow = pxy >> 16;
                 const size_t pix = (size_t)lrow * F.width + x;
                 if (ev & 64u) {
-                    s0 = s1 = s2 = st_sum = 0.f;
+                    if (n_samples == 4) { c32[K_S0][tid] = 0u; c32[K_S1][tid] = 0u; c32[K_S2][tid] = 0u; c32[K_ST][tid] = 0u; }  // 0.f
                     if (DIAG) {
                         dg.n_outer = dg.n_inner = dg.n_hits = dg.n_light = 0; dg.hit = 0; dg.res = dg.face = dg.block = 0; dg.t = 0.0;
                         for (int a = 0; a < 3; a++) dg.cube[a] = dg.voxel[a] = 0;
@@ -1340,23 +1367,26 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                     cb_add(acc, F.backdrop[0] * a, F.backdrop[1] * a, F.backdrop[2] * a, 1.0f - a);
                 }
                 count = 0;
-                st = ST_DEAD;
+                st = ST_DEAD | ((uint32_t)sample << 14);
                 if (L.present) {
                     double o[3], f[3];
                     unproject(L.inv, px, py, 0.0, o);
                     unproject(L.inv, px, py, 1.0, f);
-                    ox = o[0]; oy = o[1]; oz = o[2];
+                    const double ox = o[0], oy = o[1], oz = o[2];
+                    c64[C_OX][tid] = ox; c64[C_OY][tid] = oy; c64[C_OZ][tid] = oz;
                     const double dirx = f[0] - o[0], diry = f[1] - o[1], dirz = f[2] - o[2];
-                    t_abs = sqrt(dirx * dirx + diry * diry + dirz * dirz);  // sr.rs:146
-                    t_view = (float)(t_abs / opt.view_distance);             // sr.rs:149-151
+                    const double t_abs = sqrt(dirx * dirx + diry * diry + dirz * dirz);  // sr.rs:146
+                    c64[C_TABS][tid] = t_abs;
+                    c32[K_TVIEW][tid] = __float_as_uint((float)(t_abs / opt.view_distance));  // sr.rs:149-151
                     const RayDir rd = raydir_init(dirx, diry, dirz);
-                    dx = rd.dx; dy = rd.dy; dz = rd.dz;
+                    c64[C_DX][tid] = rd.dx; c64[C_DY][tid] = rd.dy; c64[C_DZ][tid] = rd.dz;
                     tdx = rd.tdx; tdy = rd.tdy; tdz = rd.tdz;
                     const uint32_t qx = dirx >= 0.0 ? 1u : 0u, qy = diry >= 0.0 ? 1u : 0u, qz = dirz >= 0.0 ? 1u : 0u;
                     const uint32_t octant = (qx << 2) + (qy << 1) + qz;
                     const int ohx = olx + osx_i, ohy = oly + osy_i, ohz = olz + osz_i;
                     // the sanitised direction equals the original unless it was zeroed, in which case no fast-forward happens
-                    half_over_len = 0.5 / t_abs;
+                    const double half_over_len = 0.5 / t_abs;
+                    c64[C_HOLEN][tid] = half_over_len;
                     const LvlLim ll = lvl_init(ox, oy, oz, rd, true, olx, oly, olz, ohx, ohy, ohz, true, half_over_len);
                     bool got;
                     const Lvl fs = lvl_first(ll.s, ll.lim, rd, olx, oly, olz, ohx, ohy, ohz, &got);
@@ -1370,13 +1400,14 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                     thr = outer_thr;
                     const bool dead = !got || lvl_fl(fs) != FL_INBOUNDS;
                     lax = 8u | ((fs.st >> 2) & 7u);
-                    st = ST_TRACED | (octant << 24) | (got ? ST_FRESH : 0u) | (dead ? ST_DEAD : 0u);
+                    st = ST_TRACED | (octant << 24) | (got ? ST_FRESH : 0u) | (dead ? ST_DEAD : 0u) | ((uint32_t)sample << 14);
                     if (cb_opaque(acc)) st |= ST_OPAQUE;
                     ev = 0u;
                 } else {
                     ev = EV_FINISH;
                 }
             }
+            if (run == EV_FINISH) c32[K_PXY][tid] = pxy;
             if (run == EV_SHADE) { AIC_TICK(13) } else if (run == EV_ENTER) { AIC_TICK(14) } else { AIC_TICK(15) }
             continue;
         }
@@ -1498,19 +1529,23 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
                 asm volatile(
                     "s_mov_b64 %[sv], exec\n\t"
                     "s_mov_b64 exec, %[m]\n\t"
-                    "v_mov_b64 %[tx], %[stx]\n\t"
-                    "v_mov_b64 %[ty], %[sty]\n\t"
-                    "v_mov_b64 %[tz], %[stz]\n\t"
-                    "v_mov_b64 %[lt], %[slt]\n\t"
-                    "v_mov_b32 %[rx], %[srx]\n\t"
-                    "v_mov_b32 %[ry], %[sry]\n\t"
-                    "v_mov_b32 %[rz], %[srz]\n\t"
-                    "v_mov_b32 %[bo], %[sbo]\n\t"
+                    "ds_read_b64 %[tx], %[a64] offset:%[o0]\n\t"
+                    "ds_read_b64 %[ty], %[a64] offset:%[o1]\n\t"
+                    "ds_read_b64 %[tz], %[a64] offset:%[o2]\n\t"
+                    "ds_read_b64 %[lt], %[a64] offset:%[o3]\n\t"
+                    "ds_read_b32 %[rx], %[a32] offset:%[p0]\n\t"
+                    "ds_read_b32 %[ry], %[a32] offset:%[p1]\n\t"
+                    "ds_read_b32 %[rz], %[a32] offset:%[p2]\n\t"
+                    "ds_read_b32 %[bo], %[a32] offset:%[p3]\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
                     "s_mov_b64 exec, %[sv]\n\t"
                     : [tx] "+v"(tx), [ty] "+v"(ty), [tz] "+v"(tz), [lt] "+v"(last_t), [rx] "+v"(rx), [ry] "+v"(ry), [rz] "+v"(rz),
                       [bo] "+v"(boff), [sv] "=&s"(sv)
-                    : [stx] "v"(s_tx), [sty] "v"(s_ty), [stz] "v"(s_tz), [slt] "v"(s_last), [srx] "v"(s_rx), [sry] "v"(s_ry),
-                      [srz] "v"(s_rz), [sbo] "v"(s_boff), [m] "s"(m_leave));
+                    : [a64] "v"(lds64), [a32] "v"(lds32), [m] "s"(m_leave),
+                      [o0] "n"(C_STX * AIC_WG_THREADS * 8), [o1] "n"(C_STY * AIC_WG_THREADS * 8), [o2] "n"(C_STZ * AIC_WG_THREADS * 8),
+                      [o3] "n"(C_SLAST * AIC_WG_THREADS * 8), [p0] "n"(K_SRX * AIC_WG_THREADS * 4), [p1] "n"(K_SRY * AIC_WG_THREADS * 4),
+                      [p2] "n"(K_SRZ * AIC_WG_THREADS * 4), [p3] "n"(K_SBOFF * AIC_WG_THREADS * 4)
+                    : "memory");
                 ssx = leave ? ((st & (1u << 26)) ? ostx : -ostx) : ssx;
                 ssy = leave ? ((st & (1u << 25)) ? osty : -osty) : ssy;
                 ssz = leave ? ((st & (1u << 24)) ? 2 : -2) : ssz;
@@ -1578,7 +1613,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, AIC_MIN_WAVES) void trace_image_ker
     if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(&F.counters->prof[i], (unsigned long long)prof[i]);
 #endif
     // ---- RaytraceInfo sum (renderer.rs:555): wave reduction then one atomic per wave ----
-    unsigned long long s = total_steps;
+    unsigned long long s = c32[K_STEPS][tid];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0 && s) atomicAdd(&F.counters->cubes_traced, s);
@@ -1730,7 +1765,7 @@ static void launch_trace(const DevFrame &F, hipStream_t stream) {
     // waves than tiles (each wave pulls 8x8-pixel tiles from counters->tile_next)
     const uint32_t n_tiles = F.tiles_x * F.tiles_y;
     const uint32_t wg_waves = (uint32_t)AIC_WG_THREADS / 64u;
-    const uint32_t resident_groups = F.n_cus * 4u * (uint32_t)AIC_MIN_WAVES / wg_waves;  // 4 SIMDs per CU, AIC_MIN_WAVES waves on each
+    const uint32_t resident_groups = F.n_cus * 4u * (uint32_t)(DIAG ? 2 : AIC_MIN_WAVES) / wg_waves;  // 4 SIMDs per CU, that many waves on each
     uint32_t grid = (n_tiles + wg_waves - 1u) / wg_waves;
     if (grid > resident_groups) grid = resident_groups;
     if (grid == 0) return;
