@@ -722,15 +722,17 @@ AIC_DEV uint32_t srgb8_channel(float c, const float *__restrict__ thr) {
     return (uint32_t)k;
 }
 
-// lane event bits
-constexpr uint32_t EV_SHADE = 2u, EV_ENTER = 4u, EV_FINISH = 8u, EV_NEWRAY = 16u, EV_DONE = 32u;
+// lane event word (ev): what the lane needs next. Values below 4 mean "stepping" (the wave scheduler's test), with
+//   1  EV_FRESH   the first cube of a level was emitted by the event that set the level up: look it up without stepping
+//   2  EV_DEAD    the current level's Raycaster has ended: it cannot step any further
+// and the parked kinds (EV_DEAD may ride along with SHADE / ENTER: the event still needs the ended level's state)
+constexpr uint32_t EV_FRESH = 1u, EV_DEAD = 2u, EV_SHADE = 4u, EV_ENTER = 8u, EV_FINISH = 16u, EV_NEWRAY = 32u, EV_DONE = 64u,
+                   EV_TAKE = 128u;  // with NEWRAY: take a new pixel first
 // lane state bits (st):
-//   0      ST_DEAD       the current level's Raycaster has ended: it cannot step any further
-//   9-13   flags below
+//   9-13   flags below;  14-15 the antialiasing sample being traced
 //   16-18  the suspended outer level's Face while inside a block; 21 ST_OUTER_ALIVE: that level can go on stepping
 //   24-26  sign bits of the ray direction (x: 26, y: 25, z: 24; set = component >= 0) = the sky octant
-constexpr uint32_t ST_DEAD = 1u, ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_FRESH = 1u << 11,
-                   ST_OPAQUE = 1u << 12, ST_TRACED = 1u << 13, ST_OUTER_ALIVE = 1u << 21;
+constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u << 12, ST_TRACED = 1u << 13, ST_OUTER_ALIVE = 1u << 21;
 
 #ifndef AIC_MIN_WAVES
 #define AIC_MIN_WAVES 4  // waves per SIMD the production variants are built for (128 VGPRs; cold lane state lives in LDS)
@@ -820,7 +822,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
     uint32_t thr = outer_thr;                    // codes >= thr are visible surfaces
     uint32_t raw = 0;                            // the code looked up last (read by the event it raised)
     uint32_t lax = 8u;                           // axis last stepped along (0..2), or 8 | Face set by an event (FACE_TABLE applied late)
-    uint32_t st = ST_DEAD;
+    uint32_t st = 0u;
     uint32_t count = 0;
     ColorBuf acc;
     acc.l0 = acc.l1 = acc.l2 = 0.f; acc.t = 1.0f;
@@ -860,7 +862,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
     }
     uint32_t tot_outer = 0, tot_inner = 0, tot_hits = 0, tot_light = 0;
 
-    uint32_t ev = EV_NEWRAY | 64u;  // every lane starts by taking a pixel
+    uint32_t ev = EV_NEWRAY | EV_TAKE;  // every lane starts by taking a pixel
 #ifdef AIC_PROFILE
     uint32_t prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t prof_tm = (uint32_t)__builtin_readcyclecounter();
@@ -904,7 +906,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         // Kinds: SHADE (light + composite a surface), ENTER (a block), RAY (finish / start a ray). A
         // kind is run when enough lanes wait on it to fill the wave reasonably (AIC_T_BATCH), or when
         // so few lanes can still step (AIC_N_FEW) that waiting longer only idles the wave.
-        const unsigned long long m_st = __ballot(ev == 0u);
+        const unsigned long long m_st = __ballot(ev < 4u);
         const unsigned long long b_shade = __ballot((ev & EV_SHADE) != 0u);
         const unsigned long long b_enter = __ballot((ev & EV_ENTER) != 0u);
         const unsigned long long b_ray = __ballot((ev & (EV_FINISH | EV_NEWRAY)) != 0u);
@@ -1009,7 +1011,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     // exit distance = t of the next TraceStep: the next step of this level, or -- if this
                     // level cannot step any more -- of the enclosing cube grid; none => the span is never emitted
                     double t_exit = 0.0;
-                    if (!(st & ST_DEAD)) {
+                    if (!(ev & EV_DEAD)) {
                         const int pk = pick_axis(tx, ty, tz);
                         t_exit = (pk == 0 ? tx : (pk == 1 ? ty : tz)) * as;
                     } else if (inb && (st & ST_OUTER_ALIVE)) {
@@ -1132,7 +1134,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 // suspend the outer level; its Face goes to st[16..18]
                 c64[C_STX][tid] = tx; c64[C_STY][tid] = ty; c64[C_STZ][tid] = tz; c64[C_SLAST][tid] = last_t;
                 c32[K_SRX][tid] = rx; c32[K_SRY][tid] = ry; c32[K_SRZ][tid] = rz; c32[K_SBOFF][tid] = boff;
-                st = (st & ~((7u << 16) | ST_OUTER_ALIVE)) | (face_now() << 16) | ((st & ST_DEAD) ? 0u : ST_OUTER_ALIVE);
+                st = (st & ~((7u << 16) | ST_OUTER_ALIVE)) | (face_now() << 16) | ((ev & EV_DEAD) ? 0u : ST_OUTER_ALIVE);
                 const int ilx = (int)(blk_vlo & 255u), ily = (int)((blk_vlo >> 8) & 255u), ilz = (int)((blk_vlo >> 16) & 255u);
                 const int isx = (int)(blk_vsz & 255u), isy = (int)((blk_vsz >> 8) & 255u), isz = (int)((blk_vsz >> 16) & 255u);
                 const RayDir rd = make_rd(c64[C_DX][tid], c64[C_DY][tid], c64[C_DZ][tid]);
@@ -1150,8 +1152,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 // a produced first voxel still needs its lookup (FRESH); a level that produced nothing, or ended with it, is DEAD
                 const bool dead = !got || lvl_fl(f) != FL_INBOUNDS;
                 lax = 8u | ((f.st >> 2) & 7u);
-                st = (st & ~(ST_DEAD | ST_FRESH)) | ST_IN_BLOCK | (got ? ST_FRESH : 0u) | (dead ? ST_DEAD : 0u);
-                ev &= ~EV_ENTER;
+                st |= ST_IN_BLOCK;
+                ev = (got ? EV_FRESH : 0u) | (dead ? EV_DEAD : 0u);
             }
             // -- finishing a ray: TracingState::finish + layer tail + (last sample) encode & store --
             uint32_t pxy = 0;
@@ -1257,7 +1259,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                         tot_outer += dg.n_outer; tot_inner += dg.n_inner; tot_hits += dg.n_hits; tot_light += dg.n_light;
                     }
                     sample = 0;
-                    ev = EV_NEWRAY | 64u;  // 64: take a new pixel
+                    ev = EV_NEWRAY | EV_TAKE;
                 }
             }
             // -- starting a ray: lane refill + Camera::project_ndc_into_world + Raycaster::within --
@@ -1265,7 +1267,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 // wave-level refill (uniform control flow): hand the next unassigned pixels to the
                 // lanes that finished a pixel -- ballot + prefix popcount -- pulling a fresh tile
                 // from the global counter whenever the current one is used up.
-                bool want = (ev & (EV_NEWRAY | 64u)) == (EV_NEWRAY | 64u);
+                bool want = (ev & (EV_NEWRAY | EV_TAKE)) == (EV_NEWRAY | EV_TAKE);
                 for (;;) {
                     const unsigned long long need = __ballot(want);
                     if (need == 0ull) break;
@@ -1316,7 +1318,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             if (run == EV_FINISH && (ev & EV_NEWRAY) && ev != EV_DONE) {
                 const uint32_t x = pxy & 0xffffu, lrow = pxy >> 16;
                 const size_t pix = (size_t)lrow * F.width + x;
-                if (ev & 64u) {
+                if (ev & EV_TAKE) {
                     if (n_samples == 4) { c32[K_S0][tid] = 0u; c32[K_S1][tid] = 0u; c32[K_S2][tid] = 0u; c32[K_ST][tid] = 0u; }  // 0.f
                     if (DIAG) {
                         dg.n_outer = dg.n_inner = dg.n_hits = dg.n_light = 0; dg.hit = 0; dg.res = dg.face = dg.block = 0; dg.t = 0.0;
@@ -1367,7 +1369,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     cb_add(acc, F.backdrop[0] * a, F.backdrop[1] * a, F.backdrop[2] * a, 1.0f - a);
                 }
                 count = 0;
-                st = ST_DEAD | ((uint32_t)sample << 14);
+                st = (uint32_t)sample << 14;
                 if (L.present) {
                     double o[3], f[3];
                     unproject(L.inv, px, py, 0.0, o);
@@ -1400,9 +1402,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     thr = outer_thr;
                     const bool dead = !got || lvl_fl(fs) != FL_INBOUNDS;
                     lax = 8u | ((fs.st >> 2) & 7u);
-                    st = ST_TRACED | (octant << 24) | (got ? ST_FRESH : 0u) | (dead ? ST_DEAD : 0u) | ((uint32_t)sample << 14);
+                    st = ST_TRACED | (octant << 24) | ((uint32_t)sample << 14);
                     if (cb_opaque(acc)) st |= ST_OPAQUE;
-                    ev = 0u;
+                    ev = (got ? EV_FRESH : 0u) | (dead ? EV_DEAD : 0u);
                 } else {
                     ev = EV_FINISH;
                 }
@@ -1417,52 +1419,53 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         // volume: same registers, same code, one 2-byte lookup in the shared pool
         // (SurfaceIter::next + Raycaster::next + State::step).
         //
-        // The trip is branch-free at the source level: every decision is a wave mask (SGPR pair, SALU
-        // logic), and the per-lane state is updated IN PLACE by short exec-masked instruction runs
-        // written as inline assembly. (Left to the compiler, the divergent branches of this loop turn
-        // into chains of Flow blocks with ~150 register copies per trip; measured in profiles/.)
-#pragma unroll 1
-        for (int rep = 0; rep < AIC_STEP_REPS; rep++) {
-        const unsigned long long m_act = __builtin_amdgcn_ballot_w64(ev == 0u);
-        if (rep > 0 && m_act == 0ull) break;
-        AIC_PROF(10, 1);
-        AIC_PROF(11, __popcll(m_act));
+        // The chip issues about one instruction per 4.4 cycles per SIMD whatever its kind (tools/ubench/issue_rate),
+        // so the trip is written for instruction count: every decision is a 64-bit wave mask in SGPRs (a lane flag
+        // costs nothing to test), per-lane state is updated IN PLACE by short exec-masked runs in inline assembly
+        // (left to the compiler, the divergent branches of this loop become chains of Flow blocks with ~150 register
+        // copies per trip), and the rare paths -- leaving a block, applying a pending span -- sit behind uniform
+        // branches.
         {
-            const bool act = ev == 0u;
-            const bool inb = (st & ST_IN_BLOCK) != 0;
-            const bool fresh = act && (st & ST_FRESH) != 0;     // first cube of a level: already emitted by the event
-            const bool dead = act && (st & ST_DEAD) != 0;
-            const bool stepped = act && (st & (ST_FRESH | ST_DEAD)) == 0u;  // the level takes its next step
+        typedef unsigned long long mask_t;
+        mask_t m_act = m_st;                                                           // lanes stepping
+        mask_t m_fresh = __builtin_amdgcn_ballot_w64((ev & EV_FRESH) != 0u);           // (only ever set on stepping lanes)
+        mask_t m_dead = __builtin_amdgcn_ballot_w64((ev & EV_DEAD) != 0u) & m_act;
+        mask_t m_inb = __builtin_amdgcn_ballot_w64((st & ST_IN_BLOCK) != 0u);
+        mask_t m_opq = __builtin_amdgcn_ballot_w64((st & ST_OPAQUE) != 0u);
+        mask_t m_hl = VOL ? __builtin_amdgcn_ballot_w64((st & ST_HAS_LAST) != 0u) : 0ull;
+#define AIC_LANE(m) __builtin_amdgcn_inverse_ballot_w64(m)
+#pragma unroll 1
+        for (int rep = 0; rep < AIC_STEP_REPS && m_act != 0ull; rep++) {
+            AIC_PROF(10, 1);
+            AIC_PROF(11, __popcll(m_act));
+            const mask_t m_act0 = m_act;
+            const mask_t m_step = m_act & ~(m_fresh | m_dead);  // the level takes its next step
             // -- State::step (raycast.rs:577-626) along the axis of the smallest t_max (strict <, ties to the
             //    later axis: raycast.rs:584-596): X iff tx<ty && tx<tz, Y iff !(tx<ty) && ty<tz, else Z.
             //    One exec-masked run per axis: last_t = t; t += t_delta; steps_left -= 1; offset += stride. --
             {
-                const unsigned long long m_step = __builtin_amdgcn_ballot_w64(stepped);
-                unsigned long long sv, mx, mz;
+                mask_t sv, mx;
                 asm volatile(
+                    "s_and_saveexec_b64 %[sv], %[m]\n\t"
                     "v_cmp_lt_f64 %[mx], %[tx], %[ty]\n\t"
-                    "v_cmp_lt_f64 %[mz], %[tx], %[tz]\n\t"
-                    "v_cmp_lt_f64 vcc, %[ty], %[tz]\n\t"
-                    "s_mov_b64 %[sv], exec\n\t"
-                    "s_andn2_b64 vcc, vcc, %[mx]\n\t"
-                    "s_and_b64 %[mx], %[mx], %[mz]\n\t"
-                    "s_and_b64 vcc, vcc, %[m]\n\t"
-                    "s_and_b64 %[mx], %[mx], %[m]\n\t"
-                    "s_or_b64 %[mz], %[mx], vcc\n\t"
-                    "s_andn2_b64 %[mz], %[m], %[mz]\n\t"
-                    "s_mov_b64 exec, %[mx]\n\t"
+                    "v_cmp_lt_f64 vcc, %[tx], %[tz]\n\t"
+                    "s_and_b64 exec, %[mx], vcc\n\t"              // X
                     "v_mov_b64 %[lt], %[tx]\n\t"
                     "v_add_f64 %[tx], %[tx], %[tdx]\n\t"
                     "v_add_u32 %[rx], -1, %[rx]\n\t"
                     "v_add_u32 %[bo], %[bo], %[ssx]\n\t"
                     "v_mov_b32 %[lax], 0\n\t"
-                    "s_mov_b64 exec, vcc\n\t"
+                    "s_andn2_b64 exec, %[m], exec\n\t"            // stepping lanes that did not take X
+                    "v_cmp_lt_f64 vcc, %[ty], %[tz]\n\t"
+                    "s_andn2_b64 %[mx], vcc, %[mx]\n\t"           // Y = (ty < tz) & !(tx < ty)   [mx held tx<ty]
+                    "s_andn2_b64 vcc, exec, %[mx]\n\t"            // Z = the rest
+                    "s_mov_b64 exec, %[mx]\n\t"
                     "v_mov_b64 %[lt], %[ty]\n\t"
                     "v_add_f64 %[ty], %[ty], %[tdy]\n\t"
                     "v_add_u32 %[ry], -1, %[ry]\n\t"
                     "v_add_u32 %[bo], %[bo], %[ssy]\n\t"
                     "v_mov_b32 %[lax], 1\n\t"
-                    "s_mov_b64 exec, %[mz]\n\t"
+                    "s_mov_b64 exec, vcc\n\t"
                     "v_mov_b64 %[lt], %[tz]\n\t"
                     "v_add_f64 %[tz], %[tz], %[tdz]\n\t"
                     "v_add_u32 %[rz], -1, %[rz]\n\t"
@@ -1470,25 +1473,24 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     "v_mov_b32 %[lax], 2\n\t"
                     "s_mov_b64 exec, %[sv]\n\t"
                     : [tx] "+v"(tx), [ty] "+v"(ty), [tz] "+v"(tz), [lt] "+v"(last_t), [rx] "+v"(rx), [ry] "+v"(ry), [rz] "+v"(rz),
-                      [bo] "+v"(boff), [lax] "+v"(lax), [sv] "=&s"(sv), [mx] "=&s"(mx), [mz] "=&s"(mz)
+                      [bo] "+v"(boff), [lax] "+v"(lax), [sv] "=&s"(sv), [mx] "=&s"(mx)
                     : [tdx] "v"(tdx), [tdy] "v"(tdy), [tdz] "v"(tdz), [ssx] "v"(ssx), [ssy] "v"(ssy), [ssz] "v"(ssz), [m] "s"(m_step)
                     : "vcc");
             }
             // -- left the bounds? (raycast.rs:265-274) only the axis just stepped can have run out of steps --
-            const bool is_exit = stepped && (min(rx, min(ry, rz)) == 0u);
+            const mask_t m_exit = __builtin_amdgcn_ballot_w64(min(rx, min(ry, rz)) == 0u) & m_step;
             // -- can the level step again? valid_for_stepping (raycast.rs:563-570): the smallest t_max is finite.
             //    t_max values are non-negative and NaN-free, so their order is the order of their bit patterns
             //    and the smallest one is finite iff the smallest high word is below the infinity pattern --
             const uint32_t hmin = min((uint32_t)__double2hiint(tx), min((uint32_t)__double2hiint(ty), (uint32_t)__double2hiint(tz)));
-            const bool valid = hmin < 0x7ff00000u;
-            const bool in_step = stepped && !is_exit;      // stepped into an in-bounds cube
+            const mask_t m_valid = __builtin_amdgcn_ballot_w64(hmin < 0x7ff00000u);
             // a cube is produced by a fresh level, or by a step that stays in bounds and can go on stepping
-            const bool lookup = fresh || (in_step && valid);
-            const bool level_over = is_exit || (in_step && !valid) || dead;
+            const mask_t m_lookup = m_fresh | (m_step & ~m_exit & m_valid);
+            // the level is over: it left its bounds, cannot step again, or had ended before
+            const mask_t m_over = (m_step & ~m_lookup) | m_dead;
             // -- the lookup: one u16 from the pool, for whichever level this is (scalar base + 32-bit byte offset) --
             {
-                const unsigned long long m_lookup = __builtin_amdgcn_ballot_w64(lookup);
-                unsigned long long sv;
+                mask_t sv;
                 asm volatile(
                     "s_mov_b64 %[sv], exec\n\t"
                     "s_mov_b64 exec, %[m]\n\t"
@@ -1498,34 +1500,36 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     : [bo] "v"(boff), [pool] "s"(pool_bits), [m] "s"(m_lookup)
                     : "memory");
             }
-            st &= ~ST_FRESH;  // (harmless for lanes that are not stepping: FRESH is only ever set together with ev = 0)
-            if (DIAG) { if (lookup) { if (inb) dg.n_inner++; else dg.n_outer++; } }
+            if (DIAG) { dg.n_inner += AIC_LANE(m_lookup & m_inb) ? 1u : 0u; dg.n_outer += AIC_LANE(m_lookup & ~m_inb) ? 1u : 0u; }
+            const mask_t m_produced = m_lookup | m_exit;  // the include_exit step is an Invisible TraceStep
+            // ---- TracingState::count_step_should_stop (sr.rs:625-656) ----
+            asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(count) : "s"(m_produced) : "vcc");
+            const mask_t m_stop = m_produced & (__builtin_amdgcn_ballot_w64(count > 1000u) | m_opq);
+            const mask_t m_go = m_produced & ~m_stop;
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw));
             // TraceStep of a looked-up code: voxel -- visible iff its (re-ordered) palette code is past the invisible
             // ones; cube -- the class of its block rides in the top two bits of the grid entry (aic_device.h)
-            bool is_block, is_surface;
+            mask_t m_blk, m_surf;
             if (BIG) {
                 // block tables past 16384 entries: plain 16-bit indices, classes from the table in global memory
                 uint32_t cls = 0u;
-                if (lookup && !inb) cls = (L.cls[raw >> 4] >> ((raw & 15u) << 1)) & 3u;
-                is_block = cls == 2u;
-                is_surface = lookup && (inb ? raw >= thr : cls == 1u);
+                if (AIC_LANE(m_lookup & ~m_inb)) cls = (L.cls[raw >> 4] >> ((raw & 15u) << 1)) & 3u;
+                m_blk = __builtin_amdgcn_ballot_w64(cls == 2u);
+                m_surf = (__builtin_amdgcn_ballot_w64(raw >= thr) & m_lookup & m_inb) | __builtin_amdgcn_ballot_w64(cls == 1u);
             } else {
-                is_block = lookup && !inb && raw >= (2u << kCubeClassShift);
-                is_surface = lookup && !is_block && raw >= thr;
+                m_blk = __builtin_amdgcn_ballot_w64(raw >= (2u << kCubeClassShift)) & m_lookup & ~m_inb;
+                m_surf = __builtin_amdgcn_ballot_w64(raw >= thr) & m_lookup & ~m_blk;
             }
-            const bool something = is_block || is_surface;
-            const bool produced = lookup || is_exit;  // the include_exit step is an Invisible TraceStep
+            const mask_t m_some = m_blk | m_surf;
             // -- the level is finished: resume the cube grid, or the ray is complete --
             // (degenerate rays only) a surface / block produced by a level that is over still needs this level's
-            // state for its event: end the level now, leave it on the next trip
-            const bool defer = level_over && something;
-            const bool leave = level_over && !something && inb;
-            const bool ray_over = level_over && !something && !inb;
-            st |= (defer || ray_over) ? ST_DEAD : 0u;
-            const unsigned long long m_leave = __builtin_amdgcn_ballot_w64(leave);
+            // state for its event: the level stays, marked dead, and is left on a later trip
+            const mask_t m_defer = m_over & m_some;
+            const mask_t m_leave = m_over & ~m_some & m_inb;
+            const mask_t m_rayover = m_over & ~m_some & ~m_inb;
+            mask_t m_newdead = 0ull;
             if (m_leave != 0ull) {
-                unsigned long long sv;
+                mask_t sv;
                 asm volatile(
                     "s_mov_b64 %[sv], exec\n\t"
                     "s_mov_b64 exec, %[m]\n\t"
@@ -1546,28 +1550,31 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                       [o3] "n"(C_SLAST * AIC_WG_THREADS * 8), [p0] "n"(K_SRX * AIC_WG_THREADS * 4), [p1] "n"(K_SRY * AIC_WG_THREADS * 4),
                       [p2] "n"(K_SRZ * AIC_WG_THREADS * 4), [p3] "n"(K_SBOFF * AIC_WG_THREADS * 4)
                     : "memory");
+                const bool leave = AIC_LANE(m_leave);
                 ssx = leave ? ((st & (1u << 26)) ? ostx : -ostx) : ssx;
                 ssy = leave ? ((st & (1u << 25)) ? osty : -osty) : ssy;
                 ssz = leave ? ((st & (1u << 24)) ? 2 : -2) : ssz;
                 thr = leave ? outer_thr : thr;
                 // outer level: its Face from st[16..18]; it goes on stepping if it was alive
                 lax = leave ? (8u | ((st >> 16) & 7u)) : lax;
-                st = leave ? ((st & ~(ST_IN_BLOCK | ST_DEAD)) | ((st & ST_OUTER_ALIVE) ? 0u : ST_DEAD)) : st;
+                st = leave ? (st & ~ST_IN_BLOCK) : st;
+                m_inb &= ~m_leave;
+                m_newdead = m_leave & ~__builtin_amdgcn_ballot_w64((st & ST_OUTER_ALIVE) != 0u);
             }
-            // ---- TracingState::count_step_should_stop (sr.rs:625-656) ----
-            count += produced ? 1u : 0u;
-            const bool stop = produced && (count > 1000u || (st & ST_OPAQUE) != 0u);
-            const bool go_on = produced && !stop;
             // ---- DepthIter::next (surface.rs:453-491): a pending surface's span ends at this step;
             // its contribution was computed when it was shaded, apply it now ----
             if (VOL) {
-                const bool apply = go_on && (st & ST_HAS_LAST) != 0u;
-                if (__builtin_amdgcn_ballot_w64(apply) != 0ull) {
+                const mask_t m_apply = m_go & m_hl;
+                if (m_apply != 0ull) {
+                    const bool apply = AIC_LANE(m_apply);
                     acc.l0 = apply ? acc.l0 + pend0 * acc.t : acc.l0;
                     acc.l1 = apply ? acc.l1 + pend1 * acc.t : acc.l1;
                     acc.l2 = apply ? acc.l2 + pend2 * acc.t : acc.l2;
                     acc.t = apply ? acc.t * pend_tr : acc.t;
-                    st = apply ? ((st & ~ST_HAS_LAST) | (cb_opaque(acc) ? ST_OPAQUE : 0u)) : st;
+                    const mask_t m_now_opq = __builtin_amdgcn_ballot_w64(acc.t < 1.0f / 256.0f) & m_apply;  // cb_opaque
+                    st = apply ? ((st & ~ST_HAS_LAST) | (AIC_LANE(m_now_opq) ? ST_OPAQUE : 0u)) : st;
+                    m_hl &= ~m_apply;
+                    m_opq |= m_now_opq;
                     if (DIAG && apply && pend_visible) {
                         dg.n_hits++;
                         dg.n_light += pend_d.nlight;
@@ -1580,18 +1587,26 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 }
             }
             // DepthIter emits a second, buffered item for EnterBlock (surface.rs:478-488): count it too
-            bool stop2 = false;
+            mask_t m_stop2 = 0ull;
             if (VOL) {
-                const bool second = go_on && is_block;
-                count += second ? 1u : 0u;
-                stop2 = second && (count > 1000u || (st & ST_OPAQUE) != 0u);
+                const mask_t m_second = m_go & m_blk;
+                asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(count) : "s"(m_second) : "vcc");
+                m_stop2 = m_second & (__builtin_amdgcn_ballot_w64(count > 1000u) | m_opq);
             }
-            uint32_t nev = 0u;
-            nev = (go_on && is_surface) ? EV_SHADE : nev;
-            nev = (go_on && is_block) ? EV_ENTER : nev;
-            nev = (stop || stop2 || ray_over) ? EV_FINISH : nev;
-            ev = act ? nev : ev;
+            const mask_t m_shade = m_go & m_surf;
+            const mask_t m_enter = m_go & m_blk & ~m_stop2;
+            const mask_t m_fin = m_stop | m_stop2 | m_rayover;
+            // new event words: acting lanes drop FRESH / DEAD, then take what this trip decided
+            ev = AIC_LANE(m_act0) ? 0u : ev;
+            ev = AIC_LANE(m_shade) ? EV_SHADE : ev;
+            ev = AIC_LANE(m_enter) ? EV_ENTER : ev;
+            ev = AIC_LANE(m_fin) ? EV_FINISH : ev;
+            if ((m_defer | m_newdead) != 0ull) ev = AIC_LANE((m_defer & ~m_fin) | m_newdead) ? (ev | EV_DEAD) : ev;
+            m_act &= ~(m_shade | m_enter | m_fin);
+            m_dead = m_newdead & m_act;
+            m_fresh = 0ull;
         }
+#undef AIC_LANE
         }
         AIC_TICK(12);
     }

@@ -15,13 +15,13 @@
 #define REP8(x) REP4(x) REP4(x)
 
 enum Op { ADD_U32, CNDMASK, CMP_F64, ADD_F64, FMA_F32, MOV_B32, MAD_U64_U32, MUL_LO_U32, MAD_U32_U24, MIN3_U32, SALU_AND,
-          READLANE, LDS_READ_B32, LDS_READ_U16, MIX_DDA, MOV_B64, LSHL_ADD_U64, CMP_U32, N_OPS };
+          READLANE, LDS_READ_B32, LDS_READ_U16, MIX_DDA, MOV_B64, LSHL_ADD_U64, CMP_U32, VS_MIX, VS_MIX_CMP, N_OPS };
 static const char *kNames[N_OPS] = {"v_add_u32", "v_cndmask_b32", "v_cmp_lt_f64", "v_add_f64", "v_fma_f32", "v_mov_b32",
                                     "v_mad_u64_u32", "v_mul_lo_u32", "v_mad_u32_u24", "v_min3_u32", "s_and_b64", "v_readlane_b32",
                                     "ds_read_b32", "ds_read_u16", "mix(3cmp64,3add64,8cnd,8int)", "v_mov_b64", "v_lshl_add_u64",
-                                    "v_cmp_eq_u32"};
+                                    "v_cmp_eq_u32", "16 v_add_f64 + 16 s_and_b64", "16 v_cmp_lt_f64 + 16 s_and_b64"};
 // instructions per inner block (each block is 32 instructions, except MIX = 22)
-static const int kPerBlock[N_OPS] = {32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 22, 32, 32, 32};
+static const int kPerBlock[N_OPS] = {32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 22, 32, 32, 32, 32, 32};
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t *ticks, int iters) {
@@ -109,6 +109,17 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t *ticks, int ite
                          "s_waitcnt lgkmcnt(0)\n"
                          : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6), "=&v"(a7) : "v"(la) : "memory");
             la = (la + (a0 & 1022u)) & 8190u;
+        } else if (OP == VS_MIX) {
+            // does scalar work issue beside vector work (different waves), or do both share one issue slot per SIMD?
+            asm volatile(REP4("v_add_f64 %0, %0, %8\n s_and_b64 %9, %9, %10\n v_add_f64 %1, %1, %8\n s_and_b64 %10, %10, %11\n"
+                              "v_add_f64 %2, %2, %8\n s_and_b64 %11, %11, %12\n v_add_f64 %3, %3, %8\n s_and_b64 %12, %12, %9\n")
+                         REP4("v_add_f64 %4, %4, %8\n s_and_b64 %9, %9, %10\n v_add_f64 %5, %5, %8\n s_and_b64 %10, %10, %11\n"
+                              "v_add_f64 %6, %6, %8\n s_and_b64 %11, %11, %12\n v_add_f64 %7, %7, %8\n s_and_b64 %12, %12, %9\n")
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(dc), "s"(s0), "s"(s1), "s"(s2), "s"(s3) : "scc");
+        } else if (OP == VS_MIX_CMP) {
+            asm volatile(REP4("v_cmp_lt_f64 vcc, %0, %1\n s_and_b64 %4, %4, vcc\n v_cmp_lt_f64 vcc, %1, %2\n s_and_b64 %5, %5, vcc\n"
+                              "v_cmp_lt_f64 vcc, %2, %3\n s_and_b64 %6, %6, vcc\n v_cmp_lt_f64 vcc, %3, %0\n s_and_b64 %7, %7, vcc\n")
+                         : : "v"(d0), "v"(d1), "v"(d2), "v"(d3), "s"(s0), "s"(s1), "s"(s2), "s"(s3) : "vcc", "scc");
         } else if (OP == MIX_DDA) {
             // the arithmetic skeleton of one DDA step: 3 f64 compares, 3 f64 adds, 8 selects, 8 integer ops
             asm volatile("v_cmp_lt_f64 %12, %0, %1\n v_cmp_lt_f64 %13, %0, %2\n v_cmp_lt_f64 vcc, %1, %2\n"
@@ -185,5 +196,7 @@ int main() {
     sweep<LDS_READ_B32>(n_cus);
     sweep<LDS_READ_U16>(n_cus);
     sweep<MIX_DDA>(n_cus);
+    sweep<VS_MIX>(n_cus);
+    sweep<VS_MIX_CMP>(n_cus);
     return 0;
 }
