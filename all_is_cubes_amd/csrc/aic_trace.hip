@@ -298,39 +298,30 @@ AIC_DEV NextResult lvl_next(Lvl s, const Lim lim, const RayDir rd, int lox, int 
 }
 
 // RaycastStep::intersection_point (raycast.rs:409-439) for the step currently held in `s`.
+//
+// Same arithmetic as the reference, written without per-axis control flow. For an axis the ray moves along
+// and that is not the face just crossed, the reference adds  1 - clamp((t_max - t) * d)  going up and
+// clamp(-((t_max - t) * d))  going down; -(x * d) == x * (-d) exactly, so both clamp the one product
+// (t_max - t) * |d|. That product is never NaN (t is finite, d finite and non-zero on this path), hence
+// f64::clamp(0, 1) == min(max(c, 0), 1); its only other freedom, the sign of a zero, cannot reach the result
+// (1 - +-0 == 1, and cube + +-0 == cube because an integer-valued cube coordinate is never -0).
+AIC_DEV double ip_axis(bool is_face_axis, bool within, int cube, double o, double d, double t_max, double last_t) {
+    const double cc = (double)cube;
+    const bool neg = d < 0.0;                        // signum_101(d) < 0
+    double c = (t_max - last_t) * fabs(d);
+    c = fmin(fmax(c, 0.0), 1.0);
+    const double moved = cc + (neg ? c : 1.0 - c);   // normal cube face hit
+    const double plane = cc + (neg ? 1.0 : 0.0);     // the plane just crossed
+    double v = is_face_axis ? plane : ((d == 0.0) ? o : moved);   // signum_101(d) == 0: the ray does not move from the origin
+    return within ? o : v;
+}
 AIC_DEV void intersection_point(const Lvl s, double ox, double oy, double oz, double dx, double dy, double dz, double out[3]) {
     const int face = lvl_face(s);
-    if (face == FACE_WITHIN) {
-        out[0] = ox; out[1] = oy; out[2] = oz;
-        return;
-    }
-    const int face_axis = (face - 1) % 3;
-    const double o[3] = {ox, oy, oz}, d[3] = {dx, dy, dz}, tm[3] = {s.tx, s.ty, s.tz};
-    const int cc[3] = {s.cx, s.cy, s.cz};
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        double v = (double)cc[a];
-        const int sd = signum_101(d[a]);
-        if (a == face_axis) {
-            if (sd < 0) v += 1.0;
-        } else if (sd == 0) {
-            v = o[a];
-        } else {
-            const double off = (tm[a] - s.last_t) * d[a];
-            if (sd > 0) {
-                double c = off;
-                if (c < 0.0) c = 0.0;
-                if (c > 1.0) c = 1.0;
-                v += 1. - c;
-            } else {
-                double c = -off;
-                if (c < 0.0) c = 0.0;
-                if (c > 1.0) c = 1.0;
-                v += c;
-            }
-        }
-        out[a] = v;
-    }
+    const bool within = face == FACE_WITHIN;
+    const int face_axis = face > 3 ? face - 4 : face - 1;  // Face::axis(): NX NY NZ PX PY PZ = 1..6
+    out[0] = ip_axis(face_axis == 0, within, s.cx, ox, dx, s.tx, s.last_t);
+    out[1] = ip_axis(face_axis == 1, within, s.cy, oy, dy, s.ty, s.last_t);
+    out[2] = ip_axis(face_axis == 2, within, s.cz, oz, dz, s.tz, s.last_t);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -738,16 +729,16 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u
 #define AIC_MIN_WAVES 4  // waves per SIMD the production variants are built for (128 VGPRs; cold lane state lives in LDS)
 #endif
 #ifndef AIC_T_BATCH
-#define AIC_T_BATCH 32  // run a kind of parked work once this many lanes wait on it
+#define AIC_T_BATCH 40  // run a kind of parked work once this many lanes wait on it
 #endif
 #ifndef AIC_N_FEW
-#define AIC_N_FEW 32    // ... or once at most this many lanes can still step
+#define AIC_N_FEW 24    // ... or once at most this many lanes can still step
 #endif
 #ifndef AIC_WG_THREADS
 #define AIC_WG_THREADS 256  // threads per persistent workgroup (a multiple of 64)
 #endif
 #ifndef AIC_STEP_REPS
-#define AIC_STEP_REPS 4  // DDA steps per scheduler trip
+#define AIC_STEP_REPS 8  // DDA steps per scheduler trip
 #endif
 
 // Runs Raycaster::next (raycast.rs:239-284) on a freshly initialised level until it yields its
@@ -864,7 +855,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
 
     uint32_t ev = EV_NEWRAY | EV_TAKE;  // every lane starts by taking a pixel
 #ifdef AIC_PROFILE
-    uint32_t prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t prof[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t prof_tm = (uint32_t)__builtin_readcyclecounter();
     const uint32_t prof_t0 = prof_tm;
 #define AIC_PROF(i, v) prof[i] += (uint32_t)(v)
@@ -927,6 +918,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             const int n_few = half < AIC_N_FEW ? half : AIC_N_FEW;
             if (best > 0 && (best >= t_batch || n_step <= n_few)) run = kind;
         }
+        AIC_TICK(19);
         if (run != 0u) {
             // ============================ event phase ======================================
             AIC_PROF(0, 1);
@@ -992,6 +984,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                         i0 = il[0]; i1 = il[1]; i2 = il[2];
                     }
                 }
+                AIC_TICK(18);
                 // colour record
                 float r, g, b, a, e0, e1, e2;
                 if (shade_ref & 0x80000000u) {
@@ -1262,6 +1255,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     ev = EV_NEWRAY | EV_TAKE;
                 }
             }
+            if (run == EV_FINISH) { AIC_TICK(16) }
             // -- starting a ray: lane refill + Camera::project_ndc_into_world + Raycaster::within --
             if (run == EV_FINISH) {
                 // wave-level refill (uniform control flow): hand the next unassigned pixels to the
@@ -1315,6 +1309,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     next_idx += n_need < avail ? n_need : avail;
                 }
             }
+            if (run == EV_FINISH) { AIC_TICK(17) }
             if (run == EV_FINISH && (ev & EV_NEWRAY) && ev != EV_DONE) {
                 const uint32_t x = pxy & 0xffffu, lrow = pxy >> 16;
                 const size_t pix = (size_t)lrow * F.width + x;
@@ -1625,7 +1620,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         atomicMax(&F.counters->prof[1], (unsigned long long)prof[2]);
     }
     prof[0] = 0; prof[1] = 0;
-    if (lane == 0) for (int i = 0; i < 16; i++) atomicAdd(&F.counters->prof[i], (unsigned long long)prof[i]);
+    if (lane == 0) for (int i = 0; i < 24; i++) atomicAdd(&F.counters->prof[i], (unsigned long long)prof[i]);
 #endif
     // ---- RaytraceInfo sum (renderer.rs:555): wave reduction then one atomic per wave ----
     unsigned long long s = c32[K_STEPS][tid];
