@@ -18,11 +18,8 @@ _LIB_PATH = _HERE / "libaic_oracle.so"
 
 
 def build(force: bool = False) -> Path:
-    src = _HERE / "aic_oracle.cpp"
-    hdr = _HERE / "aic_oracle.h"
-    stale = (not _LIB_PATH.exists()) or any(
-        p.stat().st_mtime > _LIB_PATH.stat().st_mtime for p in (src, hdr)
-    )
+    srcs = (_HERE / "aic_oracle.cpp", _HERE / "aic_light.inc", _HERE / "aic_oracle.h")
+    stale = (not _LIB_PATH.exists()) or any(p.stat().st_mtime > _LIB_PATH.stat().st_mtime for p in srcs)
     if force or stale:
         subprocess.run(["make", "-C", str(_HERE), "-B" if force else "-s"], check=True)
     return _LIB_PATH
@@ -384,3 +381,66 @@ def smoothstep(x: float) -> float:
 
 def coarsestep(x: float) -> float:
     return lib().orc_coarsestep(x)
+
+
+# ---- the light updater (aic_light.inc) -------------------------------------------
+
+PRIORITY_NEWLY_VISIBLE, PRIORITY_UNINIT, PRIORITY_ESTIMATED = 250, 210, 200  # space/light/queue.rs:30-43
+
+
+def compute_derived(space: Space) -> dict:
+    """block/eval/derived.rs compute_derived per block of the space's block table."""
+    n = len(space._blocks)
+    out = np.zeros((n, 32), np.float32)
+    opaque = np.zeros((n, 6), np.uint8)
+    lib().orc_compute_derived.restype = None
+    lib().orc_compute_derived(C.byref(space.c), C.c_void_p(_p(out)), C.c_void_p(_p(opaque)))
+    return {
+        "color": out[:, 0:4].copy(),
+        "face_colors": out[:, 4:28].reshape(n, 6, 4).copy(),
+        "emission": out[:, 28:31].copy(),
+        "visible": out[:, 31] != 0,
+        "opaque": opaque != 0,
+    }
+
+
+def light_chart():
+    """(weights [n,6] f32, children [n,6] u32) of the light propagation chart; node 0 is the root."""
+    f = lib().orc_light_chart
+    f.restype = C.c_uint32
+    n = int(f(None, None))
+    w = np.zeros((n, 6), np.float32)
+    c = np.zeros((n, 6), np.uint32)
+    f(C.c_void_p(_p(w)), C.c_void_p(_p(c)))
+    return w, c
+
+
+def compute_light(space: Space, cube, maximum_distance: int = 30):
+    f = lib().orc_compute_light
+    f.restype = C.c_uint64
+    cb = _i3(cube)
+    out = np.zeros(4, np.uint8)
+    cost = int(f(C.byref(space.c), C.c_int32(maximum_distance), C.c_void_p(_p(cb)), C.c_void_p(_p(out))))
+    return out, cost
+
+
+def evaluate_light(flat_space, maximum_distance: int = 30, fast: bool = True, epsilon: int = 1, batch: int = 32,
+                   queue=None, max_updates: int = 1 << 62):
+    """`Mutation::fast_evaluate_light()` (if `fast`) + `evaluate_light(epsilon)` on a flat space with
+    `LightPhysics::Rays { maximum_distance }`. Without `fast`, starts from `flat_space.light` and `queue`
+    (a list of (cube, priority)); `queue=None` enqueues every Uninitialized cube. Writes the result into
+    `flat_space.light` and returns the number of updates."""
+    sp = Space(flat_space)
+    light = np.ascontiguousarray(flat_space.light, dtype=np.uint8).copy()
+    f = lib().orc_evaluate_light
+    f.restype = C.c_uint64
+    if queue is None:
+        nq, qc, qp = -1, np.zeros(3, np.int32), np.zeros(1, np.int32)
+    else:
+        nq = len(queue)
+        qc = np.ascontiguousarray([c for c, _ in queue], dtype=np.int32).reshape(-1, 3) if nq else np.zeros((1, 3), np.int32)
+        qp = np.ascontiguousarray([p for _, p in queue], dtype=np.int32) if nq else np.zeros(1, np.int32)
+    n = int(f(C.byref(sp.c), C.c_int32(maximum_distance), C.c_int32(1 if fast else 0), C.c_int32(epsilon), C.c_int32(batch),
+              C.c_uint64(max_updates), C.c_void_p(_p(light)), C.c_int32(nq), C.c_void_p(_p(qc)), C.c_void_p(_p(qp))))
+    flat_space.light = light.reshape(np.asarray(flat_space.light).shape)
+    return n

@@ -24,8 +24,11 @@
 
 #include "aic_oracle.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
+#include <deque>
 #include <cstdint>
 #include <cstring>
 #include <limits>
@@ -1876,3 +1879,6 @@ double orc_smoothstep(double x) { return smoothstep(x); }
 double orc_coarsestep(double x) { return coarsestep(x); }
 
 }  // extern "C"
+
+// part 2: the light updater
+#include "aic_light.inc"

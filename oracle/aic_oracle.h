@@ -177,6 +177,19 @@ void orc_block_sky(const orc_space *space, uint8_t out_faces_mean[7][4]);
 double orc_smoothstep(double x);
 double orc_coarsestep(double x);
 
+/* ---- the light updater (aic_light.inc) ---- */
+/* compute_derived (block/eval/derived.rs:78-240) per block: out[n_blocks][32] = color rgba, 6 face colours rgba
+ * (nx ny nz px py pz), emission rgb, visible; out_opaque[n_blocks][6]. */
+void orc_compute_derived(const orc_space *space, float *out, uint8_t *out_opaque);
+/* the light propagation chart (space/light/chart/generator.rs): node count; weights[n][6], children[n][6] if non-null */
+uint32_t orc_light_chart(float *weights, uint32_t *children);
+/* LightStorage::compute_light (updater.rs:368-417) for one cube against space->light; returns the cost */
+uint64_t orc_compute_light(const orc_space *space, int32_t maximum_distance, const int32_t cube[3], uint8_t out_texel[4]);
+/* Mutation::fast_evaluate_light / evaluate_light (space.rs:1496-1540); see aic_light.inc */
+uint64_t orc_evaluate_light(const orc_space *space, int32_t maximum_distance, int32_t fast, int32_t epsilon, int32_t batch,
+                            uint64_t max_updates, uint8_t *light_inout, int32_t n_queue, const int32_t *queue_cubes,
+                            const int32_t *queue_priorities);
+
 #ifdef __cplusplus
 }
 #endif
