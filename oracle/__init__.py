@@ -425,11 +425,12 @@ def compute_light(space: Space, cube, maximum_distance: int = 30):
 
 
 def evaluate_light(flat_space, maximum_distance: int = 30, fast: bool = True, epsilon: int = 1, batch: int = 32,
-                   queue=None, max_updates: int = 1 << 62):
+                   queue=None, max_updates: int = 1 << 62, hb_width: int = 16):
     """`Mutation::fast_evaluate_light()` (if `fast`) + `evaluate_light(epsilon)` on a flat space with
     `LightPhysics::Rays { maximum_distance }`. Without `fast`, starts from `flat_space.light` and `queue`
     (a list of (cube, priority)); `queue=None` enqueues every Uninitialized cube. Writes the result into
-    `flat_space.light` and returns the number of updates."""
+    `flat_space.light` and returns the number of updates. `hb_width`: order of equal-priority updates -- 16 / 8 =
+    the reference's hashbrown table order with that Group::WIDTH, 0 = first-in-first-out (aic_light.inc)."""
     sp = Space(flat_space)
     light = np.ascontiguousarray(flat_space.light, dtype=np.uint8).copy()
     f = lib().orc_evaluate_light
@@ -441,6 +442,6 @@ def evaluate_light(flat_space, maximum_distance: int = 30, fast: bool = True, ep
         qc = np.ascontiguousarray([c for c, _ in queue], dtype=np.int32).reshape(-1, 3) if nq else np.zeros((1, 3), np.int32)
         qp = np.ascontiguousarray([p for _, p in queue], dtype=np.int32) if nq else np.zeros(1, np.int32)
     n = int(f(C.byref(sp.c), C.c_int32(maximum_distance), C.c_int32(1 if fast else 0), C.c_int32(epsilon), C.c_int32(batch),
-              C.c_uint64(max_updates), C.c_void_p(_p(light)), C.c_int32(nq), C.c_void_p(_p(qc)), C.c_void_p(_p(qp))))
+              C.c_uint64(max_updates), C.c_void_p(_p(light)), C.c_int32(nq), C.c_void_p(_p(qc)), C.c_void_p(_p(qp)), C.c_int32(hb_width)))
     flat_space.light = light.reshape(np.asarray(flat_space.light).shape)
     return n

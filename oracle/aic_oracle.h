@@ -188,7 +188,7 @@ uint64_t orc_compute_light(const orc_space *space, int32_t maximum_distance, con
 /* Mutation::fast_evaluate_light / evaluate_light (space.rs:1496-1540); see aic_light.inc */
 uint64_t orc_evaluate_light(const orc_space *space, int32_t maximum_distance, int32_t fast, int32_t epsilon, int32_t batch,
                             uint64_t max_updates, uint8_t *light_inout, int32_t n_queue, const int32_t *queue_cubes,
-                            const int32_t *queue_priorities);
+                            const int32_t *queue_priorities, int32_t hb_width);
 
 #ifdef __cplusplus
 }

@@ -41,6 +41,13 @@ PNG_CASES = [
     "layers_hidden_ui-all",
     "layers_ui_only-all",
     "no_character_but_ui-ray",
+    # lighting scenes: need the light updater (oracle/aic_light.inc) to reproduce
+    *[f"light_spread-{o}-all" for o in ("None", "Flat", "Coarse", "Linear", "Smoothstep")],
+    *[f"light_on_slab-{o}-all" for o in ("None", "Flat", "Coarse", "Linear", "Smoothstep")],
+    "fog-None-ray", "fog-Abrupt-all", "fog-Compromise-all", "fog-Physical-all",
+    "tone_map-Clamp-1.0-0.5-all", "tone_map-Clamp-1.0-2.0-all", "tone_map-Reinhard-0.5-0.5-all",
+    "tone_map-Reinhard-1.0-0.5-all", "tone_map-Reinhard-1.0-2.0-all",
+    "template-light-bench-all",
 ]
 
 

@@ -320,3 +320,116 @@ def atrium_like_space(seed: int = 7) -> flat.FlatSpace:
     sp.light[..., 3] = np.where(nonair, flat.STATUS_OPAQUE, flat.STATUS_VISIBLE)
     sp.light[nonair, 0:3] = 0
     return sp
+
+
+# ---------------------------------------------------------------------------------------------
+# Scenes of the reference's lighting image tests (test-renderers/cases/src/lib.rs:1354-1610). They carry no
+# light: tests light them with the oracle's restatement of fast_evaluate_light + evaluate_light(1).
+
+def _fill(sp: flat.FlatSpace, lo, size, index: int) -> None:
+    x0, y0, z0 = (int(l) - int(b) for l, b in zip(lo, sp.lo))
+    sp.block_index[x0 : x0 + size[0], y0 : y0 + size[1], z0 : z0 + size[2]] = index
+
+
+def _unlit(sp: flat.FlatSpace) -> flat.FlatSpace:
+    sp.light[...] = (0, 0, 0, flat.STATUS_UNINITIALIZED)
+    return sp
+
+
+DAY_SKY_COLOR = (243, 243, 255)  # palette.rs:63, the default Sky::Uniform (space/physics.rs DEFAULT)
+ALMOST_BLACK = (0x3D, 0x3D, 0x3D)  # palette.rs:82
+PLANK = (0xE8, 0xCC, 0x95)  # palette.rs:100
+
+
+# fog_test_universe 1354-1407: eye (0,10,0) looking along (0.4, 0, -1)
+def fog_test_space() -> flat.FlatSpace:
+    z_length = 60
+    sp = flat.FlatSpace((-30, 0, -z_length), (60, 20, z_length))
+    sp.set_sky_uniform(from_srgb8(DAY_SKY_COLOR))
+    sp.add_block(flat.air())
+    floor = sp.add_block(flat.atom((0.0, 1.0, 0.5, 1.0)))
+    wall = sp.add_block(flat.atom((1.0, 0.5, 0.5, 1.0)))
+    pillar = sp.add_block(flat.atom((*from_srgb8(ALMOST_BLACK), 1.0)))
+    lamp = sp.add_block(flat.atom((1.0, 0.05, 0.05, 1.0), (40.0, 0.05, 0.05)))
+    _fill(sp, (-30, 0, -z_length), (60, 1, z_length), floor)   # bounds.abut(NY, -1)
+    _fill(sp, (29, 0, -z_length), (1, 20, z_length), wall)     # bounds.abut(PX, -1)
+    for z in range(-z_length, 0, 2):
+        x = (z * 19) % 60 + (-30)
+        _fill(sp, (x, 1, z), (1, 10, 1), pillar)
+        sp.set((x, 8, z + 1), lamp)
+    return _unlit(sp)
+
+
+# light_spread_test_universe 1409-1444: eye (0,0,8) looking along -Z, fov 45
+def light_spread_space() -> flat.FlatSpace:
+    sp = flat.FlatSpace((-10, -10, -1), (20, 20, 5))
+    sp.set_sky_uniform(from_srgb8(DAY_SKY_COLOR))
+    sp.add_block(flat.air())
+    wall = sp.add_block(flat.atom((0.5, 0.5, 0.5, 1.0)))
+    pillar = sp.add_block(flat.atom((*from_srgb8(ALMOST_BLACK), 1.0)))
+    source = sp.add_block(flat.atom((1.0, 0.05, 0.05, 1.0), (10.0, 5.0, 0.0)))
+    _fill(sp, (-10, -10, -1), (20, 20, 1), wall)  # bounds.abut(NZ, -1)
+    sp.set((-2, 2, 0), source)
+    sp.set((-3, -1, 1), source)
+    for i in range(-4, 5):
+        sp.set((i, i, 0), pillar)
+    return _unlit(sp)
+
+
+def rotated_slab_block(height: int) -> flat.BlockDef:
+    """content::make_slab(height, R16) (content.rs:176-211: checkerboard of PLANK and PLANK * 1.06) rotated by
+    GridRotation::RXZy (rotation.rs to_basis: x -> +X, y -> +Z, z -> -Y; positive-octant transform, so
+    new = (x, 15 - z, y))."""
+    r = 16
+    plank = np.array(from_srgb8(PLANK), np.float32)
+    light = np.minimum(plank * np.float32(1.06), np.float32(1.0))  # Rgb01::saturating_scale (color.rs:512-518)
+    pal = np.stack([flat.evoxel((*plank, 1.0)), flat.evoxel((*light, 1.0))])
+    vox = np.zeros((r, r, height), np.uint16)  # rotated volume: x in [0,16), y in [0,16), z in [0,height)
+    for x in range(r):
+        for y in range(height):
+            for z in range(r):
+                vox[x, r - 1 - z, y] = (x + y + z) % 2
+    return flat.voxel_block(r, vox, pal, name="S")
+
+
+# light_on_slab_test_universe 1455-1500: eye (0.5,-6,6) looking along (0,1,-1), fov 45
+def light_on_slab_space() -> flat.FlatSpace:
+    sp = flat.FlatSpace((-10, -10, -1), (20, 20, 5))
+    sp.set_sky_uniform(from_srgb8(DAY_SKY_COLOR))
+    sp.add_block(flat.air())
+    wall = sp.add_block(flat.atom((0.5, 0.5, 0.5, 1.0)))
+    _fill(sp, (-10, -10, -1), (20, 20, 1), wall)
+    for height in range(1, 17):
+        position = height - 1
+        cube = (-3 + (position % 4) * 2, -3 + (position // 4) * 2, 0)
+        sp.set(cube, sp.add_block(rotated_slab_block(height)))
+    return _unlit(sp)
+
+
+TONE_MAP_LUMINANCE_RAMP = [1 / 64, 1 / 32, 1 / 16, 1 / 4, 1.0, 4.0, 16.0, 32.0, 64.0, 128.0]
+
+
+# tone_mapping_test_universe 1503-1597: eye = bounds.center() + (0,0,65) looking along -Z, fov 45
+def tone_mapping_space() -> flat.FlatSpace:
+    low = 0.25
+    colors = [(1, 0, 0), (1, low, 0), (1, 1, 0), (low, 1, 0), (0, 1, 0), (0, 1, low), (0, 1, 1), (0, low, 1), (0, 0, 1), (low, 0, 1),
+              (1, 0, 1), (1, 0, low), (1, 1, 1)]
+    xs, ys = 4, 4
+    size = (len(TONE_MAP_LUMINANCE_RAMP) * xs + 1, len(colors) * ys + 1, 3)
+    sp = flat.FlatSpace((-1, -1, -1), size)
+    sp.set_sky_uniform((0.0, 0.0, 0.0))
+    black = sp.add_block(flat.atom((*from_srgb8(ALMOST_BLACK), 1.0)))  # filled_with
+    sp.block_index[...] = black
+    wall = sp.add_block(flat.atom((0.5, 0.5, 0.5, 1.0)))
+    air = sp.add_block(flat.air())
+    _fill(sp, (-1, -1, -1), (size[0], size[1], 1), wall)   # abut(NZ, -1)
+    _fill(sp, (-1, -1, 1), (size[0], size[1], 1), air)     # abut(PZ, -1)
+    for i, luminance in enumerate(TONE_MAP_LUMINANCE_RAMP):
+        x = i * xs
+        for j, color in enumerate(colors):
+            y = j * ys
+            em = tuple(np.float32(c) * np.float32(luminance) for c in color)
+            source = sp.add_block(flat.atom((1.0, 1.0, 1.0, 1.0), em))
+            _fill(sp, (x, y, 0), (xs - 1, ys - 1, 1), air)
+            sp.set((x + 1, y, 0), source)
+    return _unlit(sp)
