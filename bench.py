@@ -47,7 +47,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
 
 
 def build_workload(name: str):
-    from tests import scenes
+    from all_is_cubes_amd import workloads as scenes
 
     if name == "atrium":
         space = scenes.atrium_like_space()

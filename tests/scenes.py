@@ -187,139 +187,10 @@ def ui_space() -> flat.FlatSpace:
     return sp
 
 
-# -- synthetic scenes for parity / bench (SURVEY.md 8d "S256") ------------------------------
-def _splitmix64(state: np.ndarray) -> np.ndarray:
-    with np.errstate(over="ignore"):
-        z = state + np.uint64(0x9E3779B97F4A7C15)
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        return z ^ (z >> np.uint64(31))
-
-
-def _hash3(x, y, z, seed) -> np.ndarray:
-    with np.errstate(over="ignore"):
-        h = (x.astype(np.uint64) * np.uint64(0x9E3779B1) ^ y.astype(np.uint64) * np.uint64(0x85EBCA77)
-             ^ z.astype(np.uint64) * np.uint64(0xC2B2AE3D) ^ np.uint64(seed))
-    return _splitmix64(h)
-
-
-def synthetic_blocks(resolution: int, count: int, seed: int = 1, palette_size: int = 16, translucent: bool = True):
-    """`count` distinct recursive blocks at `resolution`: spheres / slabs / lattices / 30% random fill."""
-    r = resolution
-    g = np.arange(r)
-    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
-    blocks = []
-    rng = np.random.default_rng(seed)
-    for k in range(count):
-        pal = np.zeros((palette_size, 8), np.float32)
-        cols = rng.uniform(0.05, 1.0, (palette_size, 3)).astype(np.float32)
-        pal[:, 0:3] = cols
-        pal[:, 3] = 1.0
-        pal[0] = 0.0  # index 0 = empty voxel
-        if translucent and k % 4 == 3:
-            pal[1:, 3] = np.float32(0.5)
-        if k % 8 == 5:
-            pal[1, 4:7] = (0.0, 0.8, 0.2)  # an emissive entry
-        shape = k % 4
-        hv = _hash3(X, Y, Z, seed * 1000 + k)
-        colour = (1 + (hv >> np.uint64(40)) % np.uint64(palette_size - 1)).astype(np.uint16)
-        if shape == 0:
-            c = (r - 1) / 2.0
-            mask = (X - c) ** 2 + (Y - c) ** 2 + (Z - c) ** 2 <= (0.48 * r) ** 2
-        elif shape == 1:
-            mask = Y < max(1, (r * (1 + k % 3)) // 4)
-        elif shape == 2:
-            q = max(1, r // 4)
-            mask = ((X % q == 0) & (Y % q == 0)) | ((Y % q == 0) & (Z % q == 0)) | ((X % q == 0) & (Z % q == 0))
-        else:
-            mask = (hv % np.uint64(100)) < np.uint64(30)
-        vox = np.where(mask, colour, 0).astype(np.uint16)
-        blocks.append(flat.voxel_block(r, vox, pal, name=chr(ord("a") + k % 26)))
-    return blocks
-
-
-def synthetic_space(n: int = 256, resolution: int = 32, n_blocks: int = 64, seed: int = 1, light: str = "one") -> flat.FlatSpace:
-    """S<n>: [0,n)^3, heightfield terrain <= n/2 high + 5% floating blocks (about 45% non-air)."""
-    sp = flat.FlatSpace((0, 0, 0), (n, n, n))
-    sp.set_sky_uniform((0.9, 0.9, 1.0))
-    a = sp.add_block(flat.air())
-    atoms = [sp.add_block(flat.atom(c)) for c in [(0.3, 0.6, 0.2, 1.0), (0.5, 0.45, 0.4, 1.0), (0.8, 0.75, 0.5, 1.0), (0.3, 0.5, 0.9, 0.5)]]
-    recs = [sp.add_block(b) for b in synthetic_blocks(resolution, n_blocks, seed)]
-    g = np.arange(n)
-    # smooth heightfield from a few seeded sinusoids
-    rng = np.random.default_rng(seed)
-    H = np.zeros((n, n))
-    for _ in range(6):
-        fx, fz = rng.uniform(0.5, 4.0, 2) * 2 * np.pi / n
-        ph = rng.uniform(0, 2 * np.pi, 2)
-        H += rng.uniform(0.3, 1.0) * np.sin(g[:, None] * fx + ph[0]) * np.cos(g[None, :] * fz + ph[1])
-    H = (H - H.min()) / (H.max() - H.min())
-    height = (0.15 * n + 0.35 * n * H).astype(np.int64)  # <= n/2
-    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
-    hv = _hash3(X, Y, Z, seed)
-    pick = (hv >> np.uint64(20)) % np.uint64(len(atoms) + len(recs))
-    table = np.array(atoms + recs, dtype=np.uint16)
-    solid = Y < height[:, None, :]
-    # top two layers recursive-heavy, interior atoms
-    surface_layer = Y >= (height[:, None, :] - 2)
-    rec_pick = table[len(atoms) + ((hv >> np.uint64(33)) % np.uint64(len(recs))).astype(np.int64)]
-    any_pick = table[pick.astype(np.int64)]
-    grid = np.where(solid, np.where(surface_layer, rec_pick, any_pick), a)
-    floating = (~solid) & ((hv % np.uint64(100)) < np.uint64(5)) & (Y < (3 * n) // 4)
-    grid = np.where(floating, rec_pick, grid)
-    sp.block_index[...] = grid.astype(np.uint16)
-    if light == "field":
-        nonair = sp.block_index != a
-        lv = (120 + 40 * np.sin(X * 0.05) * np.cos(Z * 0.07) + 20 * (Y / n)).clip(1, 200).astype(np.uint8)
-        sp.light[..., 0] = lv
-        sp.light[..., 1] = lv
-        sp.light[..., 2] = np.minimum(lv.astype(np.int64) + 6, 255).astype(np.uint8)
-        sp.light[..., 3] = np.where(nonair, flat.STATUS_OPAQUE, flat.STATUS_VISIBLE)
-        sp.light[nonair, 0:3] = 0
-    return sp
-
-
-def atrium_like_space(seed: int = 7) -> flat.FlatSpace:
-    """S-atrium-like: 19x35x51 cubes, R16 blocks, an open hall with floors,
-    arches and balconies; stands in for UniverseTemplate::Atrium (whose generator needs the
-    un-vendored noise crate and the block-evaluation engine)."""
-    lo = (-9, -1, -25)
-    size = (19, 35, 51)
-    sp = flat.FlatSpace(lo, size)
-    sp.set_sky_uniform(from_srgb8((243, 243, 255)))  # DAY_SKY_COLOR palette.rs:63
-    a = sp.add_block(flat.air())
-    stone = sp.add_block(flat.atom((0.55, 0.53, 0.5, 1.0)))
-    recs = [sp.add_block(b) for b in synthetic_blocks(16, 24, seed, translucent=True)]
-    sx, sy, sz = size
-    gx, gy, gz = np.arange(sx), np.arange(sy), np.arange(sz)
-    X, Y, Z = np.meshgrid(gx, gy, gz, indexing="ij")
-    hv = _hash3(X, Y, Z, seed)
-    rec = np.array(recs, np.uint16)[((hv >> np.uint64(30)) % np.uint64(len(recs))).astype(np.int64)]
-    grid = np.full(size, a, np.uint16)
-    wall = (X == 0) | (X == sx - 1) | (Z == 0) | (Z == sz - 1)
-    grid[wall] = stone
-    grid[:, 0, :] = rec[:, 0, :]  # detailed floor
-    for fy in (8, 16, 24):  # balconies along the walls
-        ring = (Y == fy) & ((X < 4) | (X >= sx - 4) | (Z < 4) | (Z >= sz - 4))
-        grid[ring] = rec[ring]
-    pillars = ((X % 6 == 3) & (Z % 6 == 3)) & (Y < 25) & ((X < 5) | (X > sx - 6))
-    grid[pillars] = rec[pillars]
-    arches = (Y == 7) & (Z % 6 == 3) & (X > 3) & (X < sx - 4)
-    grid[arches] = rec[arches]
-    grid[:, sy - 1, :] = np.where((X[:, 0, :] + Z[:, 0, :]) % 3 == 0, a, stone)  # skylights
-    sp.block_index[...] = grid
-    # an evaluated-looking light field (the template is lit by its skylights): brighter towards the
-    # roof, smooth elsewhere; cubes holding a block are STATUS_OPAQUE with no light of their own,
-    # which is what exercises the ambient-occlusion weights and the light-leak rule of
-    # get_interpolated_light (sr.rs:248-359)
-    nonair = grid != a
-    lv = (100 + 60 * (Y / sy) + 20 * np.sin(X * 0.4) * np.cos(Z * 0.3)).clip(1, 200).astype(np.uint8)
-    sp.light[..., 0] = lv
-    sp.light[..., 1] = lv
-    sp.light[..., 2] = np.minimum(lv.astype(np.int64) + 4, 255).astype(np.uint8)
-    sp.light[..., 3] = np.where(nonair, flat.STATUS_OPAQUE, flat.STATUS_VISIBLE)
-    sp.light[nonair, 0:3] = 0
-    return sp
+# -- synthetic scenes for parity / bench (SURVEY.md 8d "S256"): product-side generators, re-exported ----------
+from all_is_cubes_amd.workloads import (  # noqa: E402,F401
+    atrium_like_space, light_bench_layout, light_bench_space, synthetic_blocks, synthetic_space,
+)
 
 
 # ---------------------------------------------------------------------------------------------

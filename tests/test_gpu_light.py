@@ -79,3 +79,13 @@ def test_tone_map(ctx, golden_dir, name, tmo, maximum_intensity, exposure):
     assert_parity(got, ref)
     assert histogram_ok(image_diff(golden_dir, name, got["rgba8"]), [(10, 100), (3, 500), (1, 1 << 60)])
     assert np.abs(got["rgba8"].astype(int) - np.load(golden_dir / f"png_{name}.npy").astype(int)).max() <= 1
+
+
+# cases/src/lib.rs:1054-1105 template("light-bench"): the scene of the reference's raytracer benchmark
+def test_template_light_bench(ctx, golden_dir):
+    sp = scenes.light_bench_space()
+    direction = (0.0, 0.5, 1.0)
+    eye = tuple(oracle.eye_for_look_at(sp.lo, sp.hi, direction))
+    got, ref = render_both(ctx, sp, oracle.unaltered_colors(), COMMON_VIEWPORT, eye, tuple(-d for d in direction))
+    assert_parity(got, ref)
+    assert np.abs(got["rgba8"].astype(int) - np.load(golden_dir / "png_template-light-bench-all.npy").astype(int)).max() <= 1

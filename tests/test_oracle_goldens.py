@@ -234,3 +234,20 @@ def test_png_layers(golden_dir, name, with_world, with_ui):
     d = diff_to(golden_dir, name, out["rgba8"]).max(axis=-1)
     d[TEXT_MASK] = 0
     assert d.max() == 0
+
+
+# cases/src/lib.rs:1054-1105 template("light-bench"): UniverseTemplate::LightBench = content::testing::light_bench_space
+# at 54x16x54 (template.rs:205-208), drawn without light (UNALTERED_COLORS). Threshold [(254,20),(30,50),(1,all)];
+# reproduced pixel for pixel, which pins the restated rand/rand_xoshiro sampling in all_is_cubes_amd/workloads.py.
+def light_bench_camera(sp, size):
+    w, h = size
+    direction = (0.0, 0.5, 1.0)  # Spawn::looking_at_space(bounds, [0., 0.5, 1.]) (testing.rs:36)
+    eye = oracle.eye_for_look_at(sp.lo, sp.hi, direction)
+    q = oracle.look_at_y_up(eye, tuple(e - d for e, d in zip(eye, direction)))
+    return camera_for(w, h, eye, q)
+
+
+def test_png_template_light_bench(golden_dir):
+    sp = scenes.light_bench_space()
+    img = oracle.render(oracle.Space(sp), oracle.unaltered_colors(), light_bench_camera(sp, COMMON_VIEWPORT), threads=4)["rgba8"]
+    assert diff_to(golden_dir, "template-light-bench-all", img).max() == 0
