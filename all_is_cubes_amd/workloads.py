@@ -153,9 +153,9 @@ def atrium_like_space(seed: int = 7) -> flat.FlatSpace:
 # -- light_bench_space (all-is-cubes/src/content/testing.rs:26-141) --------------------------------------------
 # The scene of the reference's only raytracer benchmark (all-is-cubes-render/benches/raytrace.rs:28-37: size 54x16x54,
 # 64x64 viewport) and of the `template-light-bench` image test. Its sections are drawn with rand 0.10 / rand_xoshiro
-# (Xoshiro256Plus::seed_from_u64, random_range, random_bool) -- crates that are not under /root/reference; their
+# (Xoshiro256Plus::seed_from_u64, random_range, random_bool) -- crates that are not vendored with the reference; their
 # published algorithms are restated below and pinned by the golden image template-light-bench-all.png
-# (tests/test_oracle_goldens.py).
+# (tests/test_oracle_goldens.py test_png_template_light_bench).
 
 _M64 = (1 << 64) - 1
 
