@@ -763,7 +763,7 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         // had the same shape (else index order); then the cost array is cleared for this frame's record
         static const bool feedback = [] { const char *e = std::getenv("AIC_TILE_FEEDBACK"); return !e || std::atoi(e) != 0; }();
         const uint32_t n_tiles = F.macros_x * F.macros_y;  // the feedback works on macro tiles
-        if (feedback && n_tiles && !patches) {
+        if (feedback && n_tiles && !patches && !(f->flags & AIC_FRAME_NO_FEEDBACK)) {
             const uint32_t sig[4] = {f->width, local_rows, (part.n_parts << 16) | part.part, (part.strip_rows << 8) | (F.macro << 4) | (F.tile >> 3)};
             bool same = std::memcmp(sig, fs.cost_sig, sizeof(sig)) == 0 && fs.tile_cost.n >= n_tiles;
             if (same) {

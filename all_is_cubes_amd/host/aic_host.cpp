@@ -635,10 +635,12 @@ uint32_t HipRtRenderer::partition_rows(uint32_t strip_rows, uint32_t n_parts, ui
     aic_partition p{strip_rows, n_parts, part, 0};
     return aic_partition_rows(world_camera_.viewport().framebuffer_height, &p);
 }
-ImageInfo HipRtRenderer::draw_rows_to_device(void *device_out, uint32_t strip_rows, uint32_t n_parts, uint32_t part, bool counters) {
+ImageInfo HipRtRenderer::draw_rows_to_device(void *device_out, uint32_t strip_rows, uint32_t n_parts, uint32_t part, bool counters,
+                                             bool no_feedback) {
     aic_frame_desc f = make_frame();
     f.partition = aic_partition{strip_rows, n_parts, part, 0};
     if (counters) f.flags |= AIC_FRAME_COUNTERS;
+    if (no_feedback) f.flags |= AIC_FRAME_NO_FEEDBACK;
     aic_frame_info fi;
     check(aic_render(ctx_, &f, device_out, 1, &fi), "aic_render");
     return to_info(fi, f.width, f.height);

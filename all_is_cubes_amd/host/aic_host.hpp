@@ -302,7 +302,8 @@ class HipRtRenderer : public HeadlessRenderer {
     // entered the space and hit nothing ' ', one that never entered it '.', one that ran out of steps 'X'
     std::string draw_text(const std::string &line_ending = "\n");
     // multi-GPU extension: render the rows of one partition into a device buffer (no read-back)
-    ImageInfo draw_rows_to_device(void *device_out, uint32_t strip_rows, uint32_t n_parts, uint32_t part, bool counters = false);
+    ImageInfo draw_rows_to_device(void *device_out, uint32_t strip_rows, uint32_t n_parts, uint32_t part, bool counters = false,
+                                  bool no_feedback = false);
     uint32_t partition_rows(uint32_t strip_rows, uint32_t n_parts, uint32_t part) const;
     void assemble_strips(const void *gathered_device, void *out_device, uint32_t strip_rows, uint32_t n_parts);
     // streaming pair (aic_render_submit / aic_render_wait): up to AIC_MAX_IN_FLIGHT frames in flight

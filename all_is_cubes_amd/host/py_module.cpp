@@ -216,10 +216,10 @@ PYBIND11_MODULE(_host, m) {
         .def("draw", [](HipRtRenderer &r, const std::string &t) { py::gil_scoped_release rel; return r.draw(t); }, py::arg("info_text") = "")
         .def("draw_text", [](HipRtRenderer &r, const std::string &le) { py::gil_scoped_release rel; return r.draw_text(le); }, py::arg("line_ending") = "\n")
         .def("draw_rgba", [](HipRtRenderer &r, const std::string &t) { py::gil_scoped_release rel; return r.draw_rgba(t); }, py::arg("info_text") = "")
-        .def("draw_rows_to_device", [](HipRtRenderer &r, uintptr_t ptr, uint32_t strip_rows, uint32_t n_parts, uint32_t part, bool counters) {
+        .def("draw_rows_to_device", [](HipRtRenderer &r, uintptr_t ptr, uint32_t strip_rows, uint32_t n_parts, uint32_t part, bool counters, bool no_feedback) {
             py::gil_scoped_release rel;
-            return r.draw_rows_to_device(reinterpret_cast<void *>(ptr), strip_rows, n_parts, part, counters);
-        }, py::arg("device_ptr"), py::arg("strip_rows"), py::arg("n_parts"), py::arg("part"), py::arg("counters") = false)
+            return r.draw_rows_to_device(reinterpret_cast<void *>(ptr), strip_rows, n_parts, part, counters, no_feedback);
+        }, py::arg("device_ptr"), py::arg("strip_rows"), py::arg("n_parts"), py::arg("part"), py::arg("counters") = false, py::arg("no_feedback") = false)
         .def("partition_rows", &HipRtRenderer::partition_rows)
         .def("submit_rows_to_device", [](HipRtRenderer &r, uintptr_t ptr, uint32_t strip_rows, uint32_t n_parts, uint32_t part, uint32_t slot) {
             r.submit_rows_to_device(reinterpret_cast<void *>(ptr), strip_rows, n_parts, part, slot);

@@ -93,6 +93,7 @@ def main() -> int:
     ap.add_argument("--fog", type=int, default=1, help="experiment: FogOption (0 None,1 Abrupt,...); default Abrupt")
     ap.add_argument("--transparency", type=int, default=1, help="experiment: 0 Surface, 1 Volumetric; default Volumetric")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step timed region until the regions add up to this much time")
     args = ap.parse_args()
 
     import torch
@@ -241,17 +242,30 @@ def main() -> int:
     for _ in range(args.warmup):
         step()
     fence()
-    kernel_ms.clear()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu_test else dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    mean_kernel_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
+
+    def timed_region() -> float:  # EXACTLY args.steps steps between two fences; MAX over ranks
+        kernel_ms.clear()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if one_gpu_test else dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # The region is a few tens of milliseconds at the default K, so it is repeated until the regions add up to
+    # --min-seconds of GPU time (every rank runs the same count: the first region's time is agreed on first). `value`
+    # and `ms_per_step` are those of the MEDIAN region; min / max are reported beside them.
+    regions = [timed_region()]
+    n_regions = max(1, min(200, int(np.ceil(args.min_seconds / max(regions[0], 1e-6)))))
+    region_kernel_ms = [float(np.mean(kernel_ms)) if kernel_ms else 0.0]
+    for _ in range(n_regions - 1):
+        regions.append(timed_region())
+        region_kernel_ms.append(float(np.mean(kernel_ms)) if kernel_ms else 0.0)
+    order = int(np.argsort(regions)[len(regions) // 2])
+    elapsed = regions[order]
+    mean_kernel_ms = region_kernel_ms[order]
 
     # --- untimed extras: algorithmic-byte counters, read-back rate ------------------------------
     if args.verify and world > 1:
@@ -278,15 +292,60 @@ def main() -> int:
     my_bytes = 2 * info.n_outer + 2 * info.n_inner + 32 * info.n_hits + 4 * info.n_light + 4 * w * local_rows
     achieved_gbs = (my_bytes / (mean_kernel_ms * 1e-3)) / 1e9 if mean_kernel_ms > 0 else 0.0
 
-    # one frame at a time (submit, wait, repeat): the latency figure next to the streamed frame period
-    one_at_a_time_ms = None
-    if world == 1 and streamed:
-        n_l = max(3, min(10, args.steps))
+    # BASELINE.json quotes a *single-frame* raytrace: next to the streamed frame period, the time of one frame alone
+    # (submit, wait, repeat) -- "warm": tile order learnt from the identical previous frame; "cold": no feedback used or
+    # recorded, what the first frame of any sequence costs -- and of a moving camera (6 degrees per frame about the
+    # scene's axis: the feedback never applies), one frame at a time and streamed.
+    single = None
+    if world == 1 and args.workload != "orbit":
+        n_l = max(10, min(60, args.steps))
+        tgt = render_target(0).data_ptr()
+
+        def one_by_one(n, **kw):
+            renderer.synchronize()
+            ts = []
+            for _ in range(n):
+                t1 = time.perf_counter()
+                renderer.draw_rows_to_device(tgt, strip, world, rank, **kw)
+                ts.append((time.perf_counter() - t1) * 1e3)
+            return ts
+
+        one_by_one(2)
+        warm = one_by_one(n_l)
+        cold = one_by_one(n_l, no_feedback=True)
+        radius = float(np.hypot(eye[0] - target[0], eye[2] - target[2]))
+        a0 = float(np.arctan2(eye[0] - target[0], eye[2] - target[2]))
+        views = [H.look_at_y_up((target[0] + radius * np.sin(a0 + np.radians(6.0 * k)), eye[1], target[2] + radius * np.cos(a0 + np.radians(6.0 * k))), target)
+                 for k in range(60)]
+        moving = []
+        renderer.synchronize()
+        for k in range(n_l):
+            cams.world_view_transform = views[k % 60]
+            renderer.update()
+            t1 = time.perf_counter()
+            renderer.draw_rows_to_device(tgt, strip, world, rank)
+            moving.append((time.perf_counter() - t1) * 1e3)
         renderer.synchronize()
         t1 = time.perf_counter()
-        for _ in range(n_l):
-            renderer.draw_rows_to_device(render_target(0).data_ptr(), strip, world, rank)
-        one_at_a_time_ms = (time.perf_counter() - t1) / n_l * 1e3
+        for k in range(n_l):
+            cams.world_view_transform = views[k % 60]
+            renderer.update()
+            if k >= 2:
+                renderer.wait_rows(k % 2)
+            renderer.submit_rows_to_device(render_target(k).data_ptr() if local_bufs is None else local_bufs[k % len(local_bufs)].data_ptr(), strip, world, rank, k % 2)
+        renderer.wait_rows(n_l % 2)
+        renderer.wait_rows((n_l + 1) % 2)
+        moving_streamed = (time.perf_counter() - t1) / n_l * 1e3
+        cams.world_view_transform = H.look_at_y_up(eye, target)
+        renderer.update()
+        single = {
+            "single_frame_warm_ms": round(float(np.median(warm)), 4),
+            "single_frame_cold_ms": round(float(np.median(cold)), 4),
+            "single_frame_moving_camera_ms": round(float(np.median(moving)), 4),
+            "streamed_moving_camera_ms": round(moving_streamed, 4),
+            "frames": n_l,
+            "note": "medians of one frame at a time (host submit to completion); moving camera: 6 degrees per frame about the view target",
+        }
 
     fps_with_readback = None
     if world == 1:
@@ -311,14 +370,20 @@ def main() -> int:
             if pj.get("hbm_traffic_bytes_per_launch"):
                 traffic = round(pj["hbm_traffic_bytes_per_launch"] / (mean_kernel_ms * 1e-3) / 1e9, 3) if mean_kernel_ms > 0 else None
                 traffic_src = "profiles/" + os.path.basename(cands[-1]) + f" ({int(pj['hbm_traffic_bytes_per_launch'])} B/launch, GB/s at this run's kernel time)"
-            vi = pj.get("counters", {}).get("SQ_INSTS_VALU", {}).get("mean_per_launch")
+            cn = pj.get("counters", {})
+            vi = cn.get("SQ_INSTS_VALU", {}).get("mean_per_launch")
             if vi and elapsed > 0:
-                # what actually bounds the kernel: wave-level VALU instructions per frame against the chip's issue
-                # rate (1024 SIMDs, one wave64 VALU instruction per 4 cycles, 2.4 GHz nominal), at this run's frame rate
-                peak = 1024 * 2.4e9 / 4.0
-                rate = vi * args.steps / elapsed
-                valu = {"wave_insts_per_frame": int(vi), "issue_rate": round(rate / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-insts/s",
-                        "frac": round(rate / peak, 4), "note": "SQ_INSTS_VALU from the same PMC file; the binding resource (DESIGN.md 6)"}
+                # what actually bounds the kernel: instruction issue. tools/ubench/issue_rate (profiles/r02_issue_rate.txt)
+                # measures one wave-instruction per ~4.3-4.7 cycles per SIMD for this kernel's mix (f64 compare/add, selects,
+                # integer ops, SALU mask logic) at 2-8 waves per SIMD, VALU and SALU alike and not overlapping -- so the count
+                # is of ALL instructions (VALU + SALU + memory), against 1024 SIMDs x 2.4 GHz / 4.33 cycles.
+                total = sum(float(cn.get(k, {}).get("mean_per_launch") or 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"))
+                peak = 1024 * 2.4e9 / 4.33
+                rate = total * args.steps / elapsed
+                valu = {"wave_insts_per_frame": int(total), "valu_wave_insts_per_frame": int(vi), "issue_rate": round(rate / 1e9, 2), "peak": round(peak / 1e9, 1),
+                        "unit": "G wave-insts/s", "frac": round(rate / peak, 4),
+                        "note": "instruction counts from the same PMC file (one frame at a time); peak = measured issue rate of this mix "
+                                "(profiles/r02_issue_rate.txt): the binding resource (DESIGN.md 6)"}
 
     result = None
     if rank == 0:
@@ -332,6 +397,9 @@ def main() -> int:
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step_min": round(min(regions) / args.steps * 1e3, 4),
+            "ms_per_step_max": round(max(regions) / args.steps * 1e3, 4),
+            "timed_regions": len(regions),
             "frames_per_s": round(args.steps / elapsed, 3),
             "higher_is_better": True,
             "scaling": "strong",
@@ -364,9 +432,10 @@ def main() -> int:
             "device": renderer.device_name(),
         }
         if valu is not None:
-            result["valu_issue"] = valu
-        if one_at_a_time_ms is not None:
-            result["ms_per_frame_one_at_a_time"] = round(one_at_a_time_ms, 4)
+            result["issue"] = valu
+        if single is not None:
+            result["single_frame"] = single
+            result["streamed_ms"] = round(ms_per_step, 4) if streamed else None
         if fps_with_readback is not None:
             result["fps_with_readback"] = round(fps_with_readback, 3)
         if world == 1 and not args.no_cpu_baseline:

@@ -129,6 +129,9 @@ typedef struct aic_frame_desc {
                                     * tone mapping -- what a float framebuffer wants */
 #define AIC_FRAME_OUT_COLORBUF 16u /* the ColorBuf itself: premultiplied light r,g,b and transmittance
                                     * (raytracer_components.rs:20-39; raytrace_to_texture.rs:638-655 reads exactly this) */
+#define AIC_FRAME_NO_FEEDBACK 32u  /* neither use nor record the tile-cost feedback (the order in which this context hands out
+                                    * work tiles, learnt from its previous frame of the same shape and camera): a "cold" single
+                                    * frame, as the first frame of any sequence is */
 #define AIC_FRAME_PIXEL_CENTERS 4u /* one ray through each pixel centre, Viewport::normalize_fb_x/_y (viewport.rs:89-99),
                                     * as the text renderer casts them (sr.rs:400-472); default: the image path's patch
                                     * centres / antialiasing points (renderer.rs:424-451) */
