@@ -25,7 +25,7 @@ FRAME_COUNTERS, FRAME_AUX, FRAME_PIXEL_CENTERS, FRAME_OUT_LINEAR, FRAME_OUT_COLO
 # every symbol include/aic_hip.h declares
 ABI_SYMBOLS = [
     "aic_abi_version", "aic_create", "aic_destroy", "aic_last_error", "aic_device_name", "aic_upload_space",
-    "aic_clear_space", "aic_update_cubes", "aic_update_light_volume", "aic_replace_block", "aic_set_options",
+    "aic_clear_space", "aic_update_cubes", "aic_update_light_volume", "aic_replace_block", "aic_replace_blocks", "aic_compact", "aic_set_options",
     "aic_render", "aic_render_submit", "aic_render_wait", "aic_trace_patches", "aic_partition_rows", "aic_assemble_strips", "aic_read_aux", "aic_synchronize", "aic_stream",
     "aic_probe_raycast", "aic_probe_light_lut", "aic_probe_powf",
 ]
@@ -79,7 +79,7 @@ class FrameInfo(C.Structure):
 
 PIXEL_AUX_DTYPE = np.dtype(
     [("hit", "<i4"), ("cube", "<i4", (3,)), ("voxel", "<i4", (3,)), ("resolution", "<i4"), ("face", "<i4"),
-     ("block_index", "<i4"), ("cubes_traced", "<u4"), ("pad", "<u4"), ("t_distance", "<f8")],
+     ("block_index", "<i4"), ("cubes_traced", "<u4"), ("layer", "<u4"), ("t_distance", "<f8")],
     align=True,
 )
 RC_STEP_DTYPE = np.dtype([("cube", "<i4", (3,)), ("face", "<i4"), ("t_distance", "<f8"), ("intersection_point", "<f8", (3,))], align=True)
@@ -106,9 +106,11 @@ def load() -> C.CDLL:
         lib.aic_partition_rows.argtypes = [C.c_uint32, C.POINTER(Partition)]
         lib.aic_upload_space.argtypes = [C.c_void_p, C.c_int, C.POINTER(SpaceDesc)]
         lib.aic_clear_space.argtypes = [C.c_void_p, C.c_int]
+        lib.aic_compact.argtypes = [C.c_void_p, C.c_int]
         lib.aic_update_cubes.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.aic_update_light_volume.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         lib.aic_replace_block.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.POINTER(BlockDesc), C.c_void_p, C.c_void_p]
+        lib.aic_replace_blocks.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.aic_set_options.argtypes = [C.c_void_p, C.c_int, C.POINTER(Options)]
         lib.aic_render.argtypes = [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.c_int, C.POINTER(FrameInfo)]
         lib.aic_render_submit.argtypes = [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.c_uint32]
@@ -287,6 +289,28 @@ class Context:
         vox = np.ascontiguousarray(block.voxels, np.uint16)
         pal = np.ascontiguousarray(block.palette, np.float32)
         self._check(self._lib.aic_replace_block(self._h, layer, index, C.byref(d), _ptr(vox), _ptr(pal)))
+
+    def compact(self, layer: int) -> None:
+        self._check(self._lib.aic_compact(self._h, C.c_int(layer)))
+
+    def replace_blocks(self, layer: int, items) -> None:
+        """`items`: list of (index, flat.BlockDef) -- a batch of BlockEvaluation changes under one synchronisation."""
+        n = len(items)
+        idx = np.ascontiguousarray([i for i, _ in items], np.uint32)
+        descs = (BlockDesc * max(n, 1))()
+        keep, vp, pp = [], (C.c_void_p * max(n, 1))(), (C.c_void_p * max(n, 1))()
+        for k, (_, block) in enumerate(items):
+            d = descs[k]
+            d.resolution = block.resolution
+            d.vlo[:] = list(block.vlo)
+            d.vsize[:] = list(block.voxels.shape)
+            d.pal_len = len(block.palette)
+            d.flags = (flat.FLAG_ONE if block.is_one else 0) | (flat.FLAG_AIR if block.is_air else 0)
+            vox = np.ascontiguousarray(block.voxels, np.uint16)
+            pal = np.ascontiguousarray(block.palette, np.float32)
+            keep += [vox, pal]
+            vp[k], pp[k] = vox.ctypes.data, pal.ctypes.data
+        self._check(self._lib.aic_replace_blocks(self._h, layer, n, _ptr(idx), C.cast(descs, C.c_void_p), C.cast(vp, C.c_void_p), C.cast(pp, C.c_void_p)))
 
     def set_options(self, layer: int, options: Options) -> None:
         self._check(self._lib.aic_set_options(self._h, layer, C.byref(options)))

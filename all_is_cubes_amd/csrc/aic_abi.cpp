@@ -40,14 +40,15 @@ static_assert(sizeof(aic_block_desc) == 48, "aic_block_desc is 48 bytes");
 
 namespace {
 
+constexpr uint64_t kMaxPoolElems = 0x7ffffff0ull;  // u16 elements of cube grid + voxel volumes (32-bit byte offsets in the kernel)
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;    // elements in use
     size_t cap = 0;  // elements allocated
     hipError_t ensure(size_t count, bool keep = false, hipStream_t stream = nullptr) {
-        n = count;
-        if (count <= cap) return hipSuccess;
+        if (count <= cap) { n = count; return hipSuccess; }
         size_t new_cap = count + count / 4 + 16;
         T *np_ = nullptr;
         hipError_t e = hipMalloc((void **)&np_, new_cap * sizeof(T));
@@ -63,6 +64,7 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = np_;
         cap = new_cap;
+        n = count;  // only now: a failed grow leaves the buffer as it was
         return hipSuccess;
     }
     void release() {
@@ -83,6 +85,10 @@ struct Layer {
     DevBuf<DevBlock> blocks;
     DevBuf<DevPaletteEntry> palette;
     std::vector<DevBlock> host_blocks;  // mirror of the block table (for replace/append)
+    // per block: elements of the voxel pool / palette pool its current ranges can hold (so that a re-evaluated block is
+    // written in place when it fits, updating.rs:128-145), and what replaced blocks left behind (compacted past a threshold)
+    std::vector<uint32_t> vox_cap, pal_cap;
+    uint64_t garbage_vox = 0, garbage_pal = 0;
     int32_t air_index = -1;
     int32_t sky_kind = 0;
     float sky[8][3] = {};
@@ -93,7 +99,8 @@ struct Layer {
     size_t n_cubes() const { return (size_t)size[0] * (size_t)size[1] * (size_t)size[2]; }
     void release() {
         pool.release(); cls.release(); light.release(); light_alt.release(); blocks.release(); palette.release();
-        host_blocks.clear(); host_cls.clear();
+        host_blocks.clear(); host_cls.clear(); vox_cap.clear(); pal_cap.clear();
+        garbage_vox = garbage_pal = 0;
         present = false;
     }
 };
@@ -383,6 +390,20 @@ aic_ctx *aic_create(int device_id, int *status) {
                 std::memcpy(&f, &mid, 4);
                 if (enc(f) >= k) hi_b = mid; else lo_b = mid;
             }
+            // the bisection assumes enc() is monotone; libm's powf need not be at the last bit, so settle the threshold on
+            // the LOWEST float of the neighbourhood that encodes to >= k while its predecessor does not
+            for (int back = 0; back < 8 && hi_b > 1u; back++) {
+                uint32_t probe = hi_b - 1u;
+                float f;
+                std::memcpy(&f, &probe, 4);
+                bool lower_found = false;
+                for (uint32_t d = 0; d < 8u && probe > d; d++) {
+                    const uint32_t q = probe - d;
+                    std::memcpy(&f, &q, 4);
+                    if (enc(f) >= k) { hi_b = q; lower_found = true; }
+                }
+                if (!lower_found) break;
+            }
             std::memcpy(&thr[k], &hi_b, 4);
         }
         ok = ok && c->srgb_thr.ensure(256) == hipSuccess && hipMemcpy(c->srgb_thr.p, thr, sizeof(thr), hipMemcpyHostToDevice) == hipSuccess;
@@ -435,11 +456,13 @@ int aic_upload_space(aic_ctx *c, int layer, const aic_space_desc *s) {
     const size_t n = (size_t)s->size[0] * (size_t)s->size[1] * (size_t)s->size[2];
     if (n && (!s->block_index || !s->light)) return fail(c, AIC_ERR_INVALID, "space has cubes but no block_index/light");
     if (s->n_blocks > 65536) return fail(c, AIC_ERR_INVALID, "more than 65536 blocks");
-    if (n + s->n_voxels > 0xfffffff0ull) return fail(c, AIC_ERR_INVALID, "space too large (cube grid + voxel pool must index with 32 bits)");
+    // the trace kernel addresses the pool with 32-bit BYTE offsets: at most 2^31 u16 elements (4 GiB)
+    if (n + s->n_voxels > kMaxPoolElems) return fail(c, AIC_ERR_INVALID, "space too large (cube grid + voxel pool must stay within 4 GiB)");
     if (s->n_blocks && !s->blocks) return fail(c, AIC_ERR_INVALID, "blocks is null");
 
     // block table + pools
     std::vector<DevBlock> blocks(s->n_blocks);
+    std::vector<uint32_t> vox_cap(s->n_blocks, 0u), pal_cap(s->n_blocks, 0u);
     std::vector<uint16_t> vox;
     std::vector<DevPaletteEntry> pal;
     vox.reserve((size_t)s->n_voxels);
@@ -451,10 +474,15 @@ int aic_upload_space(aic_ctx *c, int layer, const aic_space_desc *s) {
         size_t nvox = one ? 1 : (size_t)(d.vsize[0] > 0 ? d.vsize[0] : 0) * (size_t)(d.vsize[1] > 0 ? d.vsize[1] : 0) * (size_t)(d.vsize[2] > 0 ? d.vsize[2] : 0);
         if ((uint64_t)d.vox_off + nvox > s->n_voxels || (uint64_t)d.pal_off + d.pal_len > s->n_palette)
             return fail(c, AIC_ERR_INVALID, "block voxel/palette range exceeds the pools");
-        if (vox.size() > 0xffffffffull || pal.size() > 0xffffffffull) return fail(c, AIC_ERR_INVALID, "pool too large");
+        // blocks may alias or overlap ranges of the input pools, so the converted pools can outgrow n_voxels / n_palette:
+        // check the running sizes before every conversion (offsets are stored in 32 bits)
+        if (n + vox.size() + nvox > kMaxPoolElems || pal.size() + d.pal_len > 0xfffffff0ull) return fail(c, AIC_ERR_INVALID, "pool too large");
+        const size_t vb = vox.size(), pb = pal.size();
         int rc = convert_block(c, d, s->voxels ? s->voxels + d.vox_off : nullptr, s->palette ? s->palette + 8 * (size_t)d.pal_off : nullptr,
                                (uint32_t)(n + vox.size()), (uint32_t)pal.size(), &blocks[i], &vox, &pal);
         if (rc != AIC_OK) return rc;
+        vox_cap[i] = (uint32_t)(vox.size() - vb);
+        pal_cap[i] = (uint32_t)(pal.size() - pb);
         if ((d.flags & AIC_BLOCK_AIR) && air_index < 0) air_index = (int32_t)i;
     }
     // validate cube indices on the host copy (the reference indexes `blocks[...]` with a bounds check)
@@ -485,6 +513,9 @@ int aic_upload_space(aic_ctx *c, int layer, const aic_space_desc *s) {
     for (int a = 0; a < 3; a++) { l.lo[a] = s->lo[a]; l.size[a] = s->size[a]; }
     l.host_blocks.swap(blocks);
     l.host_cls.swap(cls);
+    l.vox_cap.swap(vox_cap);
+    l.pal_cap.swap(pal_cap);
+    l.garbage_vox = l.garbage_pal = 0;
     l.air_index = air_index;
     l.sky_kind = s->sky_kind;
     std::memcpy(l.sky, s->sky, sizeof(l.sky));
@@ -566,42 +597,99 @@ int aic_update_light_volume(aic_ctx *c, int layer, const uint8_t *light) {
     return AIC_OK;
 }
 
-int aic_replace_block(aic_ctx *c, int layer, uint32_t index, const aic_block_desc *desc, const uint16_t *voxels, const float *palette) {
-    if (!c || !valid_layer(layer) || !desc) return fail(c, AIC_ERR_INVALID, "aic_replace_block: bad argument");
-    Layer &l = c->layers[layer];
-    if (!l.present) return fail(c, AIC_ERR_INVALID, "aic_replace_block: no space uploaded for this layer");
+namespace {
+
+// Re-packs the voxel and palette pools of a layer on the device, dropping the ranges that replaced blocks left
+// behind: the cube grid stays at offset 0, every recursive block's ranges are copied (device to device) to the
+// next free offset of fresh pools, and the block table follows. Called with no frame in flight.
+int compact_pools(aic_ctx *c, Layer &l) {
+    const size_t n = l.n_cubes();
+    uint64_t need_vox = n, need_pal = 0;
+    for (size_t i = 0; i < l.host_blocks.size(); i++) { need_vox += l.vox_cap[i]; need_pal += l.pal_cap[i]; }
+    DevBuf<uint16_t> np;
+    DevBuf<DevPaletteEntry> npal;
+    hipError_t e;
+    if ((e = np.ensure((size_t)need_vox)) != hipSuccess) return hip_fail(c, "compact pool", e);
+    if ((e = npal.ensure((size_t)(need_pal ? need_pal : 1))) != hipSuccess) { np.release(); return hip_fail(c, "compact palette", e); }
+    if (n) HIP_TRY(c, hipMemcpyAsync(np.p, l.pool.p, n * sizeof(uint16_t), hipMemcpyDeviceToDevice, c->stream));
+    uint64_t vo = n, po = 0;
+    for (size_t i = 0; i < l.host_blocks.size(); i++) {
+        DevBlock &b = l.host_blocks[i];
+        if (l.vox_cap[i]) {
+            HIP_TRY(c, hipMemcpyAsync(np.p + vo, l.pool.p + b.vox_off, (size_t)l.vox_cap[i] * sizeof(uint16_t), hipMemcpyDeviceToDevice, c->stream));
+            b.vox_off = (uint32_t)vo;
+            vo += l.vox_cap[i];
+        }
+        if (l.pal_cap[i]) {
+            HIP_TRY(c, hipMemcpyAsync(npal.p + po, l.palette.p + b.pal_off, (size_t)l.pal_cap[i] * sizeof(DevPaletteEntry), hipMemcpyDeviceToDevice, c->stream));
+            b.pal_off = (uint32_t)po;
+            po += l.pal_cap[i];
+        }
+    }
+    if (!l.host_blocks.empty())
+        HIP_TRY(c, hipMemcpyAsync(l.blocks.p, l.host_blocks.data(), l.host_blocks.size() * sizeof(DevBlock), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    l.pool.release();
+    l.palette.release();
+    l.pool = np;
+    l.palette = npal;
+    l.pool.n = (size_t)vo;
+    l.palette.n = (size_t)po;
+    l.garbage_vox = l.garbage_pal = 0;
+    return AIC_OK;
+}
+
+// One BlockEvaluation / BlockIndex change (updating.rs:128-145), issued on c->stream without synchronising.
+int replace_one(aic_ctx *c, int layer, Layer &l, uint32_t index, const aic_block_desc *desc, const uint16_t *voxels, const float *palette) {
+    if (!desc) return fail(c, AIC_ERR_INVALID, "aic_replace_block: null descriptor");
     if (index > l.host_blocks.size() || index >= 65536) return fail(c, AIC_ERR_INVALID, "aic_replace_block: index out of range");
-    HIP_TRY(c, hipSetDevice(c->device));
-    { int qrc = quiesce(c); if (qrc != AIC_OK) return qrc; }
-    // new data is appended to the pools (the old ranges become garbage until the next full upload)
+    const bool exists = index < l.host_blocks.size();
     std::vector<uint16_t> vox;
     std::vector<DevPaletteEntry> pal;
     DevBlock db;
-    const uint32_t vox_off = (uint32_t)l.pool.n, pal_off = (uint32_t)l.palette.n;
-    int rc = convert_block(c, *desc, voxels, palette, vox_off, pal_off, &db, &vox, &pal);
+    // convert first (offsets patched below), then decide where the data goes
+    int rc = convert_block(c, *desc, voxels, palette, 0u, 0u, &db, &vox, &pal);
     if (rc != AIC_OK) return rc;
+    // in place when the block's current ranges can hold the new data (the reference replaces the block in place);
+    // otherwise append and leave the old ranges as garbage for compact_pools
+    const bool fits = exists && vox.size() <= l.vox_cap[index] && pal.size() <= l.pal_cap[index];
+    uint32_t vox_off, pal_off;
     hipError_t e;
+    if (fits) {
+        vox_off = l.host_blocks[index].vox_off;
+        pal_off = l.host_blocks[index].pal_off;
+    } else {
+        vox_off = (uint32_t)l.pool.n;
+        pal_off = (uint32_t)l.palette.n;
+        if ((uint64_t)vox_off + vox.size() > kMaxPoolElems || (uint64_t)pal_off + pal.size() > 0xfffffff0ull)
+            return fail(c, AIC_ERR_INVALID, "voxel pool too large");
+        if (!vox.empty() && (e = l.pool.ensure(vox_off + vox.size(), true, c->stream)) != hipSuccess) return hip_fail(c, "grow pool", e);
+        if (!pal.empty() && (e = l.palette.ensure(pal_off + pal.size(), true, c->stream)) != hipSuccess) return hip_fail(c, "grow palette", e);
+        if (exists) { l.garbage_vox += l.vox_cap[index]; l.garbage_pal += l.pal_cap[index]; }
+    }
     if (!vox.empty()) {
-        if ((uint64_t)vox_off + vox.size() > 0xfffffff0ull) return fail(c, AIC_ERR_INVALID, "voxel pool too large");
-        if ((e = l.pool.ensure(vox_off + vox.size(), true, c->stream)) != hipSuccess) return hip_fail(c, "grow pool", e);
-        HIP_TRY(c, hipMemcpyAsync(l.pool.p + vox_off, vox.data(), vox.size() * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+        db.vox_off = vox_off;
+        HIP_TRY(c, hipMemcpy(l.pool.p + vox_off, vox.data(), vox.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     }
     if (!pal.empty()) {
-        if ((e = l.palette.ensure(pal_off + pal.size(), true, c->stream)) != hipSuccess) return hip_fail(c, "grow palette", e);
-        HIP_TRY(c, hipMemcpyAsync(l.palette.p + pal_off, pal.data(), pal.size() * sizeof(DevPaletteEntry), hipMemcpyHostToDevice, c->stream));
+        db.pal_off = pal_off;
+        HIP_TRY(c, hipMemcpy(l.palette.p + pal_off, pal.data(), pal.size() * sizeof(DevPaletteEntry), hipMemcpyHostToDevice));
     }
     bool class_changed = false;
-    if (index == l.host_blocks.size()) {
+    if (!exists) {
         l.host_blocks.push_back(db);
+        l.vox_cap.push_back((uint32_t)vox.size());
+        l.pal_cap.push_back((uint32_t)pal.size());
         if ((e = l.blocks.ensure(l.host_blocks.size(), true, c->stream)) != hipSuccess) return hip_fail(c, "grow blocks", e);
     } else {
         class_changed = block_class(l.host_blocks[index]) != block_class(db);
         l.host_blocks[index] = db;
+        if (!fits) { l.vox_cap[index] = (uint32_t)vox.size(); l.pal_cap[index] = (uint32_t)pal.size(); }
     }
-    HIP_TRY(c, hipMemcpyAsync(l.blocks.p + index, &db, sizeof(db), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpy(l.blocks.p + index, &db, sizeof(db), hipMemcpyHostToDevice));
     set_class(l.host_cls, index, block_class(db));
     if ((e = l.cls.ensure(l.host_cls.size(), true, c->stream)) != hipSuccess) return hip_fail(c, "grow classes", e);
-    HIP_TRY(c, hipMemcpyAsync(l.cls.p + index / 16u, &l.host_cls[index / 16u], sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpy(l.cls.p + index / 16u, &l.host_cls[index / 16u], sizeof(uint32_t), hipMemcpyHostToDevice));
     if (l.cls_in_code) {
         // the cube grid carries class bits: drop them if the table outgrew 14-bit indices, refresh
         // them if an existing block changed class (cubes already holding this index must follow)
@@ -613,7 +701,6 @@ int aic_replace_block(aic_ctx *c, int layer, uint32_t index, const aic_block_des
         }
         HIP_TRY(c, hipGetLastError());
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (desc->flags & AIC_BLOCK_AIR) {
         if (l.air_index < 0) l.air_index = (int32_t)index;
     } else if (l.air_index == (int32_t)index) {
@@ -626,6 +713,41 @@ int aic_replace_block(aic_ctx *c, int layer, uint32_t index, const aic_block_des
         dump_record(c, DUMP_BLOCK, (uint32_t)layer, {{h, sizeof(h)}, {desc, sizeof(*desc)}, {voxels, (size_t)nvox * 2}, {palette, (size_t)desc->pal_len * 32}});
     }
     return AIC_OK;
+}
+
+}  // namespace
+
+int aic_replace_blocks(aic_ctx *c, int layer, uint32_t n, const uint32_t *indices, const aic_block_desc *descs, const uint16_t *const *voxels,
+                       const float *const *palettes) {
+    if (!c || !valid_layer(layer) || (n && (!indices || !descs || !voxels || !palettes))) return fail(c, AIC_ERR_INVALID, "aic_replace_blocks: bad argument");
+    Layer &l = c->layers[layer];
+    if (!l.present) return fail(c, AIC_ERR_INVALID, "aic_replace_block: no space uploaded for this layer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int qrc = quiesce(c); if (qrc != AIC_OK) return qrc; }  // once for the whole batch
+    int rc = AIC_OK;
+    for (uint32_t k = 0; k < n && rc == AIC_OK; k++) rc = replace_one(c, layer, l, indices[k], &descs[k], voxels[k], palettes[k]);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (rc != AIC_OK) return rc;
+    // garbage left by blocks that outgrew their ranges: re-pack once it is worth it (more than a quarter of the pool,
+    // and more than 256 KB), instead of growing without bound until the next full upload
+    const bool big_vox = l.garbage_vox * 4 > l.pool.n && l.garbage_vox > (1u << 17);
+    const bool big_pal = l.garbage_pal * 4 > l.palette.n && l.garbage_pal > (1u << 13);
+    if (big_vox || big_pal) return compact_pools(c, l);
+    return AIC_OK;
+}
+
+int aic_compact(aic_ctx *c, int layer) {
+    if (!c || !valid_layer(layer)) return fail(c, AIC_ERR_INVALID, "aic_compact: bad argument");
+    Layer &l = c->layers[layer];
+    if (!l.present) return AIC_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int qrc = quiesce(c); if (qrc != AIC_OK) return qrc; }
+    return compact_pools(c, l);
+}
+
+int aic_replace_block(aic_ctx *c, int layer, uint32_t index, const aic_block_desc *desc, const uint16_t *voxels, const float *palette) {
+    if (!desc) return fail(c, AIC_ERR_INVALID, "aic_replace_block: bad argument");
+    return aic_replace_blocks(c, layer, 1u, &index, desc, &voxels, &palette);
 }
 
 int aic_set_options(aic_ctx *c, int layer, const aic_options *o) {

@@ -105,7 +105,7 @@ struct DevAux {  // == aic_pixel_aux
     int32_t face;
     int32_t block_index;
     uint32_t cubes_traced;
-    uint32_t pad;
+    uint32_t layer;  // layer of the first hit (0 world, 1 UI)
     double t_distance;
 };
 

@@ -670,6 +670,7 @@ AIC_DEV void get_interpolated_light(const DevLayer &L, const float *__restrict__
 
 struct Diag {
     uint32_t n_outer, n_inner, n_hits, n_light;
+    uint32_t layer;  // layer of that first hit: 0 world, 1 UI (its block_index is an index into THAT layer's block table)
     int hit;  // first Hit carrying a Position
     int cube[3], voxel[3], res, face, block;
     double t;
@@ -848,7 +849,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
     uint32_t px_steps = 0, px_steps_prev = 0;          // DIAG: steps of this pixel
     Diag dg;
     if (DIAG) {
-        dg.n_outer = dg.n_inner = dg.n_hits = dg.n_light = 0; dg.hit = 0; dg.res = dg.face = dg.block = 0; dg.t = 0.0;
+        dg.n_outer = dg.n_inner = dg.n_hits = dg.n_light = 0; dg.layer = 0; dg.hit = 0; dg.res = dg.face = dg.block = 0; dg.t = 0.0;
         for (int a = 0; a < 3; a++) dg.cube[a] = dg.voxel[a] = 0;
     }
     uint32_t tot_outer = 0, tot_inner = 0, tot_hits = 0, tot_light = 0;
@@ -1100,6 +1101,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                         dg.n_light += sd.nlight;
                         if (!dg.hit) {
                             dg.hit = 1;
+                            dg.layer = ui_pass ? 1u : 0u;
                             for (int a2 = 0; a2 < 3; a2++) { dg.cube[a2] = sd.cube[a2]; dg.voxel[a2] = sd.voxel[a2]; }
                             dg.res = sd.res; dg.face = sd.face; dg.block = sd.block; dg.t = t_enter;
                         }
@@ -1247,7 +1249,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                             a.hit = dg.hit & 1;
                             for (int k = 0; k < 3; k++) { a.cube[k] = dg.cube[k]; a.voxel[k] = dg.voxel[k]; }
                             a.resolution = dg.res; a.face = dg.face; a.block_index = dg.block;
-                            a.cubes_traced = px_steps_prev + px_steps; a.pad = 0; a.t_distance = dg.t;
+                            a.cubes_traced = px_steps_prev + px_steps; a.layer = dg.layer; a.t_distance = dg.t;
                         }
                         tot_outer += dg.n_outer; tot_inner += dg.n_inner; tot_hits += dg.n_hits; tot_light += dg.n_light;
                     }
@@ -1316,7 +1318,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 if (ev & EV_TAKE) {
                     if (n_samples == 4) { c32[K_S0][tid] = 0u; c32[K_S1][tid] = 0u; c32[K_S2][tid] = 0u; c32[K_ST][tid] = 0u; }  // 0.f
                     if (DIAG) {
-                        dg.n_outer = dg.n_inner = dg.n_hits = dg.n_light = 0; dg.hit = 0; dg.res = dg.face = dg.block = 0; dg.t = 0.0;
+                        dg.n_outer = dg.n_inner = dg.n_hits = dg.n_light = 0; dg.layer = 0; dg.hit = 0; dg.res = dg.face = dg.block = 0; dg.t = 0.0;
                         for (int a = 0; a < 3; a++) dg.cube[a] = dg.voxel[a] = 0;
                         px_steps = 0; px_steps_prev = 0;
                         if (F.use_init && F.aux) {  // continue the UI pre-pass's per-pixel record
@@ -1324,6 +1326,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                             dg.hit = a.hit;
                             for (int k = 0; k < 3; k++) { dg.cube[k] = a.cube[k]; dg.voxel[k] = a.voxel[k]; }
                             dg.res = a.resolution; dg.face = a.face; dg.block = a.block_index; dg.t = a.t_distance;
+                            dg.layer = a.layer;
                             px_steps_prev = a.cubes_traced;
                         }
                     }
@@ -1575,6 +1578,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                         dg.n_light += pend_d.nlight;
                         if (!dg.hit) {
                             dg.hit = 1;
+                            dg.layer = ui_pass ? 1u : 0u;
                             for (int a2 = 0; a2 < 3; a2++) { dg.cube[a2] = pend_d.cube[a2]; dg.voxel[a2] = pend_d.voxel[a2]; }
                             dg.res = pend_d.res; dg.face = pend_d.face; dg.block = pend_d.block; dg.t = pend_t;
                         }

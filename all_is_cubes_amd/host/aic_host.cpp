@@ -609,12 +609,13 @@ std::string HipRtRenderer::draw_text(const std::string &line_ending) {
     aic_frame_info fi;
     check(aic_render(ctx_, &f, rgba.data(), 0, &fi), "aic_render");
     if (n) check(aic_read_aux(ctx_, aux.data(), n), "aic_read_aux");
-    const std::shared_ptr<Space> &space = layers_[AIC_LAYER_WORLD].space;
     std::string out;
     for (uint32_t y = 0; y < f.height; y++) {
         for (uint32_t x = 0; x < f.width; x++) {
             const aic_pixel_aux &a = aux[(size_t)y * f.width + x];
             if (a.hit == 1) {
+                // the character comes from the block data of the layer that was hit (text.rs:52-128): aux.layer
+                const std::shared_ptr<Space> &space = layers_[a.layer == 1u ? AIC_LAYER_UI : AIC_LAYER_WORLD].space;
                 const std::string &name = (space && (size_t)a.block_index < space->n_blocks()) ? space->block((uint32_t)a.block_index).display_name : std::string();
                 if (name.empty()) out += '#';
                 else {  // first UTF-8 scalar (graphemes of more than one scalar are beyond this mirror)

@@ -157,9 +157,9 @@ typedef struct aic_pixel_aux {
     int32_t voxel[3];
     int32_t resolution;
     int32_t face;          /* Face7 discriminant */
-    int32_t block_index;
+    int32_t block_index;   /* index into the block table of the layer named by `layer` */
     uint32_t cubes_traced; /* steps taken by this pixel's rays */
-    uint32_t pad;
+    uint32_t layer;        /* AIC_LAYER_WORLD / AIC_LAYER_UI: the layer the first hit belongs to */
     double t_distance;
 } aic_pixel_aux;
 
@@ -193,6 +193,14 @@ int aic_update_light_volume(aic_ctx *ctx, int layer, const uint8_t *light);
  * palette entry. `voxels`/`palette` hold only this block's data (desc offsets are ignored). */
 int aic_replace_block(aic_ctx *ctx, int layer, uint32_t index, const aic_block_desc *desc, const uint16_t *voxels,
                       const float *palette);
+/* The same for a batch of blocks under ONE wait for the frames in flight and one synchronisation (a tick that
+ * re-evaluates many animated blocks: updating.rs:128-145 runs once per changed block index). A block whose new voxel
+ * volume and palette fit its current ranges is overwritten in place; one that outgrew them is appended, and the pools
+ * are re-packed on the device once the ranges left behind exceed a quarter of a pool. */
+int aic_replace_blocks(aic_ctx *ctx, int layer, uint32_t n, const uint32_t *indices, const aic_block_desc *descs,
+                       const uint16_t *const *voxels, const float *const *palettes);
+/* Re-pack the layer's voxel and palette pools now (done automatically by aic_replace_block(s) past a threshold). */
+int aic_compact(aic_ctx *ctx, int layer);
 /* replaces: the graphics_options DynSource (updating.rs:24,68-73). */
 int aic_set_options(aic_ctx *ctx, int layer, const aic_options *options);
 

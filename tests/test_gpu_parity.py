@@ -844,3 +844,46 @@ def test_degenerate_spaces_and_blocks(ctx):
         assert_parity(got, ref)
         fast = ctx.render(ctx.make_frame(w, h, world_inv=inv))
         assert (fast["rgba8"] == got["rgba8"]).all()
+
+
+def test_replace_blocks_in_place_batched_and_compacted(ctx):
+    """An animated block re-evaluated every tick must not grow device memory: same-size replacements are
+    written in place, a batch goes under one synchronisation, blocks that outgrow their ranges are appended and the pools
+    re-packed on the device -- and every state renders like a fresh upload of the same scene."""
+    sp = scenes.synthetic_space(n=16, resolution=16, n_blocks=6, seed=5)
+    opt = oracle.make_options()
+    eye = (8.5, 14.5, 30.0)
+    q = oracle.look_at_y_up(eye, (8.0, 6.0, 8.0))
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, 96 / 64, q, eye)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+    recs = [i for i, b in enumerate(sp.blocks) if b.resolution > 1]
+    variants = scenes.synthetic_blocks(16, 12, seed=77)
+
+    def check():
+        got = ctx.render(ctx.make_frame(96, 64, world_inv=inv), want_aux=True)
+        ref = oracle.render(oracle.Space(sp), opt, oracle.make_camera(inv, 96, 64), want_aux=True, threads=4)
+        assert_parity(got, ref)
+
+    for tick in range(40):  # same-size replacements, three blocks per tick in one call
+        items = []
+        for j, i in enumerate(recs[:3]):
+            nb = variants[(tick + j) % len(variants)]
+            sp.blocks[i] = nb
+            items.append((i, nb))
+        ctx.replace_blocks(abi.LAYER_WORLD, items)
+    check()
+    # outgrow: R32 replacements of R16 blocks (8x the voxels) force appends; repeated, they force a compaction
+    big = scenes.synthetic_blocks(32, 4, seed=9)
+    for tick in range(24):
+        i = recs[tick % 2]
+        nb = big[tick % 4] if tick % 3 else variants[tick % len(variants)]
+        sp.blocks[i] = nb
+        ctx.replace_block(abi.LAYER_WORLD, i, nb)
+    check()
+    ctx.compact(abi.LAYER_WORLD)  # the re-pack itself (also run automatically past a garbage threshold)
+    check()
+    ctx.replace_block(abi.LAYER_WORLD, recs[0], variants[0])  # and the table is still consistent afterwards
+    sp.blocks[recs[0]] = variants[0]
+    check()
