@@ -28,6 +28,9 @@ ABI_SYMBOLS = [
     "aic_clear_space", "aic_update_cubes", "aic_update_light_volume", "aic_replace_block", "aic_replace_blocks", "aic_compact", "aic_set_options",
     "aic_render", "aic_render_submit", "aic_render_wait", "aic_trace_patches", "aic_partition_rows", "aic_assemble_strips", "aic_read_aux", "aic_synchronize", "aic_stream",
     "aic_probe_raycast", "aic_probe_light_lut", "aic_probe_powf",
+    "aic_create_multi", "aic_destroy_multi", "aic_multi_device_count", "aic_multi_context", "aic_multi_last_error", "aic_multi_upload_space",
+    "aic_multi_clear_space", "aic_multi_update_cubes", "aic_multi_update_light_volume", "aic_multi_replace_blocks", "aic_multi_set_options",
+    "aic_multi_render",
 ]
 
 
@@ -241,7 +244,9 @@ class Context:
         return int(self._lib.aic_stream(self._h) or 0)
 
     # -- scene ---------------------------------------------------------------------------
-    def upload_space(self, layer: int, flat_space) -> None:
+    @staticmethod
+    def _space_desc(flat_space):
+        """(SpaceDesc, keep-alive) for aic_upload_space / aic_multi_upload_space."""
         p = flat_space.pack() if hasattr(flat_space, "pack") else flat_space
         d = SpaceDesc()
         d.lo[:] = [int(v) for v in p.lo]
@@ -262,6 +267,10 @@ class Context:
         for i in range(7):
             for j in range(4):
                 d.block_sky[i][j] = int(bs[i, j])
+        return d, p
+
+    def upload_space(self, layer: int, flat_space) -> None:
+        d, _keep = self._space_desc(flat_space)
         self._check(self._lib.aic_upload_space(self._h, layer, C.byref(d)))
 
     def clear_space(self, layer: int) -> None:
@@ -409,3 +418,74 @@ class Context:
         out = np.zeros(256, np.float32)
         self._check(self._lib.aic_probe_light_lut(self._h, out.ctypes.data))
         return out
+
+
+class MultiContext:
+    """`aic_multi`: one object over several devices (ids may repeat), the form a Rust `HipRtRenderer` would hold.
+    Scene calls are replicated; `render` deals 16-row strips to the devices and assembles the frame on the first."""
+
+    def __init__(self, device_ids):
+        self._lib = load()
+        lib = self._lib
+        lib.aic_create_multi.restype = C.c_void_p
+        lib.aic_create_multi.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        lib.aic_destroy_multi.argtypes = [C.c_void_p]
+        lib.aic_multi_last_error.restype = C.c_char_p
+        lib.aic_multi_last_error.argtypes = [C.c_void_p]
+        lib.aic_multi_device_count.argtypes = [C.c_void_p]
+        lib.aic_multi_upload_space.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.aic_multi_clear_space.argtypes = [C.c_void_p, C.c_int]
+        lib.aic_multi_set_options.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.aic_multi_update_light_volume.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.aic_multi_update_cubes.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.aic_multi_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        ids = np.ascontiguousarray(device_ids, np.int32)
+        st = C.c_int(0)
+        self._h = lib.aic_create_multi(len(ids), _ptr(ids), C.byref(st))
+        if not self._h:
+            raise AicError(st.value, "aic_create_multi failed (no usable MI355X?)")
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.aic_destroy_multi(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int) -> None:
+        if rc != AIC_OK:
+            raise AicError(rc, self._lib.aic_multi_last_error(self._h).decode())
+
+    @property
+    def device_count(self) -> int:
+        return int(self._lib.aic_multi_device_count(self._h))
+
+    def upload_space(self, layer: int, flat_space) -> None:
+        d, _keep = Context._space_desc(flat_space)
+        self._check(self._lib.aic_multi_upload_space(self._h, layer, C.byref(d)))
+
+    def clear_space(self, layer: int) -> None:
+        self._check(self._lib.aic_multi_clear_space(self._h, layer))
+
+    def set_options(self, layer: int, options: Options) -> None:
+        self._check(self._lib.aic_multi_set_options(self._h, layer, C.byref(options)))
+
+    def update_light_volume(self, layer: int, light) -> None:
+        lt = np.ascontiguousarray(light, np.uint8)
+        self._check(self._lib.aic_multi_update_light_volume(self._h, layer, _ptr(lt)))
+
+    def update_cubes(self, layer: int, xyz, block_index=None, light=None) -> None:
+        xyz = np.ascontiguousarray(xyz, np.int32).reshape(-1, 3)
+        bi = None if block_index is None else np.ascontiguousarray(block_index, np.uint16)
+        lt = None if light is None else np.ascontiguousarray(light, np.uint8).reshape(-1, 4)
+        self._check(self._lib.aic_multi_update_cubes(self._h, layer, len(xyz), _ptr(xyz), _ptr(bi), _ptr(lt)))
+
+    def render(self, frame: FrameDesc):
+        out = np.zeros((frame.height, frame.width, 4), np.uint8)
+        info = FrameInfo()
+        self._check(self._lib.aic_multi_render(self._h, C.byref(frame), _ptr(out), 0, C.byref(info)))
+        return {"rgba8": out, "info": info}

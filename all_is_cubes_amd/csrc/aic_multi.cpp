@@ -1,0 +1,197 @@
+// aic_multi.cpp -- one process, several MI355X: the multi-device context of the C ABI.
+//
+// `north_star` asks for the 8-GPU path BEHIND HeadlessRenderer: a Rust shim holds one object, not eight processes. An
+// aic_multi owns one aic_ctx per device (device ids may repeat: two contexts on one GPU are how the path is tested on a
+// single-GPU box), replicates every scene call on all of them (the scene is tiny next to 288 GB: SURVEY.md 8e), and
+// renders a frame as the reference's row loop would be split (renderer.rs:537-555 treats rows as independent work
+// items): the image is cut into 16-row strips dealt round-robin to the devices, every device traces its strips into a
+// compact local buffer (aic_render_submit on its own stream -- the traces run concurrently), the compact buffers are
+// copied to device 0 over xGMI (hipMemcpyPeerAsync: each peer uses its direct link to device 0, the same exchange the
+// multi-process path does with an RCCL gather), and aic_assemble_strips de-interleaves them into the frame.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/aic_hip.h"
+
+namespace {
+constexpr uint32_t kStripRows = 16;
+}
+
+struct aic_multi {
+    std::vector<aic_ctx *> ctx;
+    std::vector<int> dev;
+    std::vector<void *> local;       // per device: compact strips [local_rows][width] RGBA8
+    std::vector<size_t> local_bytes;
+    void *gathered = nullptr;        // on device 0: [n][max_rows][width]
+    size_t gathered_bytes = 0;
+    void *frame = nullptr;           // on device 0: the assembled frame when the caller wants a host copy
+    size_t frame_bytes = 0;
+    std::string err;
+};
+
+namespace {
+
+int mfail(aic_multi *m, int code, const std::string &msg) {
+    if (m) m->err = msg;
+    return code;
+}
+int forward(aic_multi *m, size_t i, int rc) {
+    if (rc != AIC_OK) m->err = "device " + std::to_string(m->dev[i]) + ": " + aic_last_error(m->ctx[i]);
+    return rc;
+}
+int ensure(aic_multi *m, int device, void **p, size_t *have, size_t need) {
+    if (need <= *have) return AIC_OK;
+    if (hipSetDevice(device) != hipSuccess) return mfail(m, AIC_ERR_DEVICE, "hipSetDevice failed");
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *have = 0;
+    if (hipMalloc(p, need + need / 4) != hipSuccess) return mfail(m, AIC_ERR_DEVICE, "hipMalloc failed");
+    *have = need + need / 4;
+    return AIC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+aic_multi *aic_create_multi(int n_devices, const int *device_ids, int *status) {
+    int dummy;
+    if (!status) status = &dummy;
+    if (n_devices < 1 || n_devices > 64 || !device_ids) { *status = AIC_ERR_INVALID; return nullptr; }
+    aic_multi *m = new aic_multi();
+    for (int i = 0; i < n_devices; i++) {
+        int st = AIC_OK;
+        aic_ctx *c = aic_create(device_ids[i], &st);
+        if (!c) {
+            *status = st;
+            aic_destroy_multi(m);
+            return nullptr;
+        }
+        m->ctx.push_back(c);
+        m->dev.push_back(device_ids[i]);
+    }
+    m->local.assign((size_t)n_devices, nullptr);
+    m->local_bytes.assign((size_t)n_devices, 0);
+    // let device 0 be written by its peers directly (a failure only means the copies are staged by the runtime)
+    for (int i = 1; i < n_devices; i++) {
+        if (device_ids[i] == device_ids[0]) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, device_ids[i], device_ids[0]) == hipSuccess && can && hipSetDevice(device_ids[i]) == hipSuccess)
+            (void)hipDeviceEnablePeerAccess(device_ids[0], 0);
+        (void)hipGetLastError();
+    }
+    *status = AIC_OK;
+    return m;
+}
+
+void aic_destroy_multi(aic_multi *m) {
+    if (!m) return;
+    for (size_t i = 0; i < m->ctx.size(); i++) {
+        if (m->local[i]) { (void)hipSetDevice(m->dev[i]); (void)hipFree(m->local[i]); }
+        aic_destroy(m->ctx[i]);
+    }
+    if (!m->dev.empty()) {
+        (void)hipSetDevice(m->dev[0]);
+        if (m->gathered) (void)hipFree(m->gathered);
+        if (m->frame) (void)hipFree(m->frame);
+    }
+    delete m;
+}
+
+int aic_multi_device_count(const aic_multi *m) { return m ? (int)m->ctx.size() : 0; }
+aic_ctx *aic_multi_context(aic_multi *m, int i) { return (m && i >= 0 && (size_t)i < m->ctx.size()) ? m->ctx[(size_t)i] : nullptr; }
+const char *aic_multi_last_error(const aic_multi *m) { return m ? m->err.c_str() : "no context"; }
+
+// scene calls: replicated on every device
+#define AIC_MULTI_FORWARD(call)                                            \
+    if (!m) return AIC_ERR_INVALID;                                        \
+    for (size_t i = 0; i < m->ctx.size(); i++) {                           \
+        const int rc = forward(m, i, call);                                \
+        if (rc != AIC_OK) return rc;                                       \
+    }                                                                      \
+    return AIC_OK;
+
+int aic_multi_upload_space(aic_multi *m, int layer, const aic_space_desc *s) { AIC_MULTI_FORWARD(aic_upload_space(m->ctx[i], layer, s)) }
+int aic_multi_clear_space(aic_multi *m, int layer) { AIC_MULTI_FORWARD(aic_clear_space(m->ctx[i], layer)) }
+int aic_multi_update_cubes(aic_multi *m, int layer, uint32_t n, const int32_t *xyz, const uint16_t *bi, const uint8_t *light) {
+    AIC_MULTI_FORWARD(aic_update_cubes(m->ctx[i], layer, n, xyz, bi, light))
+}
+int aic_multi_update_light_volume(aic_multi *m, int layer, const uint8_t *light) { AIC_MULTI_FORWARD(aic_update_light_volume(m->ctx[i], layer, light)) }
+int aic_multi_replace_blocks(aic_multi *m, int layer, uint32_t n, const uint32_t *indices, const aic_block_desc *descs, const uint16_t *const *voxels,
+                             const float *const *palettes) {
+    AIC_MULTI_FORWARD(aic_replace_blocks(m->ctx[i], layer, n, indices, descs, voxels, palettes))
+}
+int aic_multi_set_options(aic_multi *m, int layer, const aic_options *o) { AIC_MULTI_FORWARD(aic_set_options(m->ctx[i], layer, o)) }
+
+int aic_multi_render(aic_multi *m, const aic_frame_desc *f, void *out_rgba8, int out_is_device, aic_frame_info *info) {
+    if (!m || !f || !out_rgba8) return mfail(m, AIC_ERR_INVALID, "aic_multi_render: bad argument");
+    if (f->flags & (AIC_FRAME_AUX | AIC_FRAME_OUT_LINEAR | AIC_FRAME_OUT_COLORBUF))
+        return mfail(m, AIC_ERR_INVALID, "aic_multi_render: RGBA8 frames only (use a single context for aux records / float output)");
+    if (f->partition.n_parts > 1) return mfail(m, AIC_ERR_INVALID, "aic_multi_render partitions the frame itself");
+    const size_t n = m->ctx.size();
+    const uint32_t w = f->width, h = f->height;
+    if (info) std::memset(info, 0, sizeof(*info));
+    if (n == 1) {
+        const int rc = forward(m, 0, aic_render(m->ctx[0], f, out_rgba8, out_is_device, info));
+        return rc;
+    }
+    std::vector<uint32_t> rows(n);
+    uint32_t max_rows = 0;
+    for (size_t i = 0; i < n; i++) {
+        const aic_partition p{kStripRows, (uint32_t)n, (uint32_t)i, 0};
+        rows[i] = aic_partition_rows(h, &p);
+        if (rows[i] > max_rows) max_rows = rows[i];
+    }
+    const size_t row_bytes = (size_t)w * 4;
+    if (!w || !h) return AIC_OK;
+    for (size_t i = 0; i < n; i++) {
+        const int rc = ensure(m, m->dev[i], &m->local[i], &m->local_bytes[i], (size_t)(rows[i] ? rows[i] : 1) * row_bytes);
+        if (rc != AIC_OK) return rc;
+    }
+    { const int rc = ensure(m, m->dev[0], &m->gathered, &m->gathered_bytes, n * (size_t)max_rows * row_bytes); if (rc != AIC_OK) return rc; }
+    // 1. every device traces its strips (the submits return at once: the traces overlap)
+    for (size_t i = 0; i < n; i++) {
+        aic_frame_desc fi = *f;
+        fi.partition = aic_partition{kStripRows, (uint32_t)n, (uint32_t)i, 0};
+        const int rc = forward(m, i, aic_render_submit(m->ctx[i], &fi, m->local[i], 0));
+        if (rc != AIC_OK) return rc;
+    }
+    // 2. as each finishes, its compact strips go to device 0 (peer copy over the direct link)
+    hipStream_t s0 = (hipStream_t)aic_stream(m->ctx[0]);
+    for (size_t i = 0; i < n; i++) {
+        aic_frame_info fi;
+        const int rc = forward(m, i, aic_render_wait(m->ctx[i], 0, &fi));
+        if (rc != AIC_OK) return rc;
+        if (info) {
+            info->cubes_traced += fi.cubes_traced; info->n_outer += fi.n_outer; info->n_inner += fi.n_inner;
+            info->n_hits += fi.n_hits; info->n_light += fi.n_light; info->flaws |= fi.flaws;
+            if (fi.kernel_ms > info->kernel_ms) info->kernel_ms = fi.kernel_ms;
+        }
+        if (!rows[i]) continue;
+        char *dst = (char *)m->gathered + i * (size_t)max_rows * row_bytes;
+        if (hipSetDevice(m->dev[0]) != hipSuccess) return mfail(m, AIC_ERR_DEVICE, "hipSetDevice failed");
+        const hipError_t e = m->dev[i] == m->dev[0]
+                                 ? hipMemcpyAsync(dst, m->local[i], (size_t)rows[i] * row_bytes, hipMemcpyDeviceToDevice, s0)
+                                 : hipMemcpyPeerAsync(dst, m->dev[0], m->local[i], m->dev[i], (size_t)rows[i] * row_bytes, s0);
+        if (e != hipSuccess) return mfail(m, AIC_ERR_DEVICE, std::string("peer copy: ") + hipGetErrorString(e));
+    }
+    // 3. de-interleave on device 0
+    void *target = out_rgba8;
+    if (!out_is_device) {
+        const int rc = ensure(m, m->dev[0], &m->frame, &m->frame_bytes, (size_t)h * row_bytes);
+        if (rc != AIC_OK) return rc;
+        target = m->frame;
+    }
+    { const int rc = forward(m, 0, aic_assemble_strips(m->ctx[0], m->gathered, target, w, h, kStripRows, (uint32_t)n)); if (rc != AIC_OK) return rc; }
+    if (!out_is_device) {
+        if (hipMemcpyAsync(out_rgba8, target, (size_t)h * row_bytes, hipMemcpyDeviceToHost, s0) != hipSuccess) return mfail(m, AIC_ERR_DEVICE, "read-back failed");
+    }
+    if (hipStreamSynchronize(s0) != hipSuccess) return mfail(m, AIC_ERR_DEVICE, "synchronize failed");
+    return AIC_OK;
+}
+
+}  // extern "C"

@@ -242,6 +242,29 @@ int aic_synchronize(aic_ctx *ctx);
 /* the context's HIP stream (hipStream_t) for callers that time or order work against it */
 void *aic_stream(aic_ctx *ctx);
 
+/* --- several devices in one process ------------------------------------------------------ */
+/* No reference counterpart: the reference's renderer is one object, and so is this -- an aic_multi owns one context
+ * per device (ids may repeat), replicates the scene calls on all of them, and renders a frame by dealing 16-row
+ * strips round-robin to the devices (rows are independent work items in the reference: renderer.rs:537-555),
+ * copying each device's compact strips to device_ids[0] over its direct xGMI link (hipMemcpyPeerAsync) and
+ * de-interleaving there. The multi-PROCESS form of the same partition (one rank per GPU, RCCL gather) is what
+ * bench.py drives; both produce the single-device frame byte for byte. RGBA8 output only. */
+typedef struct aic_multi aic_multi;
+aic_multi *aic_create_multi(int n_devices, const int *device_ids, int *status);
+void aic_destroy_multi(aic_multi *m);
+int aic_multi_device_count(const aic_multi *m);
+aic_ctx *aic_multi_context(aic_multi *m, int i);
+const char *aic_multi_last_error(const aic_multi *m);
+int aic_multi_upload_space(aic_multi *m, int layer, const aic_space_desc *space);
+int aic_multi_clear_space(aic_multi *m, int layer);
+int aic_multi_update_cubes(aic_multi *m, int layer, uint32_t n, const int32_t *xyz, const uint16_t *block_index, const uint8_t *light);
+int aic_multi_update_light_volume(aic_multi *m, int layer, const uint8_t *light);
+int aic_multi_replace_blocks(aic_multi *m, int layer, uint32_t n, const uint32_t *indices, const aic_block_desc *descs,
+                             const uint16_t *const *voxels, const float *const *palettes);
+int aic_multi_set_options(aic_multi *m, int layer, const aic_options *options);
+/* out_rgba8: [height][width] RGBA8; out_is_device != 0: a device pointer on device_ids[0] */
+int aic_multi_render(aic_multi *m, const aic_frame_desc *frame, void *out_rgba8, int out_is_device, aic_frame_info *info);
+
 /* --- device-side probes used by the parity tests (not part of the render path) --------- */
 /* runs Raycaster::new(origin,dir)[.within(lo,hi,include_exit)] on the device, one ray,
  * and writes up to max_steps {cube[3], face, t_distance} records (raycast.rs:239-284). */

@@ -887,3 +887,36 @@ def test_replace_blocks_in_place_batched_and_compacted(ctx):
     ctx.replace_block(abi.LAYER_WORLD, recs[0], variants[0])  # and the table is still consistent afterwards
     sp.blocks[recs[0]] = variants[0]
     check()
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_multi_device_context_equals_single(ctx, n):
+    """aic_create_multi: the single-process multi-device path behind the C ABI (what a Rust HipRtRenderer would hold).
+    With every context on device 0 the strips still go through the whole partition -> peer copy -> assemble path, and
+    the frame must equal the single-context frame byte for byte, step counts included; scene updates are replicated."""
+    sp = scenes.synthetic_space(n=24, resolution=8, n_blocks=8, seed=11)
+    opt = to_abi_options(oracle.make_options())
+    eye = (12.5, 20.5, 40.0)
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, 200 / 117, oracle.look_at_y_up(eye, (12.0, 8.0, 12.0)), eye)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.set_options(abi.LAYER_WORLD, opt)
+    with abi.MultiContext([0] * n) as m:
+        assert m.device_count == n
+        m.upload_space(abi.LAYER_WORLD, sp)
+        m.set_options(abi.LAYER_WORLD, opt)
+        for size in [(200, 117), (64, 16), (33, 5)]:   # more strips than devices, exactly one strip, fewer rows than a strip
+            w, h = size
+            _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, (12.0, 8.0, 12.0)), eye)
+            one = ctx.render(ctx.make_frame(w, h, world_inv=inv))
+            many = m.render(abi.Context.make_frame(w, h, world_inv=inv))
+            assert (one["rgba8"] == many["rgba8"]).all()
+            assert one["info"].cubes_traced == many["info"].cubes_traced
+        # a replicated scene update
+        xyz = np.array([[12, 10, 12], [11, 10, 12]], np.int32)
+        bi = np.array([1, 1], np.uint16)
+        ctx.update_cubes(abi.LAYER_WORLD, xyz, block_index=bi)
+        m.update_cubes(abi.LAYER_WORLD, xyz, block_index=bi)
+        w, h = 96, 64
+        _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, (12.0, 8.0, 12.0)), eye)
+        assert (ctx.render(ctx.make_frame(w, h, world_inv=inv))["rgba8"] == m.render(abi.Context.make_frame(w, h, world_inv=inv))["rgba8"]).all()
