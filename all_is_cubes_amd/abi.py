@@ -26,7 +26,7 @@ FRAME_COUNTERS, FRAME_AUX, FRAME_PIXEL_CENTERS, FRAME_OUT_LINEAR, FRAME_OUT_COLO
 ABI_SYMBOLS = [
     "aic_abi_version", "aic_create", "aic_destroy", "aic_last_error", "aic_device_name", "aic_upload_space",
     "aic_clear_space", "aic_update_cubes", "aic_update_light_volume", "aic_replace_block", "aic_replace_blocks", "aic_compact", "aic_set_options",
-    "aic_render", "aic_render_submit", "aic_render_wait", "aic_trace_patches", "aic_partition_rows", "aic_assemble_strips", "aic_read_aux", "aic_synchronize", "aic_stream",
+    "aic_render", "aic_render_submit", "aic_render_wait", "aic_trace_patches", "aic_partition_rows", "aic_assemble_strips", "aic_read_aux", "aic_synchronize", "aic_stream", "aic_wait_event",
     "aic_probe_raycast", "aic_probe_light_lut", "aic_probe_powf",
     "aic_create_multi", "aic_destroy_multi", "aic_multi_device_count", "aic_multi_context", "aic_multi_last_error", "aic_multi_upload_space",
     "aic_multi_clear_space", "aic_multi_update_cubes", "aic_multi_update_light_volume", "aic_multi_replace_blocks", "aic_multi_set_options",

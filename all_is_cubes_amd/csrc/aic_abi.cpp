@@ -1081,6 +1081,15 @@ int aic_synchronize(aic_ctx *c) {
 
 void *aic_stream(aic_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
+int aic_wait_event(aic_ctx *c, void *hip_event) {
+    if (!c || !hip_event) return fail(c, AIC_ERR_INVALID, "aic_wait_event: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, (hipEvent_t)hip_event, 0));
+    for (uint32_t i = 1; i < AIC_MAX_IN_FLIGHT; i++)
+        if (c->slots[i].stream) HIP_TRY(c, hipStreamWaitEvent(c->slots[i].stream, (hipEvent_t)hip_event, 0));
+    return AIC_OK;
+}
+
 int aic_probe_raycast(aic_ctx *c, const double origin[3], const double direction[3], int use_bounds, const int32_t lo[3],
                       const int32_t hi[3], int include_exit, uint32_t max_steps, aic_rc_step *out, uint32_t *n_out, int *ended) {
     if (!c || !origin || !direction || !out || !n_out || !ended) return fail(c, AIC_ERR_INVALID, "aic_probe_raycast: bad argument");

@@ -70,11 +70,15 @@ class StripGatherPipeline:
         g = pipe.retire(slot)             # before the slot is reused: wait for its gather;
                                           # rank 0 gets the gathered strips back (de-interleave them)
 
-    The renderer writes on its own HIP stream, so `retire` waits on the host, not just on torch's
-    current stream: a slot handed back is really free. Buffers are allocated once."""
+    The renderer works on HIP streams of its own, which torch's stream semantics do not cover. `retire` therefore
+    records an event behind the finished gather and hands it to `wait_event` (the renderer's `aic_wait_event`:
+    everything it queues afterwards -- the de-interleave of this slot, the next trace into its strip buffer -- waits
+    for the event on the device; the host does not block). Without a `wait_event` hook the host waits for that one
+    event. Buffers are allocated once."""
 
-    def __init__(self, height: int, width: int, strip_rows: int, device, depth: int = 2, group=None):
+    def __init__(self, height: int, width: int, strip_rows: int, device, depth: int = 2, group=None, wait_event=None):
         self.group = group
+        self.wait_event = wait_event
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.height, self.width, self.strip_rows, self.depth = height, width, strip_rows, depth
@@ -95,9 +99,15 @@ class StripGatherPipeline:
         w = self.work[slot]
         if w is None:
             return None
-        w.wait()
+        w.wait()  # NCCL: torch's current stream now waits for the collective (not the host)
         if self.local[slot].is_cuda:
-            torch.cuda.current_stream(self.local[slot].device).synchronize()
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.local[slot].device))
+            if self.wait_event is not None:
+                self.wait_event(ev.cuda_event)
+                self._events = getattr(self, "_events", [])[-8:] + [ev]  # keep the handles alive until they have fired
+            else:
+                ev.synchronize()
         self.work[slot] = None
         self.order.remove(slot)
         return self.gathered[slot]

@@ -664,5 +664,6 @@ ImageInfo HipRtRenderer::wait_rows(uint32_t slot) {
     return to_info(fi, vp.framebuffer_width, vp.framebuffer_height);
 }
 void HipRtRenderer::synchronize() { check(aic_synchronize(ctx_), "aic_synchronize"); }
+void HipRtRenderer::wait_event(void *hip_event) { check(aic_wait_event(ctx_, hip_event), "aic_wait_event"); }
 
 }  // namespace aic::host

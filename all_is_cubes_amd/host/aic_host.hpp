@@ -314,6 +314,7 @@ class HipRtRenderer : public HeadlessRenderer {
     const StandardCameras &cameras() const { return *cameras_; }
     std::string device_name() const;
     void *stream() const;
+    void wait_event(void *hip_event);  // aic_wait_event: later frames wait for a foreign event, the host does not
     bool enable_counters = false;
 
   private:

@@ -232,5 +232,6 @@ PYBIND11_MODULE(_host, m) {
         .def("modified_viewport", &HipRtRenderer::modified_viewport)
         .def("device_name", &HipRtRenderer::device_name)
         .def("stream", [](const HipRtRenderer &r) { return reinterpret_cast<uintptr_t>(r.stream()); })
+        .def("wait_event", [](HipRtRenderer &r, uintptr_t ev) { r.wait_event(reinterpret_cast<void *>(ev)); })
         .def_readwrite("enable_counters", &HipRtRenderer::enable_counters);
 }

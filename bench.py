@@ -86,7 +86,9 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="atrium", choices=["atrium", "s256", "small", "orbit"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify", action="store_true", help="N > 1: check the assembled frame against a single-rank trace")
+    ap.add_argument("--verify", dest="verify", action="store_true", default=None,
+                    help="N > 1 (default there): check the assembled frame against a single-rank trace of the same frame")
+    ap.add_argument("--no-verify", dest="verify", action="store_false")
     ap.add_argument("--in-flight", type=int, default=0, help="frames traced concurrently (1..4); default 2 at N = 1, 4 at N > 1")
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: gather each frame before tracing the next")
     ap.add_argument("--lighting", type=int, default=3, help="experiment: LightingOption (0 None,1 Flat,2 Coarse,3 Linear,4 Smoothstep); default Linear")
@@ -155,7 +157,8 @@ def main() -> int:
     streamed = not args.no_pipeline
     depth = max(1, min(4, args.in_flight if args.in_flight > 0 else (2 if world == 1 else 4)))  # traces in flight (AIC_MAX_IN_FLIGHT = 4)
     ring = depth + 1 if streamed else 1
-    pipe = D.StripGatherPipeline(h, w, strip, "cpu" if one_gpu_test else dev, depth=ring) if world > 1 else None
+    pipe = D.StripGatherPipeline(h, w, strip, "cpu" if one_gpu_test else dev, depth=ring,
+                                 wait_event=None if one_gpu_test else renderer.wait_event) if world > 1 else None
     n_local = depth if streamed else 1
     local_bufs = [torch.empty((max(local_rows, 1), w, 4), dtype=torch.uint8, device=dev) for _ in range(n_local)] if (pipe is None or one_gpu_test) else None
     stage_buf = torch.empty((world, pipe.max_rows, w, 4), dtype=torch.uint8, device=dev) if (one_gpu_test and pipe is not None and rank == 0) else None
@@ -268,7 +271,9 @@ def main() -> int:
     mean_kernel_ms = region_kernel_ms[order]
 
     # --- untimed extras: algorithmic-byte counters, read-back rate ------------------------------
-    if args.verify and world > 1:
+    verified = None
+    if (args.verify or args.verify is None) and world > 1:
+        verified = True
         # the assembled frame of the last step must equal the same frame traced by one rank alone
         if rank == 0:
             whole = torch.empty((h, w, 4), dtype=torch.uint8, device=dev)
@@ -414,6 +419,7 @@ def main() -> int:
                 "partition": f"interleaved {strip}-row strips over {world} GPU(s), scene replicated, RCCL gather to rank 0",
                 "steps_per_ray": round(cubes_traced / rays_per_frame, 2),
                 "frames_in_flight": depth if streamed else 1,
+                "assembled_frame_equals_single_rank_frame": verified,
             },
             "roofline": {
                 "bound": "hbm",

@@ -241,6 +241,10 @@ int aic_read_aux(aic_ctx *ctx, aic_pixel_aux *out, uint64_t n_records);
 int aic_synchronize(aic_ctx *ctx);
 /* the context's HIP stream (hipStream_t) for callers that time or order work against it */
 void *aic_stream(aic_ctx *ctx);
+/* Everything the context queues from now on (on any of its streams) waits for `hip_event` (a hipEvent_t recorded by
+ * the caller on a stream of its own, e.g. after an RCCL gather that reads or writes buffers the next frames touch):
+ * orders foreign work before the context's without blocking the host. */
+int aic_wait_event(aic_ctx *ctx, void *hip_event);
 
 /* --- several devices in one process ------------------------------------------------------ */
 /* No reference counterpart: the reference's renderer is one object, and so is this -- an aic_multi owns one context
