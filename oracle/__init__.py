@@ -18,7 +18,7 @@ _LIB_PATH = _HERE / "libaic_oracle.so"
 
 
 def build(force: bool = False) -> Path:
-    srcs = (_HERE / "aic_oracle.cpp", _HERE / "aic_light.inc", _HERE / "aic_oracle.h")
+    srcs = (_HERE / "aic_oracle.cpp", _HERE / "aic_light.inc", _HERE / "aic_ortho.inc", _HERE / "aic_oracle.h")
     stale = (not _LIB_PATH.exists()) or any(p.stat().st_mtime > _LIB_PATH.stat().st_mtime for p in srcs)
     if force or stale:
         subprocess.run(["make", "-C", str(_HERE), "-B" if force else "-s"], check=True)
@@ -445,3 +445,44 @@ def evaluate_light(flat_space, maximum_distance: int = 30, fast: bool = True, ep
               C.c_uint64(max_updates), C.c_void_p(_p(light)), C.c_int32(nq), C.c_void_p(_p(qc)), C.c_void_p(_p(qp)), C.c_int32(hb_width)))
     flat_space.light = light.reshape(np.asarray(flat_space.light).shape)
     return n
+
+
+# ---- axis-aligned rays and the orthographic renderer (aic_ortho.inc) ----------
+
+def aa_raycast(origin, direction: int, bounds=None, include_exit=True, max_steps=64, sub_origin=None, zoom=None):
+    """`AaRay::new(origin, direction)[.zoom_in(cube, resolution)].cast()[.within(bounds, include_exit)]`: returns
+    (steps, ended, equivalent Ray as (origin, direction)). `zoom` = (cube, resolution)."""
+    out = np.zeros(max_steps, RC_STEP_DTYPE)
+    ended = C.c_int32(0)
+    o = _i3(origin)
+    lo, hi = (_i3(bounds[0]), _i3(bounds[1])) if bounds is not None else (_i3((0, 0, 0)), _i3((0, 0, 0)))
+    sub = None if sub_origin is None else np.ascontiguousarray(sub_origin, np.float32)
+    zc = _i3(zoom[0]) if zoom else _i3((0, 0, 0))
+    ray = np.zeros(6)
+    f = lib().orc_aa_raycast
+    f.restype = C.c_int32
+    n = f(C.c_void_p(_p(o)), C.c_int32(direction), C.c_void_p(_p(sub)) if sub is not None else None, C.c_int32(zoom[1] if zoom else 0),
+          C.c_void_p(_p(zc)), C.c_int32(1 if bounds is not None else 0), C.c_void_p(_p(lo)), C.c_void_p(_p(hi)), C.c_int32(1 if include_exit else 0),
+          C.c_int32(max_steps), C.c_void_p(_p(out)), C.byref(ended), C.c_void_p(_p(ray)))
+    return out[:n], bool(ended.value), (ray[:3].copy(), ray[3:].copy())
+
+
+def ortho_views(lo, size, resolution: int = 32):
+    """MultiOrthoCamera::new(resolution, bounds): (image (w, h), rect [5,4], transform [5,4,4], direction [5,3])."""
+    l, s = _i3(lo), _i3(size)
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    lib().orc_ortho_image_size(C.c_void_p(_p(l)), C.c_void_p(_p(s)), C.c_int32(resolution), C.byref(w), C.byref(h))
+    rect = np.zeros((5, 4), np.uint32)
+    tr = np.zeros((5, 16), np.float64)
+    di = np.zeros((5, 3), np.float64)
+    lib().orc_ortho_views(C.c_void_p(_p(l)), C.c_void_p(_p(s)), C.c_int32(resolution), C.c_void_p(_p(rect)), C.c_void_p(_p(tr)), C.c_void_p(_p(di)))
+    return (int(w.value), int(h.value)), rect, tr.reshape(5, 4, 4), di
+
+
+def render_orthographic(space: Space, resolution: int = 32):
+    """raytracer::ortho::render_orthographic: returns dict(rgba8 [h,w,4], cubes_traced)."""
+    (w, h), _, _, _ = ortho_views(space.packed.lo, space.packed.size, resolution)
+    out = np.zeros((h, w, 4), np.uint8)
+    info = np.zeros(1, INFO_DTYPE)
+    lib().orc_render_orthographic(C.byref(space.c), C.c_int32(resolution), C.c_void_p(_p(out)), C.c_void_p(_p(info)))
+    return {"rgba8": out, "cubes_traced": int(info[0]["cubes_traced"])}

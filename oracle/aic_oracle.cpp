@@ -1882,3 +1882,6 @@ double orc_coarsestep(double x) { return coarsestep(x); }
 
 // part 2: the light updater
 #include "aic_light.inc"
+
+// part 3: axis-aligned rays and the orthographic renderer
+#include "aic_ortho.inc"

@@ -190,6 +190,15 @@ uint64_t orc_evaluate_light(const orc_space *space, int32_t maximum_distance, in
                             uint64_t max_updates, uint8_t *light_inout, int32_t n_queue, const int32_t *queue_cubes,
                             const int32_t *queue_priorities, int32_t hb_width);
 
+/* ---- axis-aligned rays and the orthographic renderer (aic_ortho.inc) ---- */
+int32_t orc_aa_raycast(const int32_t origin[3], int32_t direction, const float *sub_origin, int32_t zoom_resolution,
+                       const int32_t zoom_cube[3], int32_t use_bounds, const int32_t lo[3], const int32_t hi[3],
+                       int32_t include_exit, int32_t max_steps, orc_rc_step *out, int32_t *ended, double ray_out[6]);
+void orc_ortho_image_size(const int32_t lo[3], const int32_t size[3], int32_t resolution, uint32_t *w, uint32_t *h);
+void orc_ortho_views(const int32_t lo[3], const int32_t size[3], int32_t resolution, uint32_t rect[5][4], double transform[5][16],
+                     double direction[5][3]);
+int32_t orc_render_orthographic(const orc_space *space, int32_t resolution, uint8_t *rgba8, orc_info *info);
+
 #ifdef __cplusplus
 }
 #endif
