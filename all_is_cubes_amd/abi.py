@@ -28,6 +28,7 @@ ABI_SYMBOLS = [
     "aic_clear_space", "aic_update_cubes", "aic_update_light_volume", "aic_replace_block", "aic_replace_blocks", "aic_compact", "aic_set_options",
     "aic_render", "aic_render_submit", "aic_render_wait", "aic_trace_patches", "aic_partition_rows", "aic_assemble_strips", "aic_read_aux", "aic_synchronize", "aic_stream", "aic_wait_event",
     "aic_probe_raycast", "aic_probe_light_lut", "aic_probe_powf",
+    "aic_ortho_image_size", "aic_render_orthographic",
     "aic_create_multi", "aic_destroy_multi", "aic_multi_device_count", "aic_multi_context", "aic_multi_last_error", "aic_multi_upload_space",
     "aic_multi_clear_space", "aic_multi_update_cubes", "aic_multi_update_light_volume", "aic_multi_replace_blocks", "aic_multi_set_options",
     "aic_multi_render",
@@ -298,6 +299,17 @@ class Context:
         vox = np.ascontiguousarray(block.voxels, np.uint16)
         pal = np.ascontiguousarray(block.palette, np.float32)
         self._check(self._lib.aic_replace_block(self._h, layer, index, C.byref(d), _ptr(vox), _ptr(pal)))
+
+    def render_orthographic(self, layer: int = LAYER_WORLD, resolution: int = 32):
+        """raytracer::ortho::render_orthographic of the layer's space: dict(rgba8 [h,w,4], info)."""
+        f = self._lib.aic_render_orthographic
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p]
+        w, h = C.c_uint32(0), C.c_uint32(0)
+        self._check(f(self._h, layer, resolution, None, 0, C.byref(w), C.byref(h), None))
+        out = np.zeros((h.value, w.value, 4), np.uint8)
+        info = FrameInfo()
+        self._check(f(self._h, layer, resolution, _ptr(out), 0, C.byref(w), C.byref(h), C.byref(info)))
+        return {"rgba8": out, "info": info}
 
     def compact(self, layer: int) -> None:
         self._check(self._lib.aic_compact(self._h, C.c_int(layer)))

@@ -131,6 +131,7 @@ struct aic_ctx {
     DevBuf<uint32_t> out;      // internal RGBA8 target when the caller wants a host copy
     DevBuf<DevAux> aux;
     DevBuf<unsigned char> staging;  // scratch for scatter updates / probes
+    DevBuf<DevOrthoView> ortho_views;  // aic_render_orthographic
     uint64_t aux_records = 0;
     // frames in flight: slot 0 runs on `stream` (and serves the synchronous aic_render), slot 1 on a
     // second stream so that a submitted frame's trace can start while the previous one drains
@@ -431,7 +432,7 @@ void aic_destroy(aic_ctx *c) {
         if (i > 0 && fs.stream) (void)hipStreamDestroy(fs.stream);
     }
     for (auto &l : c->layers) l.release();
-    c->lut.release(); c->srgb_thr.release(); c->out.release(); c->aux.release(); c->staging.release();
+    c->lut.release(); c->srgb_thr.release(); c->out.release(); c->aux.release(); c->staging.release(); c->ortho_views.release();
     if (c->dump) std::fclose(c->dump);
     if (c->upload_stream) (void)hipStreamDestroy(c->upload_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -803,7 +804,7 @@ bool cameras_close(const double a[16], const double b[16]) {
 
 // Queues one frame on a slot's stream: counters reset, optional UI pre-pass, the trace. No waiting.
 int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint32_t slot, bool allow_aux, const double *patches = nullptr,
-                 uint32_t n_patches = 0) {
+                 uint32_t n_patches = 0, const DevOrthoView *ortho = nullptr, int32_t ortho_n = 0) {
     aic_ctx::FrameSlot &fs = c->slots[slot];
     fs.t_begin = std::chrono::steady_clock::now();
     aic_partition part = f->partition;
@@ -838,6 +839,17 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
     F.out_mode = (f->flags & AIC_FRAME_OUT_LINEAR) ? 1 : ((f->flags & AIC_FRAME_OUT_COLORBUF) ? 2 : 0);
     F.patches = patches;
     F.n_patches = n_patches;
+    F.ortho = ortho;
+    F.ortho_n = ortho_n;
+    if (ortho_n) {
+        // render_orthographic traces with GraphicsOptions::UNALTERED_COLORS and no UI layer (ortho.rs:44, 103-131)
+        hl[1].present = 0;
+        DevOptions &o = hl[0].opt;
+        o.fog = 0; o.transparency = 1; o.lighting = 0; o.antialiasing = 0; o.debug_pixel_cost = 0; o.tone_mapping = 0;
+        o.maximum_intensity = INFINITY; o.view_distance = 200.0;
+        hl[0].exposure = 1.0f;
+        flaws = 0;
+    }
     F.antialias = (hl[0].opt.antialiasing == 2 && !F.pixel_centers) ? 1 : 0;
     F.exposure = hl[0].exposure;
     F.maximum_intensity = hl[0].opt.maximum_intensity;
@@ -885,7 +897,7 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         // had the same shape (else index order); then the cost array is cleared for this frame's record
         static const bool feedback = [] { const char *e = std::getenv("AIC_TILE_FEEDBACK"); return !e || std::atoi(e) != 0; }();
         const uint32_t n_tiles = F.macros_x * F.macros_y;  // the feedback works on macro tiles
-        if (feedback && n_tiles && !patches && !(f->flags & AIC_FRAME_NO_FEEDBACK)) {
+        if (feedback && n_tiles && !patches && !ortho_n && !(f->flags & AIC_FRAME_NO_FEEDBACK)) {
             const uint32_t sig[4] = {f->width, local_rows, (part.n_parts << 16) | part.part, (part.strip_rows << 8) | (F.macro << 4) | (F.tile >> 3)};
             bool same = std::memcmp(sig, fs.cost_sig, sizeof(sig)) == 0 && fs.tile_cost.n >= n_tiles;
             if (same) {
@@ -999,6 +1011,125 @@ int aic_render(aic_ctx *c, const aic_frame_desc *f, void *out_rgba8, int out_is_
     if (rc != AIC_OK) return rc;
     if (!out_is_device && c->slots[0].npix)
         HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->out.p, c->slots[0].npix * px_words * 4, hipMemcpyDeviceToHost, c->slots[0].stream));
+    return wait_frame(c, 0, info);
+}
+
+namespace {
+
+// raytracer::ortho::OrthoCamera::new / MultiOrthoCamera::new (ortho.rs:147-184, 213-282), on the host: five pixel-perfect
+// views (top, left, front, right, bottom) laid out around the front view. Matrices are euclid's row-vector 4x4.
+struct Mat4h { double m[16]; };
+Mat4h mat_identity() { Mat4h t{}; t.m[0] = t.m[5] = t.m[10] = t.m[15] = 1.0; return t; }
+Mat4h mat_then(const Mat4h &a, const Mat4h &b) {  // Transform3D::then
+    Mat4h o{};
+    for (int r = 0; r < 4; r++)
+        for (int cc = 0; cc < 4; cc++)
+            o.m[r * 4 + cc] = a.m[r * 4 + 0] * b.m[0 * 4 + cc] + a.m[r * 4 + 1] * b.m[1 * 4 + cc] + a.m[r * 4 + 2] * b.m[2 * 4 + cc] + a.m[r * 4 + 3] * b.m[3 * 4 + cc];
+    return o;
+}
+void ortho_view(int resolution, const int32_t lo[3], const int32_t size[3], int viewed_face /* 1 NX .. 6 PZ */, DevOrthoView *out) {
+    const int axis = (viewed_face - 1) % 3;
+    const int32_t ub[3] = {lo[0] + size[0], lo[1] + size[1], lo[2] + size[2]};
+    out->w = (uint32_t)(axis == 0 ? size[2] : size[0]) * (uint32_t)resolution;
+    out->h = (uint32_t)(axis == 1 ? size[2] : size[1]) * (uint32_t)resolution;
+    double ot[3];
+    // images of +X, +Y, +Z under the view's grid rotation (Face::clockwise / counterclockwise, face.rs:440-465)
+    int bx[3], by[3], bz[3];
+    auto set = [](int v[3], int x, int y, int z) { v[0] = x; v[1] = y; v[2] = z; };
+    switch (viewed_face) {
+        case 1: ot[0] = lo[0]; ot[1] = ub[1]; ot[2] = lo[2]; set(bx, 0, 0, 1); set(by, 0, 1, 0); set(bz, -1, 0, 0); break;   // NX: PY.clockwise()
+        case 2: ot[0] = lo[0]; ot[1] = lo[1]; ot[2] = ub[2]; set(bx, 1, 0, 0); set(by, 0, 0, 1); set(bz, 0, -1, 0); break;   // NY: PX.clockwise()
+        case 3: ot[0] = ub[0]; ot[1] = ub[1]; ot[2] = lo[2]; set(bx, -1, 0, 0); set(by, 0, 1, 0); set(bz, 0, 0, -1); break;  // NZ: 180 degrees about Y
+        case 4: ot[0] = ub[0]; ot[1] = ub[1]; ot[2] = ub[2]; set(bx, 0, 0, -1); set(by, 0, 1, 0); set(bz, 1, 0, 0); break;   // PX: PY.counterclockwise()
+        case 5: ot[0] = lo[0]; ot[1] = ub[1]; ot[2] = lo[2]; set(bx, 1, 0, 0); set(by, 0, 0, -1); set(bz, 0, 1, 0); break;   // PY: PX.counterclockwise()
+        default: ot[0] = lo[0]; ot[1] = ub[1]; ot[2] = ub[2]; set(bx, 1, 0, 0); set(by, 0, 1, 0); set(bz, 0, 0, 1); break;   // PZ: identity
+    }
+    // translation(0.5, 0.5, 0).then_scale(1, -1, 1).then(scale 1/resolution).then(rotation).then_translate(origin)
+    Mat4h t = mat_identity();
+    t.m[12] = 0.5; t.m[13] = 0.5;
+    Mat4h flip = mat_identity();
+    flip.m[5] = -1.0;
+    t = mat_then(t, flip);
+    Mat4h sc = mat_identity();
+    sc.m[0] = sc.m[5] = sc.m[10] = 1.0 / (double)resolution;
+    t = mat_then(t, sc);
+    Mat4h rot{};
+    for (int a = 0; a < 3; a++) { rot.m[0 + a] = bx[a]; rot.m[4 + a] = by[a]; rot.m[8 + a] = bz[a]; }
+    rot.m[15] = 1.0;
+    t = mat_then(t, rot);
+    Mat4h tr = mat_identity();
+    tr.m[12] = ot[0]; tr.m[13] = ot[1]; tr.m[14] = ot[2];
+    t = mat_then(t, tr);
+    std::memcpy(out->m, t.m, sizeof(t.m));
+    // transform_vector3d((0, 0, -1)) reduced to its axis (TryFrom<Ray> for AaRay keeps only the direction's axis and sign)
+    for (int a = 0; a < 3; a++) { const double d = -t.m[8 + a]; out->dir[a] = d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0); }
+}
+void multi_ortho(int resolution, const int32_t lo[3], const int32_t size[3], DevOrthoView v[5], uint32_t *w, uint32_t *h) {
+    ortho_view(resolution, lo, size, 5, &v[0]);  // top
+    ortho_view(resolution, lo, size, 1, &v[1]);  // left
+    ortho_view(resolution, lo, size, 6, &v[2]);  // front
+    ortho_view(resolution, lo, size, 4, &v[3]);  // right
+    ortho_view(resolution, lo, size, 2, &v[4]);  // bottom
+    v[0].x0 = v[1].w + 1; v[0].y0 = 0;
+    v[1].x0 = 0; v[1].y0 = v[0].h + 1;
+    v[2].x0 = v[1].w + 1; v[2].y0 = v[0].h + 1;
+    v[3].x0 = v[1].w + v[2].w + 2; v[3].y0 = v[0].h + 1;
+    v[4].x0 = v[1].w + 1; v[4].y0 = v[0].h + v[2].h + 2;
+    *w = *h = 0;
+    for (int i = 0; i < 5; i++) {
+        if (v[i].x0 + v[i].w > *w) *w = v[i].x0 + v[i].w;
+        if (v[i].y0 + v[i].h > *h) *h = v[i].y0 + v[i].h;
+    }
+}
+bool valid_ortho_resolution(int r) { return r >= 1 && r <= 128 && (r & (r - 1)) == 0; }
+
+}  // namespace
+
+int aic_ortho_image_size(const int32_t lo[3], const int32_t size[3], int resolution, uint32_t *width, uint32_t *height) {
+    if (!lo || !size || !width || !height || !valid_ortho_resolution(resolution) || size[0] < 0 || size[1] < 0 || size[2] < 0) return AIC_ERR_INVALID;
+    DevOrthoView v[5];
+    multi_ortho(resolution, lo, size, v, width, height);
+    return AIC_OK;
+}
+
+int aic_render_orthographic(aic_ctx *c, int layer, int resolution, void *out_rgba8, int out_is_device, uint32_t *width, uint32_t *height,
+                            aic_frame_info *info) {
+    if (!c || !valid_layer(layer) || !valid_ortho_resolution(resolution)) return fail(c, AIC_ERR_INVALID, "aic_render_orthographic: bad argument");
+    if (info) std::memset(info, 0, sizeof(*info));
+    Layer &l = c->layers[layer];
+    if (!l.present) return fail(c, AIC_ERR_INVALID, "aic_render_orthographic: no space uploaded for this layer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->slots[0].busy) return fail(c, AIC_ERR_INVALID, "aic_render_orthographic: a submitted frame still occupies slot 0");
+    DevOrthoView v[5];
+    uint32_t w = 0, h = 0;
+    multi_ortho(resolution, l.lo, l.size, v, &w, &h);
+    if (width) *width = w;
+    if (height) *height = h;
+    if (!out_rgba8 || !w || !h) return AIC_OK;  // size query
+    hipError_t e;
+    if ((e = c->ortho_views.ensure(5)) != hipSuccess) return hip_fail(c, "alloc ortho views", e);
+    HIP_TRY(c, hipMemcpy(c->ortho_views.p, v, sizeof(v), hipMemcpyHostToDevice));
+    aic_frame_desc f;
+    std::memset(&f, 0, sizeof(f));
+    f.width = w;
+    f.height = h;
+    static const double ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::memcpy(f.world.inverse_projection_view, ident, sizeof(ident));
+    std::memcpy(f.ui.inverse_projection_view, ident, sizeof(ident));
+    f.world.exposure = f.ui.exposure = 1.0f;
+    uint32_t *target = (uint32_t *)out_rgba8;
+    const size_t npix = (size_t)w * h;
+    if (!out_is_device) {
+        if ((e = c->out.ensure(npix)) != hipSuccess) return hip_fail(c, "alloc output", e);
+        target = c->out.p;
+    }
+    // the views are traced as the WORLD layer of the launch, whatever layer holds the space
+    const bool swap_layers = layer != AIC_LAYER_WORLD;
+    if (swap_layers) std::swap(c->layers[AIC_LAYER_WORLD], c->layers[layer]);
+    int rc = submit_frame(c, &f, target, 0, false, nullptr, 0, c->ortho_views.p, 5);
+    if (swap_layers) std::swap(c->layers[AIC_LAYER_WORLD], c->layers[layer]);
+    if (rc != AIC_OK) return rc;
+    if (!out_is_device) HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->out.p, npix * 4, hipMemcpyDeviceToHost, c->slots[0].stream));
     return wait_frame(c, 0, info);
 }
 

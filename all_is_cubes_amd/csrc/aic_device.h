@@ -109,6 +109,14 @@ struct DevAux {  // == aic_pixel_aux
     double t_distance;
 };
 
+// One view of raytracer::ortho::MultiOrthoCamera (ortho.rs:142-200): an image rectangle, the pixel -> world transform
+// (euclid row-vector 4x4, pixel centres included) and the unit direction of its axis-aligned rays.
+struct DevOrthoView {
+    uint32_t x0, y0, w, h;
+    double m[16];
+    double dir[3];
+};
+
 struct DevFrame {
     DevLayer layer;          // the layer this launch traces, BY VALUE: kernarg fields are fetched with
                              // scalar loads into SGPRs (a pointer to a device-memory struct costs a
@@ -132,6 +140,8 @@ struct DevFrame {
     int32_t use_init;        // final pass: start each sample from acc_buf (written by the UI pre-pass)
     int32_t pixel_centers;   // AIC_FRAME_PIXEL_CENTERS
     int32_t out_mode;        // 0 sRGB RGBA8 (4 B/pixel); 1 linear Rgba f32x4; 2 ColorBuf f32x4 (16 B/pixel)
+    const DevOrthoView *ortho;  // aic_render_orthographic: the views (device memory), else null
+    int32_t ortho_n;
     const double *patches;   // aic_trace_patches: [n_patches][4] NDC rectangles replacing the pixel grid (pixel i = row-major index)
     uint32_t n_patches;
     float4 *acc_buf;         // [samples][local_rows][width] ColorBuf {light rgb, transmittance}

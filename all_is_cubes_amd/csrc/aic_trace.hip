@@ -1191,7 +1191,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 if (ui_pass) {
                     F.acc_buf[(size_t)sample * npix + pix] = make_float4(acc.l0, acc.l1, acc.l2, acc.t);
                 } else {
-                    if (!cb_opaque(acc)) {  // renderer.rs:474-477: P::paint(NO_WORLD_TO_SHOW) replaces the accumulator
+                    if (!F.ortho_n && !cb_opaque(acc)) {  // renderer.rs:474-477: P::paint(NO_WORLD_TO_SHOW) replaces the accumulator
+                        // (render_orthographic has no such layer tail: ortho.rs:103-131)
                         acc.l0 = 0.f + (NO_WORLD_TO_SHOW * 1.0f) * 1.0f;
                         acc.l1 = acc.l0;
                         acc.l2 = acc.l0;
@@ -1368,13 +1369,42 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 }
                 count = 0;
                 st = (uint32_t)sample << 14;
-                if (L.present) {
-                    double o[3], f[3];
+                bool have_ray = L.present != 0;
+                double o[3] = {0.0, 0.0, 0.0}, dir[3] = {0.0, 0.0, 0.0};
+                if (have_ray && F.ortho_n) {
+                    // MultiOrthoCamera::project_pixel_into_world (ortho.rs:186-199, 284-294): the view whose rectangle holds
+                    // the pixel, its transform applied to the pixel, then TryFrom<Ray> for AaRay / From<AaRay> for Ray
+                    // (ray.rs:305-358: the origin becomes cube + f32 offset, the direction the unit axis vector).
+                    // trace_axis_aligned_ray produces what trace_ray produces on that Ray (axis_aligned.rs:8-9).
+                    int vsel = -1;
+                    for (int v = 0; v < F.ortho_n; v++) {
+                        const uint32_t vx = F.ortho[v].x0, vy = F.ortho[v].y0, vw = F.ortho[v].w, vh = F.ortho[v].h;
+                        if (vsel < 0 && x >= vx && y >= vy && x - vx < vw && y - vy < vh) vsel = v;
+                    }
+                    have_ray = false;
+                    if (vsel >= 0) {
+                        const DevOrthoView *V = &F.ortho[vsel];
+                        double p[3];
+                        unproject(V->m, (double)(x - V->x0), (double)(y - V->y0), 0.0, p);
+                        int cube[3];
+                        if (cube_containing(p, cube)) {
+                            have_ray = true;
+                            for (int a = 0; a < 3; a++) {
+                                o[a] = (double)cube[a] + (double)(float)(p[a] - (double)cube[a]);
+                                dir[a] = V->dir[a];
+                            }
+                        }
+                    }
+                } else if (have_ray) {
+                    double f[3];
                     unproject(L.inv, px, py, 0.0, o);
                     unproject(L.inv, px, py, 1.0, f);
+                    dir[0] = f[0] - o[0]; dir[1] = f[1] - o[1]; dir[2] = f[2] - o[2];
+                }
+                if (have_ray) {
                     const double ox = o[0], oy = o[1], oz = o[2];
                     c64[C_OX][tid] = ox; c64[C_OY][tid] = oy; c64[C_OZ][tid] = oz;
-                    const double dirx = f[0] - o[0], diry = f[1] - o[1], dirz = f[2] - o[2];
+                    const double dirx = dir[0], diry = dir[1], dirz = dir[2];
                     const double t_abs = sqrt(dirx * dirx + diry * diry + dirz * dirz);  // sr.rs:146
                     c64[C_TABS][tid] = t_abs;
                     c32[K_TVIEW][tid] = __float_as_uint((float)(t_abs / opt.view_distance));  // sr.rs:149-151

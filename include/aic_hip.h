@@ -246,6 +246,18 @@ void *aic_stream(aic_ctx *ctx);
  * orders foreign work before the context's without blocking the host. */
 int aic_wait_event(aic_ctx *ctx, void *hip_event);
 
+/* --- orthographic views (icons, previews) -------------------------------------------------- */
+/* replaces: raytracer::ortho::render_orthographic (all-is-cubes-render/src/raytracer/ortho.rs:30-88): five pixel-perfect
+ * axis-aligned views of the layer's space (top, left, front, right, bottom: MultiOrthoCamera, ortho.rs:142-200) at
+ * `resolution` pixels per cube, traced with GraphicsOptions::UNALTERED_COLORS by trace_axis_aligned_ray
+ * (sr.rs:126-133) and encoded with Rgba::to_srgb8; pixels between the views are transparent. out_rgba8 =
+ * [*height][*width] RGBA8 (NULL: only report the size). info->cubes_traced counts every pixel's trace; the
+ * reference's per-row pixel cache (ortho.rs:103-131) skips repeated voxel columns and so reports fewer steps for
+ * the same image. */
+int aic_ortho_image_size(const int32_t lo[3], const int32_t size[3], int resolution, uint32_t *width, uint32_t *height);
+int aic_render_orthographic(aic_ctx *ctx, int layer, int resolution, void *out_rgba8, int out_is_device, uint32_t *width,
+                            uint32_t *height, aic_frame_info *info);
+
 /* --- several devices in one process ------------------------------------------------------ */
 /* No reference counterpart: the reference's renderer is one object, and so is this -- an aic_multi owns one context
  * per device (ids may repeat), replicates the scene calls on all of them, and renders a frame by dealing 16-row

@@ -920,3 +920,28 @@ def test_multi_device_context_equals_single(ctx, n):
         w, h = 96, 64
         _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, (12.0, 8.0, 12.0)), eye)
         assert (ctx.render(ctx.make_frame(w, h, world_inv=inv))["rgba8"] == m.render(abi.Context.make_frame(w, h, world_inv=inv))["rgba8"]).all()
+
+
+@pytest.mark.parametrize("resolution", [8, 32])
+def test_render_orthographic(ctx, resolution):
+    """aic_render_orthographic = raytracer::ortho::render_orthographic (ortho.rs:30-88): five axis-aligned views, traced
+    with UNALTERED_COLORS; against the oracle's restatement: same image size, every byte equal (colours need no powf
+    here: opaque or exactly half-transparent voxels one voxel thick), step sums equal."""
+    sp = scenes.synthetic_space(n=6, resolution=8, n_blocks=8, seed=21)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    got = ctx.render_orthographic(abi.LAYER_WORLD, resolution)
+    ref = oracle.render_orthographic(oracle.Space(sp), resolution)
+    assert got["rgba8"].shape == ref["rgba8"].shape
+    d = np.abs(got["rgba8"].astype(int) - ref["rgba8"].astype(int))
+    assert d.max() <= RGBA_TOL, np.bincount(d.max(axis=-1).ravel())
+    assert got["info"].cubes_traced == ref["cubes_traced"]
+    assert (got["rgba8"][0, 0] == 0).all()  # outside the views: transparent
+    # a non-cubic space with an offset origin, through the UI layer slot
+    sp2 = scenes.synthetic_space(n=5, resolution=4, n_blocks=4, seed=3)
+    sp2.lo = (-7, 3, 11)
+    ctx.upload_space(abi.LAYER_UI, sp2)
+    got = ctx.render_orthographic(abi.LAYER_UI, 16)
+    ref = oracle.render_orthographic(oracle.Space(sp2), 16)
+    assert np.abs(got["rgba8"].astype(int) - ref["rgba8"].astype(int)).max() <= RGBA_TOL
+    assert got["info"].cubes_traced == ref["cubes_traced"]
+    ctx.clear_space(abi.LAYER_UI)
