@@ -2,6 +2,7 @@
 the scene the reference-side updates describe (updating.rs:107-172), and -- on the GPU -- a session
 recorded by the library replays to the same frames."""
 import os
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -136,4 +137,29 @@ def test_library_dump_replays_to_the_same_frames(tmp_path):
     for a, b in zip(again, live):
         assert (a == b).all()
     for a, b in zip(_oracle_frames(path), live):  # and the captured scene satisfies the usual parity bar
+        assert np.abs(a.astype(np.int16) - b.astype(np.int16)).max() <= 1
+
+
+# Any recording dropped under tests/golden/ (e.g. an Atrium or DemoCity session captured by the Rust shim with
+# AIC_DUMP, rust/all-is-cubes-hip/README.md) is replayed and held to the usual parity bar -- no code change needed.
+RECORDED = sorted((Path(__file__).resolve().parent / "golden").glob("*.aic"))
+
+
+@pytest.mark.parametrize("path", RECORDED or [None], ids=[p.name for p in RECORDED] or ["no-recording"])
+def test_recorded_sessions_parse_and_trace_on_the_oracle(path):
+    if path is None:
+        pytest.skip("no *.aic recording under tests/golden/ (none can be produced without the reference's toolchain)")
+    frames = _oracle_frames(path)
+    assert frames and all(f.ndim == 3 and f.shape[2] == 4 for f in frames)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", RECORDED or [None], ids=[p.name for p in RECORDED] or ["no-recording"])
+def test_recorded_sessions_replay_on_the_device(path):
+    if path is None:
+        pytest.skip("no *.aic recording under tests/golden/")
+    device = replay.replay(path)
+    cpu = _oracle_frames(path)
+    assert len(device) == len(cpu)
+    for a, b in zip(cpu, device):
         assert np.abs(a.astype(np.int16) - b.astype(np.int16)).max() <= 1
