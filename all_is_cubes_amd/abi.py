@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "aic_render", "aic_render_submit", "aic_render_wait", "aic_trace_patches", "aic_partition_rows", "aic_assemble_strips", "aic_read_aux", "aic_synchronize", "aic_stream", "aic_wait_event",
     "aic_probe_raycast", "aic_probe_light_lut", "aic_probe_powf",
     "aic_ortho_image_size", "aic_render_orthographic",
+    "aic_evaluate_light", "aic_read_light_volume", "aic_light_chart", "aic_probe_derived", "aic_probe_log2f",
     "aic_create_multi", "aic_destroy_multi", "aic_multi_device_count", "aic_multi_context", "aic_multi_last_error", "aic_multi_upload_space",
     "aic_multi_clear_space", "aic_multi_update_cubes", "aic_multi_update_light_volume", "aic_multi_replace_blocks", "aic_multi_set_options",
     "aic_multi_render",
@@ -46,6 +47,31 @@ class AicError(RuntimeError):
 class BlockDesc(C.Structure):
     _fields_ = [("resolution", C.c_int32), ("vlo", C.c_int32 * 3), ("vsize", C.c_int32 * 3), ("vox_off", C.c_uint32),
                 ("pal_off", C.c_uint32), ("pal_len", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_int32)]
+
+
+class LightParams(C.Structure):
+    _fields_ = [("maximum_distance", C.c_int32), ("fast", C.c_int32), ("epsilon", C.c_int32), ("batch", C.c_int32),
+                ("queue_order", C.c_int32), ("n_queue", C.c_int32), ("queue_cubes", C.c_void_p), ("queue_priorities", C.c_void_p),
+                ("max_updates", C.c_uint64)]
+
+
+class LightInfo(C.Structure):
+    _fields_ = [("updates", C.c_uint64), ("batches", C.c_uint64), ("cost", C.c_uint64), ("device_ms", C.c_double),
+                ("total_ms", C.c_double), ("queue_left", C.c_uint32), ("pad", C.c_uint32)]
+
+
+def light_chart():
+    """The light propagation chart the library generates (chart/generator.rs): (weights [n,6] f32, children [n,6] u32, depth).
+    Host-only: needs no device."""
+    lib = load()
+    lib.aic_light_chart.restype = C.c_uint32
+    lib.aic_light_chart.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+    depth = C.c_uint32(0)
+    n = lib.aic_light_chart(None, None, C.byref(depth))
+    w = np.zeros((n, 6), np.float32)
+    ch = np.zeros((n, 6), np.uint32)
+    lib.aic_light_chart(w.ctypes.data, ch.ctypes.data, C.byref(depth))
+    return w, ch, int(depth.value)
 
 
 class SpaceDesc(C.Structure):
@@ -128,6 +154,10 @@ def load() -> C.CDLL:
                                           C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
         lib.aic_probe_light_lut.argtypes = [C.c_void_p, C.c_void_p]
         lib.aic_probe_powf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.aic_evaluate_light.argtypes = [C.c_void_p, C.c_int, C.POINTER(LightParams), C.POINTER(LightInfo)]
+        lib.aic_read_light_volume.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.aic_probe_derived.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        lib.aic_probe_log2f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         assert C.sizeof(BlockDesc) == 48
         _lib = lib
     return _lib
@@ -424,6 +454,42 @@ class Context:
         y = np.ascontiguousarray(y, np.float32)
         out = np.zeros(x.shape, np.float32)
         self._check(self._lib.aic_probe_powf(self._h, _ptr(x), _ptr(y), x.size, _ptr(out)))
+        return out
+
+    def evaluate_light(self, layer: int, maximum_distance: int, fast: bool = True, epsilon: int = 1, batch: int = 32,
+                       queue_order: int = 16, queue=None, max_updates: int = 0) -> LightInfo:
+        """`Mutation::fast_evaluate_light` (if `fast`) then `Mutation::evaluate_light(epsilon)` (space.rs:1496-1540) on
+        the uploaded space, compute_light on the device. `queue`: None = every Uninitialized texel (when not `fast`), or a
+        list of ((x, y, z), priority). The layer's light volume is updated in place."""
+        p = LightParams(maximum_distance, int(fast), epsilon, batch, queue_order, -1, None, None, max_updates)
+        keep = []
+        if queue is not None:
+            qc = np.ascontiguousarray([q[0] for q in queue], np.int32).reshape(-1, 3)
+            qp = np.ascontiguousarray([q[1] for q in queue], np.int32)
+            keep = [qc, qp]
+            p.n_queue = len(qp)
+            p.queue_cubes = qc.ctypes.data
+            p.queue_priorities = qp.ctypes.data
+        info = LightInfo()
+        self._check(self._lib.aic_evaluate_light(self._h, layer, C.byref(p), C.byref(info)))
+        del keep
+        return info
+
+    def read_light_volume(self, layer: int, shape) -> np.ndarray:
+        out = np.zeros(tuple(shape) + (4,), np.uint8)
+        self._check(self._lib.aic_read_light_volume(self._h, layer, out.ctypes.data))
+        return out
+
+    def probe_derived(self, layer: int, n_blocks: int):
+        out = np.zeros((n_blocks, 32), np.float32)
+        opq = np.zeros((n_blocks, 6), np.uint8)
+        self._check(self._lib.aic_probe_derived(self._h, layer, out.ctypes.data, opq.ctypes.data))
+        return out, opq
+
+    def probe_log2f(self, x) -> np.ndarray:
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros(x.shape, np.float32)
+        self._check(self._lib.aic_probe_log2f(self._h, _ptr(x), x.size, _ptr(out)))
         return out
 
     def probe_light_lut(self) -> np.ndarray:

@@ -38,6 +38,9 @@ using namespace aic;
 static_assert(sizeof(aic_pixel_aux) == sizeof(DevAux), "aux record layout");
 static_assert(sizeof(aic_block_desc) == 48, "aic_block_desc is 48 bytes");
 
+struct LightState;                       // aic_light_host.inc
+void light_state_free(LightState *s);
+
 namespace {
 
 constexpr uint64_t kMaxPoolElems = 0x7ffffff0ull;  // u16 elements of cube grid + voxel volumes (32-bit byte offsets in the kernel)
@@ -96,12 +99,17 @@ struct Layer {
     aic_options opt;
     bool opt_set = false;
     bool cls_in_code = false;  // cube-grid entries carry the block class in bits 14-15 (aic_device.h)
+    uint64_t version = 0;      // bumped by every scene mutation; the light updater's host mirrors follow it
+    LightState *lstate = nullptr;
     size_t n_cubes() const { return (size_t)size[0] * (size_t)size[1] * (size_t)size[2]; }
     void release() {
         pool.release(); cls.release(); light.release(); light_alt.release(); blocks.release(); palette.release();
         host_blocks.clear(); host_cls.clear(); vox_cap.clear(); pal_cap.clear();
         garbage_vox = garbage_pal = 0;
         present = false;
+        version++;
+        light_state_free(lstate);
+        lstate = nullptr;
     }
 };
 
@@ -525,6 +533,7 @@ int aic_upload_space(aic_ctx *c, int layer, const aic_space_desc *s) {
                          ((uint32_t)s->block_sky[f][3] << 24);
     l.cls_in_code = cls_in_code;
     l.present = true;
+    l.version++;
     if (c->dump) {
         struct { int32_t lo[3], size[3]; uint32_t n_blocks; int32_t sky_kind; uint64_t n_voxels, n_palette; float sky[8][3]; uint8_t block_sky[7][4]; } h;
         std::memset(&h, 0, sizeof(h));
@@ -564,6 +573,7 @@ int aic_update_cubes(aic_ctx *c, int layer, uint32_t n, const int32_t *xyz, cons
     HIP_TRY(c, hipMemcpyAsync(base, xyz, b_xyz, hipMemcpyHostToDevice, c->stream));
     if (block_index) HIP_TRY(c, hipMemcpyAsync(base + b_xyz, block_index, (size_t)n * 2, hipMemcpyHostToDevice, c->stream));
     if (light) HIP_TRY(c, hipMemcpyAsync(base + b_xyz + b_bi, light, b_lt, hipMemcpyHostToDevice, c->stream));
+    l.version++;
     launch_scatter_cubes(l.pool.p, l.light.p, (const int32_t *)base, block_index ? (const uint16_t *)(base + b_xyz) : nullptr,
                          light ? (const uint32_t *)(base + b_xyz + b_bi) : nullptr, n, l.lo, l.size, l.cls_in_code ? l.cls.p : nullptr, c->stream);
     HIP_TRY(c, hipGetLastError());
@@ -591,6 +601,7 @@ int aic_update_light_volume(aic_ctx *c, int layer, const uint8_t *light) {
     if (n) HIP_TRY(c, hipMemcpyAsync(l.light_alt.p, light, n * 4, hipMemcpyHostToDevice, c->upload_stream));
     HIP_TRY(c, hipStreamSynchronize(c->upload_stream));
     std::swap(l.light, l.light_alt);
+    l.version++;
     {
         const uint64_t h = n;
         dump_record(c, DUMP_LIGHT, (uint32_t)layer, {{&h, sizeof(h)}, {light, n * 4}});
@@ -604,6 +615,7 @@ namespace {
 // behind: the cube grid stays at offset 0, every recursive block's ranges are copied (device to device) to the
 // next free offset of fresh pools, and the block table follows. Called with no frame in flight.
 int compact_pools(aic_ctx *c, Layer &l) {
+    l.version++;
     const size_t n = l.n_cubes();
     uint64_t need_vox = n, need_pal = 0;
     for (size_t i = 0; i < l.host_blocks.size(); i++) { need_vox += l.vox_cap[i]; need_pal += l.pal_cap[i]; }
@@ -642,6 +654,7 @@ int compact_pools(aic_ctx *c, Layer &l) {
 
 // One BlockEvaluation / BlockIndex change (updating.rs:128-145), issued on c->stream without synchronising.
 int replace_one(aic_ctx *c, int layer, Layer &l, uint32_t index, const aic_block_desc *desc, const uint16_t *voxels, const float *palette) {
+    l.version++;
     if (!desc) return fail(c, AIC_ERR_INVALID, "aic_replace_block: null descriptor");
     if (index > l.host_blocks.size() || index >= 65536) return fail(c, AIC_ERR_INVALID, "aic_replace_block: index out of range");
     const bool exists = index < l.host_blocks.size();
@@ -1286,3 +1299,5 @@ int aic_probe_light_lut(aic_ctx *c, float out[256]) {
 }
 
 }  // extern "C"
+
+#include "aic_light_host.inc"

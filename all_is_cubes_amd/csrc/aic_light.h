@@ -1,0 +1,63 @@
+// aic_light.h -- device-side data layout of the light updater, shared by the host code
+// (aic_light_host.inc) and the gather kernel (aic_light.hip).
+//
+// The reference's light updater (all-is-cubes/src/space/light/updater.rs) pops cubes off a priority queue,
+// computes each cube's new light by walking a precomputed tree of ray bundles ("chart") through the space,
+// and applies the result, re-queueing the cubes the result depended on. With feature "auto-threads" it computes
+// batches of queue entries against one light state (updater.rs:231-268). Here the queue and the apply step stay on
+// the host (they are sequential by definition), and the batch's compute_light calls -- all of the arithmetic --
+// run on the device, one lane per cube, against the light volume that the trace kernel reads.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aic {
+
+// chart/generator.rs FlatNode: the weight of the bundle per face and the index of the child bundle per step
+// direction (0 = none; the root is node 0 and never a child). Order nx ny nz px py pz.
+struct DevLightNode {
+    float weight[6];
+    uint32_t child[6];
+};
+static_assert(sizeof(DevLightNode) == 48, "chart node is 48 bytes");
+
+// block/eval/derived.rs: what the light updater reads of an evaluated block.
+struct DevDerived {
+    float color[4];
+    float face[6][4];   // nx ny nz px py pz
+    float emission[3];
+    uint32_t flags;     // bits 0-5: opaque per face; bit 6: visible
+};
+static_assert(sizeof(DevDerived) == 128, "derived record is 128 bytes");
+static constexpr uint32_t kDerivedVisible = 1u << 6;
+
+static constexpr uint32_t kLightFrameWords = 8;    // stack frame of the tree walk, dwords
+static constexpr uint32_t kLightDepChunk = 64;     // dependency list chunk: word 0 = next chunk (or ~0), then 63 cube indices
+
+struct LightJob {
+    const uint16_t *grid;      // cube grid (DevLayer.pool)
+    uint32_t index_mask;       // strips the class bits of the cube-grid entries (aic_device.h)
+    const uint32_t *light;     // PackedLight texels
+    const DevDerived *derived; // per block index
+    const DevLightNode *chart;
+    const float *lut;          // PackedLight scalar -> f32 (256 entries)
+    int32_t lo[3], size[3];
+    uint32_t block_sky[7];     // texels nx ny nz px py pz mean (sky.rs:83-147)
+    double max_dist_sq;        // LightPhysics::Rays { maximum_distance } squared
+    const uint32_t *cubes;     // the batch: linear cube indices
+    uint32_t n;
+    uint32_t *out;             // [n][4]: texel, dependency count, first dependency chunk, cost
+    uint32_t *dep_pool;        // chunk pool
+    uint32_t dep_chunks;       // capacity in chunks
+    uint32_t *dep_head;        // [0] next free chunk, [1] set when the pool ran out (the host grows it and reruns the batch)
+    uint32_t *stack;           // [max_depth][kLightFrameWords][stack_stride]
+    uint32_t stack_stride;     // lanes the stack was sized for (>= n)
+    uint32_t max_depth;
+};
+
+void launch_compute_light(const LightJob &job, hipStream_t stream);
+void launch_scatter_light(uint32_t *light, const uint32_t *index, const uint32_t *texel, uint32_t n, hipStream_t stream);
+void launch_probe_log2f(const float *x, float *out, uint32_t n, hipStream_t stream);
+
+}  // namespace aic

@@ -1,0 +1,434 @@
+// aic_light.hip -- the light updater's gather step on the device: Space::compute_light
+// (all-is-cubes/src/space/light/updater.rs:368-417) for a batch of cubes, one lane per cube.
+//
+// Every f32 operation is done in the reference's order (built with -ffp-contract=off), so a texel computed here is
+// the texel the reference computes: the walk of the ray-bundle tree is a depth-first recursion there
+// (walk_ray_tree, updater.rs:427-530) and an explicit stack here, visiting the bundles in the same order and
+// adding into the same accumulators. PackedLight::scalar_in's log2 (data.rs:214-218) is the correctly-rounded-table
+// log2f of glibc/musl/Rust's std on Linux, restated below and pinned to the host's libm by a test.
+//
+// Bound: this is a pointer-chasing tree walk (48-byte chart nodes, 2-byte cube lookups, 128-byte block records),
+// latency- and issue-bound like the trace kernel, not a bandwidth kernel: the chart (5.5 MB) and the scene's
+// working set live in L2. Lanes of a wave walk different subtrees; the stack is laid out [level][word][lane] so
+// that lanes at the same depth touch neighbouring addresses.
+
+#include "aic_light.h"
+
+namespace aic {
+namespace {
+
+// ---- PositiveSign / ZeroOne arithmetic (math/restricted_number.rs:240-326) ----
+__device__ __forceinline__ float ps_new_clamped(float v) { return v > 0.f ? v : 0.f; }
+__device__ __forceinline__ float ps_mul(float a, float b) {
+    const float v = a * b;
+    return (v != v) ? 0.f : v;
+}
+
+// ---- log2f: the table-driven routine of ARM optimized-routines as shipped in glibc >= 2.27 and musl
+// (what f32::log2 calls on Linux): 16-entry table of 1/c and log2(c), degree-4 polynomial, double arithmetic.
+__device__ const double kLog2Tab[16][2] = {
+    {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2},
+    {0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2},  {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2},
+    {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2}, {0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3}, {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4},
+    {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5}, {0x1p+0, 0x0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4},  {0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3},
+    {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2},
+    {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},  {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2}};
+
+__device__ float log2f_exact(float x) {
+    uint32_t ix = __float_as_uint(x);
+    if (ix == 0x3f800000u) return 0.f;
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+        if (ix * 2u == 0u) return -__builtin_inff();
+        if (ix == 0x7f800000u) return x;
+        if ((ix & 0x80000000u) || ix * 2u >= 0xff000000u) return __builtin_nanf("");
+        ix = __float_as_uint(x * 0x1p23f);  // subnormal: normalise
+        ix -= 23u << 23;
+    }
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) % 16u);
+    const uint32_t top = tmp & 0xff800000u;
+    const uint32_t iz = ix - top;
+    const int k = (int32_t)tmp >> 23;
+    const double invc = kLog2Tab[i][0], logc = kLog2Tab[i][1];
+    const double z = (double)__uint_as_float(iz);
+    const double r = z * invc - 1.0;
+    const double y0 = logc + (double)k;
+    const double r2 = r * r;
+    double y = -0x1.712b6f70a7e4dp-2 * r2 + (0x1.ecabf496832ep-2 * r + -0x1.715479ffae3dep-1);
+    const double p = 0x1.715475f35c8b8p0 * r + y0;
+    y = y * r2 + p;
+    return (float)y;
+}
+
+// data.rs:214-218 PackedLight::scalar_in: (log2(v) * 10 + 144).round() as u8 (saturating, NaN -> 0)
+__device__ __forceinline__ uint32_t packed_scalar_in(float value) {
+    const float x = roundf(log2f_exact(value) * 10.0f + 144.0f);
+    if (x != x) return 0u;
+    if (x <= 0.f) return 0u;
+    if (x >= 255.f) return 255u;
+    return (uint32_t)x;
+}
+
+__device__ __forceinline__ void normal_of(int f, int n[3]) {  // f: 0 nx 1 ny 2 nz 3 px 4 py 5 pz
+    n[0] = n[1] = n[2] = 0;
+    n[f >= 3 ? f - 3 : f] = f >= 3 ? 1 : -1;
+}
+
+struct Ctx {
+    const LightJob &J;
+    float incoming[3];
+    float total_ray_weight;
+    uint32_t cost;
+    // dependency list
+    int last_dep[3];
+    bool has_dep;
+    uint32_t n_deps, first_chunk, cur_chunk, fill;
+    float sky_value[6][3];
+
+    __device__ explicit Ctx(const LightJob &j) : J(j) {}
+
+    __device__ bool index_of(const int c[3], uint32_t *out) const {  // vol.rs:988-1023
+        const uint32_t dx = (uint32_t)c[0] - (uint32_t)J.lo[0], dy = (uint32_t)c[1] - (uint32_t)J.lo[1], dz = (uint32_t)c[2] - (uint32_t)J.lo[2];
+        if ((dx >= (uint32_t)J.size[0]) | (dy >= (uint32_t)J.size[1]) | (dz >= (uint32_t)J.size[2])) return false;
+        *out = (dx * (uint32_t)J.size[1] + dy) * (uint32_t)J.size[2] + dz;
+        return true;
+    }
+    // sky.rs:113-147 BlockSky::light_outside
+    __device__ uint32_t light_outside(const int c[3]) const {
+        int n_less = 0, n_equal = 0, which = -1;
+        for (int a = 0; a < 3; a++) {
+            int lower;
+            if (J.lo[a] == (int32_t)0x80000000) lower = -1;
+            else {
+                const int beyond = J.lo[a] - 1;
+                lower = beyond < c[a] ? -1 : (beyond == c[a] ? 0 : 1);
+            }
+            if (lower == -1) n_less++;
+            else if (lower == 0) { n_equal++; which = a; }
+        }
+        for (int a = 0; a < 3; a++) {
+            const long long hi = (long long)J.lo[a] + J.size[a];
+            const int upper = (long long)c[a] < hi ? -1 : ((long long)c[a] == hi ? 0 : 1);
+            if (upper == -1) n_less++;
+            else if (upper == 0) { n_equal++; which = 3 + a; }
+        }
+        if (n_less == 5 && n_equal == 1) return J.block_sky[which];
+        if (n_less == 6) return 0u;      // PackedLight::UNINITIALIZED_AND_BLACK
+        return 1u << 24;                 // PackedLight::NO_RAYS
+    }
+    __device__ uint32_t get_light(const int c[3]) const {  // updater.rs:572-582
+        uint32_t i;
+        if (index_of(c, &i)) return J.light[i];
+        return light_outside(c);
+    }
+    __device__ void value_of(uint32_t texel, float v[3]) const {  // data.rs:137-143
+        v[0] = J.lut[texel & 255u];
+        v[1] = J.lut[(texel >> 8) & 255u];
+        v[2] = J.lut[(texel >> 16) & 255u];
+    }
+    __device__ void add_weighted_light(const float color[3], float weight) {  // updater.rs:934-937
+        const float w = ps_new_clamped(weight);
+        for (int i = 0; i < 3; i++) incoming[i] += ps_mul(color[i], w);
+        total_ray_weight += weight;
+    }
+    // updater.rs:899-927
+    __device__ void end_of_ray(float alpha, float ray_bundle_weight, const float w[6]) {
+        if (!(ray_bundle_weight > 0.f)) return;
+        const float recip = ps_new_clamped(1.0f / ((w[0] + w[3]) + (w[1] + w[4]) + (w[2] + w[5])));
+        float sky_light[3];
+        for (int i = 0; i < 3; i++) {
+            float pf[6];
+            for (int f = 0; f < 6; f++) pf[f] = ps_mul(sky_value[f][i], ps_new_clamped(w[f]));
+            const float s = (pf[0] + pf[3]) + (pf[1] + pf[4]) + (pf[2] + pf[5]);
+            sky_light[i] = ps_mul(ps_mul(s, recip), ps_new_clamped(alpha));
+        }
+        add_weighted_light(sky_light, ray_bundle_weight);
+    }
+    __device__ void emit_dep(const int c[3]) {
+        last_dep[0] = c[0]; last_dep[1] = c[1]; last_dep[2] = c[2];
+        has_dep = true;
+        uint32_t idx;
+        if (!index_of(c, &idx)) return;  // light_needs_update ignores cubes outside the space (updater.rs:97-113)
+        if (fill == kLightDepChunk) {
+            const uint32_t next = atomicAdd(&J.dep_head[0], 1u);
+            if (next >= J.dep_chunks) {
+                J.dep_head[1] = 1u;
+                cur_chunk = 0xffffffffu;
+            } else {
+                J.dep_pool[(size_t)next * kLightDepChunk] = 0xffffffffu;
+                if (cur_chunk != 0xffffffffu) J.dep_pool[(size_t)cur_chunk * kLightDepChunk] = next;
+                else if (n_deps == 0) first_chunk = next;
+                cur_chunk = next;
+            }
+            fill = 1;
+        }
+        if (cur_chunk != 0xffffffffu) J.dep_pool[(size_t)cur_chunk * kLightDepChunk + fill] = idx;
+        fill++;
+        n_deps++;
+    }
+};
+
+// updater.rs:770-895 LightBuffer::traverse. fe: face entered, 0..5, or -1 = Face7::Within.
+__device__ void traverse(Ctx &b, float &alpha, uint32_t &dw_mask, const int hit_cube[3], int fe, const DevDerived *ev, bool &ahead_has,
+                         uint32_t &ahead, bool behind_has, uint32_t behind, const float w[6]) {
+    const uint32_t flags = ev->flags;
+    if (!(flags & kDerivedVisible)) return;
+    const bool hit_opaque_face = fe < 0 ? (flags & 63u) == 63u : ((flags >> fe) & 1u) != 0u;
+    if (hit_opaque_face && fe < 0) {
+        dw_mask = 0u;
+        alpha = 0.f;
+        return;
+    }
+    const float *scp = fe < 0 ? ev->color : ev->face[fe];
+    float sc[4] = {scp[0], scp[1], scp[2], scp[3]};
+    for (int i = 0; i < 3; i++) sc[i] = sc[i] > 1.f ? 1.f : sc[i];  // Rgba::clamp (color.rs:692-697)
+    const float hit_alpha = sc[3];
+    float wp[6];
+    for (int f = 0; f < 6; f++) wp[f] = ((dw_mask >> f) & 1u) ? w[f] : 0.f;
+    const float wsum = (wp[0] + wp[3]) + (wp[1] + wp[4]) + (wp[2] + wp[5]);
+    const float em[3] = {ev->emission[0], ev->emission[1], ev->emission[2]};
+    if (hit_alpha > 0.f && fe >= 0) {
+        int n[3];
+        normal_of(fe, n);
+        const int light_cube[3] = {hit_cube[0] + n[0], hit_cube[1] + n[1], hit_cube[2] + n[2]};
+        const uint32_t stored = behind_has ? behind : b.get_light(light_cube);
+        float sv[3];
+        b.value_of(stored, sv);
+        const float a = ps_new_clamped(alpha), ww = ps_new_clamped(wsum);
+        for (int i = 0; i < 3; i++) {
+            const float from_face = em[i] + ps_mul(ps_mul(sc[i], sv[i]), sc[3]);
+            b.incoming[i] += ps_mul(ps_mul(from_face, a), ww);
+        }
+        b.cost += 10u;
+        if (!b.has_dep || !(b.last_dep[0] == light_cube[0] && b.last_dep[1] == light_cube[1] && b.last_dep[2] == light_cube[2])) b.emit_dep(light_cube);
+        if (hit_opaque_face) alpha = 0.f;
+        else alpha *= 1.0f - hit_alpha;
+    }
+    if (hit_alpha < 1.0f) {
+        float sl[3] = {0.f, 0.f, 0.f};
+        if (fe >= 0) {
+            if (!ahead_has) { ahead = b.get_light(hit_cube); ahead_has = true; }
+            b.value_of(ahead, sl);
+        }
+        const float a = ps_new_clamped(alpha), ww = ps_new_clamped(wsum);
+        for (int i = 0; i < 3; i++) {
+            const float from_block = em[i] + ps_mul(sl[i], hit_alpha);
+            b.incoming[i] += ps_mul(ps_mul(from_block, a), ww);
+        }
+        b.cost += 10u;
+        b.emit_dep(hit_cube);
+        alpha *= 1.0f - hit_alpha;
+    }
+}
+
+__global__ void __launch_bounds__(64) compute_light_kernel(const LightJob J) {
+    const uint32_t tid = blockIdx.x * 64u + threadIdx.x;
+    if (tid >= J.n) return;
+    Ctx b(J);
+    for (int i = 0; i < 3; i++) b.incoming[i] = 0.f;
+    b.total_ray_weight = 0.f;
+    b.cost = 0u;
+    b.has_dep = false;
+    b.last_dep[0] = b.last_dep[1] = b.last_dep[2] = 0;
+    b.n_deps = 0u; b.first_chunk = 0xffffffffu; b.cur_chunk = 0xffffffffu; b.fill = kLightDepChunk;
+    for (int f = 0; f < 6; f++) b.value_of(J.block_sky[f], b.sky_value[f]);
+
+    const uint32_t ci = J.cubes[tid];
+    const uint32_t sz = (uint32_t)J.size[2], sy = (uint32_t)J.size[1];
+    const int origin[3] = {J.lo[0] + (int)(ci / (sy * sz)), J.lo[1] + (int)((ci / sz) % sy), J.lo[2] + (int)(ci % sz)};
+    const DevDerived *ev_origin = &J.derived[J.grid[ci] & J.index_mask];
+    const bool origin_is_opaque = (ev_origin->flags & 63u) == 63u;
+    const bool origin_emits = !(ev_origin->emission[0] == 0.f && ev_origin->emission[1] == 0.f && ev_origin->emission[2] == 0.f);
+
+    if (origin_is_opaque) {
+        if (origin_emits) {  // !opaque_for_light_computation (updater.rs:1031-1033)
+            const float e[3] = {ev_origin->emission[0], ev_origin->emission[1], ev_origin->emission[2]};
+            b.add_weighted_light(e, 1.0f);
+        }
+    } else {
+        // directions_to_seek_light (updater.rs:668-690)
+        uint32_t dw_mask = 0u;
+        if (ev_origin->flags & kDerivedVisible) dw_mask = 63u;
+        else {
+            bool nb_visible[6], nb_emits[6];
+            for (int f = 0; f < 6; f++) {
+                int n[3];
+                normal_of(f, n);
+                const int c[3] = {origin[0] + n[0], origin[1] + n[1], origin[2] + n[2]};
+                uint32_t i;
+                nb_visible[f] = false; nb_emits[f] = false;
+                if (b.index_of(c, &i)) {
+                    const DevDerived *d = &J.derived[J.grid[i] & J.index_mask];
+                    nb_visible[f] = (d->flags & kDerivedVisible) != 0u;
+                    nb_emits[f] = !(d->emission[0] == 0.f && d->emission[1] == 0.f && d->emission[2] == 0.f);
+                }
+            }
+            for (int f = 0; f < 6; f++) {
+                const int opp = f >= 3 ? f - 3 : f + 3;
+                if (nb_visible[opp] || nb_emits[f]) dw_mask |= 1u << f;
+            }
+        }
+
+        // walk_ray_tree (updater.rs:427-530), iteratively. The registers hold the call being executed; the frames of
+        // its callers are in J.stack.
+        uint32_t node = 0u;
+        int f_next = 0;
+        int cube[3] = {origin[0], origin[1], origin[2]};
+        int fe = -1;
+        float alpha = 1.0f;
+        bool prev_has = false, ahead_has = false;
+        uint32_t prev = 0u, ahead = 0u;
+        float rbw = 0.f, cws = 0.f;
+        uint32_t depth = 0u;
+        uint32_t *const stack = J.stack + tid;
+        const size_t sstride = J.stack_stride;
+
+        bool starting = true;
+        float ret = 0.f;
+        for (;;) {
+            const DevLightNode *nd = &J.chart[node];
+            float w[6];
+            for (int f = 0; f < 6; f++) w[f] = nd->weight[f];
+            bool returned = false;
+            if (starting) {
+                float p[6];
+                for (int f = 0; f < 6; f++) p[f] = ((dw_mask >> f) & 1u) ? w[f] : 0.f;
+                rbw = (p[0] + p[3]) + (p[1] + p[4]) + (p[2] + p[5]);
+                if (rbw <= 0.0f) {
+                    ret = rbw;
+                    returned = true;
+                } else {
+                    const double dx = ((double)cube[0] + 0.5) - ((double)origin[0] + 0.5), dy = ((double)cube[1] + 0.5) - ((double)origin[1] + 0.5),
+                                 dz = ((double)cube[2] + 0.5) - ((double)origin[2] + 0.5);
+                    const double d2 = dx * dx + dy * dy + dz * dz;
+                    uint32_t entered_index = 0u;
+                    if (d2 > J.max_dist_sq) {
+                        b.end_of_ray(alpha, rbw, w);
+                        ret = rbw;
+                        returned = true;
+                    } else {
+                        b.cost += 1u;
+                        if (!b.index_of(cube, &entered_index)) {
+                            b.end_of_ray(alpha, rbw, w);
+                            ret = rbw;
+                            returned = true;
+                        } else {
+                            ahead_has = false;
+                            ahead = 0u;
+                            traverse(b, alpha, dw_mask, cube, fe, &J.derived[J.grid[entered_index] & J.index_mask], ahead_has, ahead, prev_has, prev, w);
+                            if (!(alpha > 0.0f)) {
+                                b.end_of_ray(alpha, rbw, w);
+                                ret = rbw;
+                                returned = true;
+                            } else {
+                                cws = 0.f;
+                                f_next = 0;
+                                starting = false;
+                            }
+                        }
+                    }
+                }
+            }
+            if (!returned) {
+                // the children of this call
+                int f = f_next;
+                uint32_t child = 0u;
+                for (; f < 6; f++) {
+                    child = nd->child[f];
+                    if (child != 0u) break;
+                }
+                if (f < 6) {
+                    // push this call's frame and start the child's
+                    if (depth >= J.max_depth) { J.dep_head[1] = 2u; break; }  // cannot happen: max_depth is the chart's depth
+                    uint32_t *fr = stack + (size_t)depth * kLightFrameWords * sstride;
+                    fr[0 * sstride] = node | ((uint32_t)(f + 1) << 20) | (ahead_has ? 1u << 24 : 0u) | (dw_mask << 25);
+                    fr[1 * sstride] = (uint32_t)cube[0];
+                    fr[2 * sstride] = (uint32_t)cube[1];
+                    fr[3 * sstride] = (uint32_t)cube[2];
+                    fr[4 * sstride] = __float_as_uint(alpha);
+                    fr[5 * sstride] = ahead;
+                    fr[6 * sstride] = __float_as_uint(rbw);
+                    fr[7 * sstride] = __float_as_uint(cws);
+                    depth++;
+                    int n[3];
+                    normal_of(f, n);
+                    cube[0] += n[0]; cube[1] += n[1]; cube[2] += n[2];
+                    fe = f >= 3 ? f - 3 : f + 3;  // the child is entered through the opposite face
+                    prev_has = ahead_has;
+                    prev = ahead;
+                    node = child;
+                    starting = true;
+                    continue;
+                }
+                const float rest = rbw - cws;
+                b.end_of_ray(alpha, rest > 0.0f ? rest : 0.0f, w);
+                ret = rbw;
+            }
+            // return to the caller
+            if (depth == 0u) break;
+            depth--;
+            const uint32_t *fr = stack + (size_t)depth * kLightFrameWords * sstride;
+            const uint32_t w0 = fr[0 * sstride];
+            node = w0 & 0xfffffu;
+            f_next = (int)((w0 >> 20) & 15u);
+            ahead_has = ((w0 >> 24) & 1u) != 0u;
+            dw_mask = w0 >> 25;
+            cube[0] = (int)fr[1 * sstride];
+            cube[1] = (int)fr[2 * sstride];
+            cube[2] = (int)fr[3 * sstride];
+            alpha = __uint_as_float(fr[4 * sstride]);
+            ahead = fr[5 * sstride];
+            rbw = __uint_as_float(fr[6 * sstride]);
+            cws = __uint_as_float(fr[7 * sstride]) + ret;
+            starting = false;
+        }
+    }
+
+    // LightBuffer::finish (updater.rs:940-952)
+    uint32_t texel;
+    const float scale = ps_new_clamped(1.0f / fmaxf(b.total_ray_weight, 1.0f));
+    if (b.total_ray_weight > 0.0f) {
+        texel = packed_scalar_in(ps_mul(b.incoming[0], scale)) | (packed_scalar_in(ps_mul(b.incoming[1], scale)) << 8) |
+                (packed_scalar_in(ps_mul(b.incoming[2], scale)) << 16) | (255u << 24);
+    } else if (origin_is_opaque) {
+        texel = 128u << 24;
+    } else {
+        texel = 1u << 24;
+    }
+    uint32_t *o = J.out + 4 * (size_t)tid;
+    o[0] = texel;
+    o[1] = b.n_deps;
+    o[2] = b.first_chunk;
+    o[3] = b.cost;
+}
+
+__global__ void scatter_light_kernel(uint32_t *light, const uint32_t *index, const uint32_t *texel, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) light[index[i]] = texel[i];
+}
+
+__global__ void probe_log2f_kernel(const float *x, float *out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = log2f_exact(x[i]);
+}
+
+}  // namespace
+
+void launch_compute_light(const LightJob &job, hipStream_t stream) {
+    if (!job.n) return;
+    hipLaunchKernelGGL(compute_light_kernel, dim3((job.n + 63u) / 64u), dim3(64), 0, stream, job);
+}
+
+void launch_scatter_light(uint32_t *light, const uint32_t *index, const uint32_t *texel, uint32_t n, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(scatter_light_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, light, index, texel, n);
+}
+
+void launch_probe_log2f(const float *x, float *out, uint32_t n, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(probe_log2f_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, x, out, n);
+}
+
+}  // namespace aic

@@ -298,6 +298,50 @@ int aic_probe_powf(aic_ctx *ctx, const float *x, const float *y, uint32_t n, flo
 /* the device's PackedLight decode table (light/data.rs:301-354) */
 int aic_probe_light_lut(aic_ctx *ctx, float out[256]);
 
+/* ---- light propagation on the device ----
+ * The light volume that the tracer reads is produced in the reference by Space's light updater
+ * (all-is-cubes/src/space/light/updater.rs). These entry points run that updater against the uploaded space: the
+ * priority queue and the apply step on the host, Space::compute_light (updater.rs:368-417) for a batch of queue
+ * entries at a time on the device. The light volume is updated IN PLACE on the device (no aic_update_light_volume
+ * round trip); aic_read_light_volume copies it out. */
+typedef struct aic_light_params {
+    int32_t maximum_distance; /* LightPhysics::Rays { maximum_distance } (space.rs: u8) */
+    int32_t fast;             /* nonzero: Mutation::fast_evaluate_light first (updater.rs:537-581): discards the current
+                                 light and queue, estimates sky light per column, queues every cube near a surface */
+    int32_t epsilon;          /* Mutation::evaluate_light(epsilon, ..) (space.rs:1496-1527): stop when the queue's highest
+                                 priority is at most Priority::from_difference(epsilon) */
+    int32_t batch;            /* queue entries computed against one light state before any is applied: 32 = the reference
+                                 built with "auto-threads" (updater.rs:231-268), 1 = without; larger = throughput */
+    int32_t queue_order;      /* order of equal-priority updates: 16 or 8 = the table order of the reference's queue
+                                 (hashbrown Group::WIDTH of the build target: 16 on x86-64, 8 elsewhere); 0 = first in, first out */
+    int32_t n_queue;          /* when !fast: entries to start the queue with, inserted in order (what
+                                 modified_cube_needs_update, updater.rs:135-173, enqueues after a change); < 0: every cube
+                                 whose texel is Uninitialized, at Priority::UNINIT */
+    const int32_t *queue_cubes;      /* [n_queue][3] */
+    const int32_t *queue_priorities; /* [n_queue], 0..255 */
+    uint64_t max_updates;     /* stop once this many cubes were updated (checked between batches); 0 = run until done */
+} aic_light_params;
+typedef struct aic_light_info {
+    uint64_t updates;     /* cubes computed and applied (LightUpdatesInfo::update_count) */
+    uint64_t batches;     /* device launches */
+    uint64_t cost;        /* sum of ComputedLight::cost */
+    double device_ms;     /* time inside the gather kernel */
+    double total_ms;      /* wall time of the call */
+    uint32_t queue_left;  /* entries left in the queue (at or below epsilon, or cut off by max_updates) */
+    uint32_t pad;
+} aic_light_info;
+int aic_evaluate_light(aic_ctx *ctx, int layer, const aic_light_params *params, aic_light_info *info);
+/* the layer's current light volume, [n cubes][4] PackedLight texels, Z-major */
+int aic_read_light_volume(aic_ctx *ctx, int layer, uint8_t *out);
+/* The propagation chart (chart/generator.rs): returns the node count; fills weights[n][6] and children[n][6] when both
+ * are non-null, and the depth of the tree. Host-only: needs no device or context. */
+uint32_t aic_light_chart(float *weights, uint32_t *children, uint32_t *depth);
+/* test probes: the per-block derived properties the updater reads (derived.rs:78-240): out[n_blocks][32] = colour rgba,
+ * 6 face colours rgba (nx ny nz px py pz), emission rgb, visible; out_opaque[n_blocks][6]. And the device's f32::log2
+ * as PackedLight::scalar_in uses it (data.rs:214-218). */
+int aic_probe_derived(aic_ctx *ctx, int layer, float *out, uint8_t *out_opaque);
+int aic_probe_log2f(aic_ctx *ctx, const float *x, uint32_t n, float *out);
+
 #ifdef __cplusplus
 }
 #endif

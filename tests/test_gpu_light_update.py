@@ -1,0 +1,186 @@
+"""GPU tests (-m gpu) of the light updater on the device: `aic_evaluate_light` against the oracle's
+restatement of `Mutation::{fast_evaluate_light, evaluate_light}` -- the converged light volume byte for byte, the update
+count and the summed cost -- and, end to end (uninitialised space -> device light propagation -> device raytrace), against
+the reference's golden PNGs of its lighting image tests."""
+import copy
+import ctypes
+import ctypes.util
+
+import numpy as np
+import pytest
+
+import oracle
+from all_is_cubes_amd import abi
+from all_is_cubes_amd import workloads
+from tests import scenes
+from tests.test_gpu_parity import to_abi_options
+from tests.test_oracle_goldens import COMMON_VIEWPORT
+from tests.test_oracle_light import EXACT, LIGHTING, image_diff, lit
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = abi.Context(0)
+    yield c
+    c.close()
+
+
+SCENES = {
+    "light_spread": scenes.light_spread_space,
+    "light_on_slab": scenes.light_on_slab_space,
+    "fog": scenes.fog_test_space,
+    "tone_mapping": scenes.tone_mapping_space,
+}
+
+
+def test_device_log2f_is_libm_log2f(ctx):
+    """PackedLight::scalar_in (data.rs:214-218) takes f32::log2 = libm's log2f: the device's restatement equals it bit for bit."""
+    libm = ctypes.CDLL(ctypes.util.find_library("m"))
+    libm.log2f.restype = ctypes.c_float
+    libm.log2f.argtypes = [ctypes.c_float]
+    rng = np.random.default_rng(5)
+    bits = np.concatenate([rng.integers(1, 0x7f800000, 200000, dtype=np.uint32),
+                           np.array([0, 1, 0x007fffff, 0x00800000, 0x3f7fffff, 0x3f800000, 0x3f800001, 0x7f7fffff, 0x7f800000], np.uint32),
+                           (np.float32(2.0) ** np.arange(-30, 30, dtype=np.float32)).view(np.uint32)])
+    x = bits.view(np.float32)
+    got = ctx.probe_log2f(x)
+    want = np.array([libm.log2f(float(v)) for v in x[:20000]], np.float32)
+    assert (got[:20000].view(np.uint32) == want.view(np.uint32)).all()
+    # and the whole sample against numpy where numpy's own log2 agrees with libm on the checked prefix
+    tail = np.array([libm.log2f(float(v)) for v in x[-69:]], np.float32)
+    assert (got[-69:].view(np.uint32) == tail.view(np.uint32)).all()
+
+
+@pytest.mark.parametrize("name", list(SCENES) + ["synthetic"])
+def test_derived_matches_oracle(ctx, name):
+    sp = SCENES[name]() if name in SCENES else workloads.synthetic_space(n=8, resolution=8, n_blocks=12, seed=4)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    got, got_opaque = ctx.probe_derived(abi.LAYER_WORLD, len(sp.blocks))
+    want = oracle.compute_derived(oracle.Space(sp))
+    n = len(sp.blocks)
+    assert (got[:, 0:4].view(np.uint32) == want["color"].view(np.uint32)).all()
+    assert (got[:, 4:28].reshape(n, 6, 4).view(np.uint32) == want["face_colors"].view(np.uint32)).all()
+    assert (got[:, 28:31].view(np.uint32) == want["emission"].view(np.uint32)).all()
+    assert ((got[:, 31] != 0) == want["visible"]).all()
+    assert ((got_opaque != 0) == want["opaque"]).all()
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+@pytest.mark.parametrize("batch,order", [(32, 16), (1, 16), (32, 8), (7, 0)])
+def test_evaluate_light_matches_oracle(ctx, name, batch, order):
+    if name in ("fog", "tone_mapping") and (batch, order) != (32, 16):
+        pytest.skip("the larger scenes run in the reference configuration only")
+    sp = SCENES[name]()
+    ref = copy.deepcopy(sp)
+    n_ref = oracle.evaluate_light(ref, maximum_distance=30, fast=True, epsilon=1, batch=batch, hb_width=order)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    info = ctx.evaluate_light(abi.LAYER_WORLD, 30, fast=True, epsilon=1, batch=batch, queue_order=order)
+    got = ctx.read_light_volume(abi.LAYER_WORLD, sp.size)
+    assert info.updates == n_ref
+    assert (got == np.asarray(ref.light).reshape(got.shape)).all(), f"{(got != np.asarray(ref.light).reshape(got.shape)).any(axis=-1).sum()} texels differ"
+    assert info.queue_left >= 0 and info.batches >= (n_ref + batch - 1) // batch
+
+
+def test_relight_after_a_change(ctx):
+    """Not `fast`: start from a converged volume, change a block, queue what modified_cube_needs_update would
+    (updater.rs:135-173: the cube at NEWLY_VISIBLE and its neighbours), and run to convergence again."""
+    sp = copy.deepcopy(lit(scenes.light_spread_space))
+    lo, size = np.array(sp.lo), np.array(sp.size)
+    cube = tuple(int(v) for v in lo + size // 2 + np.array([1, 0, 1]))
+    rel = tuple(c - l for c, l in zip(cube, sp.lo))
+    old = int(sp.block_index[rel])
+    new = next(i for i in range(len(sp.blocks)) if i != old)
+    sp.block_index[rel] = new
+    queue = [(cube, 250)]
+    for f in range(6):
+        nb = list(cube)
+        nb[f % 3] += 1 if f >= 3 else -1
+        queue.append((tuple(nb), 250))
+    ref = copy.deepcopy(sp)
+    n_ref = oracle.evaluate_light(ref, maximum_distance=30, fast=False, epsilon=1, batch=32, queue=queue, hb_width=16)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    info = ctx.evaluate_light(abi.LAYER_WORLD, 30, fast=False, epsilon=1, batch=32, queue_order=16, queue=queue)
+    got = ctx.read_light_volume(abi.LAYER_WORLD, sp.size)
+    assert info.updates == n_ref and n_ref > 0
+    assert (got == np.asarray(ref.light).reshape(got.shape)).all()
+
+
+def test_uninitialized_queue_and_update_limit(ctx):
+    """queue=None enqueues every Uninitialized texel at Priority::UNINIT; max_updates cuts the run short at the same place."""
+    sp = scenes.light_on_slab_space()
+    sp.light[...] = 0  # PackedLight::UNINITIALIZED_AND_BLACK everywhere
+    ref = copy.deepcopy(sp)
+    n_ref = oracle.evaluate_light(ref, maximum_distance=12, fast=False, epsilon=1, batch=32, queue=None, max_updates=200, hb_width=16)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    info = ctx.evaluate_light(abi.LAYER_WORLD, 12, fast=False, epsilon=1, batch=32, queue_order=16, queue=None, max_updates=200)
+    got = ctx.read_light_volume(abi.LAYER_WORLD, sp.size)
+    assert info.updates == n_ref == 224  # whole batches of 32
+    assert (got == np.asarray(ref.light).reshape(got.shape)).all()
+
+
+def test_large_batches_converge_to_the_same_light(ctx):
+    """Throughput mode: thousands of queue entries per launch. The order of updates differs from the reference's, so the
+    converged texels may differ in their last log-scale unit (the reference's own order is unspecified, queue.rs:236-243)."""
+    sp = scenes.fog_test_space()
+    ref = lit(scenes.fog_test_space)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    info = ctx.evaluate_light(abi.LAYER_WORLD, 30, fast=True, epsilon=1, batch=4096, queue_order=0)
+    got = ctx.read_light_volume(abi.LAYER_WORLD, sp.size).astype(int)
+    want = np.asarray(ref.light).reshape(got.shape).astype(int)
+    assert (got[..., 3] == want[..., 3]).all()  # status
+    d = np.abs(got[..., :3] - want[..., :3])
+    print(f"batch 4096: {info.updates} updates in {info.batches} launches, device {info.device_ms:.1f} ms, total {info.total_ms:.1f} ms; "
+          f"texel difference histogram {np.bincount(d.max(axis=-1).ravel())}")
+    assert d.max() <= 3 and (d > 1).mean() < 0.01
+
+
+@pytest.mark.parametrize("option", ["Flat", "Linear"])
+def test_end_to_end_light_on_slab_golden(ctx, golden_dir, option):
+    """Uninitialised space -> aic_evaluate_light -> aic_render, all on the device, against the reference's golden image."""
+    sp = scenes.light_on_slab_space()
+    opt = oracle.unaltered_colors(lighting=LIGHTING[option])
+    w, h = COMMON_VIEWPORT
+    eye, look = (0.5, -6.0, 6.0), (0.0, 1.0, -1.0)
+    q = oracle.look_at_y_up(eye, tuple(e + l for e, l in zip(eye, look)))
+    _, _, inv = oracle.camera_matrices(45.0, opt.view_distance, w / h, q, eye)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+    ctx.evaluate_light(abi.LAYER_WORLD, 30, fast=True, epsilon=1, batch=32, queue_order=16)
+    got = ctx.render(ctx.make_frame(w, h, world_inv=inv))
+    name = f"light_on_slab-{option}-all"
+    assert name in EXACT
+    assert image_diff(golden_dir, name, got["rgba8"]).max() <= 7
+    assert np.abs(got["rgba8"].astype(int) - np.load(golden_dir / f"png_{name}.npy").astype(int)).max() <= 1
+
+
+def test_end_to_end_light_spread_golden(ctx, golden_dir):
+    sp = scenes.light_spread_space()
+    opt = oracle.unaltered_colors(lighting=3)
+    w, h = COMMON_VIEWPORT
+    eye, look = (0.0, 0.0, 8.0), (0.0, 0.0, -1.0)
+    q = oracle.look_at_y_up(eye, tuple(e + l for e, l in zip(eye, look)))
+    _, _, inv = oracle.camera_matrices(45.0, opt.view_distance, w / h, q, eye)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+    ctx.evaluate_light(abi.LAYER_WORLD, 30, fast=True, epsilon=1, batch=32, queue_order=16)
+    got = ctx.render(ctx.make_frame(w, h, world_inv=inv))
+    name = "light_spread-Linear-all"
+    assert np.abs(got["rgba8"].astype(int) - np.load(golden_dir / f"png_{name}.npy").astype(int)).max() <= 1
+
+
+def test_evaluate_light_rejects_bad_arguments(ctx):
+    sp = scenes.light_on_slab_space()
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    with pytest.raises(abi.AicError):
+        ctx.evaluate_light(abi.LAYER_WORLD, 300)
+    with pytest.raises(abi.AicError):
+        ctx.evaluate_light(abi.LAYER_WORLD, 30, queue_order=5)
+    with pytest.raises(abi.AicError):
+        ctx.evaluate_light(abi.LAYER_WORLD, 30, fast=False, queue=[((0, 0, 0), 999)])
+    ctx.clear_space(abi.LAYER_UI)
+    with pytest.raises(abi.AicError):
+        ctx.evaluate_light(abi.LAYER_UI, 30)
