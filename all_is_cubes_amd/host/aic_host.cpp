@@ -664,6 +664,20 @@ ImageInfo HipRtRenderer::wait_rows(uint32_t slot) {
     return to_info(fi, vp.framebuffer_width, vp.framebuffer_height);
 }
 void HipRtRenderer::synchronize() { check(aic_synchronize(ctx_), "aic_synchronize"); }
+HipRtRenderer::LightUpdateInfo HipRtRenderer::evaluate_light(int maximum_distance, bool fast, int epsilon, int batch, int queue_order) {
+    aic_light_params p;
+    std::memset(&p, 0, sizeof(p));
+    p.maximum_distance = maximum_distance;
+    p.fast = fast ? 1 : 0;
+    p.epsilon = epsilon;
+    p.batch = batch;
+    p.queue_order = queue_order;
+    p.n_queue = -1;
+    aic_light_info info;
+    check(aic_evaluate_light(ctx_, AIC_LAYER_WORLD, &p, &info), "aic_evaluate_light");
+    return LightUpdateInfo{info.updates, info.batches, info.cost, info.device_ms, info.total_ms, info.queue_left};
+}
+
 void HipRtRenderer::wait_event(void *hip_event) { check(aic_wait_event(ctx_, hip_event), "aic_wait_event"); }
 
 }  // namespace aic::host

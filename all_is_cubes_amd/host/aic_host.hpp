@@ -315,6 +315,11 @@ class HipRtRenderer : public HeadlessRenderer {
     std::string device_name() const;
     void *stream() const;
     void wait_event(void *hip_event);  // aic_wait_event: later frames wait for a foreign event, the host does not
+    // Light propagation on the device (aic_evaluate_light): Mutation::fast_evaluate_light (if `fast`) then
+    // Mutation::evaluate_light(epsilon) (space.rs:1496-1540) on the WORLD space as uploaded, with
+    // LightPhysics::Rays { maximum_distance }; the device's light volume is updated in place (the host Space's is not).
+    struct LightUpdateInfo { uint64_t updates, batches, cost; double device_ms, total_ms; uint32_t queue_left; };
+    LightUpdateInfo evaluate_light(int maximum_distance, bool fast = true, int epsilon = 1, int batch = 32, int queue_order = 16);
     bool enable_counters = false;
 
   private:

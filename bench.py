@@ -68,6 +68,20 @@ def build_workload(name: str):
         eye, target = (128.5, 140.5, 300.0), (128.0, 100.0, 128.0)
         view_distance = 600.0
         label = "synthetic S256 256^3 R32 (64 blocks), 3840x2160, GraphicsOptions::default() minus bloom, view_distance 600"
+    elif name == "light-bench":
+        # the reference's own benchmark scene (all-is-cubes-render/benches/raytrace.rs, all-is-cubes/benches/light.rs):
+        # content::testing::light_bench_space at 54x16x54 seen from its Spawn (looking_at_space(bounds, [0, 0.5, 1])),
+        # 64x64 viewport. Uploaded with its light Uninitialized: bench.py lights it ON THE DEVICE (aic_evaluate_light,
+        # fast_evaluate_light + evaluate_light(1) -- light.rs's "both" mode) before tracing.
+        space = scenes.light_bench_space()
+        space.light[...] = 0
+        size = (64, 64)
+        lo, hi = np.array(space.lo, float), np.array(space.hi, float)
+        d = np.array([0.0, 0.5, 1.0])
+        eye_v = (lo + hi) / 2.0 + d / np.linalg.norm(d) * float((hi - lo).max())  # camera.rs:34-40 eye_for_look_at
+        eye, target = tuple(eye_v), tuple(eye_v - d)
+        view_distance = 200.0
+        label = "light_bench_space 54x16x54 (reference bench scene), 64x64, lit on the device"
     elif name == "small":
         space = scenes.synthetic_space(n=32, resolution=8, n_blocks=8, seed=1)
         size = (320, 200)
@@ -84,7 +98,7 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="atrium", choices=["atrium", "s256", "small", "orbit"])
+    ap.add_argument("--workload", default="atrium", choices=["atrium", "s256", "small", "orbit", "light-bench"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", dest="verify", action="store_true", default=None,
                     help="N > 1 (default there): check the assembled frame against a single-rank trace of the same frame")
@@ -93,10 +107,14 @@ def main() -> int:
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: gather each frame before tracing the next")
     ap.add_argument("--lighting", type=int, default=3, help="experiment: LightingOption (0 None,1 Flat,2 Coarse,3 Linear,4 Smoothstep); default Linear")
     ap.add_argument("--fog", type=int, default=1, help="experiment: FogOption (0 None,1 Abrupt,...); default Abrupt")
-    ap.add_argument("--transparency", type=int, default=1, help="experiment: 0 Surface, 1 Volumetric; default Volumetric")
+    ap.add_argument("--transparency", type=int, default=None, help="experiment: 0 Surface, 1 Volumetric; default Volumetric (light-bench: Surface, the reference bench's 'linear-surface')")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed single-frame / moving-camera / read-back measurements (counter passes)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step timed region until the regions add up to this much time")
     args = ap.parse_args()
+    default_transparency = 0 if args.workload == "light-bench" else 1
+    if args.transparency is None:
+        args.transparency = default_transparency
 
     import torch
     import torch.distributed as dist
@@ -136,7 +154,10 @@ def main() -> int:
     opts.bloom_intensity = 0.0
     opts.view_distance = view_distance
     opts.debug_info_text = False
-    if (args.lighting, args.fog, args.transparency) != (3, 1, 1):  # experiments only; the headline run uses the defaults
+    if args.workload == "light-bench" and (args.lighting, args.fog, args.transparency) == (3, 1, 0):
+        opts.transparency = H.TransparencyOption(H.TransparencyKind(0))  # raytrace.rs "linear-surface"
+        label += ", GraphicsOptions::default() + TransparencyOption::Surface ('linear-surface')"
+    elif (args.lighting, args.fog, args.transparency) != (3, 1, 1):  # experiments only; the headline run uses the defaults
         opts.lighting_display = H.LightingOption(H.LightingKind(args.lighting))
         opts.fog = H.FogOption(args.fog)
         opts.transparency = H.TransparencyOption(H.TransparencyKind(args.transparency))
@@ -147,6 +168,21 @@ def main() -> int:
     cams.world_view_transform = H.look_at_y_up(eye, target)
     renderer = H.HipRtRenderer(cams, None, local_rank)
     renderer.update()
+    light_update = None
+    if args.workload == "light-bench":
+        # light.rs "both": fast_evaluate_light then evaluate_light(1), LightPhysics::Rays { maximum_distance: 30 },
+        # batches of 32 in the reference's queue order -- the configuration that reproduces the reference's texels
+        li = renderer.evaluate_light(30, True, 1, 32, 16)
+        light_update = {"mode": "fast_evaluate_light + evaluate_light(1), batch 32, hashbrown order", "updates": int(li["updates"]),
+                        "launches": int(li["batches"]), "device_ms": round(li["device_ms"], 3), "total_ms": round(li["total_ms"], 3),
+                        "updates_per_s": round(li["updates"] / (li["total_ms"] * 1e-3), 1) if li["total_ms"] > 0 else None}
+        # and the same work with whole-queue batches (order differs from the reference's in the last texel unit)
+        renderer.update()
+        lt = renderer.evaluate_light(30, True, 1, 8192, 0)
+        light_update["throughput_mode"] = {"batch": 8192, "updates": int(lt["updates"]), "launches": int(lt["batches"]),
+                                           "device_ms": round(lt["device_ms"], 3), "total_ms": round(lt["total_ms"], 3),
+                                           "updates_per_s": round(lt["updates"] / (lt["total_ms"] * 1e-3), 1) if lt["total_ms"] > 0 else None}
+        li = renderer.evaluate_light(30, True, 1, 32, 16)  # leave the reference-order light in place for the traced frames
 
     strip = D.STRIP_ROWS
     local_rows = renderer.partition_rows(strip, world, rank)
@@ -302,7 +338,7 @@ def main() -> int:
     # recorded, what the first frame of any sequence costs -- and of a moving camera (6 degrees per frame about the
     # scene's axis: the feedback never applies), one frame at a time and streamed.
     single = None
-    if world == 1 and args.workload != "orbit":
+    if world == 1 and args.workload != "orbit" and not args.no_extras:
         n_l = max(10, min(60, args.steps))
         tgt = render_target(0).data_ptr()
 
@@ -353,7 +389,7 @@ def main() -> int:
         }
 
     fps_with_readback = None
-    if world == 1:
+    if world == 1 and not args.no_extras:
         n_rb = max(3, min(10, args.steps))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -378,17 +414,23 @@ def main() -> int:
             cn = pj.get("counters", {})
             vi = cn.get("SQ_INSTS_VALU", {}).get("mean_per_launch")
             if vi and elapsed > 0:
-                # what actually bounds the kernel: instruction issue. tools/ubench/issue_rate (profiles/r02_issue_rate.txt)
-                # measures one wave-instruction per ~4.3-4.7 cycles per SIMD for this kernel's mix (f64 compare/add, selects,
-                # integer ops, SALU mask logic) at 2-8 waves per SIMD, VALU and SALU alike and not overlapping -- so the count
-                # is of ALL instructions (VALU + SALU + memory), against 1024 SIMDs x 2.4 GHz / 4.33 cycles.
-                total = sum(float(cn.get(k, {}).get("mean_per_launch") or 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"))
-                peak = 1024 * 2.4e9 / 4.33
-                rate = total * args.steps / elapsed
-                valu = {"wave_insts_per_frame": int(total), "valu_wave_insts_per_frame": int(vi), "issue_rate": round(rate / 1e9, 2), "peak": round(peak / 1e9, 1),
+                # What actually bounds the kernel: instruction issue. tools/ubench/issue_rate (profiles/r02_issue_rate.txt)
+                # measures, per SIMD, one wave-instruction per 4.3-4.7 cycles for the kernel's VALU mix (f64 compare/add,
+                # selects, integer ops) and 3.3-3.5 for a VALU + SALU stream at 4-8 waves per SIMD: VALU and SALU of the
+                # same SIMD do not overlap enough to matter, so the count is of ALL instructions. peak = the best sustained
+                # rate of any mixed stream measured there: 1024 SIMDs x 2.4 GHz / 3.28 cycles.
+                kinds = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM")
+                total = sum(float(cn.get(k, {}).get("mean_per_launch") or 0.0) for k in kinds)
+                peak = 1024 * 2.4e9 / 3.28
+                rate = total / (mean_kernel_ms * 1e-3) if mean_kernel_ms > 0 else 0.0
+                tc, ai = cn.get("SQ_THREAD_CYCLES_VALU", {}).get("mean_per_launch"), cn.get("SQ_ACTIVE_INST_VALU", {}).get("mean_per_launch")
+                valu = {"wave_insts_per_launch": int(total), "valu_wave_insts_per_launch": int(vi), "issue_rate": round(rate / 1e9, 2), "peak": round(peak / 1e9, 1),
                         "unit": "G wave-insts/s", "frac": round(rate / peak, 4),
-                        "note": "instruction counts from the same PMC file (one frame at a time); peak = measured issue rate of this mix "
-                                "(profiles/r02_issue_rate.txt): the binding resource (DESIGN.md 6)"}
+                        "cycles_per_inst_per_simd": round(1024 * 2.4e9 / rate, 3) if rate else None,
+                        "valu_lane_utilisation": round(tc / (ai * 64.0), 4) if tc and ai else None,
+                        "source": "profiles/" + os.path.basename(cands[-1]),
+                        "note": "instruction counts per launch from the PMC file (one frame at a time) over this run's kernel time; peak = best "
+                                "sustained VALU+SALU issue rate measured on this chip (profiles/r02_issue_rate.txt): the binding resource (DESIGN.md 6)"}
 
     result = None
     if rank == 0:
@@ -442,6 +484,8 @@ def main() -> int:
         if single is not None:
             result["single_frame"] = single
             result["streamed_ms"] = round(ms_per_step, 4) if streamed else None
+        if light_update is not None:
+            result["light_update"] = light_update
         if fps_with_readback is not None:
             result["fps_with_readback"] = round(fps_with_readback, 3)
         if world == 1 and not args.no_cpu_baseline:
@@ -487,6 +531,12 @@ def cpu_baseline(flat_space, opts, w, h, eye, target, view_distance, target_seco
     import oracle
 
     threads, cpu_note = usable_cpus()
+    extra = {}
+    if (np.asarray(flat_space.light)[..., 3] == 0).all():  # light-bench: the GPU leg lit the space on the device; here the oracle does
+        t_l = time.perf_counter()
+        n_upd = oracle.evaluate_light(flat_space, maximum_distance=30, fast=True, epsilon=1, batch=32, hb_width=16)
+        dt_l = time.perf_counter() - t_l
+        extra["light_update"] = {"updates": int(n_upd), "total_ms": round(dt_l * 1e3, 1), "updates_per_s": round(n_upd / dt_l, 1), "cores": 1}
     sp = oracle.Space(flat_space)
     oo = oracle.make_options(fog=int(opts.fog), transparency=int(opts.transparency.kind), lighting=int(opts.lighting_display.kind),
                              view_distance=view_distance)
@@ -513,6 +563,7 @@ def cpu_baseline(flat_space, opts, w, h, eye, target, view_distance, target_seco
         "sample": f"{frames} whole {w}x{h} frames of the same workload in {dt:.1f} s wall (median {1e3 * float(np.median(per_frame)):.1f} ms/frame), "
                   f"oracle/aic_oracle.cpp row-parallel on {threads} threads ({cpu_note})",
         "frames_per_s": round(frames / dt, 4),
+        **extra,
     }
 
 

@@ -148,6 +148,32 @@ pub struct aic_multi {
     _private: [u8; 0],
 }
 
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct aic_light_params {
+    pub maximum_distance: i32,
+    pub fast: i32,
+    pub epsilon: i32,
+    pub batch: i32,
+    pub queue_order: i32,
+    pub n_queue: i32,
+    pub queue_cubes: *const i32,
+    pub queue_priorities: *const i32,
+    pub max_updates: u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct aic_light_info {
+    pub updates: u64,
+    pub batches: u64,
+    pub cost: u64,
+    pub device_ms: f64,
+    pub total_ms: f64,
+    pub queue_left: u32,
+    pub pad: u32,
+}
+
 unsafe extern "C" {
     pub fn aic_create(device_id: c_int, status: *mut c_int) -> *mut aic_ctx;
     pub fn aic_destroy(ctx: *mut aic_ctx);
@@ -189,4 +215,10 @@ unsafe extern "C" {
     pub fn aic_probe_raycast(ctx: *mut aic_ctx, origin: *const f64, direction: *const f64, use_bounds: c_int, lo: *const i32, hi: *const i32, include_exit: c_int, max_steps: u32, out: *mut aic_rc_step, n_out: *mut u32, ended: *mut c_int) -> c_int;
     pub fn aic_probe_powf(ctx: *mut aic_ctx, x: *const f32, y: *const f32, n: u32, out: *mut f32) -> c_int;
     pub fn aic_probe_light_lut(ctx: *mut aic_ctx, out: *mut f32) -> c_int;
+    // light propagation on the device (Space::evaluate_light / fast_evaluate_light)
+    pub fn aic_evaluate_light(ctx: *mut aic_ctx, layer: c_int, params: *const aic_light_params, info: *mut aic_light_info) -> c_int;
+    pub fn aic_read_light_volume(ctx: *mut aic_ctx, layer: c_int, out: *mut u8) -> c_int;
+    pub fn aic_light_chart(weights: *mut f32, children: *mut u32, depth: *mut u32) -> u32;
+    pub fn aic_probe_derived(ctx: *mut aic_ctx, layer: c_int, out: *mut f32, out_opaque: *mut u8) -> c_int;
+    pub fn aic_probe_log2f(ctx: *mut aic_ctx, x: *const f32, n: u32, out: *mut f32) -> c_int;
 }

@@ -14,7 +14,7 @@ ROOT = Path(__file__).resolve().parents[1]
 
 def test_library_exports_every_declared_symbol():
     header = (ROOT / "include" / "aic_hip.h").read_text()
-    declared = set(re.findall(r"\b(aic_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(aic_[a-z0-9_]+)\s*\(", header))
     assert declared == set(abi.ABI_SYMBOLS)
     lib = abi.load()
     for sym in sorted(declared):

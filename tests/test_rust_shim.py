@@ -16,7 +16,7 @@ def strip_comments(text: str) -> str:
 
 def c_functions():
     out = {}
-    for m in re.finditer(r"\b(aic_[a-z_]+)\s*\(([^;{]*?)\)\s*;", strip_comments(HEADER), flags=re.S):
+    for m in re.finditer(r"\b(aic_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", strip_comments(HEADER), flags=re.S):
         params = m.group(2).strip()
         out[m.group(1)] = 0 if params in ("", "void") else len(params.split(","))
     return out
@@ -24,7 +24,7 @@ def c_functions():
 
 def rust_functions():
     out = {}
-    for m in re.finditer(r"pub fn (aic_[a-z_]+)\s*\(([^)]*)\)", strip_comments(FFI), flags=re.S):
+    for m in re.finditer(r"pub fn (aic_[a-z0-9_]+)\s*\(([^)]*)\)", strip_comments(FFI), flags=re.S):
         params = [p for p in m.group(2).split(",") if p.strip()]
         out[m.group(1)] = len(params)
     return out

@@ -14,16 +14,15 @@ python bench.py --workload s256 --steps 10 --warmup 2 --cpu-seconds 6 > "$O/benc
 BENCH="python bench.py --steps 20 --warmup 3 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_atrium" -- $BENCH > "$O/stats_atrium.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_s256" -- $BENCH --workload s256 --steps 5 --warmup 1 > "$O/stats_s256.log" 2>&1
-# counter passes trace one frame at a time (--no-pipeline): PMC values are device-wide over a kernel's
-# execution window, so overlapping frames would be counted into each other
-for W in atrium s256; do
-  X="--no-pipeline"; [ $W = s256 ] && X="--no-pipeline --workload s256"
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch_$W" -- $BENCH --steps 3 --warmup 1 $X > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write_$W" -- $BENCH --steps 3 --warmup 1 $X > /dev/null 2>&1
-  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$O/pmc_l2_$W" -- $BENCH --steps 3 --warmup 1 $X > /dev/null 2>&1
-  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d "$O/pmc_sq1_$W" -- $BENCH --steps 3 --warmup 1 $X > /dev/null 2>&1
-  rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 --output-format csv -d "$O/pmc_sq2_$W" -- $BENCH --steps 3 --warmup 1 $X > /dev/null 2>&1
-done
+# one frame at a time: the per-launch duration with no second frame sharing the device
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_atrium_nopipe" -- $BENCH --no-pipeline > "$O/stats_atrium_nopipe.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_s256_nopipe" -- $BENCH --workload s256 --steps 5 --warmup 1 --no-pipeline > "$O/stats_s256_nopipe.log" 2>&1
+# the reference's own bench scene, lit on the device (N2): bench line + kernel stats of the light gather kernel
+python bench.py --workload light-bench --steps 200 --warmup 10 > "$O/bench_lightbench.json" 2> "$O/bench_lightbench.err"; tail -c 700 "$O/bench_lightbench.json"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_lightbench" -- $BENCH --workload light-bench --steps 50 > "$O/stats_lightbench.log" 2>&1
+# instruction issue-rate micro-benchmark (tools/ubench/issue_rate.hip): what bounds the trace kernel
+( cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o issue_rate issue_rate.hip > /dev/null 2>&1 && timeout 300 ./issue_rate ) > "$O/issue_rate.txt" 2>&1
+bash tools/measure_pmc.sh "$TAG"
 # keep only the small CSVs (agent_info / counter_collection / kernel_stats), drop anything large
 find "$O" -type f -size +4M -delete
 du -sh "$O"

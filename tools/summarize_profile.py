@@ -7,7 +7,7 @@ Outputs: profiles/<tag>_kernel_stats_<workload>.csv (rocprofv3 --kernel-trace --
 profiles/<tag>_pmc_<workload>.json (per-launch means of every collected counter for the trace
 kernel, plus the derived HBM traffic that bench.py reports as roofline.traffic), and the bench
 JSON lines."""
-import csv, glob, json, os, shutil, sys
+import csv, glob, json, os, re, shutil, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -25,8 +25,11 @@ for wl in ("atrium", "s256"):
     p = find(f"stats_{wl}", "kernel_stats.csv")
     if p:
         shutil.copy(p, os.path.join(dst, f"{tag}_kernel_stats_{wl}.csv"))
+    p = find(f"stats_{wl}_nopipe", "kernel_stats.csv")
+    if p:
+        shutil.copy(p, os.path.join(dst, f"{tag}_kernel_stats_{wl}_nopipe.csv"))
     pmc = {}
-    for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq1", "pmc_sq2"):
+    for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq1", "pmc_sq2", "pmc_sq3"):
         p = find(f"{d}_{wl}", "counter_collection.csv")
         if not p:
             continue
@@ -36,7 +39,8 @@ for wl in ("atrium", "s256"):
                 name = row.get("Kernel_Name", "")
                 # the timed variant only: <VOL, LMODE, DIAG=false>; the DIAG=true launch is the
                 # untimed counter-collecting pass bench.py issues once after the timed region
-                if "trace_image_kernel" not in name or ", true>(" in name:
+                m = re.search(r"trace_image_kernel<[^,>]+,[^,>]+, *(true|false)", name)
+                if not m or m.group(1) == "true":
                     continue
                 acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
         for k, v in acc.items():
@@ -64,4 +68,15 @@ for wl in ("atrium", "s256"):
         if lines:
             with open(os.path.join(dst, f"{tag}_bench_{wl}.json"), "w") as f:
                 f.write(lines[-1] + "\n")
+p = find("stats_lightbench", "kernel_stats.csv")
+if p:
+    shutil.copy(p, os.path.join(dst, f"{tag}_kernel_stats_lightbench.csv"))
+b = os.path.join(src, "bench_lightbench.json")
+if os.path.exists(b):
+    lines = [l for l in open(b).read().splitlines() if l.startswith("{")]
+    if lines:
+        with open(os.path.join(dst, f"{tag}_bench_lightbench.json"), "w") as f:
+            f.write(lines[-1] + "\n")
+if os.path.exists(os.path.join(src, "issue_rate.txt")):
+    shutil.copy(os.path.join(src, "issue_rate.txt"), os.path.join(dst, f"{tag}_issue_rate.txt"))
 print(sorted(os.listdir(dst)))
