@@ -730,10 +730,10 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u
 #define AIC_MIN_WAVES 4  // waves per SIMD the production variants are built for (128 VGPRs; cold lane state lives in LDS)
 #endif
 #ifndef AIC_T_BATCH
-#define AIC_T_BATCH 40  // run a kind of parked work once this many lanes wait on it
+#define AIC_T_BATCH 32  // run a kind of parked work once this many lanes wait on it
 #endif
 #ifndef AIC_N_FEW
-#define AIC_N_FEW 24    // ... or once at most this many lanes can still step
+#define AIC_N_FEW 32    // ... or once at most this many lanes can still step
 #endif
 #ifndef AIC_WG_THREADS
 #define AIC_WG_THREADS 256  // threads per persistent workgroup (a multiple of 64)

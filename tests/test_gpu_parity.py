@@ -359,6 +359,25 @@ def test_hip_rt_renderer_update_and_draw(ctx, synth_space):
     assert img3.flaws & H.Flaws.UNSUPPORTED  # Bounce is rendered as Linear and flagged
 
 
+def test_bounce_is_flagged_and_rendered_as_linear(ctx, synth_space):
+    """LightingOption::Bounce needs the reference's RNG stream (rand 0.10 SmallRng): not reproduced. The reference says what
+    a renderer without it does -- "substitute Linear" (graphics_options.rs:460-467) -- so the frame must be the Linear
+    frame, bit for bit, and carry Flaws::UNSUPPORTED."""
+    w, h = 160, 120
+    eye = (12.5, 20.5, 40.0)
+    q = oracle.look_at_y_up(eye, (12.0, 8.0, 12.0))
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, q, eye)
+    ctx.upload_space(abi.LAYER_WORLD, synth_space)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.set_options(abi.LAYER_WORLD, abi.make_options(lighting=3))
+    linear = ctx.render(ctx.make_frame(w, h, world_inv=inv))
+    ctx.set_options(abi.LAYER_WORLD, abi.make_options(lighting=5, bounce_samples=4))
+    bounce = ctx.render(ctx.make_frame(w, h, world_inv=inv))
+    assert (bounce["rgba8"] == linear["rgba8"]).all()
+    assert bounce["info"].flaws & abi.FLAW_UNSUPPORTED
+    assert not (linear["info"].flaws & abi.FLAW_UNSUPPORTED)
+
+
 def test_multi_part_gather_on_one_gpu(ctx, synth_space):
     """The N>1 data path on a single device: render each partition to device memory, stack as the
     gather would, de-interleave with the device kernel and with the torch reference."""
