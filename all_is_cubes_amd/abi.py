@@ -51,7 +51,7 @@ class BlockDesc(C.Structure):
 
 class LightParams(C.Structure):
     _fields_ = [("maximum_distance", C.c_int32), ("fast", C.c_int32), ("epsilon", C.c_int32), ("batch", C.c_int32),
-                ("queue_order", C.c_int32), ("n_queue", C.c_int32), ("queue_cubes", C.c_void_p), ("queue_priorities", C.c_void_p),
+                ("queue_order", C.c_int32), ("n_queue", C.c_int32), ("lanes_per_cube", C.c_int32), ("reserved", C.c_int32), ("queue_cubes", C.c_void_p), ("queue_priorities", C.c_void_p),
                 ("max_updates", C.c_uint64)]
 
 
@@ -457,11 +457,11 @@ class Context:
         return out
 
     def evaluate_light(self, layer: int, maximum_distance: int, fast: bool = True, epsilon: int = 1, batch: int = 32,
-                       queue_order: int = 16, queue=None, max_updates: int = 0) -> LightInfo:
+                       queue_order: int = 16, queue=None, max_updates: int = 0, lanes_per_cube: int = 0) -> LightInfo:
         """`Mutation::fast_evaluate_light` (if `fast`) then `Mutation::evaluate_light(epsilon)` (space.rs:1496-1540) on
         the uploaded space, compute_light on the device. `queue`: None = every Uninitialized texel (when not `fast`), or a
         list of ((x, y, z), priority). The layer's light volume is updated in place."""
-        p = LightParams(maximum_distance, int(fast), epsilon, batch, queue_order, -1, None, None, max_updates)
+        p = LightParams(maximum_distance, int(fast), epsilon, batch, queue_order, -1, lanes_per_cube, 0, None, None, max_updates)
         keep = []
         if queue is not None:
             qc = np.ascontiguousarray([q[0] for q in queue], np.int32).reshape(-1, 3)

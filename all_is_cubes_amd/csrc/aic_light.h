@@ -35,6 +35,17 @@ static constexpr uint32_t kDerivedVisible = 1u << 6;
 static constexpr uint32_t kLightFrameWords = 8;    // stack frame of the tree walk, dwords
 static constexpr uint32_t kLightDepChunk = 64;     // dependency list chunk: word 0 = next chunk (or ~0), then 63 cube indices
 
+// The effective ray-bundle tree for one maximum_distance, in pre-order (children in face order): what the wave-per-cube
+// kernel walks. `end` = one past the last position of the node's subtree; nodes beyond the distance are leaves.
+struct DevTreePos {
+    float weight[6];
+    uint32_t end;
+    uint32_t parent;
+    uint32_t offset;  // cube offset from the origin cube: (dx + 256) | (dy + 256) << 10 | (dz + 256) << 20
+    uint32_t info;    // bits 0-2: face entered (0..5; 7 = Face7::Within, the root); bit 3: beyond maximum_distance
+};
+static_assert(sizeof(DevTreePos) == 40, "tree position record is 40 bytes");
+
 struct LightJob {
     const uint16_t *grid;      // cube grid (DevLayer.pool)
     uint32_t index_mask;       // strips the class bits of the cube-grid entries (aic_device.h)
@@ -54,9 +65,20 @@ struct LightJob {
     uint32_t *stack;           // [max_depth][kLightFrameWords][stack_stride]
     uint32_t stack_stride;     // lanes the stack was sized for (>= n)
     uint32_t max_depth;
+    // wave-per-cube kernel only
+    const DevTreePos *tree;
+    uint32_t n_tree;
+    const float *child_w;      // [n_tree][6 faces][6]: the weights of each position's children (zeros where there is none)
+    uint32_t seg;              // positions per lane: ceil(n_tree / 64)
+    float4 *terms;             // [waves][64][term_cap]: (incoming r, g, b, ray weight) in walk order
+    uint32_t term_cap;
+    uint32_t *cands;           // [waves][64][cand_cap]: dependency candidates in walk order (offset | conditional << 30)
+    uint32_t cand_cap;
+    uint32_t *wstack;          // [waves][max_depth][4][64]
 };
 
 void launch_compute_light(const LightJob &job, hipStream_t stream);
+void launch_compute_light_waves(const LightJob &job, uint32_t n_waves, hipStream_t stream);
 void launch_scatter_light(uint32_t *light, const uint32_t *index, const uint32_t *texel, uint32_t n, hipStream_t stream);
 void launch_probe_log2f(const float *x, float *out, uint32_t n, hipStream_t stream);
 

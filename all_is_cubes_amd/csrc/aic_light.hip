@@ -1,5 +1,6 @@
 // aic_light.hip -- the light updater's gather step on the device: Space::compute_light
-// (all-is-cubes/src/space/light/updater.rs:368-417) for a batch of cubes, one lane per cube.
+// (all-is-cubes/src/space/light/updater.rs:368-417) for a batch of cubes: compute_light_kernel, one lane per cube (the plain
+// restatement), and compute_light_wave_kernel, one wave per cube (the production mapping; same bytes).
 //
 // Every f32 operation is done in the reference's order (built with -ffp-contract=off), so a texel computed here is
 // the texel the reference computes: the walk of the ray-bundle tree is a depth-first recursion there
@@ -404,6 +405,386 @@ __global__ void __launch_bounds__(64) compute_light_kernel(const LightJob J) {
     o[3] = b.cost;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// One WAVE per cube. The walk's contributions depend only on the ray state along their own root path (alpha; the
+// direction weights are fixed per cube once the walk has started), never on the accumulators -- so the 64 lanes walk 64
+// contiguous slices of the tree's pre-order, each first replaying its slice's root path without emitting anything, and
+// write what they would have added (incoming r, g, b; ray weight) to per-lane lists. Lane 0 then adds the lists in lane
+// order = pre-order = the order of the reference's recursion, so every f32 sum is the reference's sum, at 1/64 of the
+// latency. The "rest" term a bundle adds after its children (updater.rs:521-528) is emitted by the lane that owns the
+// last position of the bundle's subtree. Dependencies go the same way: candidates per lane, then one in-order pass that
+// drops a face's light cube when it repeats the previous entry (updater.rs:838-842).
+
+struct WaveCtx {
+    const LightJob &J;
+    int origin[3];
+    uint32_t m0;            // direction weights of the walk: bit per face (updater.rs:668-690)
+    float sky_value[6][3];
+    float4 *terms;
+    uint32_t *cands;
+    uint32_t n_terms, n_cands, cost;
+
+    __device__ explicit WaveCtx(const LightJob &j) : J(j) {}
+    __device__ bool index_of(const int c[3], uint32_t *out) const {
+        const uint32_t dx = (uint32_t)c[0] - (uint32_t)J.lo[0], dy = (uint32_t)c[1] - (uint32_t)J.lo[1], dz = (uint32_t)c[2] - (uint32_t)J.lo[2];
+        if ((dx >= (uint32_t)J.size[0]) | (dy >= (uint32_t)J.size[1]) | (dz >= (uint32_t)J.size[2])) return false;
+        *out = (dx * (uint32_t)J.size[1] + dy) * (uint32_t)J.size[2] + dz;
+        return true;
+    }
+    __device__ uint32_t light_outside(const int c[3]) const {  // sky.rs:113-147
+        int n_less = 0, n_equal = 0, which = -1;
+        for (int a = 0; a < 3; a++) {
+            int lower;
+            if (J.lo[a] == (int32_t)0x80000000) lower = -1;
+            else {
+                const int beyond = J.lo[a] - 1;
+                lower = beyond < c[a] ? -1 : (beyond == c[a] ? 0 : 1);
+            }
+            if (lower == -1) n_less++;
+            else if (lower == 0) { n_equal++; which = a; }
+        }
+        for (int a = 0; a < 3; a++) {
+            const long long hi = (long long)J.lo[a] + J.size[a];
+            const int upper = (long long)c[a] < hi ? -1 : ((long long)c[a] == hi ? 0 : 1);
+            if (upper == -1) n_less++;
+            else if (upper == 0) { n_equal++; which = 3 + a; }
+        }
+        if (n_less == 5 && n_equal == 1) return J.block_sky[which];
+        if (n_less == 6) return 0u;
+        return 1u << 24;
+    }
+    __device__ uint32_t get_light(const int c[3]) const {
+        uint32_t i;
+        if (index_of(c, &i)) return J.light[i];
+        return light_outside(c);
+    }
+    __device__ void value_of(uint32_t texel, float v[3]) const {
+        v[0] = J.lut[texel & 255u];
+        v[1] = J.lut[(texel >> 8) & 255u];
+        v[2] = J.lut[(texel >> 16) & 255u];
+    }
+    __device__ float bundle_weight(const float w[6]) const {  // (weight * direction_weights).sum(), face.rs:1046-1054
+        float p[6];
+        for (int f = 0; f < 6; f++) p[f] = ((m0 >> f) & 1u) ? w[f] : 0.f;
+        return (p[0] + p[3]) + (p[1] + p[4]) + (p[2] + p[5]);
+    }
+    __device__ void emit_term(float x, float y, float z, float weight) { terms[n_terms++] = make_float4(x, y, z, weight); }
+    __device__ void emit_cand(const int c[3], uint32_t conditional) {
+        cands[n_cands++] = (uint32_t)(c[0] - origin[0] + 256) | ((uint32_t)(c[1] - origin[1] + 256) << 10) | ((uint32_t)(c[2] - origin[2] + 256) << 20) |
+                           (conditional << 30);
+    }
+    // updater.rs:899-927 + add_weighted_light
+    __device__ void end_of_ray(float alpha, float ray_bundle_weight, const float w[6]) {
+        if (!(ray_bundle_weight > 0.f)) return;
+        const float recip = ps_new_clamped(1.0f / ((w[0] + w[3]) + (w[1] + w[4]) + (w[2] + w[5])));
+        const float ww = ps_new_clamped(ray_bundle_weight);
+        float out[3];
+        for (int i = 0; i < 3; i++) {
+            float pf[6];
+            for (int f = 0; f < 6; f++) pf[f] = ps_mul(sky_value[f][i], ps_new_clamped(w[f]));
+            const float s = (pf[0] + pf[3]) + (pf[1] + pf[4]) + (pf[2] + pf[5]);
+            const float sky_light = ps_mul(ps_mul(s, recip), ps_new_clamped(alpha));
+            out[i] = ps_mul(sky_light, ww);
+        }
+        emit_term(out[0], out[1], out[2], ray_bundle_weight);
+    }
+    // walk_ray_tree up to its recursion (updater.rs:427-505) for the bundle at tree position k, entered with `alpha`.
+    // Returns whether the bundle's children are walked; then *alpha is the ray's alpha behind the cube. !emit: state only.
+    __device__ bool enter(uint32_t k, float *alpha, float *rbw_out, bool emit) {
+        const DevTreePos *nd = &J.tree[k];
+        float w[6];
+        for (int f = 0; f < 6; f++) w[f] = nd->weight[f];
+        const float rbw = bundle_weight(w);
+        *rbw_out = rbw;
+        if (rbw <= 0.0f) return false;
+        const uint32_t info = nd->info, off = nd->offset;
+        if (info & 8u) {  // beyond maximum_distance
+            if (emit) end_of_ray(*alpha, rbw, w);
+            return false;
+        }
+        if (emit) cost += 1u;
+        const int cube[3] = {origin[0] + (int)(off & 1023u) - 256, origin[1] + (int)((off >> 10) & 1023u) - 256, origin[2] + (int)((off >> 20) & 1023u) - 256};
+        uint32_t idx;
+        if (!index_of(cube, &idx)) {
+            if (emit) end_of_ray(*alpha, rbw, w);
+            return false;
+        }
+        const int fe = (info & 7u) == 7u ? -1 : (int)(info & 7u);
+        // LightBuffer::traverse (updater.rs:770-895)
+        const DevDerived *ev = &J.derived[J.grid[idx] & J.index_mask];
+        const uint32_t flags = ev->flags;
+        if (flags & kDerivedVisible) {
+            const bool hit_opaque_face = fe < 0 ? (flags & 63u) == 63u : ((flags >> fe) & 1u) != 0u;
+            if (hit_opaque_face && fe < 0) {
+                *alpha = 0.f;
+            } else {
+                const float *scp = fe < 0 ? ev->color : ev->face[fe];
+                float sc[4] = {scp[0], scp[1], scp[2], scp[3]};
+                for (int i = 0; i < 3; i++) sc[i] = sc[i] > 1.f ? 1.f : sc[i];
+                const float hit_alpha = sc[3];
+                const float em[3] = {ev->emission[0], ev->emission[1], ev->emission[2]};
+                if (hit_alpha > 0.f && fe >= 0) {
+                    int n[3];
+                    normal_of(fe, n);
+                    const int light_cube[3] = {cube[0] + n[0], cube[1] + n[1], cube[2] + n[2]};
+                    if (emit) {
+                        float sv[3];
+                        value_of(get_light(light_cube), sv);
+                        const float a = ps_new_clamped(*alpha), ww = ps_new_clamped(rbw);
+                        float t[3];
+                        for (int i = 0; i < 3; i++) t[i] = ps_mul(ps_mul(em[i] + ps_mul(ps_mul(sc[i], sv[i]), sc[3]), a), ww);
+                        emit_term(t[0], t[1], t[2], 0.f);
+                        cost += 10u;
+                        emit_cand(light_cube, 1u);
+                    }
+                    if (hit_opaque_face) *alpha = 0.f;
+                    else *alpha *= 1.0f - hit_alpha;
+                }
+                if (hit_alpha < 1.0f) {
+                    if (emit) {
+                        float sl[3] = {0.f, 0.f, 0.f};
+                        if (fe >= 0) value_of(J.light[idx], sl);
+                        const float a = ps_new_clamped(*alpha), ww = ps_new_clamped(rbw);
+                        float t[3];
+                        for (int i = 0; i < 3; i++) t[i] = ps_mul(ps_mul(em[i] + ps_mul(sl[i], hit_alpha), a), ww);
+                        emit_term(t[0], t[1], t[2], 0.f);
+                        cost += 10u;
+                        emit_cand(cube, 0u);
+                    }
+                    *alpha *= 1.0f - hit_alpha;
+                }
+            }
+        }
+        if (!(*alpha > 0.0f)) {
+            if (emit) end_of_ray(*alpha, rbw, w);
+            return false;
+        }
+        return true;
+    }
+    // what a bundle adds after its children: end_of_ray with the weight its children did not take (updater.rs:507-528)
+    __device__ void close(uint32_t k, float alpha, float rbw) {
+        const DevTreePos *nd = &J.tree[k];
+        float w[6];
+        for (int f = 0; f < 6; f++) w[f] = nd->weight[f];
+        // child_weight_sum: what each child bundle returns is its own weight (updater.rs:437-441), a function of the
+        // child's chart weights and this walk's direction weights only -- no need to have walked it
+        const float *cw = J.child_w + (size_t)k * 36u;
+        float cwv[36];
+        for (int i = 0; i < 36; i++) cwv[i] = cw[i];
+        float cws = 0.0f;
+        for (int f = 0; f < 6; f++) cws += bundle_weight(cwv + 6 * f);  // no child on that face: zeros, and x + 0 = x
+        const float rest = rbw - cws;
+        end_of_ray(alpha, rest > 0.0f ? rest : 0.0f, w);
+    }
+};
+
+__global__ void __launch_bounds__(64) compute_light_wave_kernel(const LightJob J) {
+    __shared__ uint32_t s_terms[64], s_cands[64], s_cost[64];
+    const uint32_t lane = threadIdx.x, wave = blockIdx.x;
+    WaveCtx b(J);
+    for (int f = 0; f < 6; f++) b.value_of(J.block_sky[f], b.sky_value[f]);
+    b.terms = J.terms + ((size_t)wave * 64u + lane) * J.term_cap;
+    b.cands = J.cands + ((size_t)wave * 64u + lane) * J.cand_cap;
+    uint32_t *const stack = J.wstack + (size_t)wave * J.max_depth * 4u * 64u + lane;  // frame f, word w: stack[(f * 4 + w) * 64]
+
+    for (uint32_t item = wave; item < J.n; item += gridDim.x) {
+        const uint32_t ci = J.cubes[item];
+        const uint32_t sz = (uint32_t)J.size[2], sy = (uint32_t)J.size[1];
+        b.origin[0] = J.lo[0] + (int)(ci / (sy * sz));
+        b.origin[1] = J.lo[1] + (int)((ci / sz) % sy);
+        b.origin[2] = J.lo[2] + (int)(ci % sz);
+        const DevDerived *ev_origin = &J.derived[J.grid[ci] & J.index_mask];
+        const bool origin_is_opaque = (ev_origin->flags & 63u) == 63u;
+        const bool origin_emits = !(ev_origin->emission[0] == 0.f && ev_origin->emission[1] == 0.f && ev_origin->emission[2] == 0.f);
+        b.n_terms = 0u; b.n_cands = 0u; b.cost = 0u;
+#ifdef AIC_LIGHT_TIMING
+        const long long t_begin = clock64();
+#endif
+
+        if (!origin_is_opaque) {
+            // directions_to_seek_light (updater.rs:668-690)
+            uint32_t m0 = 0u;
+            if (ev_origin->flags & kDerivedVisible) m0 = 63u;
+            else {
+                bool nb_visible[6], nb_emits[6];
+                for (int f = 0; f < 6; f++) {
+                    int n[3];
+                    normal_of(f, n);
+                    const int c[3] = {b.origin[0] + n[0], b.origin[1] + n[1], b.origin[2] + n[2]};
+                    uint32_t i;
+                    nb_visible[f] = false; nb_emits[f] = false;
+                    if (b.index_of(c, &i)) {
+                        const DevDerived *d = &J.derived[J.grid[i] & J.index_mask];
+                        nb_visible[f] = (d->flags & kDerivedVisible) != 0u;
+                        nb_emits[f] = !(d->emission[0] == 0.f && d->emission[1] == 0.f && d->emission[2] == 0.f);
+                    }
+                }
+                for (int f = 0; f < 6; f++) {
+                    const int opp = f >= 3 ? f - 3 : f + 3;
+                    if (nb_visible[opp] || nb_emits[f]) m0 |= 1u << f;
+                }
+            }
+            b.m0 = m0;
+
+            const uint32_t a = min(lane * J.seg, J.n_tree), e = min(a + J.seg, J.n_tree);
+            if (a < e) {
+                // The frames of the bundles whose children are being walked: {position, subtree end, alpha behind the cube,
+                // bundle weight}; the innermost one is kept in registers (top_*), the others in the wave's stack.
+                uint32_t depth = 0u, pos = a;
+                uint32_t top_k = 0u, top_end = 0u;
+                float top_alpha = 1.0f, top_rbw = 0.f;
+                auto spill_top = [&]() {
+                    uint32_t *fr = stack + ((depth - 1u) * 4u) * 64u;
+                    fr[0] = top_k; fr[64] = top_end; fr[128] = __float_as_uint(top_alpha); fr[192] = __float_as_uint(top_rbw);
+                };
+                auto reload_top = [&]() {
+                    const uint32_t *fr = stack + ((depth - 1u) * 4u) * 64u;
+                    top_k = fr[0]; top_end = fr[64]; top_alpha = __uint_as_float(fr[128]); top_rbw = __uint_as_float(fr[192]);
+                };
+                // replay the root path of position a: state only
+                if (a > 0u) {
+                    uint32_t n_anc = 0u;
+                    for (uint32_t t = J.tree[a].parent;; t = J.tree[t].parent) { n_anc++; if (t == 0u) break; }
+                    {
+                        uint32_t t = J.tree[a].parent;
+                        for (uint32_t i = n_anc; i-- > 0u;) { stack[(i * 4u) * 64u] = t; t = J.tree[t].parent; }
+                    }
+                    float alpha = 1.0f;
+                    for (uint32_t i = 0u; i < n_anc; i++) {
+                        const uint32_t k = stack[(i * 4u) * 64u];
+                        const uint32_t ke = J.tree[k].end;
+                        float rbw;
+                        if (!b.enter(k, &alpha, &rbw, false)) {  // the path dies here: this lane's slice starts behind that subtree
+                            pos = ke;
+                            break;
+                        }
+                        stack[(i * 4u + 1u) * 64u] = ke;
+                        stack[(i * 4u + 2u) * 64u] = __float_as_uint(alpha);
+                        stack[(i * 4u + 3u) * 64u] = __float_as_uint(rbw);
+                        depth = i + 1u;
+                    }
+                    if (depth) reload_top();
+                }
+                for (;;) {
+                    bool done = false;
+                    while (depth > 0u && pos >= top_end) {
+                        if (top_end > e) { done = true; break; }  // closes in a later lane's slice
+                        b.close(top_k, top_alpha, top_rbw);
+                        depth--;
+                        if (depth) reload_top();
+                    }
+                    if (done || pos >= e) break;
+                    float alpha = depth ? top_alpha : 1.0f;
+                    float rbw;
+                    const uint32_t k = pos;
+                    const uint32_t ke = J.tree[k].end;
+                    if (b.enter(k, &alpha, &rbw, true)) {
+                        if (k + 1u < ke) {
+                            if (depth) spill_top();
+                            depth++;
+                            top_k = k; top_end = ke; top_alpha = alpha; top_rbw = rbw;
+                            pos = k + 1u;
+                        } else {
+                            b.close(k, alpha, rbw);
+                            pos = ke;
+                        }
+                    } else {
+                        pos = ke;
+                    }
+                }
+            }
+        }
+        s_terms[lane] = b.n_terms;
+        s_cands[lane] = b.n_cands;
+        s_cost[lane] = b.cost;
+        __syncthreads();
+#ifdef AIC_LIGHT_TIMING
+        const long long t_walk = clock64();
+        if (lane == 0u) atomicAdd(&J.dep_head[2], (uint32_t)((t_walk - t_begin) >> 6));
+#endif
+
+        if (lane == 0u) {
+            float inc[3] = {0.f, 0.f, 0.f}, total = 0.f;
+            uint32_t cost = 0u;
+            if (origin_is_opaque) {
+                if (origin_emits) {  // add_weighted_light(emission, 1.0)
+                    for (int i = 0; i < 3; i++) inc[i] += ps_mul(ev_origin->emission[i], ps_new_clamped(1.0f));
+                    total += 1.0f;
+                }
+            } else {
+                for (uint32_t l = 0u; l < 64u; l++) {
+                    const float4 *t = J.terms + ((size_t)wave * 64u + l) * J.term_cap;
+                    const uint32_t n = s_terms[l];
+                    cost += s_cost[l];
+#pragma unroll 8
+                    for (uint32_t i = 0u; i < n; i++) {
+                        const float4 v = t[i];
+                        inc[0] += v.x; inc[1] += v.y; inc[2] += v.z; total += v.w;
+                    }
+                }
+            }
+            // dependencies, in walk order
+            uint32_t n_deps = 0u, first_chunk = 0xffffffffu, cur_chunk = 0xffffffffu, fill = kLightDepChunk;
+            if (!origin_is_opaque) {
+                uint32_t last = 0xffffffffu;
+                for (uint32_t l = 0u; l < 64u; l++) {
+                    const uint32_t *cd = J.cands + ((size_t)wave * 64u + l) * J.cand_cap;
+                    const uint32_t n = s_cands[l];
+                    for (uint32_t i = 0u; i < n; i++) {
+                        const uint32_t c = cd[i], key = c & 0x3fffffffu;
+                        if ((c >> 30) && key == last) continue;  // `if dependencies.last() != Some(&light_cube)`
+                        last = key;
+                        const int cube[3] = {b.origin[0] + (int)(key & 1023u) - 256, b.origin[1] + (int)((key >> 10) & 1023u) - 256,
+                                             b.origin[2] + (int)((key >> 20) & 1023u) - 256};
+                        uint32_t idx;
+                        if (!b.index_of(cube, &idx)) continue;  // light_needs_update ignores cubes outside the space
+                        if (fill == kLightDepChunk) {
+                            const uint32_t next = atomicAdd(&J.dep_head[0], 1u);
+                            if (next >= J.dep_chunks) {
+                                J.dep_head[1] = 1u;
+                                cur_chunk = 0xffffffffu;
+                            } else {
+                                J.dep_pool[(size_t)next * kLightDepChunk] = 0xffffffffu;
+                                if (cur_chunk != 0xffffffffu) J.dep_pool[(size_t)cur_chunk * kLightDepChunk] = next;
+                                else if (n_deps == 0u) first_chunk = next;
+                                cur_chunk = next;
+                            }
+                            fill = 1u;
+                        }
+                        if (cur_chunk != 0xffffffffu) J.dep_pool[(size_t)cur_chunk * kLightDepChunk + fill] = idx;
+                        fill++;
+                        n_deps++;
+                    }
+                }
+            }
+            // LightBuffer::finish (updater.rs:940-952)
+            uint32_t texel;
+            const float scale = ps_new_clamped(1.0f / fmaxf(total, 1.0f));
+            if (total > 0.0f) {
+                texel = packed_scalar_in(ps_mul(inc[0], scale)) | (packed_scalar_in(ps_mul(inc[1], scale)) << 8) |
+                        (packed_scalar_in(ps_mul(inc[2], scale)) << 16) | (255u << 24);
+            } else if (origin_is_opaque) {
+                texel = 128u << 24;
+            } else {
+                texel = 1u << 24;
+            }
+            uint32_t *o = J.out + 4 * (size_t)item;
+            o[0] = texel;
+            o[1] = n_deps;
+            o[2] = first_chunk;
+            o[3] = cost;
+#ifdef AIC_LIGHT_TIMING
+            atomicAdd(&J.dep_head[3], (uint32_t)((clock64() - t_walk) >> 6));
+            uint32_t nt = 0;
+            for (uint32_t l = 0; l < 64u; l++) nt += s_terms[l];
+            atomicAdd(&J.dep_head[6], nt);
+            atomicAdd(&J.dep_head[7], n_deps);
+#endif
+        }
+        __syncthreads();  // the lists are reused by the wave's next cube
+    }
+}
+
 __global__ void scatter_light_kernel(uint32_t *light, const uint32_t *index, const uint32_t *texel, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) light[index[i]] = texel[i];
@@ -419,6 +800,11 @@ __global__ void probe_log2f_kernel(const float *x, float *out, uint32_t n) {
 void launch_compute_light(const LightJob &job, hipStream_t stream) {
     if (!job.n) return;
     hipLaunchKernelGGL(compute_light_kernel, dim3((job.n + 63u) / 64u), dim3(64), 0, stream, job);
+}
+
+void launch_compute_light_waves(const LightJob &job, uint32_t n_waves, hipStream_t stream) {
+    if (!job.n || !n_waves) return;
+    hipLaunchKernelGGL(compute_light_wave_kernel, dim3(n_waves), dim3(64), 0, stream, job);
 }
 
 void launch_scatter_light(uint32_t *light, const uint32_t *index, const uint32_t *texel, uint32_t n, hipStream_t stream) {

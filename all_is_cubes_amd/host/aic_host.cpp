@@ -664,7 +664,7 @@ ImageInfo HipRtRenderer::wait_rows(uint32_t slot) {
     return to_info(fi, vp.framebuffer_width, vp.framebuffer_height);
 }
 void HipRtRenderer::synchronize() { check(aic_synchronize(ctx_), "aic_synchronize"); }
-HipRtRenderer::LightUpdateInfo HipRtRenderer::evaluate_light(int maximum_distance, bool fast, int epsilon, int batch, int queue_order) {
+HipRtRenderer::LightUpdateInfo HipRtRenderer::evaluate_light(int maximum_distance, bool fast, int epsilon, int batch, int queue_order, int lanes_per_cube) {
     aic_light_params p;
     std::memset(&p, 0, sizeof(p));
     p.maximum_distance = maximum_distance;
@@ -673,6 +673,7 @@ HipRtRenderer::LightUpdateInfo HipRtRenderer::evaluate_light(int maximum_distanc
     p.batch = batch;
     p.queue_order = queue_order;
     p.n_queue = -1;
+    p.lanes_per_cube = lanes_per_cube;
     aic_light_info info;
     check(aic_evaluate_light(ctx_, AIC_LAYER_WORLD, &p, &info), "aic_evaluate_light");
     return LightUpdateInfo{info.updates, info.batches, info.cost, info.device_ms, info.total_ms, info.queue_left};

@@ -319,7 +319,7 @@ class HipRtRenderer : public HeadlessRenderer {
     // Mutation::evaluate_light(epsilon) (space.rs:1496-1540) on the WORLD space as uploaded, with
     // LightPhysics::Rays { maximum_distance }; the device's light volume is updated in place (the host Space's is not).
     struct LightUpdateInfo { uint64_t updates, batches, cost; double device_ms, total_ms; uint32_t queue_left; };
-    LightUpdateInfo evaluate_light(int maximum_distance, bool fast = true, int epsilon = 1, int batch = 32, int queue_order = 16);
+    LightUpdateInfo evaluate_light(int maximum_distance, bool fast = true, int epsilon = 1, int batch = 32, int queue_order = 16, int lanes_per_cube = 0);
     bool enable_counters = false;
 
   private:

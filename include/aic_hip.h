@@ -317,6 +317,10 @@ typedef struct aic_light_params {
     int32_t n_queue;          /* when !fast: entries to start the queue with, inserted in order (what
                                  modified_cube_needs_update, updater.rs:135-173, enqueues after a change); < 0: every cube
                                  whose texel is Uninitialized, at Priority::UNINIT */
+    int32_t lanes_per_cube;   /* how compute_light is mapped to the device: 64 (or 0 = default) one wave per cube -- 64 lanes walk
+                                 64 slices of the ray-bundle tree and the contributions are added in the reference's order;
+                                 1 = one lane per cube (the plain restatement). Same results, bit for bit */
+    int32_t reserved;
     const int32_t *queue_cubes;      /* [n_queue][3] */
     const int32_t *queue_priorities; /* [n_queue], 0..255 */
     uint64_t max_updates;     /* stop once this many cubes were updated (checked between batches); 0 = run until done */

@@ -157,6 +157,8 @@ pub struct aic_light_params {
     pub batch: i32,
     pub queue_order: i32,
     pub n_queue: i32,
+    pub lanes_per_cube: i32,
+    pub reserved: i32,
     pub queue_cubes: *const i32,
     pub queue_priorities: *const i32,
     pub max_updates: u64,

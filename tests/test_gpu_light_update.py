@@ -68,15 +68,17 @@ def test_derived_matches_oracle(ctx, name):
 
 
 @pytest.mark.parametrize("name", list(SCENES))
-@pytest.mark.parametrize("batch,order", [(32, 16), (1, 16), (32, 8), (7, 0)])
-def test_evaluate_light_matches_oracle(ctx, name, batch, order):
-    if name in ("fog", "tone_mapping") and (batch, order) != (32, 16):
+@pytest.mark.parametrize("batch,order,lanes", [(32, 16, 64), (1, 16, 64), (32, 8, 64), (7, 0, 64), (32, 16, 1)])
+def test_evaluate_light_matches_oracle(ctx, name, batch, order, lanes):
+    """`lanes`: one wave per cube (64 lanes walk slices of the tree, contributions added in the reference's order) or the
+    plain one-lane-per-cube restatement: both must give the oracle's bytes."""
+    if name in ("fog", "tone_mapping") and (batch, order, lanes) != (32, 16, 64):
         pytest.skip("the larger scenes run in the reference configuration only")
     sp = SCENES[name]()
     ref = copy.deepcopy(sp)
     n_ref = oracle.evaluate_light(ref, maximum_distance=30, fast=True, epsilon=1, batch=batch, hb_width=order)
     ctx.upload_space(abi.LAYER_WORLD, sp)
-    info = ctx.evaluate_light(abi.LAYER_WORLD, 30, fast=True, epsilon=1, batch=batch, queue_order=order)
+    info = ctx.evaluate_light(abi.LAYER_WORLD, 30, fast=True, epsilon=1, batch=batch, queue_order=order, lanes_per_cube=lanes)
     got = ctx.read_light_volume(abi.LAYER_WORLD, sp.size)
     assert info.updates == n_ref
     assert (got == np.asarray(ref.light).reshape(got.shape)).all(), f"{(got != np.asarray(ref.light).reshape(got.shape)).any(axis=-1).sum()} texels differ"
