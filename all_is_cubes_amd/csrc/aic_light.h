@@ -51,6 +51,7 @@ struct LightJob {
     uint32_t index_mask;       // strips the class bits of the cube-grid entries (aic_device.h)
     const uint32_t *light;     // PackedLight texels
     const DevDerived *derived; // per block index
+    uint32_t n_blocks;
     const DevLightNode *chart;
     const float *lut;          // PackedLight scalar -> f32 (256 entries)
     int32_t lo[3], size[3];

@@ -415,6 +415,19 @@ __global__ void __launch_bounds__(64) compute_light_kernel(const LightJob J) {
 // last position of the bundle's subtree. Dependencies go the same way: candidates per lane, then one in-order pass that
 // drops a face's light cube when it repeats the previous entry (updater.rs:838-842).
 
+constexpr uint32_t kLdsFlags = 4096u;
+
+struct TreeRegs {  // one DevTreePos in registers
+    float w[6];
+    uint32_t end, offset, info;
+};
+__device__ __forceinline__ TreeRegs load_pos(const DevTreePos *t) {
+    TreeRegs r;
+    for (int f = 0; f < 6; f++) r.w[f] = t->weight[f];
+    r.end = t->end; r.offset = t->offset; r.info = t->info;
+    return r;
+}
+
 struct WaveCtx {
     const LightJob &J;
     int origin[3];
@@ -423,8 +436,11 @@ struct WaveCtx {
     float4 *terms;
     uint32_t *cands;
     uint32_t n_terms, n_cands, cost;
+    const uint32_t *lds_flags;  // DevDerived.flags of the first kLdsFlags blocks, in LDS
+    const float *lds_lut;       // the PackedLight decode table, in LDS
 
     __device__ explicit WaveCtx(const LightJob &j) : J(j) {}
+    __device__ uint32_t flags_of(uint32_t block) const { return block < kLdsFlags ? lds_flags[block] : J.derived[block].flags; }
     __device__ bool index_of(const int c[3], uint32_t *out) const {
         const uint32_t dx = (uint32_t)c[0] - (uint32_t)J.lo[0], dy = (uint32_t)c[1] - (uint32_t)J.lo[1], dz = (uint32_t)c[2] - (uint32_t)J.lo[2];
         if ((dx >= (uint32_t)J.size[0]) | (dy >= (uint32_t)J.size[1]) | (dz >= (uint32_t)J.size[2])) return false;
@@ -459,9 +475,9 @@ struct WaveCtx {
         return light_outside(c);
     }
     __device__ void value_of(uint32_t texel, float v[3]) const {
-        v[0] = J.lut[texel & 255u];
-        v[1] = J.lut[(texel >> 8) & 255u];
-        v[2] = J.lut[(texel >> 16) & 255u];
+        v[0] = lds_lut[texel & 255u];
+        v[1] = lds_lut[(texel >> 8) & 255u];
+        v[2] = lds_lut[(texel >> 16) & 255u];
     }
     __device__ float bundle_weight(const float w[6]) const {  // (weight * direction_weights).sum(), face.rs:1046-1054
         float p[6];
@@ -490,14 +506,12 @@ struct WaveCtx {
     }
     // walk_ray_tree up to its recursion (updater.rs:427-505) for the bundle at tree position k, entered with `alpha`.
     // Returns whether the bundle's children are walked; then *alpha is the ray's alpha behind the cube. !emit: state only.
-    __device__ bool enter(uint32_t k, float *alpha, float *rbw_out, bool emit) {
-        const DevTreePos *nd = &J.tree[k];
-        float w[6];
-        for (int f = 0; f < 6; f++) w[f] = nd->weight[f];
+    __device__ bool enter(const TreeRegs &nd, float *alpha, float *rbw_out, bool emit) {
+        const float *w = nd.w;
         const float rbw = bundle_weight(w);
         *rbw_out = rbw;
         if (rbw <= 0.0f) return false;
-        const uint32_t info = nd->info, off = nd->offset;
+        const uint32_t info = nd.info, off = nd.offset;
         if (info & 8u) {  // beyond maximum_distance
             if (emit) end_of_ray(*alpha, rbw, w);
             return false;
@@ -511,9 +525,10 @@ struct WaveCtx {
         }
         const int fe = (info & 7u) == 7u ? -1 : (int)(info & 7u);
         // LightBuffer::traverse (updater.rs:770-895)
-        const DevDerived *ev = &J.derived[J.grid[idx] & J.index_mask];
-        const uint32_t flags = ev->flags;
+        const uint32_t block = J.grid[idx] & J.index_mask;
+        const uint32_t flags = flags_of(block);
         if (flags & kDerivedVisible) {
+            const DevDerived *ev = &J.derived[block];
             const bool hit_opaque_face = fe < 0 ? (flags & 63u) == 63u : ((flags >> fe) & 1u) != 0u;
             if (hit_opaque_face && fe < 0) {
                 *alpha = 0.f;
@@ -580,8 +595,15 @@ struct WaveCtx {
 
 __global__ void __launch_bounds__(64) compute_light_wave_kernel(const LightJob J) {
     __shared__ uint32_t s_terms[64], s_cands[64], s_cost[64];
+    __shared__ uint32_t s_flags[kLdsFlags];
+    __shared__ float s_lut[256];
     const uint32_t lane = threadIdx.x, wave = blockIdx.x;
+    for (uint32_t i = lane; i < min(J.n_blocks, kLdsFlags); i += 64u) s_flags[i] = J.derived[i].flags;
+    for (uint32_t i = lane; i < 256u; i += 64u) s_lut[i] = J.lut[i];
+    __syncthreads();
     WaveCtx b(J);
+    b.lds_flags = s_flags;
+    b.lds_lut = s_lut;
     for (int f = 0; f < 6; f++) b.value_of(J.block_sky[f], b.sky_value[f]);
     b.terms = J.terms + ((size_t)wave * 64u + lane) * J.term_cap;
     b.cands = J.cands + ((size_t)wave * 64u + lane) * J.cand_cap;
@@ -652,9 +674,10 @@ __global__ void __launch_bounds__(64) compute_light_wave_kernel(const LightJob J
                     float alpha = 1.0f;
                     for (uint32_t i = 0u; i < n_anc; i++) {
                         const uint32_t k = stack[(i * 4u) * 64u];
-                        const uint32_t ke = J.tree[k].end;
+                        const TreeRegs nd = load_pos(&J.tree[k]);
+                        const uint32_t ke = nd.end;
                         float rbw;
-                        if (!b.enter(k, &alpha, &rbw, false)) {  // the path dies here: this lane's slice starts behind that subtree
+                        if (!b.enter(nd, &alpha, &rbw, false)) {  // the path dies here: this lane's slice starts behind that subtree
                             pos = ke;
                             break;
                         }
@@ -665,6 +688,13 @@ __global__ void __launch_bounds__(64) compute_light_wave_kernel(const LightJob J
                     }
                     if (depth) reload_top();
                 }
+#ifdef AIC_LIGHT_TIMING
+                atomicAdd(&J.dep_head[4], (uint32_t)((clock64() - t_begin) >> 6));
+                uint32_t n_iter = 0;
+#endif
+                // The position about to be visited is held in registers; while it is processed, the next position in
+                // pre-order (where the walk goes if this bundle has children and stays alive) is already being fetched.
+                TreeRegs cur = load_pos(&J.tree[pos < J.n_tree ? pos : 0u]);
                 for (;;) {
                     bool done = false;
                     while (depth > 0u && pos >= top_end) {
@@ -674,24 +704,32 @@ __global__ void __launch_bounds__(64) compute_light_wave_kernel(const LightJob J
                         if (depth) reload_top();
                     }
                     if (done || pos >= e) break;
+#ifdef AIC_LIGHT_TIMING
+                    n_iter++;
+#endif
+                    const uint32_t k = pos;
+                    const TreeRegs nxt = load_pos(&J.tree[k + 1u < J.n_tree ? k + 1u : k]);
                     float alpha = depth ? top_alpha : 1.0f;
                     float rbw;
-                    const uint32_t k = pos;
-                    const uint32_t ke = J.tree[k].end;
-                    if (b.enter(k, &alpha, &rbw, true)) {
+                    const uint32_t ke = cur.end;
+                    if (b.enter(cur, &alpha, &rbw, true)) {
                         if (k + 1u < ke) {
                             if (depth) spill_top();
                             depth++;
                             top_k = k; top_end = ke; top_alpha = alpha; top_rbw = rbw;
                             pos = k + 1u;
-                        } else {
-                            b.close(k, alpha, rbw);
-                            pos = ke;
+                            cur = nxt;
+                            continue;
                         }
-                    } else {
-                        pos = ke;
+                        b.close(k, alpha, rbw);
                     }
+                    pos = ke;
+                    if (pos == k + 1u) cur = nxt;
+                    else if (pos < e) cur = load_pos(&J.tree[pos]);
                 }
+#ifdef AIC_LIGHT_TIMING
+                atomicAdd(&J.dep_head[5], n_iter);
+#endif
             }
         }
         s_terms[lane] = b.n_terms;
