@@ -42,7 +42,7 @@ struct DevTreePos {
     uint32_t end;
     uint32_t parent;
     uint32_t offset;  // cube offset from the origin cube: (dx + 256) | (dy + 256) << 10 | (dz + 256) << 20
-    uint32_t info;    // bits 0-2: face entered (0..5; 7 = Face7::Within, the root); bit 3: beyond maximum_distance
+    uint32_t info;    // bits 0-2: face entered (0..5; 7 = Face7::Within, the root); bit 3: beyond maximum_distance; bits 8-23: depth
 };
 static_assert(sizeof(DevTreePos) == 40, "tree position record is 40 bytes");
 
@@ -70,12 +70,9 @@ struct LightJob {
     const DevTreePos *tree;
     uint32_t n_tree;
     const float *child_w;      // [n_tree][6 faces][6]: the weights of each position's children (zeros where there is none)
-    uint32_t seg;              // positions per lane: ceil(n_tree / 64)
-    float4 *terms;             // [waves][64][term_cap]: (incoming r, g, b, ray weight) in walk order
-    uint32_t term_cap;
-    uint32_t *cands;           // [waves][64][cand_cap]: dependency candidates in walk order (offset | conditional << 30)
-    uint32_t cand_cap;
-    uint32_t *wstack;          // [waves][max_depth][4][64]
+    const uint32_t *child_pos; // [n_tree][6 faces]: the position of the child stepped to through that face, 0 = none
+    float4 *terms;             // [waves][4 * n_tree]: (incoming r, g, b; ray weight) by recursion-order number
+    uint32_t *cands;           // [waves][2 * n_tree]: dependency candidates (cube offset | conditional << 30)
 };
 
 void launch_compute_light(const LightJob &job, hipStream_t stream);

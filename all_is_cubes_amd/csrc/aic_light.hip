@@ -406,38 +406,32 @@ __global__ void __launch_bounds__(64) compute_light_kernel(const LightJob J) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// One WAVE per cube. The walk's contributions depend only on the ray state along their own root path (alpha; the
-// direction weights are fixed per cube once the walk has started), never on the accumulators -- so the 64 lanes walk 64
-// contiguous slices of the tree's pre-order, each first replaying its slice's root path without emitting anything, and
-// write what they would have added (incoming r, g, b; ray weight) to per-lane lists. Lane 0 then adds the lists in lane
-// order = pre-order = the order of the reference's recursion, so every f32 sum is the reference's sum, at 1/64 of the
-// latency. The "rest" term a bundle adds after its children (updater.rs:521-528) is emitted by the lane that owns the
-// last position of the bundle's subtree. Dependencies go the same way: candidates per lane, then one in-order pass that
-// drops a face's light cube when it repeats the previous entry (updater.rs:838-842).
+// One WAVE per cube. What a bundle adds to the accumulators depends only on the ray state along its own root path (alpha;
+// the direction weights are fixed per cube once the walk has started), never on the accumulators and never on its
+// siblings. So the tree is walked LEVEL BY LEVEL: the wave keeps the frontier of live bundles (at most one per ray: 602)
+// in LDS, each lane visits frontier entries -- exactly the bundles the reference's recursion visits, no more -- and appends
+// their children, with the alpha behind the parent, to the next frontier. Every contribution is written to the slot that
+// its place in the reference's recursion order gives it -- a static number: three slots when a bundle is entered (face
+// term, volume term, end of ray), one when it is left (the "rest" term, updater.rs:521-528) -- and a bit is set in an LDS
+// bitmap. When the frontier is empty, the set bits in ascending order ARE the reference's order of additions: lane 0
+// adds them up, so every f32 sum is the reference's sum. Dependencies likewise (two slots per bundle), with the drop of a
+// face's light cube that repeats the previous entry (updater.rs:838-842) done in that ordered pass.
 
-constexpr uint32_t kLdsFlags = 4096u;
-
-struct TreeRegs {  // one DevTreePos in registers
-    float w[6];
-    uint32_t end, offset, info;
-};
-__device__ __forceinline__ TreeRegs load_pos(const DevTreePos *t) {
-    TreeRegs r;
-    for (int f = 0; f < 6; f++) r.w[f] = t->weight[f];
-    r.end = t->end; r.offset = t->offset; r.info = t->info;
-    return r;
-}
+constexpr uint32_t kLdsFlags = 1024u;   // DevDerived.flags of the first blocks, cached in LDS
+constexpr uint32_t kFrontierCap = 1024u;  // >= 602 rays
+constexpr uint32_t kOrderCap = 2048u;   // set bits gathered per pass of the ordered reduction
 
 struct WaveCtx {
     const LightJob &J;
     int origin[3];
     uint32_t m0;            // direction weights of the walk: bit per face (updater.rs:668-690)
     float sky_value[6][3];
-    float4 *terms;
-    uint32_t *cands;
-    uint32_t n_terms, n_cands, cost;
-    const uint32_t *lds_flags;  // DevDerived.flags of the first kLdsFlags blocks, in LDS
-    const float *lds_lut;       // the PackedLight decode table, in LDS
+    float4 *slots;          // [4 * n_tree] contributions by recursion-order number
+    uint32_t *cslots;       // [2 * n_tree] dependency candidates
+    uint32_t *term_bits, *cand_bits;  // LDS bitmaps
+    uint32_t cost;
+    const uint32_t *lds_flags;
+    const float *lds_lut;
 
     __device__ explicit WaveCtx(const LightJob &j) : J(j) {}
     __device__ uint32_t flags_of(uint32_t block) const { return block < kLdsFlags ? lds_flags[block] : J.derived[block].flags; }
@@ -484,13 +478,17 @@ struct WaveCtx {
         for (int f = 0; f < 6; f++) p[f] = ((m0 >> f) & 1u) ? w[f] : 0.f;
         return (p[0] + p[3]) + (p[1] + p[4]) + (p[2] + p[5]);
     }
-    __device__ void emit_term(float x, float y, float z, float weight) { terms[n_terms++] = make_float4(x, y, z, weight); }
-    __device__ void emit_cand(const int c[3], uint32_t conditional) {
-        cands[n_cands++] = (uint32_t)(c[0] - origin[0] + 256) | ((uint32_t)(c[1] - origin[1] + 256) << 10) | ((uint32_t)(c[2] - origin[2] + 256) << 20) |
-                           (conditional << 30);
+    __device__ void emit_term(uint32_t seq, float x, float y, float z, float weight) {
+        slots[seq] = make_float4(x, y, z, weight);
+        atomicOr(&term_bits[seq >> 5], 1u << (seq & 31u));
+    }
+    __device__ void emit_cand(uint32_t seq, const int c[3], uint32_t conditional) {
+        cslots[seq] = (uint32_t)(c[0] - origin[0] + 256) | ((uint32_t)(c[1] - origin[1] + 256) << 10) | ((uint32_t)(c[2] - origin[2] + 256) << 20) |
+                      (conditional << 30);
+        atomicOr(&cand_bits[seq >> 5], 1u << (seq & 31u));
     }
     // updater.rs:899-927 + add_weighted_light
-    __device__ void end_of_ray(float alpha, float ray_bundle_weight, const float w[6]) {
+    __device__ void end_of_ray(uint32_t seq, float alpha, float ray_bundle_weight, const float w[6]) {
         if (!(ray_bundle_weight > 0.f)) return;
         const float recip = ps_new_clamped(1.0f / ((w[0] + w[3]) + (w[1] + w[4]) + (w[2] + w[5])));
         const float ww = ps_new_clamped(ray_bundle_weight);
@@ -502,112 +500,153 @@ struct WaveCtx {
             const float sky_light = ps_mul(ps_mul(s, recip), ps_new_clamped(alpha));
             out[i] = ps_mul(sky_light, ww);
         }
-        emit_term(out[0], out[1], out[2], ray_bundle_weight);
+        emit_term(seq, out[0], out[1], out[2], ray_bundle_weight);
     }
-    // walk_ray_tree up to its recursion (updater.rs:427-505) for the bundle at tree position k, entered with `alpha`.
-    // Returns whether the bundle's children are walked; then *alpha is the ray's alpha behind the cube. !emit: state only.
-    __device__ bool enter(const TreeRegs &nd, float *alpha, float *rbw_out, bool emit) {
-        const float *w = nd.w;
-        const float rbw = bundle_weight(w);
-        *rbw_out = rbw;
-        if (rbw <= 0.0f) return false;
-        const uint32_t info = nd.info, off = nd.offset;
-        if (info & 8u) {  // beyond maximum_distance
-            if (emit) end_of_ray(*alpha, rbw, w);
-            return false;
-        }
-        if (emit) cost += 1u;
-        const int cube[3] = {origin[0] + (int)(off & 1023u) - 256, origin[1] + (int)((off >> 10) & 1023u) - 256, origin[2] + (int)((off >> 20) & 1023u) - 256};
-        uint32_t idx;
-        if (!index_of(cube, &idx)) {
-            if (emit) end_of_ray(*alpha, rbw, w);
-            return false;
-        }
-        const int fe = (info & 7u) == 7u ? -1 : (int)(info & 7u);
-        // LightBuffer::traverse (updater.rs:770-895)
-        const uint32_t block = J.grid[idx] & J.index_mask;
-        const uint32_t flags = flags_of(block);
-        if (flags & kDerivedVisible) {
-            const DevDerived *ev = &J.derived[block];
-            const bool hit_opaque_face = fe < 0 ? (flags & 63u) == 63u : ((flags >> fe) & 1u) != 0u;
-            if (hit_opaque_face && fe < 0) {
-                *alpha = 0.f;
-            } else {
-                const float *scp = fe < 0 ? ev->color : ev->face[fe];
-                float sc[4] = {scp[0], scp[1], scp[2], scp[3]};
-                for (int i = 0; i < 3; i++) sc[i] = sc[i] > 1.f ? 1.f : sc[i];
-                const float hit_alpha = sc[3];
-                const float em[3] = {ev->emission[0], ev->emission[1], ev->emission[2]};
-                if (hit_alpha > 0.f && fe >= 0) {
-                    int n[3];
-                    normal_of(fe, n);
-                    const int light_cube[3] = {cube[0] + n[0], cube[1] + n[1], cube[2] + n[2]};
-                    if (emit) {
-                        float sv[3];
-                        value_of(get_light(light_cube), sv);
-                        const float a = ps_new_clamped(*alpha), ww = ps_new_clamped(rbw);
-                        float t[3];
-                        for (int i = 0; i < 3; i++) t[i] = ps_mul(ps_mul(em[i] + ps_mul(ps_mul(sc[i], sv[i]), sc[3]), a), ww);
-                        emit_term(t[0], t[1], t[2], 0.f);
-                        cost += 10u;
-                        emit_cand(light_cube, 1u);
-                    }
-                    if (hit_opaque_face) *alpha = 0.f;
-                    else *alpha *= 1.0f - hit_alpha;
-                }
-                if (hit_alpha < 1.0f) {
-                    if (emit) {
-                        float sl[3] = {0.f, 0.f, 0.f};
-                        if (fe >= 0) value_of(J.light[idx], sl);
-                        const float a = ps_new_clamped(*alpha), ww = ps_new_clamped(rbw);
-                        float t[3];
-                        for (int i = 0; i < 3; i++) t[i] = ps_mul(ps_mul(em[i] + ps_mul(sl[i], hit_alpha), a), ww);
-                        emit_term(t[0], t[1], t[2], 0.f);
-                        cost += 10u;
-                        emit_cand(cube, 0u);
-                    }
-                    *alpha *= 1.0f - hit_alpha;
-                }
-            }
-        }
-        if (!(*alpha > 0.0f)) {
-            if (emit) end_of_ray(*alpha, rbw, w);
-            return false;
-        }
-        return true;
-    }
-    // what a bundle adds after its children: end_of_ray with the weight its children did not take (updater.rs:507-528)
-    __device__ void close(uint32_t k, float alpha, float rbw) {
+    // walk_ray_tree (updater.rs:427-530) for the bundle at tree position k, entered with alpha_in. Returns whether its
+    // children are to be walked, then *alpha_out is the alpha behind the cube. Everything the bundle adds -- on entering
+    // and, if it lives, after its children -- is emitted here, into its numbered slots.
+    __device__ bool visit(uint32_t k, float alpha_in, float *alpha_out) {
         const DevTreePos *nd = &J.tree[k];
         float w[6];
         for (int f = 0; f < 6; f++) w[f] = nd->weight[f];
-        // child_weight_sum: what each child bundle returns is its own weight (updater.rs:437-441), a function of the
-        // child's chart weights and this walk's direction weights only -- no need to have walked it
+        const uint32_t info = nd->info, off = nd->offset, end = nd->end;
+        // the children's chart weights, for the "rest" term below: fetched up front, beside the cube lookup
         const float *cw = J.child_w + (size_t)k * 36u;
         float cwv[36];
         for (int i = 0; i < 36; i++) cwv[i] = cw[i];
-        float cws = 0.0f;
-        for (int f = 0; f < 6; f++) cws += bundle_weight(cwv + 6 * f);  // no child on that face: zeros, and x + 0 = x
-        const float rest = rbw - cws;
-        end_of_ray(alpha, rest > 0.0f ? rest : 0.0f, w);
+        const float rbw = bundle_weight(w);
+        if (rbw <= 0.0f) return false;
+        const uint32_t depth = (info >> 8) & 0xffffu;
+        const uint32_t seq = 4u * k - depth;  // 3 per bundle entered before, 1 per bundle left before
+        float alpha = alpha_in;
+        // Every live bundle ends in exactly one end_of_ray: beyond the distance / outside the space (slot seq), the ray
+        // used up inside the cube (slot seq + 2), or -- after its children -- with the weight they did not take (the slot of
+        // the bundle's exit). The cases only select its arguments, so that the wave runs the arithmetic once.
+        bool alive = false;
+        uint32_t eseq = seq;
+        float eweight = rbw;
+        const int cube[3] = {origin[0] + (int)(off & 1023u) - 256, origin[1] + (int)((off >> 10) & 1023u) - 256, origin[2] + (int)((off >> 20) & 1023u) - 256};
+        uint32_t idx = 0u;
+        if (!(info & 8u)) {  // within maximum_distance
+            cost += 1u;
+            if (index_of(cube, &idx)) {
+                const int fe = (info & 7u) == 7u ? -1 : (int)(info & 7u);
+                // LightBuffer::traverse (updater.rs:770-895)
+                const uint32_t block = J.grid[idx] & J.index_mask;
+                const uint32_t flags = flags_of(block);
+                if (flags & kDerivedVisible) {
+                    const DevDerived *ev = &J.derived[block];
+                    const bool hit_opaque_face = fe < 0 ? (flags & 63u) == 63u : ((flags >> fe) & 1u) != 0u;
+                    if (hit_opaque_face && fe < 0) {
+                        alpha = 0.f;
+                    } else {
+                        const float *scp = fe < 0 ? ev->color : ev->face[fe];
+                        float sc[4] = {scp[0], scp[1], scp[2], scp[3]};
+                        for (int i = 0; i < 3; i++) sc[i] = sc[i] > 1.f ? 1.f : sc[i];
+                        const float hit_alpha = sc[3];
+                        const float em[3] = {ev->emission[0], ev->emission[1], ev->emission[2]};
+                        if (hit_alpha > 0.f && fe >= 0) {
+                            int n[3];
+                            normal_of(fe, n);
+                            const int light_cube[3] = {cube[0] + n[0], cube[1] + n[1], cube[2] + n[2]};
+                            float sv[3];
+                            value_of(get_light(light_cube), sv);
+                            const float a = ps_new_clamped(alpha), ww = ps_new_clamped(rbw);
+                            float t[3];
+                            for (int i = 0; i < 3; i++) t[i] = ps_mul(ps_mul(em[i] + ps_mul(ps_mul(sc[i], sv[i]), sc[3]), a), ww);
+                            emit_term(seq, t[0], t[1], t[2], 0.f);
+                            cost += 10u;
+                            emit_cand(2u * k, light_cube, 1u);
+                            if (hit_opaque_face) alpha = 0.f;
+                            else alpha *= 1.0f - hit_alpha;
+                        }
+                        if (hit_alpha < 1.0f) {
+                            float sl[3] = {0.f, 0.f, 0.f};
+                            if (fe >= 0) value_of(J.light[idx], sl);
+                            const float a = ps_new_clamped(alpha), ww = ps_new_clamped(rbw);
+                            float t[3];
+                            for (int i = 0; i < 3; i++) t[i] = ps_mul(ps_mul(em[i] + ps_mul(sl[i], hit_alpha), a), ww);
+                            emit_term(seq + 1u, t[0], t[1], t[2], 0.f);
+                            cost += 10u;
+                            emit_cand(2u * k + 1u, cube, 0u);
+                            alpha *= 1.0f - hit_alpha;
+                        }
+                    }
+                }
+                if (alpha > 0.0f) {
+                    // After the children: the weight they did not take (updater.rs:507-528). What a child returns is its own
+                    // bundle weight (updater.rs:437-441), a function of its chart weights and this walk's direction weights only.
+                    alive = true;
+                    float cws = 0.0f;
+                    for (int f = 0; f < 6; f++) cws += bundle_weight(cwv + 6 * f);  // no child on that face: zeros, and x + 0 = x
+                    const float rest = rbw - cws;
+                    eweight = rest > 0.0f ? rest : 0.0f;
+                    eseq = 4u * end - depth - 1u;
+                } else {
+                    eseq = seq + 2u;
+                }
+            }
+        }
+        end_of_ray(eseq, alpha, eweight, w);
+        *alpha_out = alpha;
+        return alive && end > k + 1u;
     }
 };
 
+// Gathers set bits of bits[*word_io, n_words) into order[] in ascending order -- all of them if they fit kOrderCap, else
+// the longest prefix of words that does -- and advances *word_io. All 64 lanes take part (no divergence around the call).
+// Returns the number gathered; 0 = nothing left; 0xffffffff = this span was empty but words remain.
+__device__ uint32_t gather_set_bits(const uint32_t *bits, uint32_t n_words, uint32_t *word_io, uint32_t *order, uint32_t lane) {
+    const uint32_t w0 = *word_io;
+    if (w0 >= n_words) return 0u;
+    uint32_t span = n_words - w0, a, e, count, incl, total;
+    for (;;) {
+        const uint32_t per = (span + 63u) / 64u;
+        a = min(w0 + lane * per, w0 + span);
+        e = min(a + per, w0 + span);
+        count = 0u;
+        for (uint32_t w = a; w < e; w++) count += __popc(bits[w]);
+        incl = count;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if ((int)lane >= d) incl += up;
+        }
+        total = __shfl(incl, 63, 64);
+        if (total <= kOrderCap || span <= kOrderCap / 32u) break;
+        span = max(kOrderCap / 32u, span / 2u);
+    }
+    uint32_t at = incl - count;
+    for (uint32_t w = a; w < e; w++) {
+        uint32_t v = bits[w];
+        while (v) { const uint32_t bpos = __ffs(v) - 1u; v &= v - 1u; order[at++] = w * 32u + bpos; }
+    }
+    __syncthreads();
+    *word_io = w0 + span;
+    return total == 0u ? 0xffffffffu : total;
+}
+
 __global__ void __launch_bounds__(64) compute_light_wave_kernel(const LightJob J) {
-    __shared__ uint32_t s_terms[64], s_cands[64], s_cost[64];
+    extern __shared__ uint32_t s_dyn[];  // term bitmap, candidate bitmap
     __shared__ uint32_t s_flags[kLdsFlags];
     __shared__ float s_lut[256];
+    __shared__ uint2 s_front[2][kFrontierCap];
+    __shared__ uint32_t s_count[2], s_cost[64];
+    __shared__ float4 s_stage[64];
+    __shared__ uint32_t s_order[kOrderCap];
     const uint32_t lane = threadIdx.x, wave = blockIdx.x;
+    const uint32_t term_words = (4u * J.n_tree + 31u) / 32u, cand_words = (2u * J.n_tree + 31u) / 32u;
+    uint32_t *const term_bits = s_dyn, *const cand_bits = s_dyn + term_words;
     for (uint32_t i = lane; i < min(J.n_blocks, kLdsFlags); i += 64u) s_flags[i] = J.derived[i].flags;
     for (uint32_t i = lane; i < 256u; i += 64u) s_lut[i] = J.lut[i];
     __syncthreads();
     WaveCtx b(J);
     b.lds_flags = s_flags;
     b.lds_lut = s_lut;
+    b.term_bits = term_bits;
+    b.cand_bits = cand_bits;
+    b.slots = J.terms + (size_t)wave * 4u * J.n_tree;
+    b.cslots = J.cands + (size_t)wave * 2u * J.n_tree;
     for (int f = 0; f < 6; f++) b.value_of(J.block_sky[f], b.sky_value[f]);
-    b.terms = J.terms + ((size_t)wave * 64u + lane) * J.term_cap;
-    b.cands = J.cands + ((size_t)wave * 64u + lane) * J.cand_cap;
-    uint32_t *const stack = J.wstack + (size_t)wave * J.max_depth * 4u * 64u + lane;  // frame f, word w: stack[(f * 4 + w) * 64]
 
     for (uint32_t item = wave; item < J.n; item += gridDim.x) {
         const uint32_t ci = J.cubes[item];
@@ -618,12 +657,14 @@ __global__ void __launch_bounds__(64) compute_light_wave_kernel(const LightJob J
         const DevDerived *ev_origin = &J.derived[J.grid[ci] & J.index_mask];
         const bool origin_is_opaque = (ev_origin->flags & 63u) == 63u;
         const bool origin_emits = !(ev_origin->emission[0] == 0.f && ev_origin->emission[1] == 0.f && ev_origin->emission[2] == 0.f);
-        b.n_terms = 0u; b.n_cands = 0u; b.cost = 0u;
+        b.cost = 0u;
 #ifdef AIC_LIGHT_TIMING
         const long long t_begin = clock64();
+        uint32_t n_rounds = 0u, n_visits = 0u;
 #endif
 
         if (!origin_is_opaque) {
+            for (uint32_t i = lane; i < term_words + cand_words; i += 64u) s_dyn[i] = 0u;
             // directions_to_seek_light (updater.rs:668-690)
             uint32_t m0 = 0u;
             if (ev_origin->flags & kDerivedVisible) m0 = 63u;
@@ -647,154 +688,119 @@ __global__ void __launch_bounds__(64) compute_light_wave_kernel(const LightJob J
                 }
             }
             b.m0 = m0;
-
-            const uint32_t a = min(lane * J.seg, J.n_tree), e = min(a + J.seg, J.n_tree);
-            if (a < e) {
-                // The frames of the bundles whose children are being walked: {position, subtree end, alpha behind the cube,
-                // bundle weight}; the innermost one is kept in registers (top_*), the others in the wave's stack.
-                uint32_t depth = 0u, pos = a;
-                uint32_t top_k = 0u, top_end = 0u;
-                float top_alpha = 1.0f, top_rbw = 0.f;
-                auto spill_top = [&]() {
-                    uint32_t *fr = stack + ((depth - 1u) * 4u) * 64u;
-                    fr[0] = top_k; fr[64] = top_end; fr[128] = __float_as_uint(top_alpha); fr[192] = __float_as_uint(top_rbw);
-                };
-                auto reload_top = [&]() {
-                    const uint32_t *fr = stack + ((depth - 1u) * 4u) * 64u;
-                    top_k = fr[0]; top_end = fr[64]; top_alpha = __uint_as_float(fr[128]); top_rbw = __uint_as_float(fr[192]);
-                };
-                // replay the root path of position a: state only
-                if (a > 0u) {
-                    uint32_t n_anc = 0u;
-                    for (uint32_t t = J.tree[a].parent;; t = J.tree[t].parent) { n_anc++; if (t == 0u) break; }
-                    {
-                        uint32_t t = J.tree[a].parent;
-                        for (uint32_t i = n_anc; i-- > 0u;) { stack[(i * 4u) * 64u] = t; t = J.tree[t].parent; }
+            if (lane == 0u) { s_front[0][0] = make_uint2(0u, __float_as_uint(1.0f)); s_count[0] = 1u; s_count[1] = 0u; }
+            __syncthreads();
+            // level by level
+            for (uint32_t cur = 0u;; cur ^= 1u) {
+                const uint32_t n_front = s_count[cur];
+                if (n_front == 0u) break;
+#ifdef AIC_LIGHT_TIMING
+                n_rounds++;
+#endif
+                for (uint32_t i = lane; i < n_front; i += 64u) {
+                    const uint2 it = s_front[cur][i];
+                    float alpha;
+#ifdef AIC_LIGHT_TIMING
+                    n_visits++;
+#endif
+                    if (b.visit(it.x, __uint_as_float(it.y), &alpha)) {
+                        const uint32_t *cp = J.child_pos + (size_t)it.x * 6u;
+                        uint32_t ch[6];
+                        for (int f = 0; f < 6; f++) ch[f] = cp[f];
+                        uint32_t nch = 0u;
+                        for (int f = 0; f < 6; f++) nch += ch[f] != 0u;
+                        uint32_t at = atomicAdd(&s_count[cur ^ 1u], nch);
+                        for (int f = 0; f < 6; f++)
+                            if (ch[f] != 0u) s_front[cur ^ 1u][at++] = make_uint2(ch[f], __float_as_uint(alpha));
                     }
-                    float alpha = 1.0f;
-                    for (uint32_t i = 0u; i < n_anc; i++) {
-                        const uint32_t k = stack[(i * 4u) * 64u];
-                        const TreeRegs nd = load_pos(&J.tree[k]);
-                        const uint32_t ke = nd.end;
-                        float rbw;
-                        if (!b.enter(nd, &alpha, &rbw, false)) {  // the path dies here: this lane's slice starts behind that subtree
-                            pos = ke;
-                            break;
-                        }
-                        stack[(i * 4u + 1u) * 64u] = ke;
-                        stack[(i * 4u + 2u) * 64u] = __float_as_uint(alpha);
-                        stack[(i * 4u + 3u) * 64u] = __float_as_uint(rbw);
-                        depth = i + 1u;
-                    }
-                    if (depth) reload_top();
                 }
-#ifdef AIC_LIGHT_TIMING
-                atomicAdd(&J.dep_head[4], (uint32_t)((clock64() - t_begin) >> 6));
-                uint32_t n_iter = 0;
-#endif
-                // The position about to be visited is held in registers; while it is processed, the next position in
-                // pre-order (where the walk goes if this bundle has children and stays alive) is already being fetched.
-                TreeRegs cur = load_pos(&J.tree[pos < J.n_tree ? pos : 0u]);
-                for (;;) {
-                    bool done = false;
-                    while (depth > 0u && pos >= top_end) {
-                        if (top_end > e) { done = true; break; }  // closes in a later lane's slice
-                        b.close(top_k, top_alpha, top_rbw);
-                        depth--;
-                        if (depth) reload_top();
-                    }
-                    if (done || pos >= e) break;
-#ifdef AIC_LIGHT_TIMING
-                    n_iter++;
-#endif
-                    const uint32_t k = pos;
-                    const TreeRegs nxt = load_pos(&J.tree[k + 1u < J.n_tree ? k + 1u : k]);
-                    float alpha = depth ? top_alpha : 1.0f;
-                    float rbw;
-                    const uint32_t ke = cur.end;
-                    if (b.enter(cur, &alpha, &rbw, true)) {
-                        if (k + 1u < ke) {
-                            if (depth) spill_top();
-                            depth++;
-                            top_k = k; top_end = ke; top_alpha = alpha; top_rbw = rbw;
-                            pos = k + 1u;
-                            cur = nxt;
-                            continue;
-                        }
-                        b.close(k, alpha, rbw);
-                    }
-                    pos = ke;
-                    if (pos == k + 1u) cur = nxt;
-                    else if (pos < e) cur = load_pos(&J.tree[pos]);
-                }
-#ifdef AIC_LIGHT_TIMING
-                atomicAdd(&J.dep_head[5], n_iter);
-#endif
+                __syncthreads();
+                if (lane == 0u) s_count[cur] = 0u;
+                __syncthreads();
             }
         }
-        s_terms[lane] = b.n_terms;
-        s_cands[lane] = b.n_cands;
         s_cost[lane] = b.cost;
         __syncthreads();
 #ifdef AIC_LIGHT_TIMING
         const long long t_walk = clock64();
-        if (lane == 0u) atomicAdd(&J.dep_head[2], (uint32_t)((t_walk - t_begin) >> 6));
+        if (lane == 0u) { atomicAdd(&J.dep_head[2], (uint32_t)((t_walk - t_begin) >> 6)); atomicAdd(&J.dep_head[4], n_rounds); }
+        atomicAdd(&J.dep_head[5], n_visits);
 #endif
 
-        if (lane == 0u) {
-            float inc[3] = {0.f, 0.f, 0.f}, total = 0.f;
-            uint32_t cost = 0u;
-            if (origin_is_opaque) {
-                if (origin_emits) {  // add_weighted_light(emission, 1.0)
-                    for (int i = 0; i < 3; i++) inc[i] += ps_mul(ev_origin->emission[i], ps_new_clamped(1.0f));
-                    total += 1.0f;
-                }
-            } else {
-                for (uint32_t l = 0u; l < 64u; l++) {
-                    const float4 *t = J.terms + ((size_t)wave * 64u + l) * J.term_cap;
-                    const uint32_t n = s_terms[l];
-                    cost += s_cost[l];
+        // ordered reduction
+        float inc[3] = {0.f, 0.f, 0.f}, total = 0.f;
+        uint32_t n_deps = 0u, first_chunk = 0xffffffffu, cur_chunk = 0xffffffffu, fill = kLightDepChunk;
+        [[maybe_unused]] uint32_t n_terms = 0u;
+        if (origin_is_opaque) {
+            if (origin_emits) {  // add_weighted_light(emission, 1.0)
+                for (int i = 0; i < 3; i++) inc[i] += ps_mul(ev_origin->emission[i], ps_new_clamped(1.0f));
+                total += 1.0f;
+            }
+        } else {
+            uint32_t word = 0u;
+            for (;;) {
+                const uint32_t got = gather_set_bits(term_bits, term_words, &word, s_order, lane);
+                if (got == 0u) break;
+                if (got == 0xffffffffu) continue;
+                n_terms += got;
+                for (uint32_t c0 = 0u; c0 < got; c0 += 64u) {  // 64 terms at a time: fetched by all lanes, added by lane 0 in order
+                    const uint32_t m = min(64u, got - c0);
+                    if (lane < m) s_stage[lane] = b.slots[s_order[c0 + lane]];
+                    __syncthreads();
+                    if (lane == 0u) {
 #pragma unroll 8
-                    for (uint32_t i = 0u; i < n; i++) {
-                        const float4 v = t[i];
-                        inc[0] += v.x; inc[1] += v.y; inc[2] += v.z; total += v.w;
-                    }
-                }
-            }
-            // dependencies, in walk order
-            uint32_t n_deps = 0u, first_chunk = 0xffffffffu, cur_chunk = 0xffffffffu, fill = kLightDepChunk;
-            if (!origin_is_opaque) {
-                uint32_t last = 0xffffffffu;
-                for (uint32_t l = 0u; l < 64u; l++) {
-                    const uint32_t *cd = J.cands + ((size_t)wave * 64u + l) * J.cand_cap;
-                    const uint32_t n = s_cands[l];
-                    for (uint32_t i = 0u; i < n; i++) {
-                        const uint32_t c = cd[i], key = c & 0x3fffffffu;
-                        if ((c >> 30) && key == last) continue;  // `if dependencies.last() != Some(&light_cube)`
-                        last = key;
-                        const int cube[3] = {b.origin[0] + (int)(key & 1023u) - 256, b.origin[1] + (int)((key >> 10) & 1023u) - 256,
-                                             b.origin[2] + (int)((key >> 20) & 1023u) - 256};
-                        uint32_t idx;
-                        if (!b.index_of(cube, &idx)) continue;  // light_needs_update ignores cubes outside the space
-                        if (fill == kLightDepChunk) {
-                            const uint32_t next = atomicAdd(&J.dep_head[0], 1u);
-                            if (next >= J.dep_chunks) {
-                                J.dep_head[1] = 1u;
-                                cur_chunk = 0xffffffffu;
-                            } else {
-                                J.dep_pool[(size_t)next * kLightDepChunk] = 0xffffffffu;
-                                if (cur_chunk != 0xffffffffu) J.dep_pool[(size_t)cur_chunk * kLightDepChunk] = next;
-                                else if (n_deps == 0u) first_chunk = next;
-                                cur_chunk = next;
-                            }
-                            fill = 1u;
+                        for (uint32_t i = 0u; i < m; i++) {
+                            const float4 v = s_stage[i];
+                            inc[0] += v.x; inc[1] += v.y; inc[2] += v.z; total += v.w;
                         }
-                        if (cur_chunk != 0xffffffffu) J.dep_pool[(size_t)cur_chunk * kLightDepChunk + fill] = idx;
-                        fill++;
-                        n_deps++;
                     }
+                    __syncthreads();
                 }
             }
+            uint32_t last = 0xffffffffu;
+            word = 0u;
+            for (;;) {
+                const uint32_t got = gather_set_bits(cand_bits, cand_words, &word, s_order, lane);
+                if (got == 0u) break;
+                if (got == 0xffffffffu) continue;
+                for (uint32_t c0 = 0u; c0 < got; c0 += 64u) {
+                    const uint32_t m = min(64u, got - c0);
+                    if (lane < m) s_stage[lane].x = __uint_as_float(b.cslots[s_order[c0 + lane]]);
+                    __syncthreads();
+                    if (lane == 0u) {
+                        for (uint32_t i = 0u; i < m; i++) {
+                            const uint32_t c = __float_as_uint(s_stage[i].x), key = c & 0x3fffffffu;
+                            if ((c >> 30) && key == last) continue;  // `if dependencies.last() != Some(&light_cube)`
+                            last = key;
+                            const int cube[3] = {b.origin[0] + (int)(key & 1023u) - 256, b.origin[1] + (int)((key >> 10) & 1023u) - 256,
+                                                 b.origin[2] + (int)((key >> 20) & 1023u) - 256};
+                            uint32_t idx;
+                            if (!b.index_of(cube, &idx)) continue;  // light_needs_update ignores cubes outside the space
+                            if (fill == kLightDepChunk) {
+                                const uint32_t next = atomicAdd(&J.dep_head[0], 1u);
+                                if (next >= J.dep_chunks) {
+                                    J.dep_head[1] = 1u;
+                                    cur_chunk = 0xffffffffu;
+                                } else {
+                                    J.dep_pool[(size_t)next * kLightDepChunk] = 0xffffffffu;
+                                    if (cur_chunk != 0xffffffffu) J.dep_pool[(size_t)cur_chunk * kLightDepChunk] = next;
+                                    else if (n_deps == 0u) first_chunk = next;
+                                    cur_chunk = next;
+                                }
+                                fill = 1u;
+                            }
+                            if (cur_chunk != 0xffffffffu) J.dep_pool[(size_t)cur_chunk * kLightDepChunk + fill] = idx;
+                            fill++;
+                            n_deps++;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        if (lane == 0u) {
+            uint32_t cost = 0u;
+            for (uint32_t l = 0u; l < 64u; l++) cost += s_cost[l];
             // LightBuffer::finish (updater.rs:940-952)
             uint32_t texel;
             const float scale = ps_new_clamped(1.0f / fmaxf(total, 1.0f));
@@ -813,13 +819,11 @@ __global__ void __launch_bounds__(64) compute_light_wave_kernel(const LightJob J
             o[3] = cost;
 #ifdef AIC_LIGHT_TIMING
             atomicAdd(&J.dep_head[3], (uint32_t)((clock64() - t_walk) >> 6));
-            uint32_t nt = 0;
-            for (uint32_t l = 0; l < 64u; l++) nt += s_terms[l];
-            atomicAdd(&J.dep_head[6], nt);
+            atomicAdd(&J.dep_head[6], n_terms);
             atomicAdd(&J.dep_head[7], n_deps);
 #endif
         }
-        __syncthreads();  // the lists are reused by the wave's next cube
+        __syncthreads();  // LDS and the slots are reused by the wave's next cube
     }
 }
 
@@ -842,7 +846,13 @@ void launch_compute_light(const LightJob &job, hipStream_t stream) {
 
 void launch_compute_light_waves(const LightJob &job, uint32_t n_waves, hipStream_t stream) {
     if (!job.n || !n_waves) return;
-    hipLaunchKernelGGL(compute_light_wave_kernel, dim3(n_waves), dim3(64), 0, stream, job);
+    const uint32_t lds = (((4u * job.n_tree + 31u) / 32u) + ((2u * job.n_tree + 31u) / 32u)) * 4u;
+    static uint32_t lds_allowed = 0u;
+    if (lds > lds_allowed) {  // more dynamic LDS than the default limit: opt in once
+        (void)hipFuncSetAttribute((const void *)compute_light_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_allowed = lds;
+    }
+    hipLaunchKernelGGL(compute_light_wave_kernel, dim3(n_waves), dim3(64), lds, stream, job);
 }
 
 void launch_scatter_light(uint32_t *light, const uint32_t *index, const uint32_t *texel, uint32_t n, hipStream_t stream) {
