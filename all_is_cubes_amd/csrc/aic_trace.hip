@@ -652,7 +652,7 @@ AIC_DEV void get_interpolated_light(const DevLayer &L, const float *__restrict__
 // RtScene::trace_patch / trace_ray_through_layers and the draw_rgba encoder
 // (renderer.rs:282-308, 424-478, 516-556). Execution model (CDNA4-first):
 //
-//  * A wave64 runs its pixels through its 64 lanes as a persistent ray pool: a lane that finishes
+//  * A wave64 runs its pixels through its 64 lanes persistently: a lane that finishes
 //    a ray is refilled with the next pixel of the wave's current 8x8 tile, and a new tile is pulled
 //    from the frame's queue when that one is used up (wave-level __ballot + prefix popcount), so
 //    lanes stay busy instead of idling behind the longest ray of a fixed packet.

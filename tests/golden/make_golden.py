@@ -48,6 +48,13 @@ PNG_CASES = [
     "tone_map-Clamp-1.0-0.5-all", "tone_map-Clamp-1.0-2.0-all", "tone_map-Reinhard-0.5-0.5-all",
     "tone_map-Reinhard-1.0-0.5-all", "tone_map-Reinhard-1.0-2.0-all",
     "template-light-bench-all",
+    # round 2, second batch
+    "debug_pixel_cost-ray",
+    "furnace-Clear-Opaque-all", "furnace-Clear-Transparent-all", "furnace-Foggy-Opaque-all", "furnace-Foggy-Transparent-all",
+    "bloom-0.0-all",
+    "no_update-all", "no_update-2-all",
+    "follow_options_change-all", "follow_options_change-2-all",
+    "template-cornell-box-all",
 ]
 
 

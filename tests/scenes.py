@@ -304,3 +304,101 @@ def tone_mapping_space() -> flat.FlatSpace:
             _fill(sp, (x, y, 0), (xs - 1, ys - 1, 1), air)
             sp.set((x + 1, y, 0), source)
     return _unlit(sp)
+
+
+# -- second batch of lighting / template cases ---------------------------------------------------------------------------
+
+NEWLY_VISIBLE = 250  # space/light/queue.rs Priority::NEWLY_VISIBLE
+
+
+def builder_light_after_sets(sp: flat.FlatSpace, sets, opaque_for_light):
+    """The light state of a space that was built empty (all AIR: every texel NO_RAYS, empty queue -- LightPhysics::
+    initialize_light, updater.rs:643-651) and then had `sets` = [(cube, block index)] applied with Mutation::set: what
+    modified_cube_needs_update (updater.rs:135-173) does per set. `opaque_for_light(block index)` = all faces opaque and no
+    emission. Writes sp.block_index / sp.light and returns the queue as [(cube, priority)] in insertion order."""
+    sp.light[...] = (0, 0, 0, 1)  # PackedLight::NO_RAYS
+    queue = []
+    lo, size = sp.lo, sp.size
+
+    def inb(c):
+        return all(lo[a] <= c[a] < lo[a] + size[a] for a in range(3))
+
+    def all_opaque(c):  # uc.get_evaluated(neighbor).opaque()[face]: only uniform blocks in these scenes
+        return inb(c) and opaque_face[int(sp.block_index[tuple(c[a] - lo[a] for a in range(3))])]
+
+    opaque_face = {i: bool(b.is_one and b.palette[0][3] >= 1.0) for i, b in enumerate(sp.blocks)}
+    for cube, index in sets:
+        sp.set(cube, index)
+        rel = tuple(cube[a] - lo[a] for a in range(3))
+        if opaque_for_light(index):
+            sp.light[rel] = (0, 0, 0, 128)  # PackedLight::OPAQUE
+            queue = [(c, p) for c, p in queue if c != tuple(cube)]
+        else:
+            queue.append((tuple(cube), NEWLY_VISIBLE))
+        for f in range(6):
+            nb = list(cube)
+            nb[f % 3] += 1 if f >= 3 else -1
+            if inb(nb) and not all_opaque(nb):
+                queue.append((tuple(nb), NEWLY_VISIBLE))
+    return queue
+
+
+# furnace 620-664: a "white furnace": three white blocks (opaque or alpha 0.5) in a 3x3x3 space under a uniform 0.75 sky;
+# m.evaluate_light(0) after the sets
+def furnace_space(transparent: bool):
+    sp = flat.FlatSpace((-1, -1, -1), (3, 3, 3))
+    sp.set_sky_uniform((0.75, 0.75, 0.75))
+    sp.add_block(flat.air())
+    white = sp.add_block(flat.atom((1.0, 1.0, 1.0, 0.5 if transparent else 1.0)))
+    queue = builder_light_after_sets(sp, [((-1, -1, 1), white), ((1, -1, 0), white), ((-1, 1, -1), white)],
+                                     lambda i: i == white and not transparent)
+    return sp, queue
+
+
+# bloom_test_universe 1332-1351: one black cube emitting (0.5, 100, 0), LightPhysics::None, black sky; eye (1.5, 3, 8)
+def bloom_test_space() -> flat.FlatSpace:
+    sp = flat.FlatSpace((0, 0, 0), (1, 1, 1))
+    sp.set_sky_uniform((0.0, 0.0, 0.0))
+    sp.block_index[...] = sp.add_block(flat.atom((0.0, 0.0, 0.0, 1.0), (0.5, 100.0, 0.0)))
+    return sp
+
+
+# follow_options_change 560-603: green opaque cube and a blue alpha-0.5 cube, set into an empty space, light never evaluated
+def follow_options_space() -> flat.FlatSpace:
+    sp = flat.FlatSpace((-1, 0, 0), (3, 1, 1))
+    sp.set_sky_uniform((0.5, 0.5, 0.5))
+    sp.add_block(flat.air())
+    green = sp.add_block(flat.atom((0.0, 1.0, 0.0, 1.0)))
+    blue = sp.add_block(flat.atom((0.0, 0.0, 1.0, 0.5)))
+    builder_light_after_sets(sp, [((0, 0, 0), green), ((1, 0, 0), blue)], lambda i: i == green)
+    return sp
+
+
+# all-is-cubes-content/src/template.rs:395-460 cornell_box at the default size 30: box_size 28
+def cornell_box_space() -> flat.FlatSpace:
+    box = 28
+    sp = flat.FlatSpace((-1, -1, -1), (box + 2, box + 2, box + 2))
+    sp.set_sky_uniform((0.0, 0.0, 0.0))
+    sp.add_block(flat.air())
+    white = sp.add_block(flat.atom((1.0, 1.0, 1.0, 1.0)))
+    red = sp.add_block(flat.atom((0.57, 0.025, 0.025, 1.0)))
+    green = sp.add_block(flat.atom((0.025, 0.236, 0.025, 1.0)))
+    e = float(np.float32(1.07) * np.sqrt(np.float32(box)))
+    light = sp.add_block(flat.atom((1.0, 1.0, 1.0, 1.0), (e, e, e), name="Light"))
+
+    def scaled(lo, hi):  # GridAab::multiply(box).divide(55): lower bounds floor, upper bounds ceil (grid_aab.rs)
+        lo2 = [(v * box) // 55 for v in lo]
+        hi2 = [(v * box + 54) // 55 for v in hi]
+        return lo2, [h - l for l, h in zip(lo2, hi2)]
+
+    _fill(sp, (0, -1, 0), (box, 1, box), white)      # floor
+    _fill(sp, (0, box, 0), (box, 1, box), white)     # ceiling
+    llo, lsz = scaled((21, 55, 23), (34, 55, 33))    # light in the ceiling: .abut(PY, 1)
+    _fill(sp, (llo[0], llo[1] + lsz[1], llo[2]), (lsz[0], 1, lsz[2]), light)
+    _fill(sp, (0, 0, -1), (box, box, 1), white)      # back wall
+    _fill(sp, (box, 0, 0), (1, box, box), green)     # right wall
+    _fill(sp, (-1, 0, 0), (1, box, box), red)        # left wall
+    for lo, size in (((29, 0, 36), (16, 16, 15)), ((10, 0, 13), (18, 33, 15))):
+        blo, bsz = scaled(lo, tuple(l + s for l, s in zip(lo, size)))
+        _fill(sp, tuple(blo), tuple(bsz), white)
+    return sp

@@ -76,7 +76,7 @@ def test_random_scene_camera_options(seed):
         ctx.upload_space(abi.LAYER_WORLD, sp)
         ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
         got = ctx.render(ctx.make_frame(w, h, world_inv=inv, backdrop=backdrop), want_aux=True)
-        # the production kernel variant (no per-pixel records; two rays per lane where the frame allows it)
+        # the production kernel variant (no per-pixel records; built for 4 waves per SIMD)
         fast = ctx.render(ctx.make_frame(w, h, world_inv=inv, backdrop=backdrop))
     assert (fast["rgba8"] == got["rgba8"]).all() and fast["info"].cubes_traced == got["info"].cubes_traced
     ref = oracle.render(oracle.Space(sp), opt, oracle.make_camera(inv, w, h), backdrop=backdrop, want_aux=True)

@@ -654,7 +654,7 @@ def test_full_size_workload_rows_and_properties(ctx, workload):
     # idempotence / schedule independence: the picture and every per-pixel record do not depend on tile order
     assert (first["rgba8"] == again["rgba8"]).all()
     assert first["info"].cubes_traced == again["info"].cubes_traced
-    fast = ctx.render(fr)  # the production kernel variant (no per-pixel records, ray pool)
+    fast = ctx.render(fr)  # the production kernel variant (no per-pixel records, 4 waves per SIMD)
     assert (fast["rgba8"] == again["rgba8"]).all() and fast["info"].cubes_traced == again["info"].cubes_traced
     for k in ("cubes_traced", "hit", "cube", "voxel", "face", "block_index"):
         assert (first["aux"][k] == again["aux"][k]).all()
