@@ -1463,7 +1463,12 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         mask_t m_hl = VOL ? __builtin_amdgcn_ballot_w64((st & ST_HAS_LAST) != 0u) : 0ull;
 #define AIC_LANE(m) __builtin_amdgcn_inverse_ballot_w64(m)
 #pragma unroll 1
+#ifdef AIC_TRIP_MIN
+        // leave the trip once no more than AIC_TRIP_MIN lanes are still stepping (the first step is always taken)
+        for (int rep = 0; rep < AIC_STEP_REPS && (rep == 0 ? m_act != 0ull : __popcll(m_act) > AIC_TRIP_MIN); rep++) {
+#else
         for (int rep = 0; rep < AIC_STEP_REPS && m_act != 0ull; rep++) {
+#endif
             AIC_PROF(10, 1);
             AIC_PROF(11, __popcll(m_act));
             const mask_t m_act0 = m_act;

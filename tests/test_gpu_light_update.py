@@ -186,3 +186,16 @@ def test_evaluate_light_rejects_bad_arguments(ctx):
     ctx.clear_space(abi.LAYER_UI)
     with pytest.raises(abi.AicError):
         ctx.evaluate_light(abi.LAYER_UI, 30)
+
+
+@pytest.mark.parametrize("maximum_distance", [3, 127, 255])
+def test_other_maximum_distances(ctx, maximum_distance):
+    """The effective tree, its LDS bitmaps (86 KB at the full chart) and the slot arrays are sized per maximum_distance."""
+    sp = scenes.light_on_slab_space()
+    ref = copy.deepcopy(sp)
+    n_ref = oracle.evaluate_light(ref, maximum_distance=maximum_distance, fast=True, epsilon=1, batch=32, max_updates=600, hb_width=16)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    info = ctx.evaluate_light(abi.LAYER_WORLD, maximum_distance, fast=True, epsilon=1, batch=32, queue_order=16, max_updates=600)
+    got = ctx.read_light_volume(abi.LAYER_WORLD, sp.size)
+    assert info.updates == n_ref
+    assert (got == np.asarray(ref.light).reshape(got.shape)).all()
