@@ -1461,6 +1461,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         mask_t m_inb = __builtin_amdgcn_ballot_w64((st & ST_IN_BLOCK) != 0u);
         mask_t m_opq = __builtin_amdgcn_ballot_w64((st & ST_OPAQUE) != 0u);
         mask_t m_hl = VOL ? __builtin_amdgcn_ballot_w64((st & ST_HAS_LAST) != 0u) : 0ull;
+        // what the trip decides for each lane is collected in masks and written to the event words once, after the loop
+        mask_t t_shade = 0ull, t_enter = 0ull, t_fin = 0ull, t_deadpark = 0ull;
 #define AIC_LANE(m) __builtin_amdgcn_inverse_ballot_w64(m)
 #pragma unroll 1
 #ifdef AIC_TRIP_MIN
@@ -1471,7 +1473,6 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
 #endif
             AIC_PROF(10, 1);
             AIC_PROF(11, __popcll(m_act));
-            const mask_t m_act0 = m_act;
             const mask_t m_step = m_act & ~(m_fresh | m_dead);  // the level takes its next step
             // -- State::step (raycast.rs:577-626) along the axis of the smallest t_max (strict <, ties to the
             //    later axis: raycast.rs:584-596): X iff tx<ty && tx<tz, Y iff !(tx<ty) && ty<tz, else Z.
@@ -1512,13 +1513,11 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             }
             // -- left the bounds? (raycast.rs:265-274) only the axis just stepped can have run out of steps --
             const mask_t m_exit = __builtin_amdgcn_ballot_w64(min(rx, min(ry, rz)) == 0u) & m_step;
-            // -- can the level step again? valid_for_stepping (raycast.rs:563-570): the smallest t_max is finite.
-            //    t_max values are non-negative and NaN-free, so their order is the order of their bit patterns
-            //    and the smallest one is finite iff the smallest high word is below the infinity pattern --
-            const uint32_t hmin = min((uint32_t)__double2hiint(tx), min((uint32_t)__double2hiint(ty), (uint32_t)__double2hiint(tz)));
-            const mask_t m_valid = __builtin_amdgcn_ballot_w64(hmin < 0x7ff00000u);
-            // a cube is produced by a fresh level, or by a step that stays in bounds and can go on stepping
-            const mask_t m_lookup = m_fresh | (m_step & ~m_exit & m_valid);
+            // -- can the level step again? valid_for_stepping (raycast.rs:563-570): "the smallest t_max is finite" held when
+            //    the level was set up (lvl_first marks a level that cannot step as dead), and a step only adds the finite
+            //    t_delta of an axis whose t_max was finite, so it holds for every level this loop sees: no per-step check --
+            // a cube is produced by a fresh level, or by a step that stays in bounds
+            const mask_t m_lookup = m_fresh | (m_step & ~m_exit);
             // the level is over: it left its bounds, cannot step again, or had ended before
             const mask_t m_over = (m_step & ~m_lookup) | m_dead;
             // -- the lookup: one u16 from the pool, for whichever level this is (scalar base + 32-bit byte offset) --
@@ -1630,16 +1629,22 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             const mask_t m_shade = m_go & m_surf;
             const mask_t m_enter = m_go & m_blk & ~m_stop2;
             const mask_t m_fin = m_stop | m_stop2 | m_rayover;
-            // new event words: acting lanes drop FRESH / DEAD, then take what this trip decided
-            ev = AIC_LANE(m_act0) ? 0u : ev;
-            ev = AIC_LANE(m_shade) ? EV_SHADE : ev;
-            ev = AIC_LANE(m_enter) ? EV_ENTER : ev;
-            ev = AIC_LANE(m_fin) ? EV_FINISH : ev;
-            if ((m_defer | m_newdead) != 0ull) ev = AIC_LANE((m_defer & ~m_fin) | m_newdead) ? (ev | EV_DEAD) : ev;
+            // a lane that parks leaves the trip with its event; one whose level ended while it still owes an event keeps DEAD
+            t_shade |= m_shade;
+            t_enter |= m_enter;
+            t_fin |= m_fin;
+            t_deadpark |= (m_defer & ~m_fin) | (m_newdead & m_fin);
             m_act &= ~(m_shade | m_enter | m_fin);
             m_dead = m_newdead & m_act;
             m_fresh = 0ull;
         }
+        // new event words: the lanes that took part drop FRESH / DEAD, then take what the trip decided; a lane still
+        // stepping whose level ended on the last step carries DEAD into the next trip
+        ev = AIC_LANE(m_st) ? 0u : ev;
+        ev = AIC_LANE(t_shade) ? EV_SHADE : ev;
+        ev = AIC_LANE(t_enter) ? EV_ENTER : ev;
+        ev = AIC_LANE(t_fin) ? EV_FINISH : ev;
+        if ((t_deadpark | m_dead) != 0ull) ev = AIC_LANE(t_deadpark | m_dead) ? (ev | EV_DEAD) : ev;
 #undef AIC_LANE
         }
         AIC_TICK(12);
