@@ -415,13 +415,13 @@ def main() -> int:
             vi = cn.get("SQ_INSTS_VALU", {}).get("mean_per_launch")
             if vi and elapsed > 0:
                 # What actually bounds the kernel: instruction issue. tools/ubench/issue_rate (profiles/r02_issue_rate.txt)
-                # measures, per SIMD, one wave-instruction per 4.3-4.7 cycles for the kernel's VALU mix (f64 compare/add,
-                # selects, integer ops) and 3.3-3.5 for a VALU + SALU stream at 4-8 waves per SIMD: VALU and SALU of the
-                # same SIMD do not overlap enough to matter, so the count is of ALL instructions. peak = the best sustained
-                # rate of any mixed stream measured there: 1024 SIMDs x 2.4 GHz / 3.28 cycles.
+                # measures, per SIMD, one wave-instruction per 2.55 cycles for the cheapest stream there is (32-bit moves, 8
+                # waves per SIMD), 4.3-4.7 for this kernel's VALU mix (f64 compare/add, selects, integer ops) and 3.3-3.5
+                # for a VALU + SALU stream. `peak` is the first -- a ceiling no kernel can exceed; the kernel's own mix
+                # cannot get closer to it than ~0.75-0.8. The count is of ALL instructions (VALU + SALU + memory).
                 kinds = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM")
                 total = sum(float(cn.get(k, {}).get("mean_per_launch") or 0.0) for k in kinds)
-                peak = 1024 * 2.4e9 / 3.28
+                peak = 1024 * 2.4e9 / 2.55
                 rate = total / (mean_kernel_ms * 1e-3) if mean_kernel_ms > 0 else 0.0
                 tc, ai = cn.get("SQ_THREAD_CYCLES_VALU", {}).get("mean_per_launch"), cn.get("SQ_ACTIVE_INST_VALU", {}).get("mean_per_launch")
                 valu = {"wave_insts_per_launch": int(total), "valu_wave_insts_per_launch": int(vi), "issue_rate": round(rate / 1e9, 2), "peak": round(peak / 1e9, 1),
@@ -429,8 +429,9 @@ def main() -> int:
                         "cycles_per_inst_per_simd": round(1024 * 2.4e9 / rate, 3) if rate else None,
                         "valu_lane_utilisation": round(tc / (ai * 64.0), 4) if tc and ai else None,
                         "source": "profiles/" + os.path.basename(cands[-1]),
-                        "note": "instruction counts per launch from the PMC file (one frame at a time) over this run's kernel time; peak = best "
-                                "sustained VALU+SALU issue rate measured on this chip (profiles/r02_issue_rate.txt): the binding resource (DESIGN.md 6)"}
+                        "note": "instruction counts per launch from the PMC file (one frame at a time) over this run's kernel time; peak = the fastest "
+                                "instruction stream measured on this chip (32-bit moves, 2.55 cycles per instruction per SIMD, profiles/r02_issue_rate.txt); "
+                                "streams of this kernel's mix reach 3.3-4.5 there: the binding resource (DESIGN.md 6)"}
 
     result = None
     if rank == 0:
