@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "aic_ortho_image_size", "aic_render_orthographic",
     "aic_evaluate_light", "aic_read_light_volume", "aic_light_chart", "aic_probe_derived", "aic_probe_log2f",
     "aic_create_multi", "aic_destroy_multi", "aic_multi_device_count", "aic_multi_context", "aic_multi_last_error", "aic_multi_upload_space",
-    "aic_multi_clear_space", "aic_multi_update_cubes", "aic_multi_update_light_volume", "aic_multi_replace_blocks", "aic_multi_set_options",
+    "aic_multi_clear_space", "aic_multi_update_cubes", "aic_multi_update_light_volume", "aic_multi_evaluate_light", "aic_multi_replace_blocks", "aic_multi_set_options",
     "aic_multi_render",
 ]
 
@@ -515,6 +515,7 @@ class MultiContext:
         lib.aic_multi_clear_space.argtypes = [C.c_void_p, C.c_int]
         lib.aic_multi_set_options.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         lib.aic_multi_update_light_volume.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.aic_multi_evaluate_light.argtypes = [C.c_void_p, C.c_int, C.POINTER(LightParams), C.POINTER(LightInfo)]
         lib.aic_multi_update_cubes.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.aic_multi_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         ids = np.ascontiguousarray(device_ids, np.int32)
@@ -555,6 +556,12 @@ class MultiContext:
     def update_light_volume(self, layer: int, light) -> None:
         lt = np.ascontiguousarray(light, np.uint8)
         self._check(self._lib.aic_multi_update_light_volume(self._h, layer, _ptr(lt)))
+
+    def evaluate_light(self, layer: int, maximum_distance: int, fast: bool = True, epsilon: int = 1, batch: int = 32, queue_order: int = 16) -> LightInfo:
+        p = LightParams(maximum_distance, int(fast), epsilon, batch, queue_order, -1, 0, 0, None, None, 0)
+        info = LightInfo()
+        self._check(self._lib.aic_multi_evaluate_light(self._h, layer, C.byref(p), C.byref(info)))
+        return info
 
     def update_cubes(self, layer: int, xyz, block_index=None, light=None) -> None:
         xyz = np.ascontiguousarray(xyz, np.int32).reshape(-1, 3)

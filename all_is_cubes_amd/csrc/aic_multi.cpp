@@ -30,6 +30,7 @@ struct aic_multi {
     size_t gathered_bytes = 0;
     void *frame = nullptr;           // on device 0: the assembled frame when the caller wants a host copy
     size_t frame_bytes = 0;
+    size_t n_cubes[2] = {0, 0};      // per layer: cubes of the uploaded space (sizes the light volume hand-over)
     std::string err;
 };
 
@@ -115,7 +116,10 @@ const char *aic_multi_last_error(const aic_multi *m) { return m ? m->err.c_str()
     }                                                                      \
     return AIC_OK;
 
-int aic_multi_upload_space(aic_multi *m, int layer, const aic_space_desc *s) { AIC_MULTI_FORWARD(aic_upload_space(m->ctx[i], layer, s)) }
+int aic_multi_upload_space(aic_multi *m, int layer, const aic_space_desc *s) {
+    if (m && s && (layer == 0 || layer == 1)) m->n_cubes[layer] = (size_t)s->size[0] * (size_t)s->size[1] * (size_t)s->size[2];
+    AIC_MULTI_FORWARD(aic_upload_space(m->ctx[i], layer, s))
+}
 int aic_multi_clear_space(aic_multi *m, int layer) { AIC_MULTI_FORWARD(aic_clear_space(m->ctx[i], layer)) }
 int aic_multi_update_cubes(aic_multi *m, int layer, uint32_t n, const int32_t *xyz, const uint16_t *bi, const uint8_t *light) {
     AIC_MULTI_FORWARD(aic_update_cubes(m->ctx[i], layer, n, xyz, bi, light))
@@ -126,6 +130,19 @@ int aic_multi_replace_blocks(aic_multi *m, int layer, uint32_t n, const uint32_t
     AIC_MULTI_FORWARD(aic_replace_blocks(m->ctx[i], layer, n, indices, descs, voxels, palettes))
 }
 int aic_multi_set_options(aic_multi *m, int layer, const aic_options *o) { AIC_MULTI_FORWARD(aic_set_options(m->ctx[i], layer, o)) }
+
+// The light updater is a sequential relaxation (it does not shard): it runs on the first device, and the resulting volume
+// is handed to the others, so that every device traces the same light.
+int aic_multi_evaluate_light(aic_multi *m, int layer, const aic_light_params *p, aic_light_info *info) {
+    if (!m || m->ctx.empty() || (layer != 0 && layer != 1)) return mfail(m, AIC_ERR_INVALID, "aic_multi_evaluate_light: bad argument");
+    int rc = forward(m, 0, aic_evaluate_light(m->ctx[0], layer, p, info));
+    if (rc != AIC_OK || m->ctx.size() == 1) return rc;
+    std::vector<uint8_t> light(m->n_cubes[layer] * 4);
+    if (light.empty()) return AIC_OK;
+    rc = forward(m, 0, aic_read_light_volume(m->ctx[0], layer, light.data()));
+    for (size_t i = 1; rc == AIC_OK && i < m->ctx.size(); i++) rc = forward(m, i, aic_update_light_volume(m->ctx[i], layer, light.data()));
+    return rc;
+}
 
 int aic_multi_render(aic_multi *m, const aic_frame_desc *f, void *out_rgba8, int out_is_device, aic_frame_info *info) {
     if (!m || !f || !out_rgba8) return mfail(m, AIC_ERR_INVALID, "aic_multi_render: bad argument");

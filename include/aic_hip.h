@@ -345,6 +345,8 @@ uint32_t aic_light_chart(float *weights, uint32_t *children, uint32_t *depth);
  * as PackedLight::scalar_in uses it (data.rs:214-218). */
 int aic_probe_derived(aic_ctx *ctx, int layer, float *out, uint8_t *out_opaque);
 int aic_probe_log2f(aic_ctx *ctx, const float *x, uint32_t n, float *out);
+/* aic_evaluate_light on the first device; the resulting light volume is handed to the others (the updater does not shard) */
+int aic_multi_evaluate_light(aic_multi *m, int layer, const aic_light_params *params, aic_light_info *info);
 
 #ifdef __cplusplus
 }

@@ -223,4 +223,5 @@ unsafe extern "C" {
     pub fn aic_light_chart(weights: *mut f32, children: *mut u32, depth: *mut u32) -> u32;
     pub fn aic_probe_derived(ctx: *mut aic_ctx, layer: c_int, out: *mut f32, out_opaque: *mut u8) -> c_int;
     pub fn aic_probe_log2f(ctx: *mut aic_ctx, x: *const f32, n: u32, out: *mut f32) -> c_int;
+    pub fn aic_multi_evaluate_light(m: *mut aic_multi, layer: c_int, params: *const aic_light_params, info: *mut aic_light_info) -> c_int;
 }

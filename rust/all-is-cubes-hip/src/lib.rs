@@ -300,6 +300,35 @@ impl HipRtRenderer {
     pub fn cameras(&self) -> &StandardCameras {
         &self.cameras
     }
+
+    /// Runs the light updater ON THE DEVICE against the world space as last uploaded: `Mutation::fast_evaluate_light`
+    /// (if `fast`) and `Mutation::evaluate_light(epsilon, ..)` (space.rs:1496-1540) with
+    /// `LightPhysics::Rays { maximum_distance }`. The device's light volume -- what the following frames trace -- is
+    /// updated in place; the host `Space`'s light is not touched. Batches of 32 in the table order of the reference's
+    /// queue on x86-64, i.e. the texels `Space::evaluate_light` itself would produce with feature "auto-threads".
+    /// Returns the number of cube updates.
+    ///
+    /// # Errors
+    /// As [`HeadlessRenderer::draw`] for device failures.
+    pub fn evaluate_light(&mut self, maximum_distance: u8, fast: bool, epsilon: u8) -> Result<u64, RenderError> {
+        let params = ffi::aic_light_params {
+            maximum_distance: i32::from(maximum_distance),
+            fast: i32::from(fast),
+            epsilon: i32::from(epsilon),
+            batch: 32,
+            queue_order: if cfg!(target_arch = "x86_64") { 16 } else { 8 }, // hashbrown's Group::WIDTH on the host the goldens came from
+            n_queue: -1,
+            lanes_per_cube: 0,
+            reserved: 0,
+            queue_cubes: core::ptr::null(),
+            queue_priorities: core::ptr::null(),
+            max_updates: 0,
+        };
+        let mut info = ffi::aic_light_info::default();
+        // SAFETY: ctx is a live context; params and info outlive the call
+        check(self.ctx.as_ptr(), unsafe { ffi::aic_evaluate_light(self.ctx.as_ptr(), ffi::AIC_LAYER_WORLD, &params, &mut info) })?;
+        Ok(info.updates)
+    }
 }
 
 impl Drop for HipRtRenderer {

@@ -199,3 +199,27 @@ def test_other_maximum_distances(ctx, maximum_distance):
     got = ctx.read_light_volume(abi.LAYER_WORLD, sp.size)
     assert info.updates == n_ref
     assert (got == np.asarray(ref.light).reshape(got.shape)).all()
+
+
+def test_multi_device_light_evaluation(ctx, golden_dir):
+    """aic_multi_evaluate_light: the updater runs on the first device and the volume is handed to the others, so that the
+    strips every device traces carry the same light: the assembled frame equals the single-context frame and the golden."""
+    sp = scenes.light_on_slab_space()
+    opt = oracle.unaltered_colors(lighting=3)
+    w, h = COMMON_VIEWPORT
+    eye, look = (0.5, -6.0, 6.0), (0.0, 1.0, -1.0)
+    q = oracle.look_at_y_up(eye, tuple(e + l for e, l in zip(eye, look)))
+    _, _, inv = oracle.camera_matrices(45.0, opt.view_distance, w / h, q, eye)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+    one_info = ctx.evaluate_light(abi.LAYER_WORLD, 30)
+    one = ctx.render(ctx.make_frame(w, h, world_inv=inv))["rgba8"]
+    with abi.MultiContext([0, 0, 0]) as m:
+        m.upload_space(abi.LAYER_WORLD, sp)
+        m.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+        info = m.evaluate_light(abi.LAYER_WORLD, 30)
+        many = m.render(abi.Context.make_frame(w, h, world_inv=inv))["rgba8"]
+    assert info.updates == one_info.updates
+    assert (one == many).all()
+    assert np.abs(many.astype(int) - np.load(golden_dir / "png_light_on_slab-Linear-all.npy").astype(int)).max() <= 1
