@@ -913,10 +913,20 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             if (c_ray > best) { best = c_ray; kind = EV_FINISH; }
             // thresholds scale with the lanes still alive, so that a wave that is running out of rays
             // (the frame's tail) keeps batching instead of running every event for a lane or two
+#ifdef AIC_SCHED_SIMPLE
+            const int t_batch = AIC_T_BATCH, n_few = AIC_N_FEW;
+#else
             const int alive = n_step + c_shade + c_enter + c_ray;
-            const int half = alive >> 1;
-            const int t_batch = half < AIC_T_BATCH ? (half > 0 ? half : 1) : AIC_T_BATCH;
-            const int n_few = half < AIC_N_FEW ? half : AIC_N_FEW;
+#ifndef AIC_FRAC_T
+#define AIC_FRAC_T 4  // eighths of the lanes alive
+#endif
+#ifndef AIC_FRAC_N
+#define AIC_FRAC_N 4
+#endif
+            const int part_t = (alive * AIC_FRAC_T) >> 3, part_n = (alive * AIC_FRAC_N) >> 3;
+            const int t_batch = part_t < AIC_T_BATCH ? (part_t > 0 ? part_t : 1) : AIC_T_BATCH;
+            const int n_few = part_n < AIC_N_FEW ? part_n : AIC_N_FEW;
+#endif
             if (best > 0 && (best >= t_batch || n_step <= n_few)) run = kind;
         }
         AIC_TICK(19);
