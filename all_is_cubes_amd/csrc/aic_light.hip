@@ -847,10 +847,14 @@ void launch_compute_light(const LightJob &job, hipStream_t stream) {
 void launch_compute_light_waves(const LightJob &job, uint32_t n_waves, hipStream_t stream) {
     if (!job.n || !n_waves) return;
     const uint32_t lds = (((4u * job.n_tree + 31u) / 32u) + ((2u * job.n_tree + 31u) / 32u)) * 4u;
-    static uint32_t lds_allowed = 0u;
-    if (lds > lds_allowed) {  // more dynamic LDS than the default limit: opt in once
+    // more dynamic LDS than the default limit needs an opt-in, per device
+    static uint32_t lds_allowed[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    uint32_t &allowed = lds_allowed[dev & 63];
+    if (lds > allowed) {
         (void)hipFuncSetAttribute((const void *)compute_light_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_allowed = lds;
+        allowed = lds;
     }
     hipLaunchKernelGGL(compute_light_wave_kernel, dim3(n_waves), dim3(64), lds, stream, job);
 }
