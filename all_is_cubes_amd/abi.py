@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "aic_render", "aic_render_submit", "aic_render_wait", "aic_trace_patches", "aic_partition_rows", "aic_assemble_strips", "aic_read_aux", "aic_synchronize", "aic_stream", "aic_wait_event",
     "aic_probe_raycast", "aic_probe_light_lut", "aic_probe_powf",
     "aic_ortho_image_size", "aic_render_orthographic",
-    "aic_evaluate_light", "aic_read_light_volume", "aic_light_chart", "aic_probe_derived", "aic_probe_log2f",
+    "aic_evaluate_light", "aic_light_cubes_changed", "aic_read_light_volume", "aic_light_chart", "aic_probe_derived", "aic_probe_log2f",
     "aic_create_multi", "aic_destroy_multi", "aic_multi_device_count", "aic_multi_context", "aic_multi_last_error", "aic_multi_upload_space",
     "aic_multi_clear_space", "aic_multi_update_cubes", "aic_multi_update_light_volume", "aic_multi_evaluate_light", "aic_multi_replace_blocks", "aic_multi_set_options",
     "aic_multi_render",
@@ -156,6 +156,7 @@ def load() -> C.CDLL:
         lib.aic_probe_powf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.aic_evaluate_light.argtypes = [C.c_void_p, C.c_int, C.POINTER(LightParams), C.POINTER(LightInfo)]
         lib.aic_read_light_volume.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.aic_light_cubes_changed.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_int]
         lib.aic_probe_derived.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         lib.aic_probe_log2f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         assert C.sizeof(BlockDesc) == 48
@@ -474,6 +475,12 @@ class Context:
         self._check(self._lib.aic_evaluate_light(self._h, layer, C.byref(p), C.byref(info)))
         del keep
         return info
+
+    def light_cubes_changed(self, layer: int, xyz, queue_order: int = 16) -> None:
+        """`modified_cube_needs_update` (updater.rs:135-173) for cubes just changed with `update_cubes`: queues them and their
+        neighbours on the layer's light update queue (drained by `evaluate_light(fast=False, queue=[])`)."""
+        xyz = np.ascontiguousarray(xyz, np.int32).reshape(-1, 3)
+        self._check(self._lib.aic_light_cubes_changed(self._h, layer, len(xyz), _ptr(xyz), queue_order))
 
     def read_light_volume(self, layer: int, shape) -> np.ndarray:
         out = np.zeros(tuple(shape) + (4,), np.uint8)

@@ -40,6 +40,9 @@ static_assert(sizeof(aic_block_desc) == 48, "aic_block_desc is 48 bytes");
 
 struct LightState;                       // aic_light_host.inc
 void light_state_free(LightState *s);
+// keeps the light updater's host mirrors in step with an aic_update_cubes call (no-op if they were not current)
+void light_state_cubes_updated(LightState *s, uint64_t version_before, uint64_t version_after, uint32_t n, const int32_t *xyz, const uint16_t *block_index,
+                               const uint8_t *light);
 
 namespace {
 
@@ -100,6 +103,7 @@ struct Layer {
     bool opt_set = false;
     bool cls_in_code = false;  // cube-grid entries carry the block class in bits 14-15 (aic_device.h)
     uint64_t version = 0;      // bumped by every scene mutation; the light updater's host mirrors follow it
+    uint64_t upload_serial = 0;  // bumped by aic_upload_space only: the light update queue lives as long as one upload
     LightState *lstate = nullptr;
     size_t n_cubes() const { return (size_t)size[0] * (size_t)size[1] * (size_t)size[2]; }
     void release() {
@@ -534,6 +538,7 @@ int aic_upload_space(aic_ctx *c, int layer, const aic_space_desc *s) {
     l.cls_in_code = cls_in_code;
     l.present = true;
     l.version++;
+    l.upload_serial++;
     if (c->dump) {
         struct { int32_t lo[3], size[3]; uint32_t n_blocks; int32_t sky_kind; uint64_t n_voxels, n_palette; float sky[8][3]; uint8_t block_sky[7][4]; } h;
         std::memset(&h, 0, sizeof(h));
@@ -574,6 +579,7 @@ int aic_update_cubes(aic_ctx *c, int layer, uint32_t n, const int32_t *xyz, cons
     if (block_index) HIP_TRY(c, hipMemcpyAsync(base + b_xyz, block_index, (size_t)n * 2, hipMemcpyHostToDevice, c->stream));
     if (light) HIP_TRY(c, hipMemcpyAsync(base + b_xyz + b_bi, light, b_lt, hipMemcpyHostToDevice, c->stream));
     l.version++;
+    light_state_cubes_updated(l.lstate, l.version - 1, l.version, n, xyz, block_index, light);
     launch_scatter_cubes(l.pool.p, l.light.p, (const int32_t *)base, block_index ? (const uint16_t *)(base + b_xyz) : nullptr,
                          light ? (const uint32_t *)(base + b_xyz + b_bi) : nullptr, n, l.lo, l.size, l.cls_in_code ? l.cls.p : nullptr, c->stream);
     HIP_TRY(c, hipGetLastError());

@@ -314,7 +314,7 @@ typedef struct aic_light_params {
                                  built with "auto-threads" (updater.rs:231-268), 1 = without; larger = throughput */
     int32_t queue_order;      /* order of equal-priority updates: 16 or 8 = the table order of the reference's queue
                                  (hashbrown Group::WIDTH of the build target: 16 on x86-64, 8 elsewhere); 0 = first in, first out */
-    int32_t n_queue;          /* when !fast: entries to start the queue with, inserted in order (what
+    int32_t n_queue;          /* when !fast: entries to ADD to the layer's queue, inserted in order (what
                                  modified_cube_needs_update, updater.rs:135-173, enqueues after a change); < 0: every cube
                                  whose texel is Uninitialized, at Priority::UNINIT */
     int32_t lanes_per_cube;   /* how compute_light is mapped to the device: 64 (or 0 = default) one wave per cube -- 64 lanes walk
@@ -335,6 +335,12 @@ typedef struct aic_light_info {
     uint32_t pad;
 } aic_light_info;
 int aic_evaluate_light(aic_ctx *ctx, int layer, const aic_light_params *params, aic_light_info *info);
+/* After aic_update_cubes changed the blocks of these cubes: what LightStorage::modified_cube_needs_update (updater.rs:135-173) does
+ * for each -- a cube that is now opaque for light gets PackedLight::OPAQUE at once, any other is queued at Priority::NEWLY_VISIBLE,
+ * and so are the neighbours that are not opaque towards it. The queue is the layer's own and lives until the next
+ * aic_upload_space: a following aic_evaluate_light with fast = 0 and n_queue = 0 drains it (in several calls if max_updates is
+ * set: a per-frame budget, as Space::step gives its light updater). */
+int aic_light_cubes_changed(aic_ctx *ctx, int layer, uint32_t n, const int32_t *xyz, int queue_order);
 /* the layer's current light volume, [n cubes][4] PackedLight texels, Z-major */
 int aic_read_light_volume(aic_ctx *ctx, int layer, uint8_t *out);
 /* The propagation chart (chart/generator.rs): returns the node count; fills weights[n][6] and children[n][6] when both

@@ -223,3 +223,72 @@ def test_multi_device_light_evaluation(ctx, golden_dir):
     assert info.updates == one_info.updates
     assert (one == many).all()
     assert np.abs(many.astype(int) - np.load(golden_dir / "png_light_on_slab-Linear-all.npy").astype(int)).max() <= 1
+
+
+def _modified_cubes_queue(sp, changes):
+    """modified_cube_needs_update (updater.rs:135-173) for [(cube, new block index)] applied to `sp` in order, in Python:
+    patches sp.block_index / sp.light and returns the queue entries [(cube, priority)] in insertion order."""
+    d = oracle.compute_derived(oracle.Space(sp))
+    opaque, emission = d["opaque"], d["emission"]
+    lo, size = sp.lo, sp.size
+
+    def inb(c):
+        return all(lo[a] <= c[a] < lo[a] + size[a] for a in range(3))
+
+    queue = []
+    for cube, index in changes:
+        sp.set(cube, index)
+        rel = tuple(cube[a] - lo[a] for a in range(3))
+        if opaque[index].all() and not emission[index].any():  # opaque_for_light_computation
+            sp.light[rel] = (0, 0, 0, 128)
+            queue = [(c, p) for c, p in queue if c != tuple(cube)]
+        else:
+            queue.append((tuple(cube), 250))
+        for f in range(6):
+            nb = list(cube)
+            nb[f % 3] += 1 if f >= 3 else -1
+            if not inb(nb):
+                continue
+            nb_block = int(sp.block_index[tuple(nb[a] - lo[a] for a in range(3))])
+            if not opaque[nb_block][(f + 3) % 6]:  # the neighbour's face towards the cube
+                queue.append((tuple(nb), 250))
+    return queue
+
+
+def test_cubes_changed_queue_and_budgeted_relight(ctx):
+    """The layer's own update queue: aic_update_cubes + aic_light_cubes_changed queue what Mutation::set would, and
+    aic_evaluate_light(fast=0, no new entries) drains it -- in one call, or in budgeted slices (a per-frame light budget)
+    with the same result, which is the oracle's for the same queue."""
+    base = copy.deepcopy(lit(scenes.light_spread_space))
+    lo, size = np.array(base.lo), np.array(base.size)
+    centre = lo + size // 2
+    air = next(i for i, b in enumerate(base.blocks) if b.is_air)
+    solid = next(i for i, b in enumerate(base.blocks) if not b.is_air)
+    c1 = tuple(int(v) for v in centre + np.array([1, 0, 1]))
+    c2 = tuple(int(v) for v in centre + np.array([-1, 0, 1]))
+    changes = []
+    for cube in (c1, c2):
+        old = int(base.block_index[tuple(cube[a] - base.lo[a] for a in range(3))])
+        changes.append((cube, solid if old == air else air))
+    ref = copy.deepcopy(base)
+    queue = _modified_cubes_queue(ref, changes)
+    n_ref = oracle.evaluate_light(ref, maximum_distance=30, fast=False, epsilon=1, batch=32, queue=queue, hb_width=16)
+    want = np.asarray(ref.light)
+
+    for budget in (0, 48):
+        ctx.upload_space(abi.LAYER_WORLD, base)
+        xyz = np.array([c for c, _ in changes], np.int32)
+        ctx.update_cubes(abi.LAYER_WORLD, xyz, block_index=np.array([i for _, i in changes], np.uint16))
+        ctx.light_cubes_changed(abi.LAYER_WORLD, xyz)
+        total, calls = 0, 0
+        while True:
+            info = ctx.evaluate_light(abi.LAYER_WORLD, 30, fast=False, epsilon=1, batch=32, queue_order=16, queue=[], max_updates=budget)
+            total += info.updates
+            calls += 1
+            if info.queue_left == 0 or calls > 10000:
+                break
+        got = ctx.read_light_volume(abi.LAYER_WORLD, base.size)
+        assert total == n_ref and n_ref > 0
+        assert (got == want.reshape(got.shape)).all()
+        if budget:
+            assert calls > 1
