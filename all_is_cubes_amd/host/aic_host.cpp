@@ -523,7 +523,8 @@ bool HipRtRenderer::sync_space(int layer, const std::shared_ptr<Space> &space, c
         }
         changed = true;
     }
-    if (todo.every_light) {  // one H2D copy of the light volume instead of a scatter (BASELINE config 5)
+    const bool dev_light = device_light && layer == AIC_LAYER_WORLD;
+    if (todo.every_light && !dev_light) {  // one H2D copy of the light volume instead of a scatter (BASELINE config 5)
         check(aic_update_light_volume(ctx_, layer, reinterpret_cast<const uint8_t *>(space->light().data())), "aic_update_light_volume");
         changed = true;
     }
@@ -538,7 +539,8 @@ bool HipRtRenderer::sync_space(int layer, const std::shared_ptr<Space> &space, c
             const PackedLight p = space->get_light(c[0], c[1], c[2]);
             lt.push_back(p.r); lt.push_back(p.g); lt.push_back(p.b); lt.push_back(p.status);
         }
-        check(aic_update_cubes(ctx_, layer, (uint32_t)bi.size(), xyz.data(), bi.data(), lt.data()), "aic_update_cubes");
+        check(aic_update_cubes(ctx_, layer, (uint32_t)bi.size(), xyz.data(), bi.data(), dev_light ? nullptr : lt.data()), "aic_update_cubes");
+        if (dev_light) check(aic_light_cubes_changed(ctx_, layer, (uint32_t)bi.size(), xyz.data(), device_light_queue_order), "aic_light_cubes_changed");
         changed = true;
     }
     todo.clear();
@@ -664,7 +666,8 @@ ImageInfo HipRtRenderer::wait_rows(uint32_t slot) {
     return to_info(fi, vp.framebuffer_width, vp.framebuffer_height);
 }
 void HipRtRenderer::synchronize() { check(aic_synchronize(ctx_), "aic_synchronize"); }
-HipRtRenderer::LightUpdateInfo HipRtRenderer::evaluate_light(int maximum_distance, bool fast, int epsilon, int batch, int queue_order, int lanes_per_cube) {
+HipRtRenderer::LightUpdateInfo HipRtRenderer::evaluate_light(int maximum_distance, bool fast, int epsilon, int batch, int queue_order, int lanes_per_cube,
+                                                              bool continue_queue, uint64_t max_updates) {
     aic_light_params p;
     std::memset(&p, 0, sizeof(p));
     p.maximum_distance = maximum_distance;
@@ -672,7 +675,8 @@ HipRtRenderer::LightUpdateInfo HipRtRenderer::evaluate_light(int maximum_distanc
     p.epsilon = epsilon;
     p.batch = batch;
     p.queue_order = queue_order;
-    p.n_queue = -1;
+    p.n_queue = continue_queue ? 0 : -1;
+    p.max_updates = max_updates;
     p.lanes_per_cube = lanes_per_cube;
     aic_light_info info;
     check(aic_evaluate_light(ctx_, AIC_LAYER_WORLD, &p, &info), "aic_evaluate_light");

@@ -319,7 +319,14 @@ class HipRtRenderer : public HeadlessRenderer {
     // Mutation::evaluate_light(epsilon) (space.rs:1496-1540) on the WORLD space as uploaded, with
     // LightPhysics::Rays { maximum_distance }; the device's light volume is updated in place (the host Space's is not).
     struct LightUpdateInfo { uint64_t updates, batches, cost; double device_ms, total_ms; uint32_t queue_left; };
-    LightUpdateInfo evaluate_light(int maximum_distance, bool fast = true, int epsilon = 1, int batch = 32, int queue_order = 16, int lanes_per_cube = 0);
+    // `continue_queue`: add nothing to the layer's update queue (what update() queued through aic_light_cubes_changed is
+    // drained); `max_updates`: stop after that many cube updates (a per-frame light budget), 0 = run to the end.
+    LightUpdateInfo evaluate_light(int maximum_distance, bool fast = true, int epsilon = 1, int batch = 32, int queue_order = 16, int lanes_per_cube = 0,
+                                   bool continue_queue = false, uint64_t max_updates = 0);
+    // true: the WORLD space's light lives on the device (evaluate_light): update() forwards block changes only, never the
+    // host Space's light texels, and queues the changed cubes for relighting (aic_light_cubes_changed)
+    bool device_light = false;
+    int device_light_queue_order = 16;
     bool enable_counters = false;
 
   private:

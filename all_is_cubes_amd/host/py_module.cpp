@@ -233,12 +233,16 @@ PYBIND11_MODULE(_host, m) {
         .def("device_name", &HipRtRenderer::device_name)
         .def("stream", [](const HipRtRenderer &r) { return reinterpret_cast<uintptr_t>(r.stream()); })
         .def("wait_event", [](HipRtRenderer &r, uintptr_t ev) { r.wait_event(reinterpret_cast<void *>(ev)); })
-        .def("evaluate_light", [](HipRtRenderer &r, int maximum_distance, bool fast, int epsilon, int batch, int queue_order, int lanes_per_cube) {
-            const HipRtRenderer::LightUpdateInfo i = r.evaluate_light(maximum_distance, fast, epsilon, batch, queue_order, lanes_per_cube);
+        .def("evaluate_light", [](HipRtRenderer &r, int maximum_distance, bool fast, int epsilon, int batch, int queue_order, int lanes_per_cube, bool continue_queue,
+                                  uint64_t max_updates) {
+            const HipRtRenderer::LightUpdateInfo i = r.evaluate_light(maximum_distance, fast, epsilon, batch, queue_order, lanes_per_cube, continue_queue, max_updates);
             py::dict d;
             d["updates"] = i.updates; d["batches"] = i.batches; d["cost"] = i.cost; d["device_ms"] = i.device_ms;
             d["total_ms"] = i.total_ms; d["queue_left"] = i.queue_left;
             return d;
-        }, py::arg("maximum_distance"), py::arg("fast") = true, py::arg("epsilon") = 1, py::arg("batch") = 32, py::arg("queue_order") = 16, py::arg("lanes_per_cube") = 0)
+        }, py::arg("maximum_distance"), py::arg("fast") = true, py::arg("epsilon") = 1, py::arg("batch") = 32, py::arg("queue_order") = 16, py::arg("lanes_per_cube") = 0, py::arg("continue_queue") = false,
+           py::arg("max_updates") = 0)
+        .def_readwrite("device_light", &HipRtRenderer::device_light)
+        .def_readwrite("device_light_queue_order", &HipRtRenderer::device_light_queue_order)
         .def_readwrite("enable_counters", &HipRtRenderer::enable_counters);
 }

@@ -62,6 +62,20 @@ def build_workload(name: str):
         eye, target = (0.5, 9.91, 10.0), (0.5, 8.0, 0.0)
         view_distance = 200.0
         label = "atrium-like 19x35x51 R16, 1920x1080, 60-frame orbit, light volume re-uploaded + camera moved every frame"
+    elif name == "relight":
+        # the sim+render loop with the light ON THE DEVICE (SURVEY.md 8f N1 + N2): every frame a lamp block is placed or
+        # removed, the changed cube and its neighbours are queued (aic_light_cubes_changed), the light updater gets a budget
+        # of cube updates (aic_evaluate_light, continuing the layer's queue), the camera moves, and the frame is traced.
+        # No light volume crosses PCIe.
+        from all_is_cubes_amd import flat
+        space = scenes.atrium_like_space()
+        space.add_block(flat.atom((1.0, 0.9, 0.7, 1.0), (8.0, 7.0, 5.0), name="lamp"))
+        space.light[...] = 0
+        size = (1920, 1080)
+        eye, target = (0.5, 9.91, 10.0), (0.5, 8.0, 0.0)
+        view_distance = 200.0
+        label = ("atrium-like 19x35x51 R16, 1920x1080, 60-frame orbit; each frame: a lamp block toggled, relit on the device "
+                 "(one launch of 1024 cube updates), camera moved")
     elif name == "s256":
         space = scenes.synthetic_space(n=256, resolution=32, n_blocks=64, seed=1)
         size = (3840, 2160)
@@ -98,7 +112,7 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="atrium", choices=["atrium", "s256", "small", "orbit", "light-bench"])
+    ap.add_argument("--workload", default="atrium", choices=["atrium", "s256", "small", "orbit", "light-bench", "relight"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", dest="verify", action="store_true", default=None,
                     help="N > 1 (default there): check the assembled frame against a single-rank trace of the same frame")
@@ -169,6 +183,26 @@ def main() -> int:
     renderer = H.HipRtRenderer(cams, None, local_rank)
     renderer.update()
     light_update = None
+    relight = None
+    if args.workload == "relight":
+        renderer.device_light = True
+        renderer.device_light_queue_order = 0
+        li = renderer.evaluate_light(30, True, 1, 8192, 0)  # the starting light: large batches to convergence
+        light_update = {"mode": "initial light: fast_evaluate_light + evaluate_light(1), batch 8192", "updates": int(li["updates"]),
+                        "launches": int(li["batches"]), "device_ms": round(li["device_ms"], 3), "total_ms": round(li["total_ms"], 3)}
+        lo_s, sz_s = np.array(flat_space.lo), np.array(flat_space.size)
+        air_i = next(i for i, b in enumerate(flat_space.blocks) if b.is_air)
+        lamp_i = len(flat_space.blocks) - 1
+        # lamp sites: air cubes of the scene's middle column region, spread over the orbit
+        bi = np.asarray(flat_space.block_index)
+        rng = np.random.default_rng(7)
+        sites = []
+        while len(sites) < 30:
+            c = rng.integers(0, sz_s)
+            if int(bi[tuple(c)]) == air_i and tuple(c) not in sites:
+                sites.append(tuple(int(v) for v in c))
+        relight = {"sites": [tuple(int(l + c) for l, c in zip(lo_s, s_)) for s_ in sites], "air": air_i, "lamp": lamp_i, "updates": 0, "calls": 0,
+                   "light_ms": 0.0, "queue_left": 0}
     if args.workload == "light-bench":
         # light.rs "both": fast_evaluate_light then evaluate_light(1), LightPhysics::Rays { maximum_distance: 30 },
         # batches of 32 in the reference's queue order -- the configuration that reproduces the reference's texels
@@ -202,6 +236,9 @@ def main() -> int:
 
     kernel_ms = []
     orbit = None
+    if args.workload == "relight":
+        views = [H.look_at_y_up((0.5 + 7.0 * np.sin(2.0 * np.pi * k / 60.0), eye[1], 7.0 * np.cos(2.0 * np.pi * k / 60.0)), target) for k in range(60)]
+        orbit = {"k": 0, "lights": None, "views": views}
     if args.workload == "orbit":
         # 60 key frames: the eye circles the atrium's axis, the light field breathes (status bytes kept)
         base = flat_space.light.copy()
@@ -244,7 +281,17 @@ def main() -> int:
     def step() -> None:
         i = frame_no[0]
         frame_no[0] += 1
-        if orbit is not None:
+        if relight is not None:
+            k = i % 60
+            x, y, z = relight["sites"][k % 30]
+            cams.world_space.set(x, y, z, relight["lamp"] if (i // 30) % 2 == 0 else relight["air"])
+            cams.world_view_transform = orbit["views"][k]
+            renderer.update()                                  # block delta -> aic_update_cubes + aic_light_cubes_changed
+            t_l = time.perf_counter()
+            li = renderer.evaluate_light(30, False, 1, 1024, 0, 0, True, 1024)
+            relight["light_ms"] += (time.perf_counter() - t_l) * 1e3
+            relight["updates"] += int(li["updates"]); relight["calls"] += 1; relight["queue_left"] = int(li["queue_left"])
+        elif orbit is not None:
             k = i % 60
             cams.world_space.load_light(orbit["lights"][k])   # SpaceChange burst -> aic_update_light_volume
             cams.world_view_transform = orbit["views"][k]
@@ -338,7 +385,7 @@ def main() -> int:
     # recorded, what the first frame of any sequence costs -- and of a moving camera (6 degrees per frame about the
     # scene's axis: the feedback never applies), one frame at a time and streamed.
     single = None
-    if world == 1 and args.workload != "orbit" and not args.no_extras:
+    if world == 1 and args.workload not in ("orbit", "relight") and not args.no_extras:
         n_l = max(10, min(60, args.steps))
         tgt = render_target(0).data_ptr()
 
@@ -403,7 +450,7 @@ def main() -> int:
     # committed per-launch figure for this workload is reported (null when none is on file
     # or when the image is partitioned differently from the profiled single-GPU launch).
     traffic, traffic_src, valu = None, None, None
-    if world == 1 and (args.lighting, args.fog, args.transparency) == (3, 1, 1) and args.workload != "orbit":
+    if world == 1 and (args.lighting, args.fog, args.transparency) == (3, 1, 1) and args.workload not in ("orbit", "relight"):
         cands = sorted(glob.glob(os.path.join(str(ROOT), "profiles", f"r*_pmc_{args.workload}.json")))
         if cands:
             with open(cands[-1]) as f:
@@ -487,6 +534,10 @@ def main() -> int:
             result["streamed_ms"] = round(ms_per_step, 4) if streamed else None
         if light_update is not None:
             result["light_update"] = light_update
+        if relight is not None and relight["calls"]:
+            result["relight"] = {"light_updates_per_frame": round(relight["updates"] / relight["calls"], 1),
+                                 "light_ms_per_frame": round(relight["light_ms"] / relight["calls"], 4),
+                                 "queue_left_at_end": relight["queue_left"], "frames_counted": relight["calls"]}
         if fps_with_readback is not None:
             result["fps_with_readback"] = round(fps_with_readback, 3)
         if world == 1 and not args.no_cpu_baseline:

@@ -292,3 +292,51 @@ def test_cubes_changed_queue_and_budgeted_relight(ctx):
         assert (got == want.reshape(got.shape)).all()
         if budget:
             assert calls > 1
+
+
+def test_host_mirror_device_light_mode(ctx):
+    """HipRtRenderer.device_light: update() forwards block changes only and queues them for relighting; evaluate_light
+    (fresh, then continuing the queue) gives the frames the C ABI path gives for the same operations."""
+    import all_is_cubes_amd as A
+    from all_is_cubes_amd import _host as H
+
+    sp = scenes.light_on_slab_space()
+    w, h = 128, 96
+    eye, look = (0.5, -6.0, 6.0), (0.0, 1.0, -1.0)
+    target = tuple(e + l for e, l in zip(eye, look))
+    cams = H.StandardCameras()
+    o = H.GraphicsOptions()  # default(): Volumetric, Linear lighting, Abrupt fog, fov 90, view distance 200
+    o.bloom_intensity = 0.0
+    cams.graphics_options = o
+    cams.viewport = H.Viewport.with_scale(1.0, w, h)
+    space = A.space_from_flat(sp)
+    cams.world_space = space
+    cams.world_view_transform = H.look_at_y_up(eye, target)
+    r = H.HipRtRenderer(cams)
+    r.device_light = True
+    r.update()
+    r.evaluate_light(30)
+    img_a = np.array(r.draw("").data)
+
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, target), eye)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.set_options(abi.LAYER_WORLD, abi.make_options(bloom_intensity=0.0))
+    ctx.evaluate_light(abi.LAYER_WORLD, 30)
+    img_b = ctx.render(ctx.make_frame(w, h, world_inv=inv))["rgba8"]
+    assert (img_a == img_b).all()
+
+    # a block change: through Space.set + update() on one side, update_cubes + light_cubes_changed on the other
+    cube = (0, 0, 2)
+    wall = 1
+    space.set(cube[0], cube[1], cube[2], wall)
+    r.update()
+    r.evaluate_light(30, fast=False, continue_queue=True)
+    img_a2 = np.array(r.draw("").data)
+    xyz = np.array([cube], np.int32)
+    ctx.update_cubes(abi.LAYER_WORLD, xyz, block_index=np.array([wall], np.uint16))
+    ctx.light_cubes_changed(abi.LAYER_WORLD, xyz)
+    ctx.evaluate_light(abi.LAYER_WORLD, 30, fast=False, queue=[])
+    img_b2 = ctx.render(ctx.make_frame(w, h, world_inv=inv))["rgba8"]
+    assert (img_a2 == img_b2).all()
+    assert (img_a2 != img_a).any()
