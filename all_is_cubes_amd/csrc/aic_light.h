@@ -76,7 +76,7 @@ struct LightJob {
 };
 
 void launch_compute_light(const LightJob &job, hipStream_t stream);
-void launch_compute_light_waves(const LightJob &job, uint32_t n_waves, hipStream_t stream);
+void launch_compute_light_waves(const LightJob &job, uint32_t n_blocks, uint32_t threads_per_cube, hipStream_t stream);
 void launch_scatter_light(uint32_t *light, const uint32_t *index, const uint32_t *texel, uint32_t n, hipStream_t stream);
 void launch_probe_log2f(const float *x, float *out, uint32_t n, hipStream_t stream);
 

@@ -420,6 +420,7 @@ __global__ void __launch_bounds__(64) compute_light_kernel(const LightJob J) {
 constexpr uint32_t kLdsFlags = 1024u;   // DevDerived.flags of the first blocks, cached in LDS
 constexpr uint32_t kFrontierCap = 1024u;  // >= 602 rays
 constexpr uint32_t kOrderCap = 2048u;   // set bits gathered per pass of the ordered reduction
+constexpr uint32_t kLightBlock = 256u;  // most threads a cube's block may have (1 or 4 waves)
 
 struct WaveCtx {
     const LightJob &J;
@@ -596,48 +597,54 @@ struct WaveCtx {
 // Gathers set bits of bits[*word_io, n_words) into order[] in ascending order -- all of them if they fit kOrderCap, else
 // the longest prefix of words that does -- and advances *word_io. All 64 lanes take part (no divergence around the call).
 // Returns the number gathered; 0 = nothing left; 0xffffffff = this span was empty but words remain.
-__device__ uint32_t gather_set_bits(const uint32_t *bits, uint32_t n_words, uint32_t *word_io, uint32_t *order, uint32_t lane) {
+__device__ uint32_t gather_set_bits(const uint32_t *bits, uint32_t n_words, uint32_t *word_io, uint32_t *order, uint32_t tid, uint32_t *s_bcast) {
     const uint32_t w0 = *word_io;
     if (w0 >= n_words) return 0u;
-    uint32_t span = n_words - w0, a, e, count, incl, total;
-    for (;;) {
-        const uint32_t per = (span + 63u) / 64u;
-        a = min(w0 + lane * per, w0 + span);
-        e = min(a + per, w0 + span);
-        count = 0u;
-        for (uint32_t w = a; w < e; w++) count += __popc(bits[w]);
-        incl = count;
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d, 64);
-            if ((int)lane >= d) incl += up;
+    if (tid < 64u) {  // the first wave gathers (wave shuffles); the other waves of the block wait at the barrier
+        const uint32_t lane = tid;
+        uint32_t span = n_words - w0, a, e, count, incl, total;
+        for (;;) {
+            const uint32_t per = (span + 63u) / 64u;
+            a = min(w0 + lane * per, w0 + span);
+            e = min(a + per, w0 + span);
+            count = 0u;
+            for (uint32_t w = a; w < e; w++) count += __popc(bits[w]);
+            incl = count;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d, 64);
+                if ((int)lane >= d) incl += up;
+            }
+            total = __shfl(incl, 63, 64);
+            if (total <= kOrderCap || span <= kOrderCap / 32u) break;
+            span = max(kOrderCap / 32u, span / 2u);
         }
-        total = __shfl(incl, 63, 64);
-        if (total <= kOrderCap || span <= kOrderCap / 32u) break;
-        span = max(kOrderCap / 32u, span / 2u);
+        uint32_t at = incl - count;
+        for (uint32_t w = a; w < e; w++) {
+            uint32_t v = bits[w];
+            while (v) { const uint32_t bpos = __ffs(v) - 1u; v &= v - 1u; order[at++] = w * 32u + bpos; }
+        }
+        if (lane == 0u) { s_bcast[0] = total; s_bcast[1] = span; }
     }
-    uint32_t at = incl - count;
-    for (uint32_t w = a; w < e; w++) {
-        uint32_t v = bits[w];
-        while (v) { const uint32_t bpos = __ffs(v) - 1u; v &= v - 1u; order[at++] = w * 32u + bpos; }
-    }
+    __syncthreads();
+    const uint32_t total = s_bcast[0], span = s_bcast[1];
     __syncthreads();
     *word_io = w0 + span;
     return total == 0u ? 0xffffffffu : total;
 }
 
-__global__ void __launch_bounds__(64) compute_light_wave_kernel(const LightJob J) {
+__global__ void __launch_bounds__(kLightBlock) compute_light_wave_kernel(const LightJob J) {
     extern __shared__ uint32_t s_dyn[];  // term bitmap, candidate bitmap
     __shared__ uint32_t s_flags[kLdsFlags];
     __shared__ float s_lut[256];
     __shared__ uint2 s_front[2][kFrontierCap];
-    __shared__ uint32_t s_count[2], s_cost[64];
+    __shared__ uint32_t s_count[2], s_cost[kLightBlock], s_bcast[2];
     __shared__ float4 s_stage[64];
     __shared__ uint32_t s_order[kOrderCap];
-    const uint32_t lane = threadIdx.x, wave = blockIdx.x;
+    const uint32_t lane = threadIdx.x, wave = blockIdx.x, nt = blockDim.x;  // `lane`: thread of the cube's block (1 or 4 waves)
     const uint32_t term_words = (4u * J.n_tree + 31u) / 32u, cand_words = (2u * J.n_tree + 31u) / 32u;
     uint32_t *const term_bits = s_dyn, *const cand_bits = s_dyn + term_words;
-    for (uint32_t i = lane; i < min(J.n_blocks, kLdsFlags); i += 64u) s_flags[i] = J.derived[i].flags;
-    for (uint32_t i = lane; i < 256u; i += 64u) s_lut[i] = J.lut[i];
+    for (uint32_t i = lane; i < min(J.n_blocks, kLdsFlags); i += nt) s_flags[i] = J.derived[i].flags;
+    for (uint32_t i = lane; i < 256u; i += nt) s_lut[i] = J.lut[i];
     __syncthreads();
     WaveCtx b(J);
     b.lds_flags = s_flags;
@@ -664,7 +671,7 @@ __global__ void __launch_bounds__(64) compute_light_wave_kernel(const LightJob J
 #endif
 
         if (!origin_is_opaque) {
-            for (uint32_t i = lane; i < term_words + cand_words; i += 64u) s_dyn[i] = 0u;
+            for (uint32_t i = lane; i < term_words + cand_words; i += nt) s_dyn[i] = 0u;
             // directions_to_seek_light (updater.rs:668-690)
             uint32_t m0 = 0u;
             if (ev_origin->flags & kDerivedVisible) m0 = 63u;
@@ -697,7 +704,7 @@ __global__ void __launch_bounds__(64) compute_light_wave_kernel(const LightJob J
 #ifdef AIC_LIGHT_TIMING
                 n_rounds++;
 #endif
-                for (uint32_t i = lane; i < n_front; i += 64u) {
+                for (uint32_t i = lane; i < n_front; i += nt) {
                     const uint2 it = s_front[cur][i];
                     float alpha;
 #ifdef AIC_LIGHT_TIMING
@@ -739,7 +746,7 @@ __global__ void __launch_bounds__(64) compute_light_wave_kernel(const LightJob J
         } else {
             uint32_t word = 0u;
             for (;;) {
-                const uint32_t got = gather_set_bits(term_bits, term_words, &word, s_order, lane);
+                const uint32_t got = gather_set_bits(term_bits, term_words, &word, s_order, lane, s_bcast);
                 if (got == 0u) break;
                 if (got == 0xffffffffu) continue;
                 n_terms += got;
@@ -760,7 +767,7 @@ __global__ void __launch_bounds__(64) compute_light_wave_kernel(const LightJob J
             uint32_t last = 0xffffffffu;
             word = 0u;
             for (;;) {
-                const uint32_t got = gather_set_bits(cand_bits, cand_words, &word, s_order, lane);
+                const uint32_t got = gather_set_bits(cand_bits, cand_words, &word, s_order, lane, s_bcast);
                 if (got == 0u) break;
                 if (got == 0xffffffffu) continue;
                 for (uint32_t c0 = 0u; c0 < got; c0 += 64u) {
@@ -800,7 +807,7 @@ __global__ void __launch_bounds__(64) compute_light_wave_kernel(const LightJob J
         }
         if (lane == 0u) {
             uint32_t cost = 0u;
-            for (uint32_t l = 0u; l < 64u; l++) cost += s_cost[l];
+            for (uint32_t l = 0u; l < nt; l++) cost += s_cost[l];
             // LightBuffer::finish (updater.rs:940-952)
             uint32_t texel;
             const float scale = ps_new_clamped(1.0f / fmaxf(total, 1.0f));
@@ -844,7 +851,7 @@ void launch_compute_light(const LightJob &job, hipStream_t stream) {
     hipLaunchKernelGGL(compute_light_kernel, dim3((job.n + 63u) / 64u), dim3(64), 0, stream, job);
 }
 
-void launch_compute_light_waves(const LightJob &job, uint32_t n_waves, hipStream_t stream) {
+void launch_compute_light_waves(const LightJob &job, uint32_t n_waves, uint32_t threads, hipStream_t stream) {
     if (!job.n || !n_waves) return;
     const uint32_t lds = (((4u * job.n_tree + 31u) / 32u) + ((2u * job.n_tree + 31u) / 32u)) * 4u;
     // more dynamic LDS than the default limit needs an opt-in, per device
@@ -856,7 +863,7 @@ void launch_compute_light_waves(const LightJob &job, uint32_t n_waves, hipStream
         (void)hipFuncSetAttribute((const void *)compute_light_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         allowed = lds;
     }
-    hipLaunchKernelGGL(compute_light_wave_kernel, dim3(n_waves), dim3(64), lds, stream, job);
+    hipLaunchKernelGGL(compute_light_wave_kernel, dim3(n_waves), dim3(threads == 256u ? 256u : 64u), lds, stream, job);
 }
 
 void launch_scatter_light(uint32_t *light, const uint32_t *index, const uint32_t *texel, uint32_t n, hipStream_t stream) {

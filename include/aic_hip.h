@@ -317,9 +317,9 @@ typedef struct aic_light_params {
     int32_t n_queue;          /* when !fast: entries to ADD to the layer's queue, inserted in order (what
                                  modified_cube_needs_update, updater.rs:135-173, enqueues after a change); < 0: every cube
                                  whose texel is Uninitialized, at Priority::UNINIT */
-    int32_t lanes_per_cube;   /* how compute_light is mapped to the device: 64 (or 0 = default) one wave per cube -- 64 lanes walk
-                                 64 slices of the ray-bundle tree and the contributions are added in the reference's order;
-                                 1 = one lane per cube (the plain restatement). Same results, bit for bit */
+    int32_t lanes_per_cube;   /* how compute_light is mapped to the device: 256 (or 0 = default) / 64: a block of four waves / one
+                                 wave per cube walks the ray-bundle tree level by level and the contributions are added in the
+                                 reference's order; 1 = one lane per cube (the plain restatement). Same results, bit for bit */
     int32_t reserved;
     const int32_t *queue_cubes;      /* [n_queue][3] */
     const int32_t *queue_priorities; /* [n_queue], 0..255 */

@@ -68,11 +68,11 @@ def test_derived_matches_oracle(ctx, name):
 
 
 @pytest.mark.parametrize("name", list(SCENES))
-@pytest.mark.parametrize("batch,order,lanes", [(32, 16, 64), (1, 16, 64), (32, 8, 64), (7, 0, 64), (32, 16, 1)])
+@pytest.mark.parametrize("batch,order,lanes", [(32, 16, 64), (1, 16, 64), (32, 8, 64), (7, 0, 64), (32, 16, 1), (32, 16, 256)])
 def test_evaluate_light_matches_oracle(ctx, name, batch, order, lanes):
     """`lanes`: one wave per cube (64 lanes walk slices of the tree, contributions added in the reference's order) or the
     plain one-lane-per-cube restatement: both must give the oracle's bytes."""
-    if name in ("fog", "tone_mapping") and (batch, order, lanes) != (32, 16, 64):
+    if name in ("fog", "tone_mapping") and (batch, order) != (32, 16):
         pytest.skip("the larger scenes run in the reference configuration only")
     sp = SCENES[name]()
     ref = copy.deepcopy(sp)
