@@ -6,9 +6,11 @@ path over the scene already resident in HBM: camera upload, (tile ordering,) tra
 for N > 1 -- the RCCL gather of the row strips to rank 0 plus the de-interleave. Frames are
 streamed the way a recording loop submits them: 2 traces in flight at N = 1 (4 at N > 1), a
 frame's gather running under the next frames' traces; every frame issued in the timed region is
-complete, gathered and assembled before the clock stops. `--no-pipeline` traces one frame at a
-time (also reported as `ms_per_frame_one_at_a_time`). The finished RGBA8 frames stay in HBM (the
-PCIe-inclusive rate is reported separately as `fps_with_readback`).
+complete, gathered and assembled before the clock stops; the K-step region is repeated until the
+regions add up to `--min-seconds` and the median region is reported (min / max beside it).
+`--no-pipeline` traces one frame at a time; the `single_frame` object reports one frame alone
+(warm / cold / moving camera). The finished RGBA8 frames stay in HBM (the PCIe-inclusive rate is
+reported separately as `fps_with_readback`).
 
 Workload (config.workload), BASELINE.json configs[1]: 1920x1080 single-frame raytrace of the
 Atrium scene at block resolution 16. The reference's Atrium generator needs the un-vendored
@@ -16,7 +18,10 @@ noise crate and the block-evaluation engine, so the stand-in i
 `atrium_like_space` (19x35x51 cubes, R16 recursive blocks, a light field, the Atrium spawn
 camera), with GraphicsOptions::default() minus bloom (Volumetric transparency, Linear lighting,
 Abrupt fog). `--workload s256` selects configs[2] (3840x2160 synthetic 256^3 Space, R32),
-`--workload orbit` configs[4] (60-frame orbit, light volume re-uploaded every frame).
+`--workload orbit` configs[4] (60-frame orbit, light volume re-uploaded every frame),
+`--workload relight` the same loop with the light computed ON THE DEVICE (a lamp toggled, 1024 cube
+updates of the light updater and one frame per step), `--workload light-bench` the reference's own
+bench scene (all-is-cubes-render/benches/raytrace.rs: light_bench_space, 64x64), lit on the device.
 
 Launch: `python bench.py --gpus 1 --steps K --warmup W`, or for N > 1
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`.
