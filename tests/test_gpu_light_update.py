@@ -11,7 +11,7 @@ import pytest
 
 import oracle
 from all_is_cubes_amd import abi
-from all_is_cubes_amd import workloads
+from all_is_cubes_amd import flat, workloads
 from tests import scenes
 from tests.test_gpu_parity import to_abi_options
 from tests.test_oracle_goldens import COMMON_VIEWPORT
@@ -340,3 +340,50 @@ def test_host_mirror_device_light_mode(ctx):
     img_b2 = ctx.render(ctx.make_frame(w, h, world_inv=inv))["rgba8"]
     assert (img_a2 == img_b2).all()
     assert (img_a2 != img_a).any()
+
+
+def _random_light_scene(seed):
+    """A small space with every kind of block the updater distinguishes: air, opaque and translucent atoms, an opaque
+    emitter, a translucent emitter, recursive blocks (full, partial, translucent, emissive voxels), an octant sky, at random."""
+    rng = np.random.default_rng(1000 + seed)
+    size = tuple(int(v) for v in rng.integers(3, 9, 3))
+    lo = tuple(int(v) for v in rng.integers(-5, 5, 3))
+    sp = flat.FlatSpace(lo, size)
+    if seed % 3 == 0:
+        sp.set_sky_octants(rng.uniform(0.0, 2.0, (8, 3)).astype(np.float32))
+    else:
+        sp.set_sky_uniform(tuple(float(v) for v in rng.uniform(0.0, 1.5, 3)))
+    ids = [sp.add_block(flat.air())]
+    ids.append(sp.add_block(flat.atom((0.8, 0.7, 0.6, 1.0))))
+    ids.append(sp.add_block(flat.atom((0.2, 0.5, 0.9, 0.5))))
+    ids.append(sp.add_block(flat.atom((1.0, 1.0, 1.0, 1.0), (4.0, 2.0, 0.5))))
+    ids.append(sp.add_block(flat.atom((0.5, 0.5, 0.5, 0.25), (0.0, 1.5, 3.0))))
+    for b in workloads.synthetic_blocks(int(rng.choice([2, 4, 8])), 8, seed=seed + 1, palette_size=6):
+        ids.append(sp.add_block(b))
+    fill = rng.uniform(0.15, 0.6)
+    choice = rng.integers(1, len(ids), size)
+    sp.block_index[...] = np.where(rng.random(size) < fill, choice, 0).astype(np.uint16)
+    sp.light[...] = 0
+    return sp
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("AIC_LIGHT_FUZZ_N", "16"))))
+def test_light_updater_fuzz(ctx, seed):
+    """Randomised differential test of the whole updater (derived block properties, fast_evaluate_light, queue order,
+    compute_light, apply): device == oracle, texel for texel, with a random distance, batch and order."""
+    sp = _random_light_scene(seed)
+    rng = np.random.default_rng(seed)
+    maxd = int(rng.choice([2, 5, 12, 30]))
+    batch = int(rng.choice([1, 5, 32, 100]))
+    order = int(rng.choice([0, 8, 16]))
+    lanes = int(rng.choice([64, 256]))
+    ref = copy.deepcopy(sp)
+    n_ref = oracle.evaluate_light(ref, maximum_distance=maxd, fast=True, epsilon=1, batch=batch, hb_width=order)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    got_d, got_o = ctx.probe_derived(abi.LAYER_WORLD, len(sp.blocks))
+    want = oracle.compute_derived(oracle.Space(sp))
+    assert (got_d[:, 0:4].view(np.uint32) == want["color"].view(np.uint32)).all() and ((got_o != 0) == want["opaque"]).all()
+    info = ctx.evaluate_light(abi.LAYER_WORLD, maxd, fast=True, epsilon=1, batch=batch, queue_order=order, lanes_per_cube=lanes)
+    got = ctx.read_light_volume(abi.LAYER_WORLD, sp.size)
+    assert info.updates == n_ref
+    assert (got == np.asarray(ref.light).reshape(got.shape)).all(), f"seed {seed}: {(got != np.asarray(ref.light).reshape(got.shape)).any(axis=-1).sum()} texels differ"
