@@ -86,13 +86,13 @@ class StripGatherPipeline:
         self.local = [torch.zeros((self.max_rows, width, 4), dtype=torch.uint8, device=device) for _ in range(depth)]
         self.gathered = [torch.empty((self.world, self.max_rows, width, 4), dtype=torch.uint8, device=device) if self.rank == 0 else None
                          for _ in range(depth)]
+        self.gather_lists = [list(g.unbind(0)) if g is not None else None for g in self.gathered]  # built once: submit() is on the frame path
         self.work = [None] * depth
         self.order: List[int] = []  # slots with a gather in flight, oldest first
 
     def submit(self, slot: int) -> None:
         assert self.work[slot] is None, "slot still in flight: retire it first"
-        gl = list(self.gathered[slot].unbind(0)) if self.rank == 0 else None
-        self.work[slot] = dist.gather(self.local[slot], gather_list=gl, dst=0, group=self.group, async_op=True)
+        self.work[slot] = dist.gather(self.local[slot], gather_list=self.gather_lists[slot], dst=0, group=self.group, async_op=True)
         self.order.append(slot)
 
     def retire(self, slot: int) -> Optional[torch.Tensor]:
