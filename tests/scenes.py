@@ -402,3 +402,54 @@ def cornell_box_space() -> flat.FlatSpace:
         blo, bsz = scaled(lo, tuple(l + s for l, s in zip(lo, size)))
         _fill(sp, tuple(blo), tuple(bsz), white)
     return sp
+
+
+# antialias_test_universe (cases/src/lib.rs:1271-1329): a floor of R2 checker voxel blocks and a wall of solid blocks, no
+# light. One floor block in nine is `make_some_voxel_blocks`' labelled block (an R16 block with a composited text glyph: needs
+# the text engine and its font); it is a full opaque cube, so a plain opaque stand-in occludes exactly as it does and only the
+# pixels that show it differ. Returns (space, index of the stand-in block).
+def antialias_test_space():
+    lo, size = (-5, -2, -60), (10, 10, 60)
+    sp = flat.FlatSpace(lo, size)
+    sp.set_sky_uniform(from_srgb8(DAY_SKY_COLOR))
+    sp.add_block(flat.air())
+    neutral = sp.add_block(flat.atom((1.0, 1.0, 1.0, 1.0)))
+    large = sp.add_block(flat.atom((1.0, 0.0, 0.0, 1.0)))
+    g = np.arange(2)
+    X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+    pal = np.stack([flat.evoxel((0.5, 0.0, 1.0, 1.0)), flat.evoxel((1.0, 1.0, 1.0, 1.0))])
+    vox = np.where((X + Y + Z) % 2 == 0, 0, 1).astype(np.uint16)
+    voxel_block_1 = sp.add_block(flat.voxel_block(2, vox, pal))
+    stand_in = sp.add_block(flat.atom((0.5, 0.5, 0.5, 1.0)))
+    for x in range(lo[0], lo[0] + size[0]):
+        for z in range(lo[2], lo[2] + size[2]):
+            sp.set((x, lo[1], z), stand_in if (x % 3 == 0 and z % 3 == 2) else voxel_block_1)   # floor: abut(NY, -1)
+    x = lo[0] + size[0] - 1                                                                       # wall: abut(PX, -1)
+    for y in range(lo[1], lo[1] + size[1]):
+        for z in range(lo[2], lo[2] + size[2]):
+            sp.set((x, y, z), large if (x + y + z) % 2 == 0 else neutral)
+    return sp, stand_in
+
+
+# sky (cases/src/lib.rs:1007-1051): one cube under an axis-coloured octant sky, seen from the side opposite `face`. The cube
+# is `make_some_voxel_blocks`' labelled block (text engine): a full opaque stand-in occludes as it does; the sky pixels are
+# what the case is about. Returns (space, eye, look direction).
+def sky_test_space(face: str):
+    sp = flat.FlatSpace((0, 0, 0), (1, 1, 1))
+    r = np.array([*from_srgb8((0x9E, 0x00, 0x00))], np.float32)   # Rgb01::UNIFORM_LUMINANCE_RED / GREEN / BLUE (color.rs:357-364)
+    g = np.array([*from_srgb8((0x00, 0x59, 0x00))], np.float32)
+    b = np.array([*from_srgb8((0x00, 0x00, 0xFF))], np.float32)
+    zero = np.zeros(3, np.float32)
+    sp.set_sky_octants(np.stack([zero, b, g, g + b, r, r + b, r + g, r + g + b]))
+    sp.block_index[...] = sp.add_block(flat.atom((0.5, 0.5, 0.5, 1.0)))
+    sp.light[...] = (0, 0, 0, 128)  # a space filled with an opaque block starts all PackedLight::OPAQUE
+    axis = "XYZ".index(face[1])
+    sign = 1.0 if face[0] == "P" else -1.0
+    eye = np.array([0.5, 0.5, 0.5])
+    eye[axis] -= sign * 2.0          # on the side opposite the sky face looked at, 1.5 from the cube's surface
+    if axis == 1:
+        eye[2] -= 0.25               # "tilt the view a little"
+    else:
+        eye[1] += 0.25
+    look = np.array([0.5, 0.5, 0.5]) - eye
+    return sp, tuple(float(v) for v in eye), tuple(float(v) for v in look)

@@ -96,3 +96,30 @@ def test_cornell_box_lit_on_the_device(ctx):
     got = ctx.read_light_volume(abi.LAYER_WORLD, sp.size)
     assert info.updates == n_ref
     assert (got == np.asarray(ref.light).reshape(got.shape)).all()
+
+
+@pytest.mark.parametrize("name,aa", [("antialias-None-all", 0), ("antialias-Always-ray", 2)])
+def test_antialias(ctx, golden_dir, name, aa):
+    """The 4-sample antialiasing path (renderer.rs:424-451) against the raytracer's own golden, on every pixel that does not
+    show the one block of the scene that needs the reference's text engine (tests/test_oracle_goldens2.py)."""
+    from tests.test_oracle_goldens2 import antialias_mask, masked_antialias_diff
+    sp, stand_in = scenes.antialias_test_space()
+    got, ref = render_both(ctx, sp, oracle.unaltered_colors(antialiasing=aa), COMMON_VIEWPORT, (0.0, 0.0, 0.0), (0.4, -0.2, -1.0))
+    assert_parity(got, ref)
+    assert masked_antialias_diff(golden_dir, name, got["rgba8"], antialias_mask(sp, stand_in)).max() == 0
+
+
+@pytest.mark.parametrize("face", ["NX", "NY", "NZ", "PX", "PY", "PZ"])
+def test_sky(ctx, golden_dir, face):
+    """The octant sky from six directions against the `sky-*` goldens, outside the pixels of the cube (whose block needs
+    the reference's text engine)."""
+    from tests.test_oracle_goldens import neighbourhood_diff
+    sp, eye, look = scenes.sky_test_space(face)
+    got, ref = render_both(ctx, sp, oracle.unaltered_colors(lighting=3), COMMON_VIEWPORT, eye, look)
+    assert_parity(got, ref)
+    cube = np.asarray(got["aux"]["hit"]) != 0
+    d = neighbourhood_diff(got["rgba8"], np.load(golden_dir / f"png_sky-{face}-all.npy")).max(axis=-1)
+    grown = cube.copy()
+    grown[1:, :] |= cube[:-1, :]; grown[:-1, :] |= cube[1:, :]; grown[:, 1:] |= cube[:, :-1]; grown[:, :-1] |= cube[:, 1:]
+    d[grown] = 0
+    assert d.max() <= 4

@@ -102,3 +102,55 @@ def test_png_template_cornell_box(golden_dir):
     d = diff_to(golden_dir, "template-cornell-box-all", img)
     assert histogram_ok(d, [(254, 20), (30, 50), (1, 1 << 60)]), np.bincount(d.max(axis=-1).ravel())
     print("cornell-box difference histogram", np.bincount(d.max(axis=-1).ravel()))
+
+
+def antialias_mask(sp, stand_in, size=COMMON_VIEWPORT):
+    """Pixels that may show the stand-in block in an antialiasing sample: the four samples of a pixel sit at odd eighths
+    of it (renderer.rs:427-433), which are pixel centres of the same view at four times the resolution; any of a pixel's
+    4x4 sub-pixels counts (a superset of its four samples)."""
+    w, h = size
+    cam2 = spawn_camera((4 * w, 4 * h), (0.0, 0.0, 0.0), (0.4, -0.2, -1.0))
+    aux = oracle.render(oracle.Space(sp), oracle.unaltered_colors(), cam2, threads=4, want_aux=True)["aux"]
+    shows = (np.asarray(aux["hit"]) != 0) & (np.asarray(aux["block_index"]) == stand_in)
+    cam1 = spawn_camera((w, h), (0.0, 0.0, 0.0), (0.4, -0.2, -1.0))  # ... and, without antialiasing, the pixel centre itself
+    aux1 = oracle.render(oracle.Space(sp), oracle.unaltered_colors(), cam1, threads=4, want_aux=True)["aux"]
+    centre = (np.asarray(aux1["hit"]) != 0) & (np.asarray(aux1["block_index"]) == stand_in)
+    return shows.reshape(h, 4, w, 4).any(axis=(1, 3)) | centre
+
+
+def masked_antialias_diff(golden_dir, name, img, mask):
+    d = diff_to(golden_dir, name, img).max(axis=-1)
+    d[mask] = 0
+    return d
+
+
+# cases/src/lib.rs:169-183 antialias: UNALTERED_COLORS + AntialiasingOption; Threshold [(5, 1000), (40, 1)].
+# "antialias-Always-ray" is the raytracer's own golden: the 4-sample path (renderer.rs:424-451), pinned on every pixel that
+# does not show the one block this repo cannot build.
+@pytest.mark.parametrize("name,aa", [("antialias-None-all", 0), ("antialias-Always-ray", 2)])
+def test_png_antialias(golden_dir, name, aa):
+    sp, stand_in = scenes.antialias_test_space()
+    cam = spawn_camera(COMMON_VIEWPORT, (0.0, 0.0, 0.0), (0.4, -0.2, -1.0))
+    img = oracle.render(oracle.Space(sp), oracle.unaltered_colors(antialiasing=aa), cam, threads=4)["rgba8"]
+    mask = antialias_mask(sp, stand_in)
+    d = masked_antialias_diff(golden_dir, name, img, mask)
+    print(name, "masked fraction", round(float(mask.mean()), 3), "difference histogram", np.bincount(d.ravel()))
+    assert mask.mean() < 0.15
+    assert d.max() == 0  # stricter than the case's Threshold [(5, 1000), (40, 1)]: every unmasked pixel equals the golden
+
+
+# cases/src/lib.rs:1007-1051 sky(face): UNALTERED_COLORS + Linear lighting, threshold 4. Every pixel that does not show the
+# cube (the labelled block this repo cannot build) is sky: the octant sky's sampling and the six view directions are pinned.
+@pytest.mark.parametrize("face", ["NX", "NY", "NZ", "PX", "PY", "PZ"])
+def test_png_sky(golden_dir, face):
+    sp, eye, look = scenes.sky_test_space(face)
+    cam = spawn_camera(COMMON_VIEWPORT, eye, look)
+    out = oracle.render(oracle.Space(sp), oracle.unaltered_colors(lighting=3), cam, threads=2, want_aux=True)
+    cube = np.asarray(out["aux"]["hit"]) != 0
+    d = neighbourhood_diff(out["rgba8"], np.load(golden_dir / f"png_sky-{face}-all.npy")).max(axis=-1)
+    grown = cube.copy()
+    grown[1:, :] |= cube[:-1, :]; grown[:-1, :] |= cube[1:, :]; grown[:, 1:] |= cube[:, :-1]; grown[:, :-1] |= cube[:, 1:]
+    d[grown] = 0
+    print(face, "cube pixels", int(cube.sum()), "difference histogram", np.bincount(d.ravel()))
+    assert 0.02 < cube.mean() < 0.5
+    assert d.max() <= 4
