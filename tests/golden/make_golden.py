@@ -58,6 +58,7 @@ PNG_CASES = [
     # compared under a mask (one block of the scene needs the text engine): see tests/test_oracle_goldens2.py
     "antialias-Always-ray", "antialias-None-all",
     *[f"sky-{f}-all" for f in ("NX", "NY", "NZ", "PX", "PY", "PZ")],
+    "viewport_zero-all", "viewport_zero-2-all", "layers_none_but_text-all",
 ]
 
 

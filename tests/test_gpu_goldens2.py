@@ -123,3 +123,23 @@ def test_sky(ctx, golden_dir, face):
     grown[1:, :] |= cube[:-1, :]; grown[:-1, :] |= cube[1:, :]; grown[:, 1:] |= cube[:, :-1]; grown[:, :-1] |= cube[:, 1:]
     d[grown] = 0
     assert d.max() <= 4
+
+
+@pytest.mark.parametrize("name,with_world", [("viewport_zero-all", True), ("viewport_zero-2-all", True), ("layers_none_but_text-all", False)])
+def test_text_overlay_cases(ctx, golden_dir, name, with_world):
+    """Frames whose goldens carry the host-side info text: compared outside the text's bounding region."""
+    from tests.test_oracle_goldens import TEXT_MASK
+    w, h = COMMON_VIEWPORT
+    if with_world:
+        ctx.upload_space(abi.LAYER_WORLD, scenes.one_cube_space())
+        ctx.set_options(abi.LAYER_WORLD, to_abi_options(oracle.unaltered_colors()))
+    else:
+        ctx.clear_space(abi.LAYER_WORLD)
+    ctx.clear_space(abi.LAYER_UI)
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, (0, 0, 0, 1), (0.5, 0.5, 2.0))
+    # a zero-area viewport first, as the case does: an empty image, and the renderer is fine afterwards
+    assert ctx.render(ctx.make_frame(0, 0, world_inv=inv))["rgba8"].shape == (0, 0, 4)
+    img = ctx.render(ctx.make_frame(w, h, world_inv=inv))["rgba8"]
+    d = diff_to(golden_dir, name, img).max(axis=-1)
+    d[TEXT_MASK] = 0
+    assert d.max() <= 2
