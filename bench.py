@@ -4,7 +4,7 @@
 Metric (BASELINE.json): Mrays/s (+ frames/s) at 1920x1080. One "step" = one frame of the hot
 path over the scene already resident in HBM: camera upload, (tile ordering,) trace kernel, and --
 for N > 1 -- the RCCL gather of the row strips to rank 0 plus the de-interleave. Frames are
-streamed the way a recording loop submits them: 2 traces in flight at N = 1 (4 at N > 1), a
+streamed the way a recording loop submits them: 2 traces in flight at N = 1 (4 at N = 2, 8 from N = 4), a
 frame's gather running under the next frames' traces; every frame issued in the timed region is
 complete, gathered and assembled before the clock stops; the K-step region is repeated until the
 regions add up to `--min-seconds` and the median region is reported (min / max beside it).
@@ -122,7 +122,7 @@ def main() -> int:
     ap.add_argument("--verify", dest="verify", action="store_true", default=None,
                     help="N > 1 (default there): check the assembled frame against a single-rank trace of the same frame")
     ap.add_argument("--no-verify", dest="verify", action="store_false")
-    ap.add_argument("--in-flight", type=int, default=0, help="frames traced concurrently (1..4); default 2 at N = 1, 4 at N > 1")
+    ap.add_argument("--in-flight", type=int, default=0, help="frames traced concurrently (1..8); default 2 at N = 1, 4 at N = 2..3, 8 at N >= 4")
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: gather each frame before tracing the next")
     ap.add_argument("--lighting", type=int, default=3, help="experiment: LightingOption (0 None,1 Flat,2 Coarse,3 Linear,4 Smoothstep); default Linear")
     ap.add_argument("--fog", type=int, default=1, help="experiment: FogOption (0 None,1 Abrupt,...); default Abrupt")
@@ -230,7 +230,8 @@ def main() -> int:
     # frame i's last rays finish) and, for N > 1, frame i-2's RCCL gather running under them.
     # --no-pipeline: one frame at a time, gathered before the next is traced.
     streamed = not args.no_pipeline
-    depth = max(1, min(4, args.in_flight if args.in_flight > 0 else (2 if world == 1 else 4)))  # traces in flight (AIC_MAX_IN_FLIGHT = 4)
+    # traces in flight (AIC_MAX_IN_FLIGHT = 8): a rank's share of a frame shrinks with N while a ray's latency does not
+    depth = max(1, min(8, args.in_flight if args.in_flight > 0 else (2 if world == 1 else (4 if world < 4 else 8))))
     ring = depth + 1 if streamed else 1
     pipe = D.StripGatherPipeline(h, w, strip, "cpu" if one_gpu_test else dev, depth=ring,
                                  wait_event=None if one_gpu_test else renderer.wait_event) if world > 1 else None

@@ -217,7 +217,7 @@ int aic_render(aic_ctx *ctx, const aic_frame_desc *frame, void *out_rgba8, int o
  * GPU while the previous frame's last rays finish. out_device must be a device pointer; the
  * AIC_FRAME_AUX flag is ignored here (use aic_render). Scene updates wait for every frame in
  * flight before touching device memory. */
-#define AIC_MAX_IN_FLIGHT 4u
+#define AIC_MAX_IN_FLIGHT 8u
 int aic_render_submit(aic_ctx *ctx, const aic_frame_desc *frame, void *out_device, uint32_t slot);
 int aic_render_wait(aic_ctx *ctx, uint32_t slot, aic_frame_info *info);
 /* replaces: RtScene::trace_patch (renderer.rs:418-451) for a batch of pixel rectangles -- the call
