@@ -428,11 +428,11 @@ def main() -> int:
         for k in range(n_l):
             cams.world_view_transform = views[k % 60]
             renderer.update()
-            if k >= 2:
-                renderer.wait_rows(k % 2)
-            renderer.submit_rows_to_device(render_target(k).data_ptr() if local_bufs is None else local_bufs[k % len(local_bufs)].data_ptr(), strip, world, rank, k % 2)
-        renderer.wait_rows(n_l % 2)
-        renderer.wait_rows((n_l + 1) % 2)
+            if k >= depth:
+                renderer.wait_rows(k % depth)
+            renderer.submit_rows_to_device(render_target(k).data_ptr() if local_bufs is None else local_bufs[k % len(local_bufs)].data_ptr(), strip, world, rank, k % depth)
+        for k in range(max(0, n_l - depth), n_l):
+            renderer.wait_rows(k % depth)
         moving_streamed = (time.perf_counter() - t1) / n_l * 1e3
         cams.world_view_transform = H.look_at_y_up(eye, target)
         renderer.update()
