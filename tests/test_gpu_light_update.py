@@ -376,7 +376,7 @@ def test_light_updater_fuzz(ctx, seed):
     maxd = int(rng.choice([2, 5, 12, 30]))
     batch = int(rng.choice([1, 5, 32, 100]))
     order = int(rng.choice([0, 8, 16]))
-    lanes = int(rng.choice([64, 256]))
+    lanes = int(rng.choice([1, 64, 256]))
     ref = copy.deepcopy(sp)
     n_ref = oracle.evaluate_light(ref, maximum_distance=maxd, fast=True, epsilon=1, batch=batch, hb_width=order)
     ctx.upload_space(abi.LAYER_WORLD, sp)
