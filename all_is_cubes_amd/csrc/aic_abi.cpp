@@ -145,6 +145,7 @@ struct aic_ctx {
     DevBuf<unsigned char> staging;  // scratch for scatter updates / probes
     DevBuf<DevOrthoView> ortho_views;  // aic_render_orthographic
     uint64_t aux_records = 0;
+    bool streaming_submit = false;  // set around aic_render_submit: frames meant to overlap are sized for throughput, synchronous ones for latency
     // frames in flight: slot 0 runs on `stream` (and serves the synchronous aic_render), slot 1 on a
     // second stream so that a submitted frame's trace can start while the previous one drains
     struct FrameSlot {
@@ -892,6 +893,7 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
     }
     F.light_lut = c->lut.p;
     F.n_cus = c->n_cus;
+    F.tiles_per_wave = c->streaming_submit ? 4u : 1u;
     F.srgb_thr = c->srgb_thr.p;
     F.counters = fs.counters.p;
 
@@ -1188,7 +1190,10 @@ int aic_render_submit(aic_ctx *c, const aic_frame_desc *f, void *out_device, uin
     if (!c || !f || slot >= AIC_MAX_IN_FLIGHT) return fail(c, AIC_ERR_INVALID, "aic_render_submit: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->slots[slot].busy) return fail(c, AIC_ERR_INVALID, "aic_render_submit: slot busy (aic_render_wait it first)");
-    return submit_frame(c, f, (uint32_t *)out_device, slot, false);
+    c->streaming_submit = true;
+    const int rc = submit_frame(c, f, (uint32_t *)out_device, slot, false);
+    c->streaming_submit = false;
+    return rc;
 }
 
 int aic_render_wait(aic_ctx *c, uint32_t slot, aic_frame_info *info) {

@@ -136,6 +136,7 @@ struct DevFrame {
     uint32_t macro;             // tiles are handed out macro x macro at a time (a power of two): neighbours stay together
     uint32_t macros_x, macros_y;  // macro-tile grid; tile_order / tile_cost are indexed by macro tile
     uint32_t n_cus;          // compute units of the device (sizes the persistent grid)
+    uint32_t tiles_per_wave; // host-side: tiles a wave should get on average when the frame is smaller than the chip (1 = latency, 4 = streamed frames)
     int32_t pass;            // 0: final pass (world layer + encode); 1: UI pre-pass
     int32_t use_init;        // final pass: start each sample from acc_buf (written by the UI pre-pass)
     int32_t pixel_centers;   // AIC_FRAME_PIXEL_CENTERS

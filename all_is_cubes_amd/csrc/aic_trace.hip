@@ -1832,12 +1832,13 @@ static void launch_trace(const DevFrame &F, hipStream_t stream) {
     const uint32_t n_tiles = F.tiles_x * F.tiles_y;
     const uint32_t wg_waves = (uint32_t)AIC_WG_THREADS / 64u;
     const uint32_t resident_groups = F.n_cus * 4u * (uint32_t)(DIAG ? 2 : AIC_MIN_WAVES) / wg_waves;  // 4 SIMDs per CU, that many waves on each
-    // A frame smaller than the chip (a rank's strips of a multi-GPU frame) gets a grid in proportion to its tiles -- four
-    // tiles per wave, so that lanes are refilled instead of waves ending after one tile, and the kernels of several such
-    // frames in flight are resident side by side (an eighth of a 1080p frame, 8 in flight: 0.111 ms per frame against
-    // 0.138 with one tile per wave) -- but never fewer than 128 workgroups' worth of waves when the tiles allow it: a tiny
-    // frame (an icon, the 64x64 bench scene) is a matter of latency, not of occupancy.
-    static const uint32_t tiles_per_wave = [] { const char *e = std::getenv("AIC_TILES_PER_WAVE"); const int v = e ? std::atoi(e) : 4; return (uint32_t)(v > 0 ? v : 4); }();
+    // A frame smaller than the chip that is STREAMED (aic_render_submit: a rank's strips of a multi-GPU frame, several in
+    // flight) gets a grid in proportion to its tiles -- four tiles per wave, so that lanes are refilled instead of waves ending
+    // after one tile, and the kernels of the frames in flight are resident side by side (an eighth of a 1080p frame, 8 in
+    // flight: 0.105 ms per frame against 0.138 with one tile per wave). A synchronous frame (aic_render) is a matter of
+    // latency: one tile per wave, as many waves as there are tiles.
+    static const uint32_t tpw_override = [] { const char *e = std::getenv("AIC_TILES_PER_WAVE"); const int v = e ? std::atoi(e) : 0; return (uint32_t)(v > 0 ? v : 0); }();
+    const uint32_t tiles_per_wave = tpw_override ? tpw_override : (F.tiles_per_wave ? F.tiles_per_wave : 1u);
     const uint32_t by_tiles = (n_tiles + wg_waves - 1u) / wg_waves;
     uint32_t grid = (n_tiles + wg_waves * tiles_per_wave - 1u) / (wg_waves * tiles_per_wave);
     const uint32_t floor_groups = by_tiles < 128u ? by_tiles : 128u;
