@@ -454,6 +454,30 @@ def main() -> int:
             renderer.draw_rgba("")
         fps_with_readback = n_rb / (time.perf_counter() - t1)
 
+    # The reference's own Criterion benches (all-is-cubes-render/benches/raytrace.rs:92-114) time `renderer.draw_rgba(..)` -- a finished
+    # 64x64 image in host memory -- for two option sets; the same call, the same scene, the same two option sets, per call:
+    criterion = None
+    if world == 1 and args.workload == "light-bench" and not args.no_extras:
+        criterion = {}
+        for bench_name, lighting_kind in (("flat-surface", 1), ("linear-surface", 3)):
+            o2 = H.GraphicsOptions()
+            o2.transparency = H.TransparencyOption(H.TransparencyKind(0))
+            o2.lighting_display = H.LightingOption(H.LightingKind(lighting_kind))
+            cams.graphics_options = o2
+            renderer.update()
+            for _ in range(20):
+                renderer.draw_rgba("")
+            ts = []
+            for _ in range(300):
+                t1 = time.perf_counter()
+                renderer.draw_rgba("")
+                ts.append((time.perf_counter() - t1) * 1e6)
+            criterion[bench_name] = {"median_us": round(float(np.median(ts)), 2), "min_us": round(float(np.min(ts)), 2), "samples": len(ts)}
+        criterion["note"] = ("wall time of HipRtRenderer.draw_rgba (64x64 image delivered to host memory), as the reference's Criterion group "
+                             "'threaded'/'serial' measures RtRenderer::draw_rgba; GraphicsOptions::default() + the bench's two changes")
+        cams.graphics_options = opts
+        renderer.update()
+
     # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs of
     # this same command, corrected as MI355X_MICROARCH.md prescribes; tools/measure.sh +
     # tools/summarize_profile.py). PMC collection cannot run inside the timed bench, so the
@@ -547,6 +571,8 @@ def main() -> int:
         if single is not None:
             result["single_frame"] = single
             result["streamed_ms"] = round(ms_per_step, 4) if streamed else None
+        if criterion is not None:
+            result["criterion_equivalent"] = criterion
         if light_update is not None:
             result["light_update"] = light_update
         if relight is not None and relight["calls"]:
