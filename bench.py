@@ -626,10 +626,17 @@ def cpu_baseline(flat_space, opts, w, h, eye, target, view_distance, target_seco
     threads, cpu_note = usable_cpus()
     extra = {}
     if (np.asarray(flat_space.light)[..., 3] == 0).all():  # light-bench: the GPU leg lit the space on the device; here the oracle does
+        import copy
+        one = copy.deepcopy(flat_space)
         t_l = time.perf_counter()
-        n_upd = oracle.evaluate_light(flat_space, maximum_distance=30, fast=True, epsilon=1, batch=32, hb_width=16)
+        oracle.evaluate_light(one, maximum_distance=30, fast=True, epsilon=1, batch=32, hb_width=16, threads=1)
+        dt_one = time.perf_counter() - t_l
+        # the reference computes a batch's 32 cubes on its rayon pool (updater.rs:231-247): the port does the same on `threads` threads
+        t_l = time.perf_counter()
+        n_upd = oracle.evaluate_light(flat_space, maximum_distance=30, fast=True, epsilon=1, batch=32, hb_width=16, threads=threads)
         dt_l = time.perf_counter() - t_l
-        extra["light_update"] = {"updates": int(n_upd), "total_ms": round(dt_l * 1e3, 1), "updates_per_s": round(n_upd / dt_l, 1), "cores": 1}
+        extra["light_update"] = {"updates": int(n_upd), "total_ms": round(dt_l * 1e3, 1), "updates_per_s": round(n_upd / dt_l, 1), "cores": threads,
+                                 "one_core_ms": round(dt_one * 1e3, 1)}
     sp = oracle.Space(flat_space)
     oo = oracle.make_options(fog=int(opts.fog), transparency=int(opts.transparency.kind), lighting=int(opts.lighting_display.kind),
                              view_distance=view_distance)

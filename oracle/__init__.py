@@ -425,7 +425,7 @@ def compute_light(space: Space, cube, maximum_distance: int = 30):
 
 
 def evaluate_light(flat_space, maximum_distance: int = 30, fast: bool = True, epsilon: int = 1, batch: int = 32,
-                   queue=None, max_updates: int = 1 << 62, hb_width: int = 16):
+                   queue=None, max_updates: int = 1 << 62, hb_width: int = 16, threads: int = 1):
     """`Mutation::fast_evaluate_light()` (if `fast`) + `evaluate_light(epsilon)` on a flat space with
     `LightPhysics::Rays { maximum_distance }`. Without `fast`, starts from `flat_space.light` and `queue`
     (a list of (cube, priority)); `queue=None` enqueues every Uninitialized cube. Writes the result into
@@ -433,6 +433,7 @@ def evaluate_light(flat_space, maximum_distance: int = 30, fast: bool = True, ep
     the reference's hashbrown table order with that Group::WIDTH, 0 = first-in-first-out (aic_light.inc)."""
     sp = Space(flat_space)
     light = np.ascontiguousarray(flat_space.light, dtype=np.uint8).copy()
+    lib().orc_set_light_threads(C.c_int32(threads))  # a batch's compute_light calls on that many threads (results unchanged)
     f = lib().orc_evaluate_light
     f.restype = C.c_uint64
     if queue is None:

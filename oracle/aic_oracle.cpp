@@ -33,6 +33,8 @@
 #include <cstring>
 #include <limits>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <vector>
 
 namespace {

@@ -186,6 +186,7 @@ uint32_t orc_light_chart(float *weights, uint32_t *children);
 /* LightStorage::compute_light (updater.rs:368-417) for one cube against space->light; returns the cost */
 uint64_t orc_compute_light(const orc_space *space, int32_t maximum_distance, const int32_t cube[3], uint8_t out_texel[4]);
 /* Mutation::fast_evaluate_light / evaluate_light (space.rs:1496-1540); see aic_light.inc */
+void orc_set_light_threads(int32_t n);
 uint64_t orc_evaluate_light(const orc_space *space, int32_t maximum_distance, int32_t fast, int32_t epsilon, int32_t batch,
                             uint64_t max_updates, uint8_t *light_inout, int32_t n_queue, const int32_t *queue_cubes,
                             const int32_t *queue_priorities, int32_t hb_width);
