@@ -73,6 +73,7 @@ struct LightJob {
     const uint32_t *child_pos; // [n_tree][6 faces]: the position of the child stepped to through that face, 0 = none
     float4 *terms;             // [waves][4 * n_tree]: (incoming r, g, b; ray weight) by recursion-order number
     uint32_t *cands;           // [waves][2 * n_tree]: dependency candidates (cube offset | conditional << 30)
+    uint2 *vlist;              // [waves][n_tree]: the bundles the walk visits, level after level: {tree position, alpha it is entered with}
 };
 
 void launch_compute_light(const LightJob &job, hipStream_t stream);
