@@ -630,38 +630,42 @@ struct WaveCtx {
 };
 
 // Gathers set bits of bits[*word_io, n_words) into order[] in ascending order -- all of them if they fit kOrderCap, else
-// the longest prefix of words that does -- and advances *word_io. All 64 lanes take part (no divergence around the call).
-// Returns the number gathered; 0 = nothing left; 0xffffffff = this span was empty but words remain.
-__device__ uint32_t gather_set_bits(const uint32_t *bits, uint32_t n_words, uint32_t *word_io, uint32_t *order, uint32_t tid, uint32_t *s_bcast) {
+// the longest prefix of words that does -- and advances *word_io. All threads of the block take part (no divergence
+// around the call): each counts and then writes out a contiguous stretch of words; `s_scan` (>= 4 words) carries the
+// waves' counts. Returns the number gathered; 0 = nothing left; 0xffffffff = this span was empty but words remain.
+__device__ uint32_t gather_set_bits(const uint32_t *bits, uint32_t n_words, uint32_t *word_io, uint32_t *order, uint32_t tid, uint32_t nt, uint32_t *s_scan) {
     const uint32_t w0 = *word_io;
     if (w0 >= n_words) return 0u;
-    if (tid < 64u) {  // the first wave gathers (wave shuffles); the other waves of the block wait at the barrier
-        const uint32_t lane = tid;
-        uint32_t span = n_words - w0, a, e, count, incl, total;
-        for (;;) {
-            const uint32_t per = (span + 63u) / 64u;
-            a = min(w0 + lane * per, w0 + span);
-            e = min(a + per, w0 + span);
-            count = 0u;
-            for (uint32_t w = a; w < e; w++) count += __popc(bits[w]);
-            incl = count;
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up = __shfl_up(incl, d, 64);
-                if ((int)lane >= d) incl += up;
-            }
-            total = __shfl(incl, 63, 64);
-            if (total <= kOrderCap || span <= kOrderCap / 32u) break;
-            span = max(kOrderCap / 32u, span / 2u);
+    const uint32_t wl = tid & 63u, wid = tid >> 6, nw = nt >> 6;
+    uint32_t span = n_words - w0, a, e, count, incl, total, base;
+    for (;;) {
+        const uint32_t per = (span + nt - 1u) / nt;
+        a = min(w0 + tid * per, w0 + span);
+        e = min(a + per, w0 + span);
+        count = 0u;
+        for (uint32_t w = a; w < e; w++) count += __popc(bits[w]);
+        incl = count;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if ((int)wl >= d) incl += up;
         }
-        uint32_t at = incl - count;
-        for (uint32_t w = a; w < e; w++) {
-            uint32_t v = bits[w];
-            while (v) { const uint32_t bpos = __ffs(v) - 1u; v &= v - 1u; order[at++] = w * 32u + bpos; }
+        if (wl == 63u) s_scan[wid] = incl;
+        __syncthreads();
+        base = 0u; total = 0u;
+        for (uint32_t q = 0u; q < nw; q++) {
+            const uint32_t t = s_scan[q];
+            if (q < wid) base += t;
+            total += t;
         }
-        if (lane == 0u) { s_bcast[0] = total; s_bcast[1] = span; }
+        __syncthreads();
+        if (total <= kOrderCap || span <= kOrderCap / 32u) break;
+        span = max(kOrderCap / 32u, span / 2u);
     }
-    __syncthreads();
-    const uint32_t total = s_bcast[0], span = s_bcast[1];
+    uint32_t at = base + incl - count;
+    for (uint32_t w = a; w < e; w++) {
+        uint32_t v = bits[w];
+        while (v) { const uint32_t bpos = __ffs(v) - 1u; v &= v - 1u; order[at++] = w * 32u + bpos; }
+    }
     __syncthreads();
     *word_io = w0 + span;
     return total == 0u ? 0xffffffffu : total;
@@ -671,8 +675,9 @@ __global__ void __launch_bounds__(kLightBlock) compute_light_wave_kernel(const L
     extern __shared__ uint32_t s_dyn[];  // term bitmap, candidate bitmap
     __shared__ uint32_t s_flags[kLdsFlags];
     __shared__ float s_lut[256];
-    __shared__ uint32_t s_count[2], s_cost[kLightBlock], s_bcast[2];
-    __shared__ float4 s_stage[64];
+    __shared__ uint32_t s_count[2], s_scan[4], s_chunk[8], s_first;
+    __shared__ float s_sum[4];
+    __shared__ float4 s_stage[kLightBlock];
     __shared__ uint32_t s_order[kOrderCap];
     const uint32_t lane = threadIdx.x, wave = blockIdx.x, nt = blockDim.x;  // `lane`: thread of the cube's block (1 or 4 waves)
     const uint32_t term_words = (4u * J.n_tree + 31u) / 32u, cand_words = (2u * J.n_tree + 31u) / 32u;
@@ -759,6 +764,9 @@ __global__ void __launch_bounds__(kLightBlock) compute_light_wave_kernel(const L
                 hi = s_count[0];
                 __syncthreads();
             }
+#ifdef AIC_LIGHT_TIMING
+            if (lane == 0u) atomicAdd(&J.dep_head[6], (uint32_t)((clock64() - t_begin) >> 6));
+#endif
             // 2. what every visited bundle adds: independent of one another, all lanes at once
             for (uint32_t i = lane; i < hi; i += nt) {
                 const uint2 it = vlist[i];
@@ -769,7 +777,13 @@ __global__ void __launch_bounds__(kLightBlock) compute_light_wave_kernel(const L
                 (void)b.visit(it.x, __uint_as_float(it.y), &alpha);
             }
         }
-        s_cost[lane] = b.cost;
+        uint32_t cost = b.cost;  // summed over the block: an integer, any order
+        for (int d = 32; d > 0; d >>= 1) cost += __shfl_down(cost, d, 64);
+        if ((lane & 63u) == 0u) s_scan[lane >> 6] = cost;
+        if (lane == 0u) s_first = 0xffffffffu;
+        __syncthreads();
+        cost = 0u;
+        for (uint32_t q = 0u; q < (nt >> 6); q++) cost += s_scan[q];
         __syncthreads();
 #ifdef AIC_LIGHT_TIMING
         const long long t_walk = clock64();
@@ -777,80 +791,114 @@ __global__ void __launch_bounds__(kLightBlock) compute_light_wave_kernel(const L
         atomicAdd(&J.dep_head[5], n_visits);
 #endif
 
-        // ordered reduction
+        // Ordered reduction. The set bits in ascending order are the reference's order of additions. They are gathered by
+        // the whole block, the terms fetched a block's worth at a time (the next fetch in flight while this one is added),
+        // and lanes 0..3 add them in that order: red, green, blue and the weight, one chain of f32 additions each, which is
+        // what `LightBuffer` does to its four accumulators.
         float inc[3] = {0.f, 0.f, 0.f}, total = 0.f;
-        uint32_t n_deps = 0u, first_chunk = 0xffffffffu, cur_chunk = 0xffffffffu, fill = kLightDepChunk;
-        [[maybe_unused]] uint32_t n_terms = 0u;
+        uint32_t n_deps = 0u;
         if (origin_is_opaque) {
             if (origin_emits) {  // add_weighted_light(emission, 1.0)
                 for (int i = 0; i < 3; i++) inc[i] += ps_mul(ev_origin->emission[i], ps_new_clamped(1.0f));
                 total += 1.0f;
             }
         } else {
+            float acc = 0.f;
             uint32_t word = 0u;
             for (;;) {
-                const uint32_t got = gather_set_bits(term_bits, term_words, &word, s_order, lane, s_bcast);
+                const uint32_t got = gather_set_bits(term_bits, term_words, &word, s_order, lane, nt, s_scan);
                 if (got == 0u) break;
                 if (got == 0xffffffffu) continue;
-                n_terms += got;
-                for (uint32_t c0 = 0u; c0 < got; c0 += 64u) {  // 64 terms at a time: fetched by all lanes, added by lane 0 in order
-                    const uint32_t m = min(64u, got - c0);
-                    if (lane < m) s_stage[lane] = b.slots[s_order[c0 + lane]];
+                float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (lane < got) nxt = b.slots[s_order[lane]];
+                for (uint32_t c0 = 0u; c0 < got; c0 += nt) {
+                    const uint32_t m = min(nt, got - c0);
+                    s_stage[lane] = nxt;
                     __syncthreads();
-                    if (lane == 0u) {
-#pragma unroll 8
-                        for (uint32_t i = 0u; i < m; i++) {
-                            const float4 v = s_stage[i];
-                            inc[0] += v.x; inc[1] += v.y; inc[2] += v.z; total += v.w;
-                        }
+                    if (c0 + nt + lane < got) nxt = b.slots[s_order[c0 + nt + lane]];
+                    if (lane < 4u) {
+                        const float *sf = reinterpret_cast<const float *>(s_stage) + lane;
+#pragma unroll 16
+                        for (uint32_t i = 0u; i < m; i++) acc += sf[4u * i];
                     }
                     __syncthreads();
                 }
             }
-            uint32_t last = 0xffffffffu;
+            if (lane < 4u) s_sum[lane] = acc;
+            // Dependencies: a candidate is dropped if it is a face cube equal to the candidate before it (`if
+            // dependencies.last() != Some(&light_cube)`, updater.rs:838-842 -- "the last pushed" and "the candidate before" are
+            // the same cube whenever the test can succeed) or lies outside the space (light_needs_update ignores those); the
+            // kept ones go to the cube's chunk list in order, a block's worth at a time.
+            uint32_t prev_key = 0xffffffffu, cur_chunk = 0xffffffffu;
+            uint32_t *const s_keys = reinterpret_cast<uint32_t *>(s_stage);
+            const uint32_t wl = lane & 63u, wid = lane >> 6;
             word = 0u;
             for (;;) {
-                const uint32_t got = gather_set_bits(cand_bits, cand_words, &word, s_order, lane, s_bcast);
+                const uint32_t got = gather_set_bits(cand_bits, cand_words, &word, s_order, lane, nt, s_scan);
                 if (got == 0u) break;
                 if (got == 0xffffffffu) continue;
-                for (uint32_t c0 = 0u; c0 < got; c0 += 64u) {
-                    const uint32_t m = min(64u, got - c0);
-                    if (lane < m) s_stage[lane].x = __uint_as_float(b.cslots[s_order[c0 + lane]]);
+                uint32_t nxt = 0u;
+                if (lane < got) nxt = b.cslots[s_order[lane]];
+                for (uint32_t c0 = 0u; c0 < got; c0 += nt) {
+                    const uint32_t m = min(nt, got - c0);
+                    const uint32_t cnd = nxt, key = cnd & 0x3fffffffu;
+                    s_keys[lane] = key;
                     __syncthreads();
-                    if (lane == 0u) {
-                        for (uint32_t i = 0u; i < m; i++) {
-                            const uint32_t c = __float_as_uint(s_stage[i].x), key = c & 0x3fffffffu;
-                            if ((c >> 30) && key == last) continue;  // `if dependencies.last() != Some(&light_cube)`
-                            last = key;
-                            const int cube[3] = {b.origin[0] + (int)(key & 1023u) - 256, b.origin[1] + (int)((key >> 10) & 1023u) - 256,
-                                                 b.origin[2] + (int)((key >> 20) & 1023u) - 256};
-                            uint32_t idx;
-                            if (!b.index_of(cube, &idx)) continue;  // light_needs_update ignores cubes outside the space
-                            if (fill == kLightDepChunk) {
-                                const uint32_t next = atomicAdd(&J.dep_head[0], 1u);
-                                if (next >= J.dep_chunks) {
-                                    J.dep_head[1] = 1u;
-                                    cur_chunk = 0xffffffffu;
-                                } else {
-                                    J.dep_pool[(size_t)next * kLightDepChunk] = 0xffffffffu;
-                                    if (cur_chunk != 0xffffffffu) J.dep_pool[(size_t)cur_chunk * kLightDepChunk] = next;
-                                    else if (n_deps == 0u) first_chunk = next;
-                                    cur_chunk = next;
-                                }
-                                fill = 1u;
+                    if (c0 + nt + lane < got) nxt = b.cslots[s_order[c0 + nt + lane]];
+                    const uint32_t before = lane ? s_keys[lane - 1u] : prev_key;
+                    const uint32_t last_key = s_keys[m - 1u];
+                    bool keep = lane < m && !((cnd >> 30) && key == before);
+                    uint32_t idx = 0u;
+                    if (keep) {
+                        const int cube[3] = {b.origin[0] + (int)(key & 1023u) - 256, b.origin[1] + (int)((key >> 10) & 1023u) - 256,
+                                             b.origin[2] + (int)((key >> 20) & 1023u) - 256};
+                        keep = b.index_of(cube, &idx);
+                    }
+                    const unsigned long long kept = __ballot(keep);
+                    if (wl == 0u) s_scan[wid] = (uint32_t)__popcll(kept);
+                    __syncthreads();
+                    uint32_t base = 0u, stage_total = 0u;
+                    for (uint32_t q = 0u; q < (nt >> 6); q++) {
+                        const uint32_t t = s_scan[q];
+                        if (q < wid) base += t;
+                        stage_total += t;
+                    }
+                    // the chunks this stretch of the list needs: 63 dependencies per chunk behind its link word
+                    const uint32_t first_ord = n_deps / (kLightDepChunk - 1u);
+                    const uint32_t last_ord = (n_deps + stage_total - 1u) / (kLightDepChunk - 1u);  // unused when stage_total == 0
+                    if (lane == 0u && stage_total != 0u) {
+                        uint32_t cc = cur_chunk;
+                        s_chunk[0] = cc;
+                        for (uint32_t ord = first_ord + (n_deps % (kLightDepChunk - 1u) != 0u ? 1u : 0u); ord <= last_ord; ord++) {
+                            const uint32_t next = atomicAdd(&J.dep_head[0], 1u);
+                            if (next >= J.dep_chunks) {
+                                J.dep_head[1] = 1u;  // the host grows the pool and computes the batch again
+                                cc = 0xffffffffu;
+                            } else {
+                                J.dep_pool[(size_t)next * kLightDepChunk] = 0xffffffffu;
+                                if (cc != 0xffffffffu) J.dep_pool[(size_t)cc * kLightDepChunk] = next;
+                                else if (ord == 0u) s_first = next;
+                                cc = next;
                             }
-                            if (cur_chunk != 0xffffffffu) J.dep_pool[(size_t)cur_chunk * kLightDepChunk + fill] = idx;
-                            fill++;
-                            n_deps++;
+                            s_chunk[ord - first_ord] = cc;
                         }
                     }
                     __syncthreads();
+                    if (keep) {
+                        const uint32_t d = n_deps + base + (uint32_t)__popcll(kept & ((1ull << wl) - 1ull));
+                        const uint32_t chunk = s_chunk[d / (kLightDepChunk - 1u) - first_ord];
+                        if (chunk != 0xffffffffu) J.dep_pool[(size_t)chunk * kLightDepChunk + 1u + d % (kLightDepChunk - 1u)] = idx;
+                    }
+                    if (stage_total != 0u) cur_chunk = s_chunk[last_ord - first_ord];
+                    n_deps += stage_total;
+                    prev_key = last_key;
+                    __syncthreads();
                 }
             }
+            if (lane == 0u) { inc[0] = s_sum[0]; inc[1] = s_sum[1]; inc[2] = s_sum[2]; total = s_sum[3]; }
         }
         if (lane == 0u) {
-            uint32_t cost = 0u;
-            for (uint32_t l = 0u; l < nt; l++) cost += s_cost[l];
+            const uint32_t first_chunk = s_first;
             // LightBuffer::finish (updater.rs:940-952)
             uint32_t texel;
             const float scale = ps_new_clamped(1.0f / fmaxf(total, 1.0f));
@@ -869,7 +917,6 @@ __global__ void __launch_bounds__(kLightBlock) compute_light_wave_kernel(const L
             o[3] = cost;
 #ifdef AIC_LIGHT_TIMING
             atomicAdd(&J.dep_head[3], (uint32_t)((clock64() - t_walk) >> 6));
-            atomicAdd(&J.dep_head[6], n_terms);
             atomicAdd(&J.dep_head[7], n_deps);
 #endif
         }
