@@ -79,6 +79,16 @@ struct LightJob {
 void launch_compute_light(const LightJob &job, hipStream_t stream);
 void launch_compute_light_waves(const LightJob &job, uint32_t n_blocks, uint32_t threads_per_cube, hipStream_t stream);
 void launch_scatter_light(uint32_t *light, const uint32_t *index, const uint32_t *texel, uint32_t n, hipStream_t stream);
+
+// What a small batch needs done on the device before its launch, passed in the kernel argument itself (no copies): the
+// texels the previous batch changed, this batch's cubes, and the cleared counters.
+static constexpr uint32_t kLightPrepMax = 64;
+struct LightPrep {
+    uint32_t *light, *cubes_out, *head;
+    uint32_t n_scatter, n_cubes;
+    uint32_t scatter_index[kLightPrepMax], scatter_texel[kLightPrepMax], cubes[kLightPrepMax];
+};
+void launch_prepare_light_batch(const LightPrep &prep, hipStream_t stream);
 void launch_probe_log2f(const float *x, float *out, uint32_t n, hipStream_t stream);
 
 }  // namespace aic

@@ -929,6 +929,13 @@ __global__ void scatter_light_kernel(uint32_t *light, const uint32_t *index, con
     if (i < n) light[index[i]] = texel[i];
 }
 
+__global__ void __launch_bounds__(64) prepare_light_batch_kernel(const LightPrep P) {
+    const uint32_t i = threadIdx.x;
+    if (i < P.n_scatter) P.light[P.scatter_index[i]] = P.scatter_texel[i];
+    if (i < P.n_cubes) P.cubes_out[i] = P.cubes[i];
+    if (i < 8u) P.head[i] = 0u;
+}
+
 __global__ void probe_log2f_kernel(const float *x, float *out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = log2f_exact(x[i]);
@@ -959,6 +966,10 @@ void launch_compute_light_waves(const LightJob &job, uint32_t n_waves, uint32_t 
 void launch_scatter_light(uint32_t *light, const uint32_t *index, const uint32_t *texel, uint32_t n, hipStream_t stream) {
     if (!n) return;
     hipLaunchKernelGGL(scatter_light_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, light, index, texel, n);
+}
+
+void launch_prepare_light_batch(const LightPrep &prep, hipStream_t stream) {
+    hipLaunchKernelGGL(prepare_light_batch_kernel, dim3(1), dim3(64), 0, stream, prep);
 }
 
 void launch_probe_log2f(const float *x, float *out, uint32_t n, hipStream_t stream) {
