@@ -70,10 +70,10 @@ struct LightJob {
     const DevTreePos *tree;
     uint32_t n_tree;
     const float *child_w;      // [n_tree][6 faces][6]: the weights of each position's children (zeros where there is none)
-    const uint32_t *child_pos; // [n_tree][6 faces]: the position of the child stepped to through that face, 0 = none
+    const uint2 *child_ent;    // [n_tree][6 faces]: the child stepped to through that face: {position | (info & 15) << 28, offset}; position 0 = none
     float4 *terms;             // [waves][4 * n_tree]: (incoming r, g, b; ray weight) by recursion-order number
     uint32_t *cands;           // [waves][2 * n_tree]: dependency candidates (cube offset | conditional << 30)
-    uint2 *vlist;              // [waves][n_tree]: the bundles the walk visits, level after level: {tree position, alpha it is entered with}
+    uint4 *vlist;              // [waves][n_tree]: the bundles the walk visits, level after level: {tree position, alpha it is entered with, offset, info & 15}
 };
 
 void launch_compute_light(const LightJob &job, hipStream_t stream);

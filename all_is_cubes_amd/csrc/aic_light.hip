@@ -505,19 +505,10 @@ struct WaveCtx {
     // The part of walk_ray_tree that the bundle's CHILDREN depend on: is the bundle alive behind its cube, and with what
     // alpha (updater.rs:440-496; the alpha arithmetic of LightBuffer::traverse, updater.rs:800-893, without the light it
     // gathers). This is the critical path of the walk -- one level waits for the one before -- so it is kept apart from
-    // `visit`, which computes what the bundle adds to the light and depends on nothing but {k, alpha_in}.
-    __device__ bool expand(uint32_t k, float alpha_in, float *alpha_out) const {
-        const DevTreePos *nd = &J.tree[k];
-        float w[6];
-        for (int f = 0; f < 6; f++) w[f] = nd->weight[f];
-        const uint32_t info = nd->info, off = nd->offset, end = nd->end;
-        if (bundle_weight(w) <= 0.0f) return false;
-        if (info & 8u) return false;
-        const int cube[3] = {origin[0] + (int)(off & 1023u) - 256, origin[1] + (int)((off >> 10) & 1023u) - 256, origin[2] + (int)((off >> 20) & 1023u) - 256};
-        uint32_t idx;
-        if (!index_of(cube, &idx)) return false;
-        const int fe = (info & 7u) == 7u ? -1 : (int)(info & 7u);
-        const uint32_t block = J.grid[idx] & J.index_mask;
+    // `visit`, which computes what the bundle adds to the light and depends on nothing but {k, alpha_in}. `block` is the
+    // block at the bundle's cube, `fi` the face the bundle enters it through (7: the origin cube).
+    __device__ bool alpha_behind(uint32_t block, uint32_t fi, float alpha_in, float *alpha_out) const {
+        const int fe = fi == 7u ? -1 : (int)fi;
         const uint32_t flags = flags_of(block);
         float alpha = alpha_in;
         if (flags & kDerivedVisible) {
@@ -534,9 +525,8 @@ struct WaveCtx {
                 if (hit_alpha < 1.0f) alpha *= 1.0f - hit_alpha;
             }
         }
-        if (!(alpha > 0.0f)) return false;
         *alpha_out = alpha;
-        return end > k + 1u;
+        return alpha > 0.0f;
     }
     // walk_ray_tree (updater.rs:427-530) for the bundle at tree position k, entered with alpha_in. Returns whether its
     // children are to be walked, then *alpha_out is the alpha behind the cube. Everything the bundle adds -- on entering
@@ -734,29 +724,41 @@ __global__ void __launch_bounds__(kLightBlock) compute_light_wave_kernel(const L
                 }
             }
             b.m0 = m0;
-            uint2 *const vlist = J.vlist + (size_t)wave * J.n_tree;
-            if (lane == 0u) { vlist[0] = make_uint2(0u, __float_as_uint(1.0f)); s_count[0] = 1u; }
+            uint4 *const vlist = J.vlist + (size_t)wave * J.n_tree;
+            if (lane == 0u) { vlist[0] = make_uint4(0u, __float_as_uint(1.0f), J.tree[0].offset, J.tree[0].info & 15u); s_count[0] = 1u; }
             __syncthreads();
             // 1. which bundles does the walk visit? Level by level: a level's bundles decide their children's alpha. The list of
             //    visited bundles doubles as the frontier: level L is the stretch [lo, hi) that level L-1 appended.
-            //    (A frontier kept in LDS beside the list was measured slower: 0.50 s against 0.43 s for the bench scene.)
+            //    A level is a chain of dependent fetches and little else, so the chain is kept short: an entry carries its
+            //    cube offset and face, and everything that depends on the entry alone -- the cube's block, the bundle's
+            //    weights, its children -- is fetched side by side before anything is decided.
             uint32_t lo = 0u, hi = 1u;
             while (lo < hi) {
 #ifdef AIC_LIGHT_TIMING
                 n_rounds++;
 #endif
                 for (uint32_t i = lo + lane; i < hi; i += nt) {
-                    const uint2 it = vlist[i];
+                    const uint4 it = vlist[i];
+                    const uint2 *ce = J.child_ent + (size_t)it.x * 6u;
+                    uint2 ch[6];
+                    for (int f = 0; f < 6; f++) ch[f] = ce[f];
+                    const DevTreePos *nd = &J.tree[it.x];
+                    float w[6];
+                    for (int f = 0; f < 6; f++) w[f] = nd->weight[f];
+                    const int cube[3] = {b.origin[0] + (int)(it.z & 1023u) - 256, b.origin[1] + (int)((it.z >> 10) & 1023u) - 256,
+                                         b.origin[2] + (int)((it.z >> 20) & 1023u) - 256};
+                    uint32_t idx = 0u;
+                    const bool inside = b.index_of(cube, &idx);
+                    uint32_t block = J.grid[idx] & J.index_mask;  // cube 0's if outside: unused then
+                    uint32_t nch = 0u;
+                    for (int f = 0; f < 6; f++) nch += ch[f].x != 0u;
+                    float bw = b.bundle_weight(w);
+                    asm volatile("" : "+v"(nch), "+v"(bw), "+v"(block));  // the three fetches stay here, ahead of the decisions
                     float alpha;
-                    if (b.expand(it.x, __uint_as_float(it.y), &alpha)) {
-                        const uint32_t *cp = J.child_pos + (size_t)it.x * 6u;
-                        uint32_t ch[6];
-                        for (int f = 0; f < 6; f++) ch[f] = cp[f];
-                        uint32_t nch = 0u;
-                        for (int f = 0; f < 6; f++) nch += ch[f] != 0u;
+                    if (!(it.w & 8u) && inside && bw > 0.0f && b.alpha_behind(block, it.w & 7u, __uint_as_float(it.y), &alpha) && nch != 0u) {
                         uint32_t at = atomicAdd(&s_count[0], nch);
                         for (int f = 0; f < 6; f++)
-                            if (ch[f] != 0u) vlist[at++] = make_uint2(ch[f], __float_as_uint(alpha));
+                            if (ch[f].x != 0u) vlist[at++] = make_uint4(ch[f].x & 0x0fffffffu, __float_as_uint(alpha), ch[f].y, ch[f].x >> 28);
                     }
                 }
                 __syncthreads();
@@ -769,7 +771,7 @@ __global__ void __launch_bounds__(kLightBlock) compute_light_wave_kernel(const L
 #endif
             // 2. what every visited bundle adds: independent of one another, all lanes at once
             for (uint32_t i = lane; i < hi; i += nt) {
-                const uint2 it = vlist[i];
+                const uint4 it = vlist[i];
                 float alpha;
 #ifdef AIC_LIGHT_TIMING
                 n_visits++;
