@@ -702,31 +702,35 @@ __global__ void __launch_bounds__(kLightBlock) compute_light_wave_kernel(const L
         if (!origin_is_opaque) {
             for (uint32_t i = lane; i < term_words + cand_words; i += nt) s_dyn[i] = 0u;
             // directions_to_seek_light (updater.rs:668-690)
-            uint32_t m0 = 0u;
-            if (ev_origin->flags & kDerivedVisible) m0 = 63u;
-            else {
-                bool nb_visible[6], nb_emits[6];
-                for (int f = 0; f < 6; f++) {
-                    int n[3];
-                    normal_of(f, n);
-                    const int c[3] = {b.origin[0] + n[0], b.origin[1] + n[1], b.origin[2] + n[2]};
-                    uint32_t i;
-                    nb_visible[f] = false; nb_emits[f] = false;
-                    if (b.index_of(c, &i)) {
-                        const DevDerived *d = &J.derived[J.grid[i] & J.index_mask];
-                        nb_visible[f] = (d->flags & kDerivedVisible) != 0u;
-                        nb_emits[f] = !(d->emission[0] == 0.f && d->emission[1] == 0.f && d->emission[2] == 0.f);
-                    }
-                }
-                for (int f = 0; f < 6; f++) {
-                    const int opp = f >= 3 ? f - 3 : f + 3;
-                    if (nb_visible[opp] || nb_emits[f]) m0 |= 1u << f;
+            // (the six neighbours are looked at by six lanes at once: each is a chain of dependent fetches)
+            bool nb_visible = false, nb_emits = false;
+            const bool origin_visible = (ev_origin->flags & kDerivedVisible) != 0u;
+            if (!origin_visible && lane < 6u) {
+                int n[3];
+                normal_of((int)lane, n);
+                const int c[3] = {b.origin[0] + n[0], b.origin[1] + n[1], b.origin[2] + n[2]};
+                uint32_t i;
+                if (b.index_of(c, &i)) {
+                    const DevDerived *d = &J.derived[J.grid[i] & J.index_mask];
+                    nb_visible = (d->flags & kDerivedVisible) != 0u;
+                    nb_emits = !(d->emission[0] == 0.f && d->emission[1] == 0.f && d->emission[2] == 0.f);
                 }
             }
-            b.m0 = m0;
+            const uint32_t vis = (uint32_t)__ballot(nb_visible), emi = (uint32_t)__ballot(nb_emits);
+            if (lane == 0u) {
+                uint32_t m0 = 0u;
+                if (origin_visible) m0 = 63u;
+                else
+                    for (int f = 0; f < 6; f++) {
+                        const int opp = f >= 3 ? f - 3 : f + 3;
+                        if (((vis >> opp) & 1u) || ((emi >> f) & 1u)) m0 |= 1u << f;
+                    }
+                s_scan[0] = m0;
+            }
             uint4 *const vlist = J.vlist + (size_t)wave * J.n_tree;
             if (lane == 0u) { vlist[0] = make_uint4(0u, __float_as_uint(1.0f), J.tree[0].offset, J.tree[0].info & 15u); s_count[0] = 1u; }
             __syncthreads();
+            b.m0 = s_scan[0];
             // 1. which bundles does the walk visit? Level by level: a level's bundles decide their children's alpha. The list of
             //    visited bundles doubles as the frontier: level L is the stretch [lo, hi) that level L-1 appended.
             //    A level is a chain of dependent fetches and little else, so the chain is kept short: an entry carries its
