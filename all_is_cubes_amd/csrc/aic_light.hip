@@ -661,7 +661,7 @@ __device__ uint32_t gather_set_bits(const uint32_t *bits, uint32_t n_words, uint
     return total == 0u ? 0xffffffffu : total;
 }
 
-__global__ void __launch_bounds__(kLightBlock) compute_light_wave_kernel(const LightJob J) {
+__device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
     extern __shared__ uint32_t s_dyn[];  // term bitmap, candidate bitmap
     __shared__ uint32_t s_flags[kLdsFlags];
     __shared__ float s_lut[256];
@@ -730,7 +730,7 @@ __global__ void __launch_bounds__(kLightBlock) compute_light_wave_kernel(const L
             uint4 *const vlist = J.vlist + (size_t)wave * J.n_tree;
             if (lane == 0u) { vlist[0] = make_uint4(0u, __float_as_uint(1.0f), J.tree[0].offset, J.tree[0].info & 15u); s_count[0] = 1u; }
             __syncthreads();
-            b.m0 = s_scan[0];
+            b.m0 = __builtin_amdgcn_readfirstlane(s_scan[0]);  // the same in every lane: keep it in a scalar register
             // 1. which bundles does the walk visit? Level by level: a level's bundles decide their children's alpha. The list of
             //    visited bundles doubles as the frontier: level L is the stretch [lo, hi) that level L-1 appended.
             //    A level is a chain of dependent fetches and little else, so the chain is kept short: an entry carries its
@@ -930,6 +930,14 @@ __global__ void __launch_bounds__(kLightBlock) compute_light_wave_kernel(const L
     }
 }
 
+// Two builds of the same body. A small batch (the reference's 32 cubes) is a latency problem: one block per CU at most, and
+// the register allocator is left alone (131 VGPRs). A large batch is an occupancy problem: a CU's LDS holds four cubes'
+// blocks, which needs four waves per SIMD, i.e. at most 128 VGPRs -- three fewer, at the price of a few stack slots.
+__global__ void __launch_bounds__(kLightBlock) compute_light_wave_kernel(const LightJob J) { compute_light_wave_body(J); }
+__global__ void __launch_bounds__(kLightBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) compute_light_wave_kernel_dense(const LightJob J) {
+    compute_light_wave_body(J);
+}
+
 __global__ void scatter_light_kernel(uint32_t *light, const uint32_t *index, const uint32_t *texel, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) light[index[i]] = texel[i];
@@ -964,9 +972,11 @@ void launch_compute_light_waves(const LightJob &job, uint32_t n_waves, uint32_t 
     uint32_t &allowed = lds_allowed[dev & 63];
     if (lds > allowed) {
         (void)hipFuncSetAttribute((const void *)compute_light_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)compute_light_wave_kernel_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         allowed = lds;
     }
-    hipLaunchKernelGGL(compute_light_wave_kernel, dim3(n_waves), dim3(threads == 256u ? 256u : 64u), lds, stream, job);
+    if (n_waves > 256u) hipLaunchKernelGGL(compute_light_wave_kernel_dense, dim3(n_waves), dim3(threads == 256u ? 256u : 64u), lds, stream, job);
+    else hipLaunchKernelGGL(compute_light_wave_kernel, dim3(n_waves), dim3(threads == 256u ? 256u : 64u), lds, stream, job);
 }
 
 void launch_scatter_light(uint32_t *light, const uint32_t *index, const uint32_t *texel, uint32_t n, hipStream_t stream) {
