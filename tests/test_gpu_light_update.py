@@ -122,6 +122,26 @@ def test_uninitialized_queue_and_update_limit(ctx):
     assert (got == np.asarray(ref.light).reshape(got.shape)).all()
 
 
+@pytest.mark.parametrize("batch", [32, 100])
+def test_dependency_pool_grows_when_a_batch_overflows_it(batch, monkeypatch):
+    """The dependency lists go through a chunk pool on the device; a batch that runs out of chunks is computed again with a
+    larger pool (aic_evaluate_light). A fresh context started with a four-chunk pool (test hook) must still give the
+    oracle's bytes -- with the small-batch path (cubes and texels in the launch arguments) and the copying path."""
+    monkeypatch.setenv("AIC_LIGHT_DEP_POOL_CHUNKS", "4")
+    sp = scenes.light_spread_space()
+    ref = copy.deepcopy(sp)
+    n_ref = oracle.evaluate_light(ref, maximum_distance=30, fast=True, epsilon=1, batch=batch, hb_width=16)
+    c = abi.Context(0)
+    try:
+        c.upload_space(abi.LAYER_WORLD, sp)
+        info = c.evaluate_light(abi.LAYER_WORLD, 30, fast=True, epsilon=1, batch=batch, queue_order=16)
+        got = c.read_light_volume(abi.LAYER_WORLD, sp.size)
+    finally:
+        c.close()
+    assert info.updates == n_ref
+    assert (got == np.asarray(ref.light).reshape(got.shape)).all()
+
+
 def test_large_batches_converge_to_the_same_light(ctx):
     """Throughput mode: thousands of queue entries per launch. The order of updates differs from the reference's, so the
     converged texels may differ in their last log-scale unit (the reference's own order is unspecified, queue.rs:236-243)."""
