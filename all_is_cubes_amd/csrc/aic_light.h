@@ -70,10 +70,18 @@ struct LightJob {
     const DevTreePos *tree;
     uint32_t n_tree;
     const float *child_w;      // [n_tree][6 faces][6]: the weights of each position's children (zeros where there is none)
-    const uint2 *child_ent;    // [n_tree][6 faces]: the child stepped to through that face: {position | (info & 15) << 28, offset}; position 0 = none
+    // What the walk's expansion pass reads. A child entry is {position | (which of its six weights are > 0) << 22 | (info & 15) << 28,
+    // cube offset}; position 0 = no child.
+    const uint2 *child_ent;    // [n_tree][6 faces]: the child stepped to through that face
+    const uint4 *node;         // [n_tree]: {its only child's entry (two words; unused unless it has exactly one), number of children, 0}
+    uint32_t root_meta;        // the root's (info & 15) | weight mask << 4
     float4 *terms;             // [waves][4 * n_tree]: (incoming r, g, b; ray weight) by recursion-order number
     uint32_t *cands;           // [waves][2 * n_tree]: dependency candidates (cube offset | conditional << 30)
-    uint4 *vlist;              // [waves][n_tree]: the bundles the walk visits, level after level: {tree position, alpha it is entered with, offset, info & 15}
+    // The walk's work queue: the root and the children of branching bundles, {tree position, alpha it is entered with, cube
+    // offset, (info & 15) | weight mask << 4 | kLightQueueValid}. All zero between cubes: a nonzero last word publishes an entry.
+    uint4 *front;              // [waves][n_front]
+    uint32_t n_front;          // 1 + the number of positions whose parent has more than one child
+    float *valpha;             // [waves][n_tree]: the alpha a visited bundle is entered with
 };
 
 void launch_compute_light(const LightJob &job, hipStream_t stream);
@@ -82,6 +90,7 @@ void launch_scatter_light(uint32_t *light, const uint32_t *index, const uint32_t
 
 // What a small batch needs done on the device before its launch, passed in the kernel argument itself (no copies): the
 // texels the previous batch changed, this batch's cubes, and the cleared counters.
+static constexpr uint32_t kLightQueueValid = 0x80000000u;
 static constexpr uint32_t kLightPrepMax = 64;
 struct LightPrep {
     uint32_t *light, *cubes_out, *head;

@@ -662,16 +662,16 @@ __device__ uint32_t gather_set_bits(const uint32_t *bits, uint32_t n_words, uint
 }
 
 __device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
-    extern __shared__ uint32_t s_dyn[];  // term bitmap, candidate bitmap
+    extern __shared__ uint32_t s_dyn[];  // term bitmap, candidate bitmap, visited bitmap
     __shared__ uint32_t s_flags[kLdsFlags];
     __shared__ float s_lut[256];
-    __shared__ uint32_t s_count[2], s_scan[4], s_chunk[8], s_first;
+    __shared__ uint32_t s_count[3], s_scan[4], s_chunk[8], s_first;
     __shared__ float s_sum[4];
     __shared__ float4 s_stage[kLightBlock];
     __shared__ uint32_t s_order[kOrderCap];
     const uint32_t lane = threadIdx.x, wave = blockIdx.x, nt = blockDim.x;  // `lane`: thread of the cube's block (1 or 4 waves)
-    const uint32_t term_words = (4u * J.n_tree + 31u) / 32u, cand_words = (2u * J.n_tree + 31u) / 32u;
-    uint32_t *const term_bits = s_dyn, *const cand_bits = s_dyn + term_words;
+    const uint32_t term_words = (4u * J.n_tree + 31u) / 32u, cand_words = (2u * J.n_tree + 31u) / 32u, vis_words = (J.n_tree + 31u) / 32u;
+    uint32_t *const term_bits = s_dyn, *const cand_bits = s_dyn + term_words, *const vis_bits = cand_bits + cand_words;
     for (uint32_t i = lane; i < min(J.n_blocks, kLdsFlags); i += nt) s_flags[i] = J.derived[i].flags;
     for (uint32_t i = lane; i < 256u; i += nt) s_lut[i] = J.lut[i];
     __syncthreads();
@@ -700,7 +700,7 @@ __device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
 #endif
 
         if (!origin_is_opaque) {
-            for (uint32_t i = lane; i < term_words + cand_words; i += nt) s_dyn[i] = 0u;
+            for (uint32_t i = lane; i < term_words + cand_words + vis_words; i += nt) s_dyn[i] = i == term_words + cand_words ? 1u : 0u;  // the root is visited
             // directions_to_seek_light (updater.rs:668-690)
             // (the six neighbours are looked at by six lanes at once: each is a chain of dependent fetches)
             bool nb_visible = false, nb_emits = false;
@@ -727,60 +727,123 @@ __device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
                     }
                 s_scan[0] = m0;
             }
-            uint4 *const vlist = J.vlist + (size_t)wave * J.n_tree;
-            if (lane == 0u) { vlist[0] = make_uint4(0u, __float_as_uint(1.0f), J.tree[0].offset, J.tree[0].info & 15u); s_count[0] = 1u; }
+            uint4 *const front = J.front + (size_t)wave * J.n_front;
+            float *const valpha = J.valpha + (size_t)wave * J.n_tree;
+            if (lane == 0u) {
+                front[0] = make_uint4(0u, __float_as_uint(1.0f), J.tree[0].offset, J.root_meta | kLightQueueValid);
+                valpha[0] = 1.0f;
+                s_count[0] = 0u;  // entries claimed
+                s_count[1] = 1u;  // entries appended
+                s_count[2] = 0u;  // entries walked to their end
+            }
             __syncthreads();
             b.m0 = __builtin_amdgcn_readfirstlane(s_scan[0]);  // the same in every lane: keep it in a scalar register
-            // 1. which bundles does the walk visit? Level by level: a level's bundles decide their children's alpha. The list of
-            //    visited bundles doubles as the frontier: level L is the stretch [lo, hi) that level L-1 appended.
-            //    A level is a chain of dependent fetches and little else, so the chain is kept short: an entry carries its
-            //    cube offset and face, and everything that depends on the entry alone -- the cube's block, the bundle's
-            //    weights, its children -- is fetched side by side before anything is decided.
-            uint32_t lo = 0u, hi = 1u;
-            while (lo < hi) {
-#ifdef AIC_LIGHT_TIMING
-                n_rounds++;
-#endif
-                for (uint32_t i = lo + lane; i < hi; i += nt) {
-                    const uint4 it = vlist[i];
-                    const uint2 *ce = J.child_ent + (size_t)it.x * 6u;
-                    uint2 ch[6];
-                    for (int f = 0; f < 6; f++) ch[f] = ce[f];
-                    const DevTreePos *nd = &J.tree[it.x];
-                    float w[6];
-                    for (int f = 0; f < 6; f++) w[f] = nd->weight[f];
-                    const int cube[3] = {b.origin[0] + (int)(it.z & 1023u) - 256, b.origin[1] + (int)((it.z >> 10) & 1023u) - 256,
-                                         b.origin[2] + (int)((it.z >> 20) & 1023u) - 256};
-                    uint32_t idx = 0u;
-                    const bool inside = b.index_of(cube, &idx);
-                    uint32_t block = J.grid[idx] & J.index_mask;  // cube 0's if outside: unused then
-                    uint32_t nch = 0u;
-                    for (int f = 0; f < 6; f++) nch += ch[f].x != 0u;
-                    float bw = b.bundle_weight(w);
-                    asm volatile("" : "+v"(nch), "+v"(bw), "+v"(block));  // the three fetches stay here, ahead of the decisions
-                    float alpha;
-                    if (!(it.w & 8u) && inside && bw > 0.0f && b.alpha_behind(block, it.w & 7u, __uint_as_float(it.y), &alpha) && nch != 0u) {
-                        uint32_t at = atomicAdd(&s_count[0], nch);
-                        for (int f = 0; f < 6; f++)
-                            if (ch[f].x != 0u) vlist[at++] = make_uint4(ch[f].x & 0x0fffffffu, __float_as_uint(alpha), ch[f].y, ch[f].x >> 28);
+            // 1. Which bundles does the walk visit, and with what alpha? A bundle decides its children's alpha, so this is the
+            //    serial part, a chain of dependent fetches and little else: its length decides what a small batch costs.
+            //    Nearly all of the tree is chains (24 140 of the 25 183 positions of maximum_distance 30 have exactly one
+            //    child; no path from the root branches more than nine times). So a lane walks: it follows a bundle's only child
+            //    at once, and where a bundle branches it appends the children to a queue and looks for other work -- no
+            //    barriers, so the walk lasts as long as its deepest path (about 25 to 50 steps) and not as long as the sum of
+            //    the longest chains of barrier-separated rounds. Lanes never wait for one another (an idle lane looks at the
+            //    queue once per step of its wave; the wave leaves when every appended entry has been walked to its end), so
+            //    lanes of one wave cannot block each other. A visited bundle is a bit in `vis_bits` and its alpha in `valpha`:
+            //    neither waits for anything. A step fetches two things side by side, 16 bytes of the bundle (its only
+            //    child's entry, its number of children) and the block at its cube; where that cube is, the face it is entered
+            //    through and whether the walk's directions give the bundle any weight came with the entry.
+            {
+                volatile uint32_t *const q = s_count;
+                bool active = false;
+                uint32_t claim = 0xffffffffu, k = 0u, off = 0u, meta = 0u, guard = 0u;
+                float alpha_in = 0.f;
+                for (;;) {
+                    if (!active) {
+                        // the claim counter may run ahead of the appended count: such a claim is served when the entry arrives
+                        if (claim == 0xffffffffu && q[0] < q[1]) claim = atomicAdd(&s_count[0], 1u);
+                        if (claim != 0xffffffffu && claim < q[1]) {
+                            const uint32_t w = __hip_atomic_load(&front[claim].w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (w != 0u) {
+                                const uint4 e = front[claim];
+                                k = e.x; alpha_in = __uint_as_float(e.y); off = e.z; meta = w & 0x3ffu;
+                                active = true;
+                                claim = 0xffffffffu;
+                            }
+                        }
+                    }
+                    if (active) {
+                        uint4 nd = J.node[k];
+                        const int cube[3] = {b.origin[0] + (int)(off & 1023u) - 256, b.origin[1] + (int)((off >> 10) & 1023u) - 256,
+                                             b.origin[2] + (int)((off >> 20) & 1023u) - 256};
+                        uint32_t idx = 0u;
+                        const bool inside = b.index_of(cube, &idx);
+                        uint32_t block = J.grid[idx] & J.index_mask;  // cube 0's if outside: unused then
+                        asm volatile("" : "+v"(nd.z), "+v"(block));  // the two fetches stay here, ahead of the decisions
+                        float alpha;
+                        // (weight * direction_weights).sum() > 0: some weight the walk's directions select is positive
+                        if ((meta & 8u) || !inside || !(b.m0 & (meta >> 4)) || !b.alpha_behind(block, meta & 7u, alpha_in, &alpha) || nd.z == 0u) {
+                            atomicAdd(&s_count[2], 1u);
+                            active = false;
+                        } else if (nd.z == 1u) {
+                            k = nd.x & 0x3fffffu;
+                            atomicOr(&vis_bits[k >> 5], 1u << (k & 31u));
+                            valpha[k] = alpha;
+                            off = nd.y;
+                            meta = (nd.x >> 28) | (((nd.x >> 22) & 63u) << 4);
+                            alpha_in = alpha;
+                        } else {
+                            const uint2 *ce = J.child_ent + (size_t)k * 6u;
+                            uint2 ch[6];
+                            for (int f = 0; f < 6; f++) ch[f] = ce[f];
+                            const uint32_t at0 = atomicAdd(&s_count[1], nd.z);
+                            uint32_t at = at0;
+                            for (int f = 0; f < 6; f++)
+                                if (ch[f].x != 0u) {
+                                    const uint32_t ck = ch[f].x & 0x3fffffu;
+                                    atomicOr(&vis_bits[ck >> 5], 1u << (ck & 31u));
+                                    valpha[ck] = alpha;
+                                    uint32_t *const ent = reinterpret_cast<uint32_t *>(&front[at++]);
+                                    ent[0] = ck; ent[1] = __float_as_uint(alpha); ent[2] = ch[f].y;
+                                }
+                            at = at0;
+                            for (int f = 0; f < 6; f++)  // published behind the rest of the entry
+                                if (ch[f].x != 0u)
+                                    __hip_atomic_store(&front[at++].w, (ch[f].x >> 28) | (((ch[f].x >> 22) & 63u) << 4) | kLightQueueValid, __ATOMIC_RELEASE,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                            atomicAdd(&s_count[2], 1u);
+                            active = false;
+                        }
+                    }
+                    if (__ballot(active) == 0ull) {  // nobody in this wave is walking
+                        const uint32_t done = q[2];  // read before the appended count: equal means nothing is left anywhere
+                        if (done == q[1]) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (++guard > (1u << 22)) {  // cannot happen; a GPU that spins forever is worse than an error
+                        J.dep_head[1] = 3u;
+                        break;
                     }
                 }
-                __syncthreads();
-                lo = hi;
-                hi = s_count[0];
-                __syncthreads();
             }
+            __syncthreads();
+            for (uint32_t i = lane, n = s_count[1]; i < n; i += nt) front[i].w = 0u;  // the queue is left as it was found
 #ifdef AIC_LIGHT_TIMING
+            n_rounds = s_count[1];
             if (lane == 0u) atomicAdd(&J.dep_head[6], (uint32_t)((clock64() - t_begin) >> 6));
 #endif
             // 2. what every visited bundle adds: independent of one another, all lanes at once
-            for (uint32_t i = lane; i < hi; i += nt) {
-                const uint4 it = vlist[i];
-                float alpha;
+            uint32_t vword = 0u;
+            for (;;) {
+                const uint32_t got = gather_set_bits(vis_bits, vis_words, &vword, s_order, lane, nt, s_scan);
+                if (got == 0u) break;
+                if (got == 0xffffffffu) continue;
+                for (uint32_t i = lane; i < got; i += nt) {
+                    const uint32_t k = s_order[i];
+                    float alpha;
 #ifdef AIC_LIGHT_TIMING
-                n_visits++;
+                    n_visits++;
 #endif
-                (void)b.visit(it.x, __uint_as_float(it.y), &alpha);
+                    (void)b.visit(k, valpha[k], &alpha);
+                }
+                __syncthreads();  // s_order is written again by the next gather
             }
         }
         uint32_t cost = b.cost;  // summed over the block: an integer, any order
@@ -964,7 +1027,7 @@ void launch_compute_light(const LightJob &job, hipStream_t stream) {
 
 void launch_compute_light_waves(const LightJob &job, uint32_t n_waves, uint32_t threads, hipStream_t stream) {
     if (!job.n || !n_waves) return;
-    const uint32_t lds = (((4u * job.n_tree + 31u) / 32u) + ((2u * job.n_tree + 31u) / 32u)) * 4u;
+    const uint32_t lds = (((4u * job.n_tree + 31u) / 32u) + ((2u * job.n_tree + 31u) / 32u) + ((job.n_tree + 31u) / 32u)) * 4u;
     // more dynamic LDS than the default limit needs an opt-in, per device
     static uint32_t lds_allowed[64] = {0};
     int dev = 0;
