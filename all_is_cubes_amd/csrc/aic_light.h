@@ -63,6 +63,10 @@ struct LightJob {
     uint32_t *dep_pool;        // chunk pool
     uint32_t dep_chunks;       // capacity in chunks
     uint32_t *dep_head;        // [0] next free chunk, [1] set when the pool ran out (the host grows it and reruns the batch)
+    // When `out` and `dep_pool` are pinned host memory (small batches: no copy back), the counters stay on the device for the
+    // allocator's atomics and the last block to finish copies them to `host_head` ([8], pinned); `done_count`: blocks finished.
+    uint32_t *host_head;
+    uint32_t *done_count;
     uint32_t *stack;           // [max_depth][kLightFrameWords][stack_stride]
     uint32_t stack_stride;     // lanes the stack was sized for (>= n)
     uint32_t max_depth;
@@ -89,7 +93,8 @@ void launch_compute_light_waves(const LightJob &job, uint32_t n_blocks, uint32_t
 void launch_scatter_light(uint32_t *light, const uint32_t *index, const uint32_t *texel, uint32_t n, hipStream_t stream);
 
 // What a small batch needs done on the device before its launch, passed in the kernel argument itself (no copies): the
-// texels the previous batch changed, this batch's cubes, and the cleared counters.
+// texels the previous batch changed, this batch's cubes, and the cleared counters (head[0..7] and the word behind them,
+// which is LightJob::done_count when that is in use).
 static constexpr uint32_t kLightQueueValid = 0x80000000u;
 static constexpr uint32_t kLightPrepMax = 64;
 struct LightPrep {

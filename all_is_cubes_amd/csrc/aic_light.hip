@@ -991,6 +991,17 @@ __device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
         }
         __syncthreads();  // LDS and the slots are reused by the wave's next cube
     }
+    if (J.host_head) {
+        // the results went straight to host memory; the counters the host wants with them are copied by the last block out
+        __syncthreads();
+        if (lane == 0u) {
+            __threadfence();
+            if (atomicAdd(J.done_count, 1u) == gridDim.x - 1u) {
+                __threadfence();
+                for (int i = 0; i < 8; i++) J.host_head[i] = __hip_atomic_load(&J.dep_head[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // Two builds of the same body. A small batch (the reference's 32 cubes) is a latency problem: one block per CU at most, and
@@ -1010,7 +1021,7 @@ __global__ void __launch_bounds__(64) prepare_light_batch_kernel(const LightPrep
     const uint32_t i = threadIdx.x;
     if (i < P.n_scatter) P.light[P.scatter_index[i]] = P.scatter_texel[i];
     if (i < P.n_cubes) P.cubes_out[i] = P.cubes[i];
-    if (i < 8u) P.head[i] = 0u;
+    if (i < 9u) P.head[i] = 0u;
 }
 
 __global__ void probe_log2f_kernel(const float *x, float *out, uint32_t n) {
