@@ -74,25 +74,35 @@ class StripGatherPipeline:
     records an event behind the finished gather and hands it to `wait_event` (the renderer's `aic_wait_event`:
     everything it queues afterwards -- the de-interleave of this slot, the next trace into its strip buffer -- waits
     for the event on the device; the host does not block). Without a `wait_event` hook the host waits for that one
-    event. Buffers are allocated once."""
+    event. Buffers are allocated once.
 
-    def __init__(self, height: int, width: int, strip_rows: int, device, depth: int = 2, group=None, wait_event=None):
+    `frames` > 1 makes a slot hold that many consecutive frames, gathered by ONE collective (`frame_buffer(slot, k)` is
+    frame k's strip buffer; `retire` then returns [world, frames, max_rows, width, 4] and `assemble` de-interleaves frame
+    k of it). At 8 ranks a rank's share of a 1080p frame is traced in about 0.1 ms, which is also what one gather call
+    costs the host: several frames per collective keep the exchange step off the frame period."""
+
+    def __init__(self, height: int, width: int, strip_rows: int, device, depth: int = 2, group=None, wait_event=None, frames: int = 1):
         self.group = group
         self.wait_event = wait_event
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.height, self.width, self.strip_rows, self.depth = height, width, strip_rows, depth
         self.max_rows = max_partition_rows(height, strip_rows, self.world)
-        self.local = [torch.zeros((self.max_rows, width, 4), dtype=torch.uint8, device=device) for _ in range(depth)]
-        self.gathered = [torch.empty((self.world, self.max_rows, width, 4), dtype=torch.uint8, device=device) if self.rank == 0 else None
-                         for _ in range(depth)]
-        self.gather_lists = [list(g.unbind(0)) if g is not None else None for g in self.gathered]  # built once: submit() is on the frame path
+        self.frames = max(1, int(frames))
+        self.buffers = [torch.zeros((self.frames, self.max_rows, width, 4), dtype=torch.uint8, device=device) for _ in range(depth)]
+        full = [torch.empty((self.world, self.frames, self.max_rows, width, 4), dtype=torch.uint8, device=device) if self.rank == 0 else None
+                for _ in range(depth)]
+        self.gather_lists = [list(g.unbind(0)) if g is not None else None for g in full]  # built once: submit() is on the frame path
+        # one frame per slot: the slot IS the frame's strip buffer, and what comes back is [world, max_rows, width, 4]
+        self.local = [b[0] for b in self.buffers] if self.frames == 1 else self.buffers
+        self.gathered = [(g[:, 0] if self.frames == 1 else g) if g is not None else None for g in full]
+        self._index = None
         self.work = [None] * depth
         self.order: List[int] = []  # slots with a gather in flight, oldest first
 
     def submit(self, slot: int) -> None:
         assert self.work[slot] is None, "slot still in flight: retire it first"
-        self.work[slot] = dist.gather(self.local[slot], gather_list=self.gather_lists[slot], dst=0, group=self.group, async_op=True)
+        self.work[slot] = dist.gather(self.buffers[slot], gather_list=self.gather_lists[slot], dst=0, group=self.group, async_op=True)
         self.order.append(slot)
 
     def retire(self, slot: int) -> Optional[torch.Tensor]:
@@ -111,6 +121,22 @@ class StripGatherPipeline:
         self.work[slot] = None
         self.order.remove(slot)
         return self.gathered[slot]
+
+    def frame_buffer(self, slot: int, k: int = 0) -> torch.Tensor:
+        """Frame k of a slot: this rank's strips [max_rows, width, 4], contiguous."""
+        return self.buffers[slot][k]
+
+    def assemble(self, gathered: torch.Tensor, k: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """De-interleave frame k of what `retire` returned (rank 0) into a [height, width, 4] frame with tensor indexing
+        (for one frame per slot the renderer's own `aic_assemble_strips` does this on its stream)."""
+        g = gathered[:, k] if gathered.dim() == 5 else gathered
+        if self._index is None or self._index[0].device != g.device:
+            y = torch.arange(self.height, device=g.device)
+            strip = y // self.strip_rows
+            self._index = (strip % self.world, (strip // self.world) * self.strip_rows + (y % self.strip_rows))
+        if out is None:
+            return g[self._index[0], self._index[1]]
+        return out.copy_(g[self._index[0], self._index[1]])
 
     def oldest(self) -> Optional[int]:
         return self.order[0] if self.order else None

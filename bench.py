@@ -123,6 +123,9 @@ def main() -> int:
                     help="N > 1 (default there): check the assembled frame against a single-rank trace of the same frame")
     ap.add_argument("--no-verify", dest="verify", action="store_false")
     ap.add_argument("--in-flight", type=int, default=0, help="frames traced concurrently (1..8); default 4 at N < 4, 8 at N >= 4")
+    ap.add_argument("--frames-per-gather", type=int, default=0,
+                    help="N > 1: consecutive frames moved to rank 0 by one collective; default 1 at N < 8, 4 at N >= 8 (a gather call costs the host about "
+                         "what an eighth of a frame costs the device)")
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: gather each frame before tracing the next")
     ap.add_argument("--lighting", type=int, default=3, help="experiment: LightingOption (0 None,1 Flat,2 Coarse,3 Linear,4 Smoothstep); default Linear")
     ap.add_argument("--fog", type=int, default=1, help="experiment: FogOption (0 None,1 Abrupt,...); default Abrupt")
@@ -232,12 +235,14 @@ def main() -> int:
     streamed = not args.no_pipeline
     # traces in flight (AIC_MAX_IN_FLIGHT = 8): a rank's share of a frame shrinks with N while a ray's latency does not
     depth = max(1, min(8, args.in_flight if args.in_flight > 0 else (4 if world < 4 else 8)))
-    ring = depth + 1 if streamed else 1
+    per_gather = max(1, min(depth, args.frames_per_gather if args.frames_per_gather > 0 else (1 if world < 8 else 4))) if streamed else 1
+    ring = ((depth + per_gather - 1) // per_gather + (1 if per_gather == 1 else 2)) if streamed else 1  # group slots: the groups being traced, one being gathered
     pipe = D.StripGatherPipeline(h, w, strip, "cpu" if one_gpu_test else dev, depth=ring,
-                                 wait_event=None if one_gpu_test else renderer.wait_event) if world > 1 else None
+                                 wait_event=None if one_gpu_test else renderer.wait_event, frames=per_gather) if world > 1 else None
     n_local = depth if streamed else 1
     local_bufs = [torch.empty((max(local_rows, 1), w, 4), dtype=torch.uint8, device=dev) for _ in range(n_local)] if (pipe is None or one_gpu_test) else None
-    stage_buf = torch.empty((world, pipe.max_rows, w, 4), dtype=torch.uint8, device=dev) if (one_gpu_test and pipe is not None and rank == 0) else None
+    stage_buf = (torch.empty((world, pipe.max_rows, w, 4) if per_gather == 1 else (world, per_gather, pipe.max_rows, w, 4), dtype=torch.uint8, device=dev)
+                 if (one_gpu_test and pipe is not None and rank == 0) else None)
     frame_buf = torch.empty((h, w, 4), dtype=torch.uint8, device=dev) if (rank == 0 and world > 1) else None
 
     kernel_ms = []
@@ -261,18 +266,28 @@ def main() -> int:
     frame_no = [0]
     traced = []  # frames whose trace is in flight: (frame number, render slot)
 
-    def finish(slot) -> None:  # a gathered frame leaves the ring: de-interleave it on rank 0
+    filled = {}  # group slot -> frames of it traced since its last gather
+
+    def slot_of(i):  # frame i belongs to group i // per_gather, which lives in this ring slot
+        return (i // per_gather) % ring
+
+    def finish(slot) -> None:  # a gathered group of frames leaves the ring: de-interleave each on rank 0
         g = pipe.retire(slot)
+        n_valid = filled.pop(slot, 0)
         if rank == 0 and g is not None:
             if one_gpu_test:
                 stage_buf.copy_(g)
                 torch.cuda.synchronize()
                 g = stage_buf
-            renderer.assemble_strips(g.data_ptr(), frame_buf.data_ptr(), strip, world)
+            if per_gather == 1:
+                renderer.assemble_strips(g.data_ptr(), frame_buf.data_ptr(), strip, world)
+            else:
+                for k in range(n_valid):
+                    pipe.assemble(g, k, out=frame_buf)
 
     def render_target(i):
         if pipe is not None and not one_gpu_test:
-            return pipe.local[i % ring]
+            return pipe.frame_buffer(slot_of(i), i % per_gather)
         return local_bufs[i % n_local]
 
     def complete_oldest() -> None:  # the oldest traced frame: wait for it, hand its strips to the gather
@@ -281,8 +296,10 @@ def main() -> int:
         kernel_ms.append(info.kernel_ms)
         if pipe is not None:
             if one_gpu_test:
-                pipe.local[i % ring][:local_rows].copy_(local_bufs[i % n_local][:local_rows])
-            pipe.submit(i % ring)
+                pipe.frame_buffer(slot_of(i), i % per_gather)[:local_rows].copy_(local_bufs[i % n_local][:local_rows])
+            filled[slot_of(i)] = i % per_gather + 1
+            if i % per_gather == per_gather - 1:
+                pipe.submit(slot_of(i))
 
     def step() -> None:
         i = frame_no[0]
@@ -313,14 +330,17 @@ def main() -> int:
             return
         if len(traced) == depth:
             complete_oldest()
-        if pipe is not None:
-            finish(i % ring)  # the gather that last used this ring slot (frame i-3)
+        if pipe is not None and i % per_gather == 0:
+            finish(slot_of(i))  # the gather that last used this ring slot
         renderer.submit_rows_to_device(render_target(i).data_ptr(), strip, world, rank, i % depth)
         traced.append((i, i % depth))
 
     def drain() -> None:  # every frame issued so far is traced, gathered and assembled
         while traced:
             complete_oldest()
+        if pipe is not None:
+            for slot in [sl for sl in filled if pipe.work[sl] is None]:  # a group the fence cut short travels as it is
+                pipe.submit(slot)
         while pipe is not None and pipe.oldest() is not None:
             finish(pipe.oldest())
 
@@ -543,6 +563,7 @@ def main() -> int:
                 "partition": f"interleaved {strip}-row strips over {world} GPU(s), scene replicated, RCCL gather to rank 0",
                 "steps_per_ray": round(cubes_traced / rays_per_frame, 2),
                 "frames_in_flight": depth if streamed else 1,
+                "frames_per_gather": per_gather if world > 1 else None,
                 "assembled_frame_equals_single_rank_frame": verified,
             },
             "roofline": {

@@ -111,6 +111,59 @@ def _pipeline_worker(rank, world, port, h, w, strip, frames, q):
         dist.destroy_process_group()
 
 
+def _grouped_pipeline_worker(rank, world, port, h, w, strip, frames, per_gather, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def frame_image(f):
+            y, x = np.mgrid[0:h, 0:w]
+            return np.stack([(x + 3 * f) % 256, (y * 7 + f) % 256, (x ^ y) % 256, np.full_like(x, f)], -1).astype(np.uint8)
+
+        pipe = D.StripGatherPipeline(h, w, strip, "cpu", depth=2, frames=per_gather)
+        rows = D.partition_rows(h, strip, world, rank)
+        done = []
+
+        def finish(slot, n_valid):
+            g = pipe.retire(slot)
+            if rank == 0 and g is not None:
+                for k in range(n_valid):
+                    done.append(pipe.assemble(g, k).numpy().copy())
+
+        valid = {}
+        for f in range(frames):
+            group, k = divmod(f, per_gather)
+            slot = group % pipe.depth
+            if k == 0:
+                finish(slot, valid.pop(slot, 0))                # the group that last used this slot leaves the ring
+            pipe.frame_buffer(slot, k)[: len(rows)] = torch.from_numpy(frame_image(f)[rows])
+            valid[slot] = k + 1
+            if k == per_gather - 1 or f == frames - 1:          # a full group, or the last, partial one
+                pipe.submit(slot)
+        while pipe.oldest() is not None:
+            s_ = pipe.oldest()
+            finish(s_, valid.pop(s_, 0))
+        if rank == 0:
+            q.put(bool(len(done) == frames and all((done[f] == frame_image(f)).all() for f in range(frames))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gather_of_several_frames_per_collective():
+    """`frames` > 1: one collective moves several consecutive frames; they come back whole and in order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    h, w, strip = 70, 12, 16
+    port = _free_port()
+    procs = [ctx.Process(target=_grouped_pipeline_worker, args=(r, 2, port, h, w, strip, 11, 3, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 def test_two_rank_pipelined_gather_keeps_frames_in_order():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
