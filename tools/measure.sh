@@ -20,6 +20,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_s256_nopipe" -
 # the reference's own bench scene, lit on the device (N2): bench line + kernel stats of the light gather kernel
 python bench.py --workload light-bench --steps 200 --warmup 10 > "$O/bench_lightbench.json" 2> "$O/bench_lightbench.err"; tail -c 700 "$O/bench_lightbench.json"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_lightbench" -- $BENCH --workload light-bench --steps 50 > "$O/stats_lightbench.log" 2>&1
+# the sim + render loop with the light updated on the device every frame
+python bench.py --workload relight --steps 200 --warmup 10 --no-cpu-baseline > "$O/bench_relight.json" 2> "$O/bench_relight.err"; tail -c 600 "$O/bench_relight.json"
 # instruction issue-rate micro-benchmark (tools/ubench/issue_rate.hip): what bounds the trace kernel
 ( cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o issue_rate issue_rate.hip > /dev/null 2>&1 && timeout 300 ./issue_rate ) > "$O/issue_rate.txt" 2>&1
 bash tools/measure_pmc.sh "$TAG"

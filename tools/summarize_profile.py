@@ -71,12 +71,13 @@ for wl in ("atrium", "s256"):
 p = find("stats_lightbench", "kernel_stats.csv")
 if p:
     shutil.copy(p, os.path.join(dst, f"{tag}_kernel_stats_lightbench.csv"))
-b = os.path.join(src, "bench_lightbench.json")
-if os.path.exists(b):
-    lines = [l for l in open(b).read().splitlines() if l.startswith("{")]
-    if lines:
-        with open(os.path.join(dst, f"{tag}_bench_lightbench.json"), "w") as f:
-            f.write(lines[-1] + "\n")
+for name in ("lightbench", "relight"):
+    b = os.path.join(src, f"bench_{name}.json")
+    if os.path.exists(b):
+        lines = [l for l in open(b).read().splitlines() if l.startswith("{")]
+        if lines:
+            with open(os.path.join(dst, f"{tag}_bench_{name}.json"), "w") as f:
+                f.write(lines[-1] + "\n")
 if os.path.exists(os.path.join(src, "issue_rate.txt")):
     shutil.copy(os.path.join(src, "issue_rate.txt"), os.path.join(dst, f"{tag}_issue_rate.txt"))
 print(sorted(os.listdir(dst)))
