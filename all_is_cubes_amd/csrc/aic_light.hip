@@ -751,7 +751,21 @@ __device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
             //    child's entry, its number of children) and the block at its cube; where that cube is, the face it is entered
             //    through and whether the walk's directions give the bundle any weight came with the entry.
             {
+                // The queue's counters. As built, the reads below go through a volatile generic pointer, which the compiler turns
+                // into system-coherent flat loads that each wait for all of the wave's outstanding memory operations.
+                // -DAIC_LIGHT_LDS_COUNTERS reads them as LDS atomics instead (`done` acquired before the appended count is
+                // read): untested on hardware when this was written, so not the default.
+#ifdef AIC_LIGHT_LDS_COUNTERS
+                struct {
+                    uint32_t *c;
+                    __device__ uint32_t operator[](int i) const {
+                        return i == 2 ? __hip_atomic_load(&c[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                      : __hip_atomic_load(&c[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                } const q = {s_count};
+#else
                 volatile uint32_t *const q = s_count;
+#endif
                 bool active = false;
                 uint32_t claim = 0xffffffffu, k = 0u, off = 0u, meta = 0u, guard = 0u;
                 float alpha_in = 0.f;
