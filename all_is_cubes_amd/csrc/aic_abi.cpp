@@ -93,7 +93,9 @@ struct Layer {
     std::vector<DevBlock> host_blocks;  // mirror of the block table (for replace/append)
     // per block: elements of the voxel pool / palette pool its current ranges can hold (so that a re-evaluated block is
     // written in place when it fits, updating.rs:128-145), and what replaced blocks left behind (compacted past a threshold)
-    std::vector<uint32_t> vox_cap, pal_cap;
+    // vox_base / pal_base: where the block's reserved ranges start. Kept apart from host_blocks[i].vox_off / pal_off, which are
+    // 0 while the block has no voxels (an atom written over a voxel block keeps its reservation for the next re-evaluation).
+    std::vector<uint32_t> vox_cap, pal_cap, vox_base, pal_base;
     uint64_t garbage_vox = 0, garbage_pal = 0;
     int32_t air_index = -1;
     int32_t sky_kind = 0;
@@ -108,7 +110,7 @@ struct Layer {
     size_t n_cubes() const { return (size_t)size[0] * (size_t)size[1] * (size_t)size[2]; }
     void release() {
         pool.release(); cls.release(); light.release(); light_alt.release(); blocks.release(); palette.release();
-        host_blocks.clear(); host_cls.clear(); vox_cap.clear(); pal_cap.clear();
+        host_blocks.clear(); host_cls.clear(); vox_cap.clear(); pal_cap.clear(); vox_base.clear(); pal_base.clear();
         garbage_vox = garbage_pal = 0;
         present = false;
         version++;
@@ -476,7 +478,7 @@ int aic_upload_space(aic_ctx *c, int layer, const aic_space_desc *s) {
 
     // block table + pools
     std::vector<DevBlock> blocks(s->n_blocks);
-    std::vector<uint32_t> vox_cap(s->n_blocks, 0u), pal_cap(s->n_blocks, 0u);
+    std::vector<uint32_t> vox_cap(s->n_blocks, 0u), pal_cap(s->n_blocks, 0u), vox_base(s->n_blocks, 0u), pal_base(s->n_blocks, 0u);
     std::vector<uint16_t> vox;
     std::vector<DevPaletteEntry> pal;
     vox.reserve((size_t)s->n_voxels);
@@ -497,6 +499,8 @@ int aic_upload_space(aic_ctx *c, int layer, const aic_space_desc *s) {
         if (rc != AIC_OK) return rc;
         vox_cap[i] = (uint32_t)(vox.size() - vb);
         pal_cap[i] = (uint32_t)(pal.size() - pb);
+        vox_base[i] = (uint32_t)(n + vb);
+        pal_base[i] = (uint32_t)pb;
         if ((d.flags & AIC_BLOCK_AIR) && air_index < 0) air_index = (int32_t)i;
     }
     // validate cube indices on the host copy (the reference indexes `blocks[...]` with a bounds check)
@@ -529,6 +533,8 @@ int aic_upload_space(aic_ctx *c, int layer, const aic_space_desc *s) {
     l.host_cls.swap(cls);
     l.vox_cap.swap(vox_cap);
     l.pal_cap.swap(pal_cap);
+    l.vox_base.swap(vox_base);
+    l.pal_base.swap(pal_base);
     l.garbage_vox = l.garbage_pal = 0;
     l.air_index = air_index;
     l.sky_kind = s->sky_kind;
@@ -631,30 +637,45 @@ int compact_pools(aic_ctx *c, Layer &l) {
     hipError_t e;
     if ((e = np.ensure((size_t)need_vox)) != hipSuccess) return hip_fail(c, "compact pool", e);
     if ((e = npal.ensure((size_t)(need_pal ? need_pal : 1))) != hipSuccess) { np.release(); return hip_fail(c, "compact palette", e); }
-    if (n) HIP_TRY(c, hipMemcpyAsync(np.p, l.pool.p, n * sizeof(uint16_t), hipMemcpyDeviceToDevice, c->stream));
+    // the new offsets go into copies of the tables: the layer keeps pointing at its old pools until every copy has landed
+    std::vector<DevBlock> blocks = l.host_blocks;
+    std::vector<uint32_t> vbase = l.vox_base, pbase = l.pal_base;
     uint64_t vo = n, po = 0;
-    for (size_t i = 0; i < l.host_blocks.size(); i++) {
-        DevBlock &b = l.host_blocks[i];
+    e = n ? hipMemcpyAsync(np.p, l.pool.p, n * sizeof(uint16_t), hipMemcpyDeviceToDevice, c->stream) : hipSuccess;
+    for (size_t i = 0; e == hipSuccess && i < blocks.size(); i++) {
+        DevBlock &b = blocks[i];
         if (l.vox_cap[i]) {
-            HIP_TRY(c, hipMemcpyAsync(np.p + vo, l.pool.p + b.vox_off, (size_t)l.vox_cap[i] * sizeof(uint16_t), hipMemcpyDeviceToDevice, c->stream));
-            b.vox_off = (uint32_t)vo;
+            e = hipMemcpyAsync(np.p + vo, l.pool.p + l.vox_base[i], (size_t)l.vox_cap[i] * sizeof(uint16_t), hipMemcpyDeviceToDevice, c->stream);
+            if ((b.kind & 255u) != 0u) b.vox_off = (uint32_t)vo;  // a block that is a single voxel at the moment keeps offset 0 (its reservation moves all the same)
+            vbase[i] = (uint32_t)vo;
             vo += l.vox_cap[i];
         }
-        if (l.pal_cap[i]) {
-            HIP_TRY(c, hipMemcpyAsync(npal.p + po, l.palette.p + b.pal_off, (size_t)l.pal_cap[i] * sizeof(DevPaletteEntry), hipMemcpyDeviceToDevice, c->stream));
-            b.pal_off = (uint32_t)po;
+        if (e == hipSuccess && l.pal_cap[i]) {
+            e = hipMemcpyAsync(npal.p + po, l.palette.p + l.pal_base[i], (size_t)l.pal_cap[i] * sizeof(DevPaletteEntry), hipMemcpyDeviceToDevice, c->stream);
+            if ((b.kind & 255u) != 0u) b.pal_off = (uint32_t)po;
+            pbase[i] = (uint32_t)po;
             po += l.pal_cap[i];
         }
     }
-    if (!l.host_blocks.empty())
-        HIP_TRY(c, hipMemcpyAsync(l.blocks.p, l.host_blocks.data(), l.host_blocks.size() * sizeof(DevBlock), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (e == hipSuccess && !blocks.empty())
+        e = hipMemcpyAsync(l.blocks.p, blocks.data(), blocks.size() * sizeof(DevBlock), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        // nothing was committed: put the old block table back on the device (best effort) and drop the new pools
+        if (!l.host_blocks.empty()) (void)hipMemcpy(l.blocks.p, l.host_blocks.data(), l.host_blocks.size() * sizeof(DevBlock), hipMemcpyHostToDevice);
+        np.release();
+        npal.release();
+        return hip_fail(c, "compact pools", e);
+    }
     l.pool.release();
     l.palette.release();
     l.pool = np;
     l.palette = npal;
     l.pool.n = (size_t)vo;
     l.palette.n = (size_t)po;
+    l.host_blocks.swap(blocks);
+    l.vox_base.swap(vbase);
+    l.pal_base.swap(pbase);
     l.garbage_vox = l.garbage_pal = 0;
     return AIC_OK;
 }
@@ -677,8 +698,9 @@ int replace_one(aic_ctx *c, int layer, Layer &l, uint32_t index, const aic_block
     uint32_t vox_off, pal_off;
     hipError_t e;
     if (fits) {
-        vox_off = l.host_blocks[index].vox_off;
-        pal_off = l.host_blocks[index].pal_off;
+        // the reserved ranges, not host_blocks[index].vox_off / pal_off: those are 0 after a replacement that had no voxels
+        vox_off = l.vox_base[index];
+        pal_off = l.pal_base[index];
     } else {
         vox_off = (uint32_t)l.pool.n;
         pal_off = (uint32_t)l.palette.n;
@@ -701,11 +723,16 @@ int replace_one(aic_ctx *c, int layer, Layer &l, uint32_t index, const aic_block
         l.host_blocks.push_back(db);
         l.vox_cap.push_back((uint32_t)vox.size());
         l.pal_cap.push_back((uint32_t)pal.size());
+        l.vox_base.push_back(vox_off);
+        l.pal_base.push_back(pal_off);
         if ((e = l.blocks.ensure(l.host_blocks.size(), true, c->stream)) != hipSuccess) return hip_fail(c, "grow blocks", e);
     } else {
         class_changed = block_class(l.host_blocks[index]) != block_class(db);
         l.host_blocks[index] = db;
-        if (!fits) { l.vox_cap[index] = (uint32_t)vox.size(); l.pal_cap[index] = (uint32_t)pal.size(); }
+        if (!fits) {
+            l.vox_cap[index] = (uint32_t)vox.size(); l.pal_cap[index] = (uint32_t)pal.size();
+            l.vox_base[index] = vox_off; l.pal_base[index] = pal_off;
+        }
     }
     HIP_TRY(c, hipMemcpy(l.blocks.p + index, &db, sizeof(db), hipMemcpyHostToDevice));
     set_class(l.host_cls, index, block_class(db));
@@ -980,9 +1007,9 @@ int wait_frame(aic_ctx *c, uint32_t slot, aic_frame_info *info) {
     float kernel_ms = 0.f;
     if (fs.busy) {
         DevCounters hc;
+        fs.busy = false;  // released whatever happens below: a frame that failed must not block its slot for good
         HIP_TRY(c, hipMemcpyAsync(&hc, fs.counters.p, sizeof(hc), hipMemcpyDeviceToHost, fs.stream));
         HIP_TRY(c, hipStreamSynchronize(fs.stream));
-        fs.busy = false;
         HIP_TRY(c, hipEventElapsedTime(&kernel_ms, fs.ev0, fs.ev1));
         if (info) {
             info->cubes_traced = hc.cubes_traced;

@@ -117,10 +117,19 @@ const char *aic_multi_last_error(const aic_multi *m) { return m ? m->err.c_str()
     return AIC_OK;
 
 int aic_multi_upload_space(aic_multi *m, int layer, const aic_space_desc *s) {
-    if (m && s && (layer == 0 || layer == 1)) m->n_cubes[layer] = (size_t)s->size[0] * (size_t)s->size[1] * (size_t)s->size[2];
-    AIC_MULTI_FORWARD(aic_upload_space(m->ctx[i], layer, s))
+    if (!m) return AIC_ERR_INVALID;
+    if (layer == 0 || layer == 1) m->n_cubes[layer] = 0;  // known only once every device has accepted the space
+    for (size_t i = 0; i < m->ctx.size(); i++) {
+        const int rc = forward(m, i, aic_upload_space(m->ctx[i], layer, s));
+        if (rc != AIC_OK) return rc;
+    }
+    if (s && (layer == 0 || layer == 1)) m->n_cubes[layer] = (size_t)s->size[0] * (size_t)s->size[1] * (size_t)s->size[2];  // validated by aic_upload_space
+    return AIC_OK;
 }
-int aic_multi_clear_space(aic_multi *m, int layer) { AIC_MULTI_FORWARD(aic_clear_space(m->ctx[i], layer)) }
+int aic_multi_clear_space(aic_multi *m, int layer) {
+    if (m && (layer == 0 || layer == 1)) m->n_cubes[layer] = 0;
+    AIC_MULTI_FORWARD(aic_clear_space(m->ctx[i], layer))
+}
 int aic_multi_update_cubes(aic_multi *m, int layer, uint32_t n, const int32_t *xyz, const uint16_t *bi, const uint8_t *light) {
     AIC_MULTI_FORWARD(aic_update_cubes(m->ctx[i], layer, n, xyz, bi, light))
 }
@@ -171,18 +180,28 @@ int aic_multi_render(aic_multi *m, const aic_frame_desc *f, void *out_rgba8, int
     }
     { const int rc = ensure(m, m->dev[0], &m->gathered, &m->gathered_bytes, n * (size_t)max_rows * row_bytes); if (rc != AIC_OK) return rc; }
     // 1. every device traces its strips (the submits return at once: the traces overlap)
+    // A failure from here on must not leave slot 0 of the other contexts busy (every later frame would fail with "slot
+    // busy"): whatever was submitted is waited for before the error is returned.
+    size_t submitted = 0, waited = 0;
+    auto drain = [&](int rc, const std::string &msg) {
+        for (size_t k = waited; k < submitted; k++) (void)aic_render_wait(m->ctx[k], 0, nullptr);
+        if (!msg.empty()) m->err = msg;
+        return rc;
+    };
     for (size_t i = 0; i < n; i++) {
         aic_frame_desc fi = *f;
         fi.partition = aic_partition{kStripRows, (uint32_t)n, (uint32_t)i, 0};
         const int rc = forward(m, i, aic_render_submit(m->ctx[i], &fi, m->local[i], 0));
-        if (rc != AIC_OK) return rc;
+        if (rc != AIC_OK) return drain(rc, m->err);
+        submitted = i + 1;
     }
     // 2. as each finishes, its compact strips go to device 0 (peer copy over the direct link)
     hipStream_t s0 = (hipStream_t)aic_stream(m->ctx[0]);
     for (size_t i = 0; i < n; i++) {
         aic_frame_info fi;
         const int rc = forward(m, i, aic_render_wait(m->ctx[i], 0, &fi));
-        if (rc != AIC_OK) return rc;
+        waited = i + 1;  // the slot is released by aic_render_wait whatever it returns
+        if (rc != AIC_OK) return drain(rc, m->err);
         if (info) {
             info->cubes_traced += fi.cubes_traced; info->n_outer += fi.n_outer; info->n_inner += fi.n_inner;
             info->n_hits += fi.n_hits; info->n_light += fi.n_light; info->flaws |= fi.flaws;
@@ -190,11 +209,11 @@ int aic_multi_render(aic_multi *m, const aic_frame_desc *f, void *out_rgba8, int
         }
         if (!rows[i]) continue;
         char *dst = (char *)m->gathered + i * (size_t)max_rows * row_bytes;
-        if (hipSetDevice(m->dev[0]) != hipSuccess) return mfail(m, AIC_ERR_DEVICE, "hipSetDevice failed");
+        if (hipSetDevice(m->dev[0]) != hipSuccess) return drain(AIC_ERR_DEVICE, "hipSetDevice failed");
         const hipError_t e = m->dev[i] == m->dev[0]
                                  ? hipMemcpyAsync(dst, m->local[i], (size_t)rows[i] * row_bytes, hipMemcpyDeviceToDevice, s0)
                                  : hipMemcpyPeerAsync(dst, m->dev[0], m->local[i], m->dev[i], (size_t)rows[i] * row_bytes, s0);
-        if (e != hipSuccess) return mfail(m, AIC_ERR_DEVICE, std::string("peer copy: ") + hipGetErrorString(e));
+        if (e != hipSuccess) return drain(AIC_ERR_DEVICE, std::string("peer copy: ") + hipGetErrorString(e));
     }
     // 3. de-interleave on device 0
     void *target = out_rgba8;

@@ -908,6 +908,39 @@ def test_replace_blocks_in_place_batched_and_compacted(ctx):
     check()
 
 
+def test_replace_block_voxel_atom_voxel_keeps_its_range(ctx):
+    """a voxel block replaced by an atom (no voxels: its table entry holds offsets 0) and then by a voxel
+    block of the old size must be written into the block's own reserved range, not over the cube grid at pool offset 0 --
+    and a compaction in the atom state must move the reservation, not a copy of the cube grid."""
+    sp = scenes.synthetic_space(n=12, resolution=8, n_blocks=5, seed=11)
+    opt = oracle.make_options()
+    eye = (6.5, 11.5, 22.0)
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, 96 / 64, oracle.look_at_y_up(eye, (6.0, 4.0, 6.0)), eye)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+    recs = [i for i, b in enumerate(sp.blocks) if b.resolution > 1]
+    variants = scenes.synthetic_blocks(8, 6, seed=21)
+
+    def check():
+        got = ctx.render(ctx.make_frame(96, 64, world_inv=inv), want_aux=True)
+        ref = oracle.render(oracle.Space(sp), opt, oracle.make_camera(inv, 96, 64), want_aux=True, threads=4)
+        assert_parity(got, ref)
+
+    for k, i in enumerate(recs[:3]):
+        for nb in (flat.atom((0.9, 0.1, 0.1, 1.0)), variants[k], flat.atom((0.0, 0.0, 0.0, 0.0)), variants[k + 1]):
+            sp.blocks[i] = nb
+            ctx.replace_block(abi.LAYER_WORLD, i, nb)
+            check()
+    sp.blocks[recs[0]] = flat.atom((0.1, 0.9, 0.1, 1.0))  # compaction while one reservation belongs to an atom ...
+    ctx.replace_block(abi.LAYER_WORLD, recs[0], sp.blocks[recs[0]])
+    ctx.compact(abi.LAYER_WORLD)
+    check()
+    sp.blocks[recs[0]] = variants[5]  # ... and the reservation is still usable afterwards
+    ctx.replace_block(abi.LAYER_WORLD, recs[0], sp.blocks[recs[0]])
+    check()
+
+
 @pytest.mark.parametrize("n", [2, 3, 8])
 def test_multi_device_context_equals_single(ctx, n):
     """aic_create_multi: the single-process multi-device path behind the C ABI (what a Rust HipRtRenderer would hold).
