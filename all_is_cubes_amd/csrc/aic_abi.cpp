@@ -241,6 +241,14 @@ int convert_block(aic_ctx *c, const aic_block_desc &d, const uint16_t *voxels, c
             return fail(c, AIC_ERR_INVALID, "block voxel bounds exceed GridAab::for_block(resolution)");
     }
     if (d.pal_len == 0 && nvox > 0) return fail(c, AIC_ERR_INVALID, "block has voxels but an empty palette");
+    // Evoxel colours are the reference's Rgba = PositiveSign<f32> x 3 + ZeroOne<f32> (math/color.rs:288-314): components that type
+    // cannot hold (NaN, negative, alpha above 1) are rejected here, and the kernel's powf / compositing rely on it
+    for (uint32_t i = 0; i < (one ? 1u : d.pal_len) && palette; i++) {
+        const float *e = palette + 8 * (size_t)i;
+        for (int k = 0; k < 7; k++)
+            if (!(e[k] >= 0.f)) return fail(c, AIC_ERR_INVALID, "palette entry has a negative or NaN component");
+        if (!(e[3] <= 1.f)) return fail(c, AIC_ERR_INVALID, "palette entry has alpha above 1");
+    }
     if (one || d.resolution == 1) {
         // Evoxels::single_voxel() (voxel_storage.rs:364-385)
         const float *e = nullptr;

@@ -25,9 +25,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstddef>
 #include <cstdlib>
 
 #include "aic_device.h"
+#include "aic_lightmath.h"
 
 namespace aic {
 
@@ -339,8 +341,6 @@ AIC_DEV float ps_mul(float a, float b) {  // PositiveSign::mul: 0*inf => 0
     float v = a * b;
     return (v != v) ? 0.f : v;
 }
-// f32::powf / f32::exp evaluated in f64 and rounded once
-AIC_DEV float powf_exact(float x, float y) { return (float)pow((double)x, (double)y); }
 
 // f32::powf as the reference's libm computes it on x86-64 Linux. Rust's `f32::powf` is the C library's
 // powf; glibc's (sysdeps/ieee754/flt-32/e_powf.c, from ARM's optimized-routines; not under
@@ -349,7 +349,7 @@ AIC_DEV float powf_exact(float x, float y) { return (float)pow((double)x, (doubl
 // once. Table and coefficient values are the published __powf_log2_data / __exp2f_data. The
 // multiply-adds are fused, as in the FMA build glibc selects on every current x86-64 CPU.
 // Domain: 0 < x < 1 normal, y > 0 finite (everything apply_transmittance feeds it); the caller
-// falls back to powf_exact otherwise. ~40 instructions instead of ~270; pinned against the host's
+// handles the rest of what can reach it (x == 0, x == 1, y == 0, y == +inf) itself. ~40 instructions instead of ~270; pinned against the host's
 // powf on a million inputs (tests/test_gpu_encode.py).
 __device__ const double kPowLog2Tab[16][2] = {
     {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2},
@@ -380,6 +380,10 @@ AIC_DEV bool powf_table_domain(float x, float y) {  // 0 < x < 1 normal; y > 0 f
     const uint32_t ix = __float_as_uint(x), iy = __float_as_uint(y);
     return ix >= 0x00800000u && ix < 0x3f800000u && iy > 0u && iy < 0x7f800000u;
 }
+// A 64-bit literal that is materialised where it is used (two s_mov). Left to itself the compiler hoists such constants out of
+// the persistent loop into VGPR pairs, runs out of registers, spills them to scratch at kernel start (every lane of every wave
+// storing the same 8 bytes: most of round 2's 46 MB of WRITE_SIZE per frame) and reloads them from memory in every SHADE event.
+AIC_DEV double KC(double v) { asm volatile("" : "+s"(v)); return v; }
 AIC_DEV float powf_table(float x, float y, const double *s_pow) {
     const uint32_t ix = __float_as_uint(x);
     // log2_inline
@@ -393,10 +397,10 @@ AIC_DEV float powf_table(float x, float y, const double *s_pow) {
     const double r = fma(z, invc, -1.0);
     const double y0 = logc + (double)k;
     const double r2 = r * r;
-    double yy = fma(0x1.27616c9496e0bp-2, r, -0x1.71969a075c67ap-2);
-    const double pp = fma(0x1.ec70a6ca7baddp-2, r, -0x1.7154748bef6c8p-1);
+    double yy = fma(KC(0x1.27616c9496e0bp-2), r, KC(-0x1.71969a075c67ap-2));
+    const double pp = fma(KC(0x1.ec70a6ca7baddp-2), r, KC(-0x1.7154748bef6c8p-1));
     const double r4 = r2 * r2;
-    double q = fma(0x1.71547652ab82bp+0, r, y0);
+    double q = fma(KC(0x1.71547652ab82bp+0), r, y0);
     q = fma(pp, r2, q);
     yy = fma(yy, r4, q);
     const double ylogx = (double)y * yy;
@@ -404,21 +408,40 @@ AIC_DEV float powf_table(float x, float y, const double *s_pow) {
     // general path rounds into the subnormals by itself
     if (ylogx <= -150.0) return 0.0f;
     // exp2_inline
-    double kd = ylogx + 0x1.8p+47;
+    double kd = ylogx + KC(0x1.8p+47);
     const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
-    kd -= 0x1.8p+47;
+    kd -= KC(0x1.8p+47);
     const double rr = ylogx - kd;
     unsigned long long t = (unsigned long long)__double_as_longlong(s_pow[32u + (uint32_t)(ki & 31u)]);
     t += ki << 47;
     const double sc = __longlong_as_double((long long)t);
-    const double zz = fma(0x1.c6af84b912394p-5, rr, 0x1.ebfce50fac4f3p-3);
+    const double zz = fma(KC(0x1.c6af84b912394p-5), rr, KC(0x1.ebfce50fac4f3p-3));
     const double rr2 = rr * rr;
-    double e = fma(0x1.62e42ff0c52d6p-1, rr, 1.0);
+    double e = fma(KC(0x1.62e42ff0c52d6p-1), rr, 1.0);
     e = fma(zz, rr2, e);
     e = e * sc;
     return (float)e;
 }
-AIC_DEV float expf_exact(float x) { return (float)exp((double)x); }
+// f32::exp as the reference's libm computes it (glibc sysdeps/ieee754/flt-32/e_expf.c, from ARM's optimized-routines; restated
+// from the published algorithm like powf_table above): x * 32/ln2 split into an integer and a remainder, 2^(k/32) from the
+// same 32-entry table as powf's exp2 step, a cubic in the remainder, all in f64, rounded to f32 once. Domain: |x| < 88 (the fog
+// term feeds it [-1.6, 0]); no overflow / underflow handling.
+AIC_DEV float expf_table(float x, const double *s_pow) {
+    const double z = KC(0x1.71547652b82fep+5) * (double)x;  // InvLn2N = N / ln 2, N = 32
+    double kd = z + KC(0x1.8p+52);
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd -= KC(0x1.8p+52);
+    const double r = z - kd;
+    unsigned long long t = (unsigned long long)__double_as_longlong(s_pow[32u + (uint32_t)(ki & 31u)]);
+    t += ki << 47;
+    const double sc = __longlong_as_double((long long)t);
+    const double zz = fma(KC(0x1.c6af84b912394p-20), r, KC(0x1.ebfce50fac4f3p-13));  // poly_scaled: C0 / N^3, C1 / N^2
+    const double r2 = r * r;
+    double y = fma(KC(0x1.62e42ff0c52d6p-6), r, 1.0);                                // C2 / N
+    y = fma(zz, r2, y);
+    y = y * sc;
+    return (float)y;
+}
 
 struct ColorBuf {  // raytracer_components.rs:20-39
     float l0, l1, l2, t;
@@ -461,190 +484,35 @@ AIC_DEV uint32_t round_sat_u8(float x) {  // `(x).round() as u8`
 // ---------------------------------------------------------------------------------------
 // light (space/light/data.rs, space/sky.rs, sr.rs:241-359)
 
-AIC_DEV uint32_t light_outside(const DevLayer &L, int cx, int cy, int cz) {  // sky.rs:113-147
-    const int c[3] = {cx, cy, cz};
-    int n_less = 0, n_equal = 0, which = -1;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        int lower;
-        if (L.lo[a] == I32_MIN_) lower = -1;
-        else {
-            int beyond = L.lo[a] - 1;
-            lower = beyond < c[a] ? -1 : (beyond == c[a] ? 0 : 1);
-        }
-        int hi = L.lo[a] + L.size[a];
-        int upper = c[a] < hi ? -1 : (c[a] == hi ? 0 : 1);
-        if (lower == -1) n_less++;
-        else if (lower == 0) { n_equal++; which = a; }
-        if (upper == -1) n_less++;
-        else if (upper == 0) { n_equal++; which = 3 + a; }
-    }
-    if (n_less == 5 && n_equal == 1) return L.block_sky[which];
-    if (n_less == 6) return 0u;                 // UNINITIALIZED_AND_BLACK
-    return 1u << 24;                             // NO_RAYS (status 1)
+// The light volume of the layer as aic_lightmath.h sees it (every field a kernel argument: SGPRs)
+// Each field goes through an empty asm so that it is an opaque scalar: a select between elements of a kernel-argument array
+// (`axis == 0 ? L.lo[0] : ...`) is otherwise folded into ONE load with a selected address, and a kernel-argument array that is
+// indexed per lane gets copied to scratch memory.
+AIC_DEV int opaque_s(int v) { asm volatile("" : "+s"(v)); return v; }
+AIC_DEV uint32_t opaque_s(uint32_t v) { asm volatile("" : "+s"(v)); return v; }
+AIC_DEV float opaque_s(float v) { asm volatile("" : "+s"(v)); return v; }
+template <class LayerT>
+AIC_DEV LightGridView light_view(const LayerT &L) {
+    LightGridView G;
+    G.light = L.light;
+    G.lo_x = opaque_s(L.lo[0]); G.lo_y = opaque_s(L.lo[1]); G.lo_z = opaque_s(L.lo[2]);
+    G.size_x = opaque_s(L.size[0]); G.size_y = opaque_s(L.size[1]); G.size_z = opaque_s(L.size[2]);
+    G.sky_nx = opaque_s(L.block_sky[0]); G.sky_ny = opaque_s(L.block_sky[1]); G.sky_nz = opaque_s(L.block_sky[2]);
+    G.sky_px = opaque_s(L.block_sky[3]); G.sky_py = opaque_s(L.block_sky[4]); G.sky_pz = opaque_s(L.block_sky[5]);
+    G.sky_mean = opaque_s(L.block_sky[6]);
+    return G;
 }
 
-template <bool DIAG>
-AIC_DEV uint32_t get_packed_light(const DevLayer &L, int cx, int cy, int cz, uint32_t &nlight) {  // sr.rs:241-246
+template <bool DIAG, class LayerT>
+AIC_DEV uint32_t get_packed_light(const LayerT &L, int cx, int cy, int cz, uint32_t &nlight) {  // sr.rs:241-246
     if (DIAG) nlight++;
     uint32_t dx = (uint32_t)cx - (uint32_t)L.lo[0];
     uint32_t dy = (uint32_t)cy - (uint32_t)L.lo[1];
     uint32_t dz = (uint32_t)cz - (uint32_t)L.lo[2];
     if ((dx >= (uint32_t)L.size[0]) | (dy >= (uint32_t)L.size[1]) | (dz >= (uint32_t)L.size[2]))
-        return light_outside(L, cx, cy, cz);
+        return lm_light_outside(light_view(L), cx, cy, cz);
     size_t idx = ((size_t)dx * (size_t)L.size[1] + dy) * (size_t)L.size[2] + dz;
     return L.light[idx];
-}
-
-AIC_DEV void texel_value_ao(uint32_t t, const float *lut, float out[4]) {  // data.rs:145-158
-    out[0] = lut[t & 255u];
-    out[1] = lut[(t >> 8) & 255u];
-    out[2] = lut[(t >> 16) & 255u];
-    uint32_t status = t >> 24;
-    out[3] = status == 255u ? 1.0f : (status == 128u ? 0.25f : 0.0f);
-}
-AIC_DEV void mix4(const float a[4], const float b[4], float amount, float out[4]) {  // sr.rs:491-497
-#pragma unroll
-    for (int i = 0; i < 4; i++) out[i] = a[i] + (b[i] - a[i]) * amount;
-}
-
-AIC_DEV double coarsestep(double x) {  // surface.rs:509-514
-    double f = floor(x * 4.0);
-    if (f < 0.0) f = 0.0;
-    if (f > 3.0) f = 3.0;
-    return (f + 0.5) / 4.0;
-}
-AIC_DEV double smoothstep(double x) {  // surface.rs:516-520
-    if (x < 0.0) x = 0.0;
-    if (x > 1.0) x = 1.0;
-    return 3. * (x * x) - 2. * (x * x * x);
-}
-
-// SpaceRaytracer::get_interpolated_light (sr.rs:248-359).
-//
-// Same arithmetic as the reference, organised around what is actually distinct: the tangent
-// frame of a face is two signed coordinate axes, so
-//   * dot(surface_point, frame_axis) is  +-surface_point[axis]  (the +-0 terms of the reference's
-//     three-term dot product cannot change the value that `- 0.5` is applied to);
-//   * the four sample offsets dir_1*{-.5,+.5} + dir_2*{-.5,+.5} are exactly +-0.5 on the two
-//     tangent axes and 0 on the normal axis, so the 4 (x2 planes) sample cubes are built from only
-//     5 distinct floor() values per plane instead of 12;
-//   * the light-grid index of a texel is a sum of three per-axis contributions.
-// Texel decode, the light-leak rule, the bilinear/trilinear mix4 chain and the final weight
-// division are unchanged, operation for operation.
-template <bool DIAG>
-AIC_DEV void get_interpolated_light(const DevLayer &L, const float *__restrict__ lut, const int cube[3], const double sp[3], int face,
-                                    int mode, float out[3], uint32_t &nlight) {
-    const double eps = 0.5 / 256.0;
-    // face -> (normal axis, sign) and the rotation_from_nz tangent frame (face.rs:395-404)
-    int an, a1, a2;
-    double ns, s1, s2;
-    switch (face) {
-        case 1: an = 0; ns = -1.0; a1 = 1; s1 = 1.0; a2 = 2; s2 = 1.0; break;    // NX: +Y, +Z
-        case 2: an = 1; ns = -1.0; a1 = 2; s1 = 1.0; a2 = 0; s2 = 1.0; break;    // NY: +Z, +X
-        case 3: an = 2; ns = -1.0; a1 = 0; s1 = 1.0; a2 = 1; s2 = 1.0; break;    // NZ: +X, +Y
-        case 4: an = 0; ns = 1.0; a1 = 1; s1 = -1.0; a2 = 2; s2 = 1.0; break;    // PX: -Y, +Z
-        case 5: an = 1; ns = 1.0; a1 = 2; s1 = 1.0; a2 = 0; s2 = -1.0; break;    // PY: +Z, -X
-        case 6: an = 2; ns = 1.0; a1 = 0; s1 = 1.0; a2 = 1; s2 = -1.0; break;    // PZ: +X, -Y
-        default: an = 2; ns = 0.0; a1 = 0; s1 = 1.0; a2 = 1; s2 = 1.0; break;    // Within: IDENTITY frame, zero normal
-    }
-    auto pick3d = [](int a, double x, double y, double z) { return a == 0 ? x : (a == 1 ? y : z); };
-    auto pick3i = [](int a, int x, int y, int z) { return a == 0 ? x : (a == 1 ? y : z); };
-    const double spn = pick3d(an, sp[0], sp[1], sp[2]), sp1 = pick3d(a1, sp[0], sp[1], sp[2]), sp2 = pick3d(a2, sp[0], sp[1], sp[2]);
-
-    double mix_1 = rem_euclid1(s1 * sp1 - 0.5);
-    double mix_2 = rem_euclid1(s2 * sp2 - 0.5);
-    double g1 = s1, g2 = s2;  // dir_1 / dir_2 along their axes
-    if (mix_1 > 0.5) { mix_1 = 1.0 - mix_1; g1 = -g1; }
-    if (mix_2 > 0.5) { mix_2 = 1.0 - mix_2; g2 = -g2; }
-    if (mode == 2) { mix_1 = coarsestep(mix_1); mix_2 = coarsestep(mix_2); }
-    else if (mode == 4) { mix_1 = smoothstep(mix_1); mix_2 = smoothstep(mix_2); }
-    const float m1 = (float)mix_1, m2 = (float)mix_2;
-
-    // height of the surface inside its cube: face.dot(sp) - face.dot(cube centre) + 0.5
-    const double cn = (double)pick3i(an, cube[0], cube[1], cube[2]) + 0.5;
-    const double height_in_cube = (ns == 0.0) ? 0.5 : ((ns * spn) - (ns * cn) + 0.5);
-
-    // per-role grid parameters (role = normal / tangent-1 / tangent-2 axis)
-    const int lo_n = pick3i(an, L.lo[0], L.lo[1], L.lo[2]), lo_1 = pick3i(a1, L.lo[0], L.lo[1], L.lo[2]), lo_2 = pick3i(a2, L.lo[0], L.lo[1], L.lo[2]);
-    const uint32_t sz_n = (uint32_t)pick3i(an, L.size[0], L.size[1], L.size[2]), sz_1 = (uint32_t)pick3i(a1, L.size[0], L.size[1], L.size[2]),
-                   sz_2 = (uint32_t)pick3i(a2, L.size[0], L.size[1], L.size[2]);
-    const uint32_t stride_x = (uint32_t)L.size[1] * (uint32_t)L.size[2], stride_y = (uint32_t)L.size[2];
-    const uint32_t st_n = (uint32_t)pick3i(an, (int)stride_x, (int)stride_y, 1), st_1 = (uint32_t)pick3i(a1, (int)stride_x, (int)stride_y, 1),
-                   st_2 = (uint32_t)pick3i(a2, (int)stride_x, (int)stride_y, 1);
-
-    // Cube::containing on one coordinate: in i32 range -> floor, else "no cube" (cube.rs:97-119)
-    auto fl = [](double v, bool &ok) -> int {
-        ok = ok && (v >= -2147483648.0) && (v < 2147483648.0);
-        return (int)floor(v);
-    };
-    // the two tangent axes are shared by both planes: sample positions sp +- 0.5 along dir_1 / dir_2
-    bool ok1n = true, ok1f = true, ok2n = true, ok2f = true;
-    const int v1n = fl(sp1 + g1 * -0.5, ok1n), v1f = fl(sp1 + g1 * 0.5, ok1f);
-    const int v2n = fl(sp2 + g2 * -0.5, ok2n), v2f = fl(sp2 + g2 * 0.5, ok2f);
-    const uint32_t d1n = (uint32_t)v1n - (uint32_t)lo_1, d1f = (uint32_t)v1f - (uint32_t)lo_1;
-    const uint32_t d2n = (uint32_t)v2n - (uint32_t)lo_2, d2f = (uint32_t)v2f - (uint32_t)lo_2;
-
-    // One plane of four texels. The four light-grid loads are issued together (clamped index, no
-    // branch in front of them); the rare "outside the space" / "no cube" cases are patched afterwards.
-    auto fetch2d = [&](double on, float res[4]) {
-        bool okn = true;
-        const int vn = fl(on, okn);
-        const uint32_t dn = (uint32_t)vn - (uint32_t)lo_n;
-        const bool in_n = dn < sz_n, in_1n = d1n < sz_1, in_1f = d1f < sz_1, in_2n = d2n < sz_2, in_2f = d2f < sz_2;
-        const uint32_t bn = dn * st_n, b1n = d1n * st_1, b1f = d1f * st_1, b2n = d2n * st_2, b2f = d2f * st_2;
-        const bool i00 = in_n & in_1n & in_2n, i01 = in_n & in_1n & in_2f, i10 = in_n & in_1f & in_2n, i11 = in_n & in_1f & in_2f;
-        uint32_t t00 = L.light[i00 ? bn + b1n + b2n : 0u];  // near12
-        uint32_t t01 = L.light[i01 ? bn + b1n + b2f : 0u];  // near1far2
-        uint32_t t10 = L.light[i10 ? bn + b1f + b2n : 0u];  // near2far1
-        uint32_t t11 = L.light[i11 ? bn + b1f + b2f : 0u];  // far12
-        const bool k00 = okn & ok1n & ok2n, k01 = okn & ok1n & ok2f, k10 = okn & ok1f & ok2n, k11 = okn & ok1f & ok2f;
-        if (DIAG) nlight += (k00 ? 1u : 0u) + (k01 ? 1u : 0u) + (k10 ? 1u : 0u) + (k11 ? 1u : 0u);
-        if (!(i00 & i01 & i10 & i11)) {
-            // outside the space: BlockSky::light_outside on the reassembled cube; numerical overflow
-            // (no containing cube): BlockSky::mean (sr.rs:307-311)
-            auto patch = [&](bool inb, bool ok, int v1, int v2, uint32_t t) -> uint32_t {
-                if (!ok) return L.block_sky[6];
-                if (inb) return t;
-                const int c0 = an == 0 ? vn : (a1 == 0 ? v1 : v2);
-                const int c1 = an == 1 ? vn : (a1 == 1 ? v1 : v2);
-                const int c2 = an == 2 ? vn : (a1 == 2 ? v1 : v2);
-                return light_outside(L, c0, c1, c2);
-            };
-            t00 = patch(i00, k00, v1n, v2n, t00);
-            t01 = patch(i01, k01, v1n, v2f, t01);
-            t10 = patch(i10, k10, v1f, v2n, t10);
-            t11 = patch(i11, k11, v1f, v2f, t11);
-        }
-        // light-leak fix: both side texels invalid => far corner := near corner
-        if ((t01 >> 24) != 255u && (t10 >> 24) != 255u) t11 = t00;
-        float a[4], b[4], c[4], d[4], ab[4], cd[4];
-        texel_value_ao(t00, lut, a);
-        texel_value_ao(t01, lut, b);
-        texel_value_ao(t10, lut, c);
-        texel_value_ao(t11, lut, d);
-        mix4(a, b, m2, ab);
-        mix4(c, d, m2, cd);
-        mix4(ab, cd, m1, res);
-    };
-
-    float front[4], fin[4];
-    fetch2d(spn + ns * (1.0 - eps), front);
-    if (height_in_cube > (1.0 - eps)) {
-        fin[0] = front[0]; fin[1] = front[1]; fin[2] = front[2]; fin[3] = front[3];
-    } else {
-        float same[4];
-        fetch2d(spn + ns * eps, same);
-        mix4(same, front, (float)height_in_cube, fin);
-    }
-    const float w = fmaxf(fin[3], 0.1f);
-    if (__ballot(w != 1.0f) == 0ull) {  // x / 1.0f == x: fully lit neighbourhoods (the usual case) need no division
-        out[0] = fin[0]; out[1] = fin[1]; out[2] = fin[2];
-    } else {
-        out[0] = fin[0] / w;
-        out[1] = fin[1] / w;
-        out[2] = fin[2] / w;
-    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -683,7 +551,8 @@ struct SurfDiag {  // DIAG only: identity of a pending surface
 };
 
 // camera (camera_struct.rs:238-257; euclid Transform3D::transform_point3d)
-AIC_DEV void unproject(const double *__restrict__ m, double x, double y, double z, double out[3]) {
+template <class MatP>
+AIC_DEV void unproject(MatP m, double x, double y, double z, double out[3]) {
     const double px = x * m[0] + y * m[4] + z * m[8] + m[12];
     const double py = x * m[1] + y * m[5] + z * m[9] + m[13];
     const double pz = x * m[2] + y * m[6] + z * m[10] + m[14];
@@ -776,8 +645,6 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
     // image is exhausted, so cheap (sky) and expensive (geometry) tiles balance dynamically ----
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t tile_x0 = 0, tile_y0 = 0;  // wave-uniform: pixel origin of the tile the refill is drawing from
-    const DevLayer &L = F.layer;
-    const DevOptions &opt = L.opt;
     // small decode tables live in LDS for the life of the persistent workgroup
     __shared__ float s_lut[256];     // PackedLight scalar decode (light/data.rs:301-354)
     __shared__ float s_thr[256];     // sRGB8 encode thresholds
@@ -789,19 +656,18 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
     }
     __syncthreads();
     const float *lut = s_lut;
-    const bool ui_pass = F.pass == 1;
-    const bool include_sky = !ui_pass;
-    const bool fog_on = (opt.fog != 0) && include_sky;
-    const size_t npix = (size_t)F.width * F.local_rows;
-    const int n_samples = F.antialias ? 4 : 1;
-
-    const int olx = L.lo[0], oly = L.lo[1], olz = L.lo[2];
-    const int osx_i = L.size[0], osy_i = L.size[1], osz_i = L.size[2];
-    const int ostx = 2 * osy_i * osz_i, osty = 2 * osz_i;  // byte strides of the cube grid (z: 2)
+    // Kernel arguments and the persistent loop. The stepping phase needs three scalars of them (the pool pointer and the cube
+    // grid's two byte strides, below); everything else is wanted by events only. Left as plain uses of `F`, the compiler
+    // fetches all ~250 dwords of DevFrame before the loop, keeps what fits in SGPRs and parks the rest in VGPR lanes
+    // (v_writelane / v_readlane + hazard nops: round 2's 92 spilled SGPRs and two VGPRs lost to them). Instead every event
+    // phase reads the arguments it needs through an OPAQUE pointer to the kernel-argument segment (see the event phase):
+    // scalar loads that hit the constant cache, issued where they are used, holding no register across the loop.
+    const int ostx = 2 * F.layer.size[1] * F.layer.size[2], osty = 2 * F.layer.size[2];  // byte strides of the cube grid (z: 2)
+    const bool ui_pass_s = F.pass == 1;  // (DIAG builds: the stepping phase labels first hits with their layer)
     // cube grid at offset 0, then every block's voxel volume. The pointer is laundered through an
     // s_mov so that it is a computed SGPR pair rather than a re-loadable kernel argument: under SGPR
     // pressure the compiler would otherwise re-fetch it (s_load + wait) in front of every lookup.
-    unsigned long long pool_bits = (unsigned long long)L.pool;
+    unsigned long long pool_bits = (unsigned long long)F.layer.pool;
     asm volatile("s_mov_b64 %0, %1" : "=s"(pool_bits) : "s"(pool_bits));
     // BIG: block tables past 16384 entries -- plain 16-bit indices in the grid, classes from L.cls
     const uint32_t idx_mask = BIG ? 0xffffu : kCubeIndexMask;
@@ -867,16 +733,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
 #define AIC_PROF(i, v)
 #define AIC_TICK(i)
 #endif
-    const uint32_t tile_px = F.tile * F.tile;  // pixels per tile: 256 or 64
-    const uint32_t macro_shift = (uint32_t)__ffs((int)F.macro) - 1u;
-    const uint32_t n_virtual = (F.macros_x * F.macros_y) << (macro_shift * 2u);  // work items incl. the macro tiles' overhang
-    uint32_t next_idx = tile_px;  // wave-uniform: next unassigned pixel of tile_cur (tile_px = tile exhausted)
+    uint32_t next_idx = F.tile * F.tile;  // wave-uniform: next unassigned pixel of tile_cur (tile_px = tile exhausted)
 
-    // sky colour seen along this ray (Sky::sample, sky.rs:32-41); the octant was fixed at ray start
-    auto sky_now = [&](float out[3]) {
-        const int idx = (L.sky_kind != 0) ? (int)((st >> 24) & 7u) : 0;
-        out[0] = L.sky[idx][0]; out[1] = L.sky[idx][1]; out[2] = L.sky[idx][2];
-    };
     // FACE_TABLE (raycast.rs:618-623) applied late: the Face of the cube the level is in
     auto face_now = [&]() -> uint32_t {
         if (lax & 8u) return lax & 7u;
@@ -934,6 +792,36 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         AIC_TICK(19);
         if (run != 0u) {
             // ============================ event phase ======================================
+            // the kernel arguments, through an opaque pointer (see the top of the kernel): `F`, `L`, `opt` below shadow the
+            // by-value parameter for the whole phase
+            typedef const __attribute__((address_space(4))) DevFrame KFrame;
+            KFrame *Fq = (KFrame *)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(Fq));
+            KFrame &F = *Fq;
+            const auto &L = F.layer;
+            const auto &opt = L.opt;
+            const bool ui_pass = F.pass == 1;
+            const bool include_sky = !ui_pass;
+            const bool fog_on = (opt.fog != 0) && include_sky;
+            const size_t npix = (size_t)F.width * F.local_rows;
+            const int n_samples = F.antialias ? 4 : 1;
+            const int olx = L.lo[0], oly = L.lo[1], olz = L.lo[2];
+            const int osx_i = L.size[0], osy_i = L.size[1], osz_i = L.size[2];
+            const uint32_t tile_px = F.tile * F.tile;  // pixels per tile: 256 or 64
+            const uint32_t macro_shift = (uint32_t)__ffs((int)F.macro) - 1u;
+            const uint32_t macro_px_shift = macro_shift + (uint32_t)__ffs((int)F.tile) - 1u;  // log2 of a macro tile's edge in pixels
+            const uint32_t n_virtual = (F.macros_x * F.macros_y) << (macro_shift * 2u);  // work items incl. the macro tiles' overhang
+            // sky colour seen along this ray (Sky::sample, sky.rs:32-41); the octant was fixed at ray start. An octant sky is
+            // read per lane from the kernel-argument segment as ordinary memory: indexing the array per lane in registers
+            // would make the compiler keep a copy of it in scratch.
+            auto sky_now = [&](float out[3]) {
+                if (L.sky_kind != 0) {
+                    const float *p = (const float *)((const char *)(const void *)Fq + offsetof(DevFrame, layer) + offsetof(DevLayer, sky)) + 3u * ((st >> 24) & 7u);
+                    out[0] = p[0]; out[1] = p[1]; out[2] = p[2];
+                } else {
+                    out[0] = L.sky[0][0]; out[1] = L.sky[0][1]; out[2] = L.sky[0][2];
+                }
+            };
             AIC_PROF(0, 1);
             AIC_PROF(1, c_shade + c_enter + c_ray);
             AIC_PROF(4, run == EV_SHADE ? 1 : 0); AIC_PROF(5, run == EV_SHADE ? c_shade : 0);
@@ -991,10 +879,15 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                         } else {
                             intersection_point(ca, ox, oy, oz, dx, dy, dz, ip);
                         }
-                        const int oc[3] = {ocx, ocy, ocz};
-                        float il[3];
-                        get_interpolated_light<DIAG>(L, lut, oc, ip, face, opt.lighting, il, nl);
-                        i0 = il[0]; i1 = il[1]; i2 = il[2];
+                        // get_interpolated_light (sr.rs:248-359; aic_lightmath.h), then rgb / max(weight, 0.1)
+                        float fin[4];
+                        lm_interpolated_light(light_view(L), lut, ocx, ocy, ocz, ip[0], ip[1], ip[2], face, opt.lighting, fin, DIAG ? &nl : nullptr);
+                        const float w = fmaxf(fin[3], 0.1f);
+                        if (__ballot(w != 1.0f) == 0ull) {  // x / 1.0f == x: fully lit neighbourhoods (the usual case) need no division
+                            i0 = fin[0]; i1 = fin[1]; i2 = fin[2];
+                        } else {
+                            i0 = fin[0] / w; i1 = fin[1] / w; i2 = fin[2] / w;
+                        }
                     }
                 }
                 AIC_TICK(18);
@@ -1040,8 +933,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                         float depth_t;
                         if (unit_t == 0.0f) depth_t = 0.0f;
                         else if (unit_t == 1.0f) depth_t = 1.0f;
-                        else if (powf_table_domain(unit_t, thickness)) depth_t = powf_table(unit_t, thickness, s_pow);
-                        else depth_t = powf_exact(unit_t, thickness);
+                        else if (!(thickness < __uint_as_float(0x7f800000u))) depth_t = 0.0f;  // powf(0 < x < 1, +inf) == 0
+                        else depth_t = powf_table(unit_t, thickness, s_pow);  // 0 < unit_t < 1 normal (aic_upload_* reject alpha outside [0, 1]), thickness > 0 finite
                         a = zo_clamped(1.0f - depth_t);
                         const float ec = (unit_t == 1.0f) ? thickness : (depth_t - 1.f) / (unit_t - 1.f);
                         coeff = fmaxf(ec, 0.0f);
@@ -1074,7 +967,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                             // +0.0 + rel^4 * 1.0 == rel^4 exactly -- no exp needed
                             amount = zo_clamped((sq * sq) * 1.0f);
                         } else {
-                            const float fog_exp = 1.0f - expf_exact(-1.6f * rel);
+                            const float fog_exp = 1.0f - expf_table(-1.6f * rel, s_pow);
                             const float fudged = fog_exp / 0.79810348f;
                             amount = zo_clamped(fudged * (1.0f - fog_blend) + (sq * sq) * fog_blend);
                         }
@@ -1196,7 +1089,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     // longest ray of the macro tile so far. Only rays long enough to matter for the frame's
                     // tail are recorded (the rest leave their tile at cost 0: handed out last, in index
                     // order), and the plain read filters out almost every atomic.
-                    uint32_t *tc = &F.tile_cost[(lrow / (F.tile << macro_shift)) * F.macros_x + x / (F.tile << macro_shift)];
+                    uint32_t *tc = &F.tile_cost[(lrow >> macro_px_shift) * F.macros_x + (x >> macro_px_shift)];  // tile edge and macro are powers of two
                     if (count > *tc) atomicMax(tc, count);
                 }
                 const size_t pix = (size_t)lrow * F.width + x;
@@ -1301,8 +1194,12 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                         uint32_t mt = t >> m_shift;
                         const uint32_t inner = t & ((1u << m_shift) - 1u);
                         if (F.tile_order) mt = F.tile_order[mt];
-                        const uint32_t tx_ = ((mt % F.macros_x) << macro_shift) + (inner & ((1u << macro_shift) - 1u));
-                        const uint32_t ty_ = ((mt / F.macros_x) << macro_shift) + (inner >> macro_shift);
+                        // (divisors taken through opaque_s: a division by a loop-invariant value is otherwise expanded into a
+                        //  reciprocal that is computed before the persistent loop and then lives in -- or is spilled from -- a VGPR)
+                        const uint32_t mx_ = opaque_s(F.macros_x);
+                        const uint32_t mrow = mt / mx_;
+                        const uint32_t tx_ = ((mt - mrow * mx_) << macro_shift) + (inner & ((1u << macro_shift) - 1u));
+                        const uint32_t ty_ = (mrow << macro_shift) + (inner >> macro_shift);
                         tile_x0 = tx_ * F.tile;
                         tile_y0 = ty_ * F.tile;
                         if (tile_x0 >= F.width || tile_y0 >= F.local_rows) continue;  // a macro tile's overhang past the image edge
@@ -1345,14 +1242,16 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     }
                 }
                 // global row of this local row under the strip partition
-                const uint32_t y = (F.part + (lrow / F.strip_rows) * F.n_parts) * F.strip_rows + (lrow % F.strip_rows);
+                const uint32_t srows = opaque_s(F.strip_rows), fw = opaque_s(F.width), fh = opaque_s(F.height);
+                const uint32_t strip = lrow / srows;
+                const uint32_t y = (F.part + strip * F.n_parts) * srows + (lrow - strip * srows);
                 double x0, x1, y0, y1;  // the pixel's NdcRect {min: (x0, y0), max: (x1, y1)} (renderer.rs:537-550)
                 if (F.patches) {
                     const double *r = F.patches + 4u * pix;
                     x0 = r[0]; y0 = r[1]; x1 = r[2]; y1 = r[3];
                 } else {
-                    x0 = fb_x_edge(F.width, x); x1 = fb_x_edge(F.width, x + 1);
-                    y0 = fb_y_edge(F.height, y); y1 = fb_y_edge(F.height, y + 1);
+                    x0 = fb_x_edge(fw, x); x1 = fb_x_edge(fw, x + 1);
+                    y0 = fb_y_edge(fh, y); y1 = fb_y_edge(fh, y + 1);
                 }
                 double px, py;  // renderer.rs:428-433 sample points, else the patch centre
                 if (n_samples == 4) {
@@ -1361,8 +1260,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     px = x0 + (x1 - x0) * ux;
                     py = y0 + (y1 - y0) * uy;
                 } else if (F.pixel_centers) {  // Viewport::normalize_fb_x / _y (viewport.rs:89-99): the text renderer's rays
-                    px = ((double)x + 0.5) / (double)F.width * 2.0 - 1.0;
-                    py = -(((double)y + 0.5) / (double)F.height * 2.0 - 1.0);
+                    px = ((double)x + 0.5) / (double)fw * 2.0 - 1.0;
+                    py = -(((double)y + 0.5) / (double)fh * 2.0 - 1.0);
                 } else {
                     px = (x0 + x1) / 2.0;
                     py = (y0 + y1) / 2.0;
@@ -1376,7 +1275,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 }
                 if (DIAG && sample > 0) dg.hit = dg.hit | 2;  // only the first sample's position is reported
                 if (!ui_pass && F.has_backdrop) {  // Exception::Backdrop hit: ColorBuf::from(Rgba)
-                    const float a = F.backdrop[3];
+                    const float a = opaque_s(F.backdrop[3]);
                     cb_add(acc, F.backdrop[0] * a, F.backdrop[1] * a, F.backdrop[2] * a, 1.0f - a);
                 }
                 count = 0;
@@ -1557,7 +1456,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             if (BIG) {
                 // block tables past 16384 entries: plain 16-bit indices, classes from the table in global memory
                 uint32_t cls = 0u;
-                if (AIC_LANE(m_lookup & ~m_inb)) cls = (L.cls[raw >> 4] >> ((raw & 15u) << 1)) & 3u;
+                if (AIC_LANE(m_lookup & ~m_inb)) cls = (F.layer.cls[raw >> 4] >> ((raw & 15u) << 1)) & 3u;
                 m_blk = __builtin_amdgcn_ballot_w64(cls == 2u);
                 m_surf = (__builtin_amdgcn_ballot_w64(raw >= thr) & m_lookup & m_inb) | __builtin_amdgcn_ballot_w64(cls == 1u);
             } else {
@@ -1624,7 +1523,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                         dg.n_light += pend_d.nlight;
                         if (!dg.hit) {
                             dg.hit = 1;
-                            dg.layer = ui_pass ? 1u : 0u;
+                            dg.layer = ui_pass_s ? 1u : 0u;
                             for (int a2 = 0; a2 < 3; a2++) { dg.cube[a2] = pend_d.cube[a2]; dg.voxel[a2] = pend_d.voxel[a2]; }
                             dg.res = pend_d.res; dg.face = pend_d.face; dg.block = pend_d.block; dg.t = pend_t;
                         }
@@ -1811,6 +1710,10 @@ __global__ void probe_raycast_kernel(const double *od, int use_bounds, const int
     }
     *n_out = n;
 }
+
+// f32::powf evaluated in f64 and rounded once: only for the probe below, outside powf_table's domain (the trace kernel never
+// leaves that domain)
+AIC_DEV float powf_exact(float x, float y) { return (float)pow((double)x, (double)y); }
 
 // aic_probe_powf: the device's powf (table path where its domain allows, as the trace kernel chooses)
 __global__ void probe_powf_kernel(const float *x, const float *y, float *out, uint32_t n) {

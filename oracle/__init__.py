@@ -375,6 +375,15 @@ def block_sky(space: Space) -> np.ndarray:
     return out
 
 
+def interpolated_light(space: Space, cube, surface_point, face: int, lighting: int = 3):
+    """get_interpolated_light (sr.rs:248-359) of one surface -> (rgb f32[3], number of get_packed_light calls)."""
+    out = np.zeros(3, np.float32)
+    f = lib().orc_interpolated_light
+    f.restype = C.c_uint32
+    n = f(C.byref(space.c), C.c_void_p(_p(_i3(cube))), C.c_void_p(_p(_d3(surface_point))), C.c_int32(face), C.c_int32(lighting), C.c_void_p(_p(out)))
+    return out, int(n)
+
+
 def smoothstep(x: float) -> float:
     return lib().orc_smoothstep(x)
 

@@ -1877,6 +1877,17 @@ void orc_block_sky(const orc_space *space, uint8_t out_faces_mean[7][4]) {
     out_faces_mean[6][0] = bs.mean.r; out_faces_mean[6][1] = bs.mean.g; out_faces_mean[6][2] = bs.mean.b; out_faces_mean[6][3] = bs.mean.status;
 }
 
+// get_interpolated_light (sr.rs:248-359) for one surface: (cube, surface point, face, LightingOption) -> illumination rgb and the
+// number of get_packed_light calls. For the host-compiled device arithmetic (tests/test_lightmath_host.py).
+uint32_t orc_interpolated_light(const orc_space *space, const int32_t cube[3], const double surface_point[3], int32_t face,
+                                int32_t lighting, float out_rgb[3]) {
+    SR rt(space, nullptr);
+    Counters cn{};
+    const Rgb v = get_interpolated_light(rt, I3{{cube[0], cube[1], cube[2]}}, v3(surface_point[0], surface_point[1], surface_point[2]), face, lighting, &cn);
+    out_rgb[0] = v.r; out_rgb[1] = v.g; out_rgb[2] = v.b;
+    return (uint32_t)cn.n_light;
+}
+
 double orc_smoothstep(double x) { return smoothstep(x); }
 double orc_coarsestep(double x) { return coarsestep(x); }
 

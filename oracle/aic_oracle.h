@@ -174,6 +174,9 @@ void orc_to_srgb8(const float rgba[4], uint8_t out[4]);
 float orc_packed_light_scalar_out(uint8_t v);
 uint8_t orc_packed_light_scalar_in(float v);
 void orc_block_sky(const orc_space *space, uint8_t out_faces_mean[7][4]);
+/* get_interpolated_light (sr.rs:248-359) of one surface; returns the number of get_packed_light calls */
+uint32_t orc_interpolated_light(const orc_space *space, const int32_t cube[3], const double surface_point[3], int32_t face,
+                                int32_t lighting, float out_rgb[3]);
 double orc_smoothstep(double x);
 double orc_coarsestep(double x);
 
