@@ -157,6 +157,7 @@ struct aic_ctx {
         DevBuf<float4> acc;  // UI pre-pass accumulators
         // cost feedback: the longest ray of every tile of the slot's last frame, and the tile order made from it
         DevBuf<uint32_t> tile_cost, tile_order;
+        DevBuf<uint4> orphans;  // ray migration (aic_trace.hip): hot lane state of the rays handed over in the frame's tail
         uint32_t cost_sig[4] = {0, 0, 0, 0};  // width, local rows, partition of the frame tile_cost describes
         double cost_cam[16] = {0};            // ... and its world camera
         bool busy = false;
@@ -449,7 +450,7 @@ void aic_destroy(aic_ctx *c) {
     for (uint32_t i = 0; i < AIC_MAX_IN_FLIGHT; i++) {
         aic_ctx::FrameSlot &fs = c->slots[i];
         if (fs.stream) (void)hipStreamSynchronize(fs.stream);
-        fs.counters.release(); fs.acc.release(); fs.tile_cost.release(); fs.tile_order.release();
+        fs.counters.release(); fs.acc.release(); fs.tile_cost.release(); fs.tile_order.release(); fs.orphans.release();
         if (fs.ev0) (void)hipEventDestroy(fs.ev0);
         if (fs.ev1) (void)hipEventDestroy(fs.ev1);
         if (i > 0 && fs.stream) (void)hipStreamDestroy(fs.stream);
@@ -978,6 +979,17 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         const size_t samples = F.antialias ? 4 : 1;
         if ((e = fs.acc.ensure(samples * npix)) != hipSuccess) return hip_fail(c, "alloc accumulators", e);
         F.acc_buf = fs.acc.p;
+    }
+    {
+        // ray migration in the frame's tail (an experiment: needs a library built with -DAIC_RAY_MIGRATION=1, see aic_trace.hip):
+        // AIC_MIGRATE_K=<n> makes a wave hand its rays over once it is down to n of them; off by default
+        static const uint32_t migrate_k = [] { const char *e = std::getenv("AIC_MIGRATE_K"); const int v = e ? std::atoi(e) : 0; return (uint32_t)(v < 0 ? 0 : (v > 64 ? 64 : v)); }();
+        if (migrate_k && !diag) {
+            const size_t groups = (size_t)c->n_cus * 4u;  // the persistent grid never exceeds the resident workgroups (launch_trace)
+            if ((e = fs.orphans.ensure(groups * 256u * (kOrphanDwords / 4u))) != hipSuccess) return hip_fail(c, "alloc migration buffer", e);
+            F.orphans = fs.orphans.p;
+            F.migrate_k = migrate_k;
+        }
     }
     HIP_TRY(c, hipEventRecord(fs.ev0, fs.stream));
     if (ui) {

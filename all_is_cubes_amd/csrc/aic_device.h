@@ -155,7 +155,12 @@ struct DevFrame {
     uint32_t *tile_cost;
     const float *light_lut;  // 256 floats
     const float *srgb_thr;   // 256 floats: srgb_thr[k] = smallest linear value whose sRGB8 encoding is >= k
+    // ray migration in the frame's tail (aic_trace.hip): hot lane state of the rays a wave hands over, kOrphanDwords dwords per
+    // (workgroup, LDS column); a wave hands its rays over once the tile queue is dry and it has at most migrate_k of them (0: off)
+    uint4 *orphans;
+    uint32_t migrate_k;
 };
+constexpr uint32_t kOrphanDwords = 40u;
 
 // Largest work tile edge in pixels (DevFrame.tile is 8 by default, 16 with AIC_TILE=16); row strips of
 // the multi-GPU partition are a multiple of it.

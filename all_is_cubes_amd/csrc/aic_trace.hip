@@ -654,6 +654,23 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         s_lut[i] = F.light_lut[i];
         s_thr[i] = F.srgb_thr[i];
     }
+    // ---- ray migration in the frame's tail (an experiment, compiled in with -DAIC_RAY_MIGRATION=1) ----
+    // Once the tile queue is dry every wave still holds up to 64 rays at random stages and drains them at falling lane
+    // utilisation: the tail of a single frame is a quarter to a third of its duration (profiles/r03_wave_tail.txt). With this
+    // switch a wave that is down to a few rays hands them over: it parks their hot registers in global memory (`orphans`; their
+    // cold state is already in the workgroup's LDS columns, which stay valid), publishes the columns in s_pool_col and exits;
+    // the workgroup's ANCHOR wave adopts them into its own idle lanes (a lane just switches to the orphan's column). Results
+    // cannot change -- a ray is a pure function of its own state, which moves as a whole -- and do not (frame hashes and
+    // step counts equal for every threshold, 300-seed fuzz green). MEASURED: no gain (C2 one frame 0.960 ms without,
+    // 0.968 / 0.973 / 0.985 ms handing over at <= 8 / 16 / 32 rays; profiles/r03_experiments.txt): the tail is not waves
+    // competing for issue slots, it is the serial latency of the last rays themselves, which a merged wave does not shorten.
+#ifndef AIC_RAY_MIGRATION
+#define AIC_RAY_MIGRATION 0
+#endif
+    constexpr bool MIGRATE = (AIC_RAY_MIGRATION != 0) && !DIAG;
+    __shared__ uint32_t s_mig[4];  // [0] orphans published  [1] orphans adopted  [2] waves of the workgroup still running  [3] donors' lock
+    __shared__ uint8_t s_pool_col[AIC_WG_THREADS];
+    if (MIGRATE && threadIdx.x == 0) { s_mig[0] = 0u; s_mig[1] = 0u; s_mig[2] = (uint32_t)AIC_WG_THREADS / 64u; s_mig[3] = 0u; }
     __syncthreads();
     const float *lut = s_lut;
     // Kernel arguments and the persistent loop. The stepping phase needs three scalars of them (the pool pointer and the cube
@@ -701,11 +718,16 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
     __shared__ double c64[N_C64][AIC_WG_THREADS];
     __shared__ uint32_t c32[N_C32][AIC_WG_THREADS];
     const uint32_t tid = threadIdx.x;
-    // LDS byte addresses of this thread's columns (the low half of a generic LDS pointer is the LDS offset)
-    const uint32_t lds64 = (uint32_t)(uintptr_t)&c64[0][tid], lds32 = (uint32_t)(uintptr_t)&c32[0][tid];
+    uint32_t col = tid;  // the LDS column holding this lane's ray: its own, or an adopted ray's (ray migration)
+    // LDS byte addresses of the lane's columns (the low half of a generic LDS pointer is the LDS offset)
+    uint32_t lds64 = (uint32_t)(uintptr_t)&c64[0][col], lds32 = (uint32_t)(uintptr_t)&c32[0][col];
     c32[K_STEPS][tid] = 0u;
     c32[K_BLK][tid] = 0u;
     c32[K_PXY][tid] = 0u;
+    const uint32_t mig_k = MIGRATE ? F.migrate_k : 0u;
+    const bool anchor = (threadIdx.x >> 6) == 0u;   // the wave of the workgroup that adopts, never hands over, and leaves last
+    bool dry = false;                               // wave-uniform: this wave has seen the tile queue exhausted
+    bool donated = false;
     SurfDiag pend_d;
     double pend_t = 0.0;
     bool pend_visible = false;
@@ -761,10 +783,63 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         const unsigned long long m_st = __ballot(ev < 4u);
         const unsigned long long b_shade = __ballot((ev & EV_SHADE) != 0u);
         const unsigned long long b_enter = __ballot((ev & EV_ENTER) != 0u);
-        const unsigned long long b_ray = __ballot((ev & (EV_FINISH | EV_NEWRAY)) != 0u);
+        unsigned long long b_ray = __ballot((ev & (EV_FINISH | EV_NEWRAY)) != 0u);
         if ((m_st | b_shade | b_enter | b_ray) == 0ull) break;
+        bool only_waiting = false;  // ray migration, anchor wave: every lane that is not done waits for a ray to adopt
+        if (MIGRATE && dry && anchor && mig_k != 0u) {
+            // lanes that found the queue dry wait for orphans; they ask for a ray phase only when there is one to adopt, or
+            // when nothing else is left in the wave (the ray phase then decides whether anything can still come)
+            const unsigned long long b_wait = __ballot(ev == (EV_NEWRAY | EV_TAKE));
+            if (b_wait != 0ull) {
+                const bool others = (m_st | b_shade | b_enter | (b_ray & ~b_wait)) != 0ull;
+                const bool to_adopt = __hip_atomic_load(&s_mig[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) !=
+                                      __hip_atomic_load(&s_mig[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (others && !to_adopt) b_ray &= ~b_wait;
+                only_waiting = !others;
+            }
+        }
         const int n_step = __popcll(m_st);
         const int c_shade = __popcll(b_shade), c_enter = __popcll(b_enter), c_ray = __popcll(b_ray);
+        if (MIGRATE && dry && !anchor && n_step + c_shade + c_enter + c_ray <= (int)mig_k) {
+            // ---- hand this wave's last rays over to the workgroup's anchor wave and leave ----
+            typedef const __attribute__((address_space(4))) DevFrame KFrame;
+            KFrame *Fq = (KFrame *)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(Fq));
+            const unsigned long long live = m_st | b_shade | b_enter | b_ray;
+            uint32_t base = 0u;
+            if (lane == 0u) {
+                while (atomicCAS(&s_mig[3], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(2);  // one donor at a time
+                base = __hip_atomic_load(&s_mig[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            base = (uint32_t)__shfl((int)base, 0, 64);
+            if ((live >> lane) & 1ull) {
+                const uint32_t rank = (uint32_t)__popcll(live & ((1ull << lane) - 1ull));
+                s_pool_col[base + rank] = (uint8_t)col;
+                uint4 *dst = Fq->orphans + ((size_t)blockIdx.x * (uint32_t)AIC_WG_THREADS + col) * (kOrphanDwords / 4u);
+                const unsigned long long b0 = (unsigned long long)__double_as_longlong(tx), b1 = (unsigned long long)__double_as_longlong(ty),
+                                         b2 = (unsigned long long)__double_as_longlong(tz), b3 = (unsigned long long)__double_as_longlong(last_t),
+                                         b4 = (unsigned long long)__double_as_longlong(tdx), b5 = (unsigned long long)__double_as_longlong(tdy),
+                                         b6 = (unsigned long long)__double_as_longlong(tdz);
+                dst[0] = make_uint4((uint32_t)b0, (uint32_t)(b0 >> 32), (uint32_t)b1, (uint32_t)(b1 >> 32));
+                dst[1] = make_uint4((uint32_t)b2, (uint32_t)(b2 >> 32), (uint32_t)b3, (uint32_t)(b3 >> 32));
+                dst[2] = make_uint4((uint32_t)b4, (uint32_t)(b4 >> 32), (uint32_t)b5, (uint32_t)(b5 >> 32));
+                dst[3] = make_uint4((uint32_t)b6, (uint32_t)(b6 >> 32), rx, ry);
+                dst[4] = make_uint4(rz, boff, (uint32_t)ssx, (uint32_t)ssy);
+                dst[5] = make_uint4((uint32_t)ssz, thr, raw, lax);
+                dst[6] = make_uint4(st, count, ev, blk_pal_off);
+                dst[7] = make_uint4(blk_geo, blk_vsz, __float_as_uint(acc.l0), __float_as_uint(acc.l1));
+                dst[8] = make_uint4(__float_as_uint(acc.l2), __float_as_uint(acc.t), __float_as_uint(pend0), __float_as_uint(pend1));
+                dst[9] = make_uint4(__float_as_uint(pend2), __float_as_uint(pend_tr), 0u, 0u);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the stores above (global and LDS) before the publication below
+            if (lane == 0u) {
+                __hip_atomic_store(&s_mig[0], base + (uint32_t)__popcll(live), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&s_mig[3], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&s_mig[2], 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // one wave fewer
+            }
+            donated = true;
+            break;
+        }
         uint32_t run = 0u;  // kind to run this trip (an EV_* bit), 0 = step
         {
             int best = c_shade;
@@ -839,7 +914,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 const uint32_t blk_res = 1u << (blk_geo >> 24), blk_vlo = blk_geo & 0xffffffu;
                 const double as = inb ? __hiloint2double((int)((1023u - (blk_geo >> 24)) << 20), 0) : 1.0;  // 1 / resolution
                 const double t_enter = last_t * as;  // surface.rs:385-386
-                const uint32_t s_rx = c32[K_SRX][tid], s_ry = c32[K_SRY][tid], s_rz = c32[K_SRZ][tid];
+                const uint32_t s_rx = c32[K_SRX][col], s_ry = c32[K_SRY][col], s_rz = c32[K_SRZ][col];
                 // the Space cube, and the current level's cube in absolute coordinates
                 const int ocx = coord(posx, osx_i, inb ? s_rx : rx) + olx, ocy = coord(posy, osy_i, inb ? s_ry : ry) + oly,
                           ocz = coord(posz, osz_i, inb ? s_rz : rz) + olz;
@@ -867,8 +942,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                         i0 = lut[txl & 255u]; i1 = lut[(txl >> 8) & 255u]; i2 = lut[(txl >> 16) & 255u];
                     } else {
                         double ip[3];
-                        const double ox = c64[C_OX][tid], oy = c64[C_OY][tid], oz = c64[C_OZ][tid];
-                        const double dx = c64[C_DX][tid], dy = c64[C_DY][tid], dz = c64[C_DZ][tid];
+                        const double ox = c64[C_OX][col], oy = c64[C_OY][col], oz = c64[C_OZ][col];
+                        const double dx = c64[C_DX][col], dy = c64[C_DY][col], dz = c64[C_DZ][col];
                         if (inb) {
                             const double kd = (double)blk_res;
                             double vp[3];
@@ -914,14 +989,14 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                         const int pk = pick_axis(tx, ty, tz);
                         t_exit = (pk == 0 ? tx : (pk == 1 ? ty : tz)) * as;
                     } else if (inb && (st & ST_OUTER_ALIVE)) {
-                        const double s_tx = c64[C_STX][tid], s_ty = c64[C_STY][tid], s_tz = c64[C_STZ][tid];
+                        const double s_tx = c64[C_STX][col], s_ty = c64[C_STY][col], s_tz = c64[C_STZ][col];
                         const int pk = pick_axis(s_tx, s_ty, s_tz);  // the suspended outer level's next step
                         t_exit = pk == 0 ? s_tx : (pk == 1 ? s_ty : s_tz);
                     } else {
                         will_flush = false;
                     }
                     // trace_through_span (sr.rs:720-740) + apply_transmittance (raytracer_components.rs:215-258)
-                    float thickness = (float)((t_exit - t_enter) * c64[C_TABS][tid]);
+                    float thickness = (float)((t_exit - t_enter) * c64[C_TABS][col]);
                     thickness = fmaxf(thickness, 0.0f);
                     float coeff;
                     if (thickness == 0.0f) {
@@ -958,7 +1033,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                         float sky[3];
                         sky_now(sky);
                         const float fog_blend = opt.fog == 1 ? 1.0f : (opt.fog == 2 ? 0.5f : 0.0f);
-                        float rel = (float)t_enter * __uint_as_float(c32[K_TVIEW][tid]);
+                        float rel = (float)t_enter * __uint_as_float(c32[K_TVIEW][col]);
                         rel = rel < 0.0f ? 0.0f : (rel > 1.0f ? 1.0f : rel);
                         const float sq = rel * rel;
                         float amount;
@@ -984,7 +1059,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     sd.cube[0] = ocx; sd.cube[1] = ocy; sd.cube[2] = ocz;
                     if (inb) {
                         sd.voxel[0] = ca.cx; sd.voxel[1] = ca.cy; sd.voxel[2] = ca.cz;
-                        sd.res = (int)blk_res; sd.block = (int)c32[K_BLK][tid];
+                        sd.res = (int)blk_res; sd.block = (int)c32[K_BLK][col];
                     } else {
                         sd.voxel[0] = sd.voxel[1] = sd.voxel[2] = 0;
                         sd.res = 1; sd.block = (int)(shade_ref & 0xffffu);
@@ -1018,27 +1093,27 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             //    advanced to its first in-bounds voxel (or to its end) --
             if (run == EV_ENTER && (ev & EV_ENTER)) {
                 const uint32_t blk_index = raw & idx_mask;
-                c32[K_BLK][tid] = blk_index;
+                c32[K_BLK][col] = blk_index;
                 const DevBlock *tb = &L.blocks[blk_index];
                 const uint32_t blk_res = tb->kind & 255u;
                 const uint32_t blk_vlo = tb->vlo_packed;
                 blk_geo = ((31u - (uint32_t)__clz((int)blk_res)) << 24) | blk_vlo;
                 blk_vsz = tb->vsize_packed;
                 blk_pal_off = tb->pal_off;
-                const double ox = c64[C_OX][tid], oy = c64[C_OY][tid], oz = c64[C_OZ][tid];
+                const double ox = c64[C_OX][col], oy = c64[C_OY][col], oz = c64[C_OZ][col];
                 const uint32_t n_invisible = tb->n_invisible;
                 const uint32_t vox_off = tb->vox_off;
                 const double kd = (double)blk_res;
                 const int acx = coord(posx, osx_i, rx) + olx, acy = coord(posy, osy_i, ry) + oly, acz = coord(posz, osz_i, rz) + olz;
                 const double sx_ = (ox - (double)acx) * kd, sy_ = (oy - (double)acy) * kd, sz_ = (oz - (double)acz) * kd;
                 // suspend the outer level; its Face goes to st[16..18]
-                c64[C_STX][tid] = tx; c64[C_STY][tid] = ty; c64[C_STZ][tid] = tz; c64[C_SLAST][tid] = last_t;
-                c32[K_SRX][tid] = rx; c32[K_SRY][tid] = ry; c32[K_SRZ][tid] = rz; c32[K_SBOFF][tid] = boff;
+                c64[C_STX][col] = tx; c64[C_STY][col] = ty; c64[C_STZ][col] = tz; c64[C_SLAST][col] = last_t;
+                c32[K_SRX][col] = rx; c32[K_SRY][col] = ry; c32[K_SRZ][col] = rz; c32[K_SBOFF][col] = boff;
                 st = (st & ~((7u << 16) | ST_OUTER_ALIVE)) | (face_now() << 16) | ((ev & EV_DEAD) ? 0u : ST_OUTER_ALIVE);
                 const int ilx = (int)(blk_vlo & 255u), ily = (int)((blk_vlo >> 8) & 255u), ilz = (int)((blk_vlo >> 16) & 255u);
                 const int isx = (int)(blk_vsz & 255u), isy = (int)((blk_vsz >> 8) & 255u), isz = (int)((blk_vsz >> 16) & 255u);
-                const RayDir rd = make_rd(c64[C_DX][tid], c64[C_DY][tid], c64[C_DZ][tid]);
-                const LvlLim ll = lvl_init(sx_, sy_, sz_, rd, true, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz, true, c64[C_HOLEN][tid]);
+                const RayDir rd = make_rd(c64[C_DX][col], c64[C_DY][col], c64[C_DZ][col]);
+                const LvlLim ll = lvl_init(sx_, sy_, sz_, rd, true, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz, true, c64[C_HOLEN][col]);
                 bool got;
                 const Lvl f = lvl_first(ll.s, ll.lim, rd, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz, &got);
                 tx = f.tx; ty = f.ty; tz = f.tz; last_t = f.last_t;
@@ -1058,8 +1133,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             // -- finishing a ray: TracingState::finish + layer tail + (last sample) encode & store --
             uint32_t pxy = 0;
             int sample = 0;
+            bool want = false, adopted = false;
             if (run == EV_FINISH) {
-                pxy = c32[K_PXY][tid];
+                pxy = c32[K_PXY][col];
                 sample = (int)((st >> 14) & 3u);
             }
             if (run == EV_FINISH && (ev & EV_FINISH)) {
@@ -1104,10 +1180,10 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                         acc.t = 1.0f * (1.0f - 1.0f);
                     }
                     if (n_samples == 4) {
-                        c32[K_S0][tid] = __float_as_uint(__uint_as_float(c32[K_S0][tid]) + acc.l0);
-                        c32[K_S1][tid] = __float_as_uint(__uint_as_float(c32[K_S1][tid]) + acc.l1);
-                        c32[K_S2][tid] = __float_as_uint(__uint_as_float(c32[K_S2][tid]) + acc.l2);
-                        c32[K_ST][tid] = __float_as_uint(__uint_as_float(c32[K_ST][tid]) + acc.t);
+                        c32[K_S0][col] = __float_as_uint(__uint_as_float(c32[K_S0][col]) + acc.l0);
+                        c32[K_S1][col] = __float_as_uint(__uint_as_float(c32[K_S1][col]) + acc.l1);
+                        c32[K_S2][col] = __float_as_uint(__uint_as_float(c32[K_S2][col]) + acc.l2);
+                        c32[K_ST][col] = __float_as_uint(__uint_as_float(c32[K_ST][col]) + acc.t);
                     }
                 }
                 sample++;
@@ -1117,8 +1193,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     if (!ui_pass) {
                         ColorBuf pixel;
                         if (n_samples == 4) {  // ColorBuf::mean (raytracer_components.rs:97-102)
-                            pixel.l0 = __uint_as_float(c32[K_S0][tid]) / 4.0f; pixel.l1 = __uint_as_float(c32[K_S1][tid]) / 4.0f;
-                            pixel.l2 = __uint_as_float(c32[K_S2][tid]) / 4.0f; pixel.t = __uint_as_float(c32[K_ST][tid]) / 4.0f;
+                            pixel.l0 = __uint_as_float(c32[K_S0][col]) / 4.0f; pixel.l1 = __uint_as_float(c32[K_S1][col]) / 4.0f;
+                            pixel.l2 = __uint_as_float(c32[K_S2][col]) / 4.0f; pixel.t = __uint_as_float(c32[K_ST][col]) / 4.0f;
                         } else {
                             pixel = acc;
                         }
@@ -1169,7 +1245,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 // wave-level refill (uniform control flow): hand the next unassigned pixels to the
                 // lanes that finished a pixel -- ballot + prefix popcount -- pulling a fresh tile
                 // from the global counter whenever the current one is used up.
-                bool want = (ev & (EV_NEWRAY | EV_TAKE)) == (EV_NEWRAY | EV_TAKE);
+                want = (ev & (EV_NEWRAY | EV_TAKE)) == (EV_NEWRAY | EV_TAKE);
                 for (;;) {
                     const unsigned long long need = __ballot(want);
                     if (need == 0ull) break;
@@ -1178,16 +1254,59 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                         // each, row-major inside), and the macro tiles are taken in `tile_order` -- the
                         // previous frame's costliest first -- so that long rays start early while
                         // neighbouring tiles still run together and share their cache lines
-                        uint32_t t = 0;
-                        const int leader = __ffsll((long long)need) - 1;
-                        if ((int)lane == leader) t = atomicAdd(&F.counters->tile_next, 1u);
-                        t = (uint32_t)__shfl((int)t, leader, 64);
-                        if (t >= n_virtual) {  // image exhausted: these lanes are done
+                        uint32_t t = n_virtual;
+                        if (!dry) {
+                            const int leader = __ffsll((long long)need) - 1;
+                            if ((int)lane == leader) t = atomicAdd(&F.counters->tile_next, 1u);
+                            t = (uint32_t)__shfl((int)t, leader, 64);
+                        }
+                        if (t >= n_virtual) {  // image exhausted
 #ifdef AIC_PROFILE
                             if (prof[2] == 0u) prof[2] = (uint32_t)__builtin_readcyclecounter() - prof_t0;  // wave saw the queue run dry
 #endif
-                            if (want) ev = EV_DONE;
+                            dry = true;
                             next_idx = tile_px;
+                            if (!(MIGRATE && mig_k != 0u && anchor)) {  // these lanes are done
+                                if (want) ev = EV_DONE;
+                                break;
+                            }
+                            // ---- the anchor wave: adopt rays the workgroup's other waves handed over (ray migration) ----
+                            // `running` is read before `published`: a donor publishes before it signs off, so "no other wave
+                            // running" and then "nothing published that was not adopted" means nothing can come any more
+                            const uint32_t running = __hip_atomic_load(&s_mig[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const uint32_t published = __hip_atomic_load(&s_mig[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const uint32_t taken = __hip_atomic_load(&s_mig[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (only this wave writes it)
+                            const uint32_t n_need = (uint32_t)__popcll(need);
+                            const uint32_t k = published - taken < n_need ? published - taken : n_need;
+                            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                            if (want && rank < k) {
+                                col = s_pool_col[taken + rank];
+                                lds64 = (uint32_t)(uintptr_t)&c64[0][col];
+                                lds32 = (uint32_t)(uintptr_t)&c32[0][col];
+                                const uint4 *src = F.orphans + ((size_t)blockIdx.x * (uint32_t)AIC_WG_THREADS + col) * (kOrphanDwords / 4u);
+                                const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], q5 = src[5], q6 = src[6], q7 = src[7], q8 = src[8], q9 = src[9];
+                                tx = __longlong_as_double((long long)(((unsigned long long)q0.y << 32) | q0.x));
+                                ty = __longlong_as_double((long long)(((unsigned long long)q0.w << 32) | q0.z));
+                                tz = __longlong_as_double((long long)(((unsigned long long)q1.y << 32) | q1.x));
+                                last_t = __longlong_as_double((long long)(((unsigned long long)q1.w << 32) | q1.z));
+                                tdx = __longlong_as_double((long long)(((unsigned long long)q2.y << 32) | q2.x));
+                                tdy = __longlong_as_double((long long)(((unsigned long long)q2.w << 32) | q2.z));
+                                tdz = __longlong_as_double((long long)(((unsigned long long)q3.y << 32) | q3.x));
+                                rx = q3.z; ry = q3.w;
+                                rz = q4.x; boff = q4.y; ssx = (int)q4.z; ssy = (int)q4.w;
+                                ssz = (int)q5.x; thr = q5.y; raw = q5.z; lax = q5.w;
+                                st = q6.x; count = q6.y; ev = q6.z; blk_pal_off = q6.w;
+                                blk_geo = q7.x; blk_vsz = q7.y; acc.l0 = __uint_as_float(q7.z); acc.l1 = __uint_as_float(q7.w);
+                                acc.l2 = __uint_as_float(q8.x); acc.t = __uint_as_float(q8.y); pend0 = __uint_as_float(q8.z); pend1 = __uint_as_float(q8.w);
+                                pend2 = __uint_as_float(q9.x); pend_tr = __uint_as_float(q9.y);
+                                want = false;
+                                adopted = true;  // (the ray goes on from its own state at the wave's next scheduler pass)
+                            }
+                            if (k != 0u && lane == 0u) __hip_atomic_store(&s_mig[1], taken + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (want) {
+                                if (running == 1u && published == taken + k) ev = EV_DONE;  // nothing can come any more
+                                else if (only_waiting) __builtin_amdgcn_s_sleep(16);        // asked again at the wave's next ray phase
+                            }
                             break;
                         }
                         const uint32_t m_shift = macro_shift * 2u;
@@ -1222,11 +1341,11 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 }
             }
             if (run == EV_FINISH) { AIC_TICK(17) }
-            if (run == EV_FINISH && (ev & EV_NEWRAY) && ev != EV_DONE) {
+            if (run == EV_FINISH && (ev & EV_NEWRAY) && ev != EV_DONE && !want && !adopted) {  // (`want`: the anchor wave's lanes waiting for an orphan)
                 const uint32_t x = pxy & 0xffffu, lrow = pxy >> 16;
                 const size_t pix = (size_t)lrow * F.width + x;
                 if (ev & EV_TAKE) {
-                    if (n_samples == 4) { c32[K_S0][tid] = 0u; c32[K_S1][tid] = 0u; c32[K_S2][tid] = 0u; c32[K_ST][tid] = 0u; }  // 0.f
+                    if (n_samples == 4) { c32[K_S0][col] = 0u; c32[K_S1][col] = 0u; c32[K_S2][col] = 0u; c32[K_ST][col] = 0u; }  // 0.f
                     if (DIAG) {
                         dg.n_outer = dg.n_inner = dg.n_hits = dg.n_light = 0; dg.layer = 0; dg.hit = 0; dg.res = dg.face = dg.block = 0; dg.t = 0.0;
                         for (int a = 0; a < 3; a++) dg.cube[a] = dg.voxel[a] = 0;
@@ -1314,20 +1433,20 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 }
                 if (have_ray) {
                     const double ox = o[0], oy = o[1], oz = o[2];
-                    c64[C_OX][tid] = ox; c64[C_OY][tid] = oy; c64[C_OZ][tid] = oz;
+                    c64[C_OX][col] = ox; c64[C_OY][col] = oy; c64[C_OZ][col] = oz;
                     const double dirx = dir[0], diry = dir[1], dirz = dir[2];
                     const double t_abs = sqrt(dirx * dirx + diry * diry + dirz * dirz);  // sr.rs:146
-                    c64[C_TABS][tid] = t_abs;
-                    c32[K_TVIEW][tid] = __float_as_uint((float)(t_abs / opt.view_distance));  // sr.rs:149-151
+                    c64[C_TABS][col] = t_abs;
+                    c32[K_TVIEW][col] = __float_as_uint((float)(t_abs / opt.view_distance));  // sr.rs:149-151
                     const RayDir rd = raydir_init(dirx, diry, dirz);
-                    c64[C_DX][tid] = rd.dx; c64[C_DY][tid] = rd.dy; c64[C_DZ][tid] = rd.dz;
+                    c64[C_DX][col] = rd.dx; c64[C_DY][col] = rd.dy; c64[C_DZ][col] = rd.dz;
                     tdx = rd.tdx; tdy = rd.tdy; tdz = rd.tdz;
                     const uint32_t qx = dirx >= 0.0 ? 1u : 0u, qy = diry >= 0.0 ? 1u : 0u, qz = dirz >= 0.0 ? 1u : 0u;
                     const uint32_t octant = (qx << 2) + (qy << 1) + qz;
                     const int ohx = olx + osx_i, ohy = oly + osy_i, ohz = olz + osz_i;
                     // the sanitised direction equals the original unless it was zeroed, in which case no fast-forward happens
                     const double half_over_len = 0.5 / t_abs;
-                    c64[C_HOLEN][tid] = half_over_len;
+                    c64[C_HOLEN][col] = half_over_len;
                     const LvlLim ll = lvl_init(ox, oy, oz, rd, true, olx, oly, olz, ohx, ohy, ohz, true, half_over_len);
                     bool got;
                     const Lvl fs = lvl_first(ll.s, ll.lim, rd, olx, oly, olz, ohx, ohy, ohz, &got);
@@ -1348,7 +1467,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     ev = EV_FINISH;
                 }
             }
-            if (run == EV_FINISH) c32[K_PXY][tid] = pxy;
+            if (run == EV_FINISH && !want && !adopted) c32[K_PXY][col] = pxy;
             if (run == EV_SHADE) { AIC_TICK(13) } else if (run == EV_ENTER) { AIC_TICK(14) } else { AIC_TICK(15) }
             continue;
         }
@@ -1577,6 +1696,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
     prof[0] = 0; prof[1] = 0;
     if (lane == 0) for (int i = 0; i < 24; i++) atomicAdd(&F.counters->prof[i], (unsigned long long)prof[i]);
 #endif
+    if (MIGRATE && !anchor && !donated && lane == 0u)  // (a wave that handed its rays over has signed off already)
+        __hip_atomic_fetch_add(&s_mig[2], 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     // ---- RaytraceInfo sum (renderer.rs:555): wave reduction then one atomic per wave ----
     unsigned long long s = c32[K_STEPS][tid];
 #pragma unroll
