@@ -596,10 +596,101 @@ Rendering HipRtRenderer::draw_rgba(const std::string &info_text) {  // renderer.
     if (fi.flaws & AIC_FLAW_UNSUPPORTED) r.flaws |= Flaws::UNSUPPORTED;
     if (fi.flaws & AIC_FLAW_NO_BLOOM) r.flaws |= Flaws::NO_BLOOM;
     if (had_cursor_) r.flaws |= Flaws::NO_CURSOR;
-    // The info-text overlay (renderer.rs:205-217, 659-683) is host-side font rasterisation in the
-    // reference shim and is not part of this path; a non-empty text is reported, not drawn.
-    if (!info_text.empty() && world_camera_.options().debug_info_text) r.flaws |= Flaws::OTHER;
+    // The info-text overlay (renderer.rs:205-217, 659-683): drawn over the finished frame on the host, in the encoder's
+    // black and white, when the world camera's options ask for it.
+    if (!info_text.empty() && world_camera_.options().debug_info_text && f.width && f.height) {
+        uint8_t black[4], white[4];
+        const float k0[3] = {0.f, 0.f, 0.f}, k1[3] = {1.f, 1.f, 1.f};
+        encode_paint(world_camera_, k0, black);
+        encode_paint(world_camera_, k1, white);
+        draw_info_text(r.data.data(), f.width, f.height, black, white, info_text);
+    }
     return r;
+}
+
+// ---- the info-text overlay ---------------------------------------------------------------------------------------------
+
+#include "font_system16.inc"
+
+namespace {
+// FontDef::char_to_glyph_index (text/font.rs:214-229): ISO-8859-1 plus the curly quotes; anything else is '?'
+uint32_t glyph_index_of(uint32_t c) {
+    if (c == 0x2018u || c == 0x2019u) c = '\'';
+    if (c == 0x201cu || c == 0x201du) c = '"';
+    if (c >= 0x20u && c <= 0x7fu) return c - 0x20u;
+    if (c >= 0xa0u && c <= 0xffu) return c - 0x40u;
+    return 0x1fu;
+}
+bool glyph_bit(uint32_t g, int x, int y) { return x >= 0 && x < 7 && y >= 0 && y < 16 && ((kFontSystem16[g][y] >> x) & 1u) != 0u; }
+}  // namespace
+
+void draw_info_text(uint8_t *rgba, uint32_t width, uint32_t height, const uint8_t outline[4], const uint8_t foreground[4], const std::string &text) {
+    constexpr int kCellW = 7, kCellH = 16;  // FONT_SYSTEM_16 metrics (font.rs:23-30)
+    constexpr int kOriginX = 5, kOriginY = 5;  // renderer.rs:668
+    // text::compute_layout with Left / BodyTop / Back in GridAab::ORIGIN_CUBE, no outline expansion (layout.rs:101-265): the
+    // first line's glyph origins are at y = 0, every further line 16 lower (y is up there; draw_str_monospaced flips it), and
+    // a glyph that draws nothing (space) still advances the cursor.
+    int cursor_x = 0, line = 0;
+    for (size_t i = 0; i < text.size();) {
+        // next UTF-8 scalar (`str::chars`); malformed input cannot occur in a Rust &str, here it decodes to U+FFFD
+        uint32_t c = (unsigned char)text[i];
+        size_t len = 1;
+        if (c >= 0xf0u) { len = 4; c &= 0x07u; } else if (c >= 0xe0u) { len = 3; c &= 0x0fu; } else if (c >= 0xc0u) { len = 2; c &= 0x1fu; } else if (c >= 0x80u) { c = 0xfffdu; }
+        if (i + len > text.size()) { c = 0xfffdu; len = 1; }
+        else for (size_t k = 1; k < len; k++) c = (c << 6) | ((unsigned char)text[i + k] & 0x3fu);
+        i += len;
+        if (c == '\n') { cursor_x = 0; line++; continue; }
+        const uint32_t g = glyph_index_of(c);
+        const int gx0 = cursor_x, gy0 = line * kCellH;
+        cursor_x += kCellW;
+        // Glyphs::new / Glyphs::get (font.rs:340-520): the stored box is the bounding box of the glyph's set pixels grown by one
+        // pixel on every side; inside it a set pixel is Foreground, a pixel 8-adjacent to one (within this glyph) is Outline
+        int minx = 99, miny = 99, maxx = -1, maxy = -1;
+        for (int y = 0; y < kCellH; y++)
+            for (int x = 0; x < kCellW; x++)
+                if (glyph_bit(g, x, y)) { minx = std::min(minx, x); maxx = std::max(maxx, x); miny = std::min(miny, y); maxy = std::max(maxy, y); }
+        if (maxx < 0) continue;  // draws nothing
+        for (int y = miny - 1; y <= maxy + 1; y++)
+            for (int x = minx - 1; x <= maxx + 1; x++) {
+                const uint8_t *paint;
+                if (glyph_bit(g, x, y)) paint = foreground;
+                else {
+                    bool near = false;
+                    for (int dy = -1; dy <= 1 && !near; dy++)
+                        for (int dx = -1; dx <= 1; dx++)
+                            if (glyph_bit(g, x + dx, y + dy)) { near = true; break; }
+                    if (!near) continue;
+                    paint = outline;
+                }
+                const int px = gx0 + x + kOriginX, py = gy0 + y + kOriginY;
+                if (px < 0 || py < 0 || (uint32_t)px >= width || (uint32_t)py >= height) continue;
+                std::memcpy(rgba + ((size_t)py * width + (size_t)px) * 4, paint, 4);
+            }
+    }
+}
+
+void encode_paint(const Camera &camera, const float rgb_in[3], uint8_t out[4]) {
+    const GraphicsOptions &o = camera.options();
+    float c[3];
+    for (int k = 0; k < 3; k++) {  // rgb * exposure (PositiveSign: 0 * inf = 0)
+        const float v = rgb_in[k] * camera.exposure();
+        c[k] = (v != v) ? 0.f : v;
+    }
+    if (std::isfinite(o.maximum_intensity)) {  // ToneMappingOperator::apply (graphics_options.rs:352-368)
+        if (o.tone_mapping == ToneMappingOperator::Clamp) {
+            for (int k = 0; k < 3; k++) c[k] = c[k] > o.maximum_intensity ? o.maximum_intensity : c[k];
+        } else {
+            const float lum = c[1] * 0.7152f + (c[0] * 0.2126f + c[2] * 0.0722f);  // Rgb::luminance (color.rs)
+            const float scale = 1.0f / (1.0f + lum / o.maximum_intensity);
+            for (int k = 0; k < 3; k++) { const float v = c[k] * scale; c[k] = (v != v) ? 0.f : v; }
+        }
+    }
+    for (int k = 0; k < 3; k++) {  // component_to_srgb8 (color.rs:1038-1054)
+        const float e = c[k] <= 0.0031308f ? c[k] * (323.f / 25.f) : (211.f * std::pow(c[k], 5.f / 12.f) - 11.f) / 200.f;
+        const float r = std::round(e * 255.f);
+        out[k] = !(r > 0.f) ? 0 : (r >= 255.f ? 255 : (uint8_t)r);
+    }
+    out[3] = 255;
 }
 
 std::string HipRtRenderer::draw_text(const std::string &line_ending) {

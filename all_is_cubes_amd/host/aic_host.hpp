@@ -260,6 +260,15 @@ struct Rendering {  // headless.rs:52-67
     ImageInfo info;
 };
 
+// The info-text overlay (renderer.rs:659-683 `draw_info_text`): `text` drawn with Builtin::FontSystem16 by
+// FontDef::draw_str_monospaced (all-is-cubes/src/text/font.rs:178-203) at offset (5, 5) into an RGBA8 image of width x
+// height, outline pixels in `outline`, glyph pixels in `foreground`, in the reference's call order (a later glyph's outline
+// may overwrite an earlier glyph's edge, as it does there). Pixels outside the image are dropped.
+void draw_info_text(uint8_t *rgba, uint32_t width, uint32_t height, const uint8_t outline[4], const uint8_t foreground[4], const std::string &text);
+// Camera::post_process_color(color).to_srgb8() (camera_struct.rs:376-382, math/color.rs:669-676, 1038-1054) of an opaque
+// colour: what the reference's encoder makes of the overlay's black and white paints
+void encode_paint(const class Camera &camera, const float rgb[3], uint8_t out[4]);
+
 struct UiViewState {  // stdcam.rs UiViewState
     std::shared_ptr<Space> space;
     ViewTransform view_transform;

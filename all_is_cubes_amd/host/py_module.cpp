@@ -80,6 +80,11 @@ PYBIND11_MODULE(_host, m) {
         for (int a = 0; a < 3; a++) { b.lo[a] = lo[a]; b.hi[a] = hi[a]; }
         return a3(eye_for_look_at(b, v3(dir)));
     });
+    m.def("draw_info_text", [](py::array_t<uint8_t, py::array::c_style> image, const std::string &text, const std::array<uint8_t, 4> &outline,
+                               const std::array<uint8_t, 4> &foreground) {
+        if (image.ndim() != 3 || image.shape(2) != 4) throw std::invalid_argument("draw_info_text: image must be [h][w][4] uint8");
+        draw_info_text(image.mutable_data(), (uint32_t)image.shape(1), (uint32_t)image.shape(0), outline.data(), foreground.data(), text);
+    }, py::arg("image"), py::arg("text"), py::arg("outline") = std::array<uint8_t, 4>{0, 0, 0, 255}, py::arg("foreground") = std::array<uint8_t, 4>{255, 255, 255, 255});
     m.def("rotation_around_y", [](double radians) { Quat q = rotation_around_y(radians); return std::array<double, 4>{q.i, q.j, q.k, q.r}; });
 
     py::class_<Camera>(m, "Camera")

@@ -14,6 +14,9 @@ What is extracted (all of it is DATA held by the reference's own tests, no sourc
 * ``srgb_decode_lut.npy`` -- the 256-entry sRGB8 -> linear table
   (``all-is-cubes-base/src/math/color.rs`` ``CONST_SRGB_LOOKUP_TABLE``), needed to restate
   scenes whose blocks are declared as sRGB8 colours (``color_srgb_ramp``, ``emission``).
+* ``font_system16.npy`` (+ ``all_is_cubes_amd/host/font_system16.inc``, the same table as a C array for the host mirror)
+  -- the glyph bitmaps of ``all-is-cubes/src/text/font-system-7x16.png`` (Builtin::FontSystem16), which the info-text
+  overlay is drawn with (renderer.rs:659-683).
 * ``packed_light_lut.npy`` -- the 256-entry ``PACKED_LIGHT_SCALAR_LOOKUP_TABLE``
   (``all-is-cubes/src/space/light/data.rs:301-354``); the product *generates* its table from
   the defining formula and the test asserts equality with this fixture.
@@ -59,6 +62,8 @@ PNG_CASES = [
     "antialias-Always-ray", "antialias-None-all",
     *[f"sky-{f}-all" for f in ("NX", "NY", "NZ", "PX", "PY", "PZ")],
     "viewport_zero-all", "viewport_zero-2-all", "layers_none_but_text-all",
+    # round 3: the info-text overlay (renderer.rs:659-683) drawn by the host mirror
+    "info_text-1.0-all", "info_text-1.5-ray", "info_text-2.0-ray",
 ]
 
 
@@ -91,8 +96,43 @@ def ascii_frames() -> list[str]:
     return frames
 
 
+def font_system16() -> np.ndarray:
+    """The 192 glyph bitmaps of Builtin::FontSystem16 (all-is-cubes/src/text/font.rs:23-30: `font-system-7x16.png`, 16 glyphs
+    per row, 7x16 cells) as [glyph][row] bytes, bit x of a byte = pixel x of the row; a pixel is set where the atlas has
+    r > 0 && a > 0 (font.rs `rgba_to_bit`)."""
+    from PIL import Image
+
+    im = np.asarray(Image.open(REF / "all-is-cubes/src/text/font-system-7x16.png").convert("RGBA"), dtype=np.uint8)
+    assert im.shape[1] == 7 * 16 and im.shape[0] % 16 == 0
+    bits = (im[..., 0] > 0) & (im[..., 3] > 0)
+    n = (im.shape[0] // 16) * 16
+    out = np.zeros((n, 16), np.uint8)
+    for g in range(n):
+        cell = bits[(g // 16) * 16:(g // 16) * 16 + 16, (g % 16) * 7:(g % 16) * 7 + 7]
+        out[g] = (cell * (1 << np.arange(7))).sum(axis=1)
+    return out
+
+
+def write_font_inc(glyphs: np.ndarray) -> None:
+    """The product's copy of the font: a generated table in the host mirror's source tree (the overlay is drawn by the
+    product's host code, so the data has to ship with it)."""
+    path = OUT.parent.parent / "all_is_cubes_amd" / "host" / "font_system16.inc"
+    lines = ["// GENERATED by tests/golden/make_golden.py from the reference's font atlas all-is-cubes/src/text/font-system-7x16.png",
+             "// (Builtin::FontSystem16, text/font.rs:23-30): 192 glyphs x 16 rows, bit x of a byte = pixel x of the row (7 wide).",
+             "// Data, not code: the pixels of a bitmap font. Glyph index = character - 0x20 (0x20..0x7f) or - 0x40 (0xa0..0xff).",
+             f"static const unsigned char kFontSystem16[{glyphs.shape[0]}][16] = {{"]
+    for g in glyphs:
+        lines.append("    {" + ", ".join(f"0x{v:02x}" for v in g) + "},")
+    lines.append("};")
+    path.write_text("\n".join(lines) + "\n")
+
+
 def main() -> int:
     from PIL import Image
+
+    glyphs = font_system16()
+    np.save(OUT / "font_system16.npy", glyphs)
+    write_font_inc(glyphs)
 
     for case in PNG_CASES:
         im = Image.open(REF / "test-renderers/expected/renderers" / f"{case}.png").convert("RGBA")

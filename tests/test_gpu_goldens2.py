@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle
-from all_is_cubes_amd import abi
+from all_is_cubes_amd import abi, flat
 from tests import scenes
 from tests.test_gpu_light import render_both
 from tests.test_gpu_parity import assert_parity, to_abi_options
@@ -127,8 +127,9 @@ def test_sky(ctx, golden_dir, face):
 
 @pytest.mark.parametrize("name,with_world", [("viewport_zero-all", True), ("viewport_zero-2-all", True), ("layers_none_but_text-all", False)])
 def test_text_overlay_cases(ctx, golden_dir, name, with_world):
-    """Frames whose goldens carry the host-side info text: compared outside the text's bounding region."""
-    from tests.test_oracle_goldens import TEXT_MASK
+    """Frames whose goldens carry the "hello world" info text (renderer.rs:659-683): drawn over the device's frame by the host
+    mirror's draw_info_text, then the whole image is compared."""
+    from tests.test_oracle_goldens import with_info_text
     w, h = COMMON_VIEWPORT
     if with_world:
         ctx.upload_space(abi.LAYER_WORLD, scenes.one_cube_space())
@@ -140,6 +141,31 @@ def test_text_overlay_cases(ctx, golden_dir, name, with_world):
     # a zero-area viewport first, as the case does: an empty image, and the renderer is fine afterwards
     assert ctx.render(ctx.make_frame(0, 0, world_inv=inv))["rgba8"].shape == (0, 0, 4)
     img = ctx.render(ctx.make_frame(w, h, world_inv=inv))["rgba8"]
-    d = diff_to(golden_dir, name, img).max(axis=-1)
-    d[TEXT_MASK] = 0
-    assert d.max() <= 2
+    assert diff_to(golden_dir, name, with_info_text(img)).max() <= 2
+
+
+@pytest.mark.parametrize("scale,name", [(1.0, "info_text-1.0-all"), (1.5, "info_text-1.5-ray"), (2.0, "info_text-2.0-ray")])
+def test_info_text_through_the_headless_renderer(golden_dir, scale, name):
+    """cases/src/lib.rs:667-711 info_text, end to end through the host mirror of HeadlessRenderer: an empty space with an orange
+    sky traced on the device, the info text drawn over the frame by HipRtRenderer::draw (renderer.rs:205-217, 659-683; the
+    default GraphicsOptions::debug_info_text is on). The reference's own expected images, pixel for pixel."""
+    import all_is_cubes_amd as A
+    from all_is_cubes_amd import _host as H
+    from tests.test_info_text import INFO_TEXT
+
+    sp = flat.FlatSpace((0, 0, 0), (1, 1, 1))
+    sp.set_sky_uniform((1.0, 0.5, 0.0))
+    sp.add_block(flat.air())
+    cams = H.StandardCameras()
+    cams.graphics_options = H.GraphicsOptions.unaltered_colors()
+    cams.viewport = H.Viewport.with_scale(1.0, int(128 * scale), int(96 * scale))
+    cams.world_space = A.space_from_flat(sp)
+    cams.world_view_transform = H.look_at_y_up((0.5, 0.5, 2.0), (0.5, 0.5, 0.0))
+    r = H.HipRtRenderer(cams)
+    r.update()
+    img = r.draw(INFO_TEXT)
+    ref = np.load(golden_dir / f"png_{name}.npy")
+    assert img.data.shape == ref.shape and (img.data == ref).all()
+    assert not (img.flaws & H.Flaws.OTHER)
+    plain = r.draw("")  # no text: the bare sky
+    assert (plain.data == np.array([255, 188, 0, 255], np.uint8)).all()

@@ -151,9 +151,8 @@ def test_golden_layers(ctx, golden_dir, name, with_world, with_ui):
     got, ref = render_both(ctx, scenes.one_cube_space() if with_world else None, opt, COMMON_VIEWPORT, (0.5, 0.5, 2.0),
                            ui=scenes.ui_space() if with_ui else None)
     assert_parity(got, ref)
-    d = diff_to(golden_dir, name, got["rgba8"]).max(axis=-1)
-    d[0:26, 0:100] = 0  # host-side info text region (renderer.rs:659-683), outside the hot path
-    assert d.max() <= RGBA_TOL
+    from tests.test_oracle_goldens import with_info_text  # the "hello world" overlay (renderer.rs:659-683)
+    assert diff_to(golden_dir, name, with_info_text(got["rgba8"])).max() <= RGBA_TOL
 
 
 def test_viewport_zero(ctx):

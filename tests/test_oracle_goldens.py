@@ -209,9 +209,13 @@ def test_viewport_zero():
 
 # cases/src/lib.rs:890-973 layers_*: world + UI layer (UI rays first, include_sky=false;
 # renderer.rs:454-478), Flat lighting fed by BlockSky::light_outside (sky.rs:113-147), and the
-# NO_WORLD_TO_SHOW fallback. The "hello world" info text is drawn host-side by the reference
-# (renderer.rs:659-683) and is outside the hot path, so its bounding region is masked.
-TEXT_MASK = (slice(0, 26), slice(0, 100))
+# NO_WORLD_TO_SHOW fallback. The "hello world" info text is drawn over the finished frame (renderer.rs:659-683): by the host
+# mirror's draw_info_text here (pinned on its own by tests/test_info_text.py), so the whole golden is compared.
+def with_info_text(img, text="hello world"):
+    from all_is_cubes_amd import _host as H
+    out = np.ascontiguousarray(img).copy()
+    H.draw_info_text(out, text)
+    return out
 
 
 @pytest.mark.parametrize(
@@ -231,9 +235,7 @@ def test_png_layers(golden_dir, name, with_world, with_ui):
         ui_cam=ui_cam if with_ui else None,
         threads=2,
     )
-    d = diff_to(golden_dir, name, out["rgba8"]).max(axis=-1)
-    d[TEXT_MASK] = 0
-    assert d.max() == 0
+    assert diff_to(golden_dir, name, with_info_text(out["rgba8"])).max() == 0
 
 
 # cases/src/lib.rs:1054-1105 template("light-bench"): UniverseTemplate::LightBench = content::testing::light_bench_space

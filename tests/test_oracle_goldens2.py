@@ -157,13 +157,10 @@ def test_png_sky(golden_dir, face):
 
 
 # cases/src/lib.rs:1167-1212 viewport_zero (the frames after the viewport grows back from 0x0) and 934-946
-# layers_none_but_text: the "hello world" info text is drawn host-side by the reference (renderer.rs:659-683) and is outside
-# the hot path, so its bounding region is masked as in the layers_* tests.
+# layers_none_but_text: with the "hello world" info text drawn over the frame (renderer.rs:659-683) as in the layers_* tests.
 @pytest.mark.parametrize("name,with_world", [("viewport_zero-all", True), ("viewport_zero-2-all", True), ("layers_none_but_text-all", False)])
 def test_png_text_overlay_cases(golden_dir, name, with_world):
-    from tests.test_oracle_goldens import TEXT_MASK
+    from tests.test_oracle_goldens import with_info_text
     cam = camera_for(*COMMON_VIEWPORT, (0.5, 0.5, 2.0))
     img = oracle.render(oracle.Space(scenes.one_cube_space()) if with_world else None, oracle.unaltered_colors(), cam)["rgba8"]
-    d = diff_to(golden_dir, name, img).max(axis=-1)
-    d[TEXT_MASK] = 0
-    assert d.max() <= 2  # COLOR_ROUNDING_MAX_DIFF
+    assert diff_to(golden_dir, name, with_info_text(img)).max() <= 2  # COLOR_ROUNDING_MAX_DIFF
