@@ -11,14 +11,22 @@
 //! | `UpdatingSpaceRaytracer::update`, everything (121-131) | `aic_upload_space`                     |
 //! | ... blocks (139-153)                                   | `aic_replace_blocks`                   |
 //! | ... cubes (155-166)                                    | `aic_update_cubes`                     |
-//! | `RtRenderer::draw_rgba` (renderer.rs:282-308)          | `aic_render`                           |
+//! | `RtRenderer::draw_rgba` (renderer.rs:282-308)          | `aic_render` / `aic_multi_render`      |
+//! | `draw_info_text` (renderer.rs:659-683)                 | the same few lines, on the host        |
+//!
+//! One renderer may span several GPUs of a node ([`HipRtRenderer::with_devices`]): the scene is replicated, every device
+//! traces its interleaved 16-row strips and device 0 assembles the frame (`aic_create_multi`, csrc/aic_multi.cpp).
+//! [`HipRtRenderer::set_device_light`] hands the light itself over to the device: block edits are queued there
+//! (`aic_light_cubes_changed`) and [`HipRtRenderer::evaluate_light_budgeted`] advances the light between frames.
 //!
 //! With `AIC_DUMP=path` in the environment the library records every call it receives; the recording replays on
 //! a machine without the Rust toolchain (`python -m all_is_cubes_amd.replay path` in the MI355X repository) -- that is
 //! how a real Atrium / DemoCity scene reaches its benchmark and parity tests.
 //!
-//! NOTE: written against all-is-cubes 0.10.0; it has not been compiled in the repository that carries it (no Rust
-//! toolchain there). Expect to adjust imports to the workspace it is dropped into.
+//! NOTE: written against all-is-cubes 0.10.0. THIS CRATE HAS NEVER BEEN COMPILED: the repository that carries it has no Rust
+//! toolchain (tests/test_rust_shim.py only keeps `ffi.rs` in step with include/aic_hip.h). Expect to adjust imports and
+//! signatures to the workspace it is dropped into; the C++ host mirror (all_is_cubes_amd/host/) is the tested twin of this
+//! file, function for function.
 
 #![warn(missing_docs)]
 
@@ -30,6 +38,8 @@ use all_is_cubes::character::Cursor;
 use all_is_cubes::listen::{self, Listen as _};
 use all_is_cubes::math::{Cube, Rgba, ZeroOne};
 use all_is_cubes::space::{BlockIndex, Space, SpaceChange};
+use all_is_cubes::text;
+use all_is_cubes::universe;
 use all_is_cubes::universe::{Handle, ReadTicket};
 use all_is_cubes_render::camera::{
     AntialiasingOption, Camera, FogOption, GraphicsOptions, Layers, LightingOption, StandardCameras, ToneMappingOperator,
@@ -88,36 +98,145 @@ impl core::fmt::Display for HipInfo {
     }
 }
 
+/// One context per HIP device (`aic_create`), or the single-process multi-device context (`aic_create_multi`).
+#[derive(Clone, Copy)]
+enum Device {
+    One(NonNull<ffi::aic_ctx>),
+    Many(NonNull<ffi::aic_multi>),
+}
+
+impl Device {
+    fn check(self, rc: core::ffi::c_int) -> Result<(), RenderError> {
+        if rc == ffi::AIC_OK {
+            return Ok(());
+        }
+        // SAFETY: both return a NUL-terminated string owned by the context
+        let message = unsafe {
+            CStr::from_ptr(match self {
+                Device::One(c) => ffi::aic_last_error(c.as_ptr()),
+                Device::Many(m) => ffi::aic_multi_last_error(m.as_ptr()),
+            })
+        }
+        .to_string_lossy()
+        .into_owned();
+        match rc {
+            // the reference asserts on the same conditions (e.g. output length, renderer.rs:193-197)
+            ffi::AIC_ERR_INVALID => panic!("libaic_hip rejected a call: {message}"),
+            // RenderError has no device variant yet (lib.rs:46-54 "TODO: add errors for out of memory, lost GPU");
+            // until it does, a lost device is reported the way an unreadable scene is. (Whether `HandleError` can be
+            // built from a message outside its crate is unchecked -- this file was never compiled: a maintainer adds the
+            // RenderError variant that TODO asks for.)
+            _ => {
+                log::error!("libaic_hip: {message}");
+                Err(RenderError::Read(all_is_cubes::universe::HandleError::from_message(message)))
+            }
+        }
+    }
+    /// The context the light updater runs on (a sequential relaxation: it does not shard; csrc/aic_multi.cpp).
+    fn first_ctx(self) -> *mut ffi::aic_ctx {
+        match self {
+            Device::One(c) => c.as_ptr(),
+            // SAFETY: a live multi context has at least one device
+            Device::Many(m) => unsafe { ffi::aic_multi_context(m.as_ptr(), 0) },
+        }
+    }
+    // SAFETY (every method below): the context is live, the borrowed arguments outlive the call, the library copies them
+    fn upload_space(self, layer: core::ffi::c_int, desc: &ffi::aic_space_desc) -> Result<(), RenderError> {
+        self.check(unsafe {
+            match self {
+                Device::One(c) => ffi::aic_upload_space(c.as_ptr(), layer, desc),
+                Device::Many(m) => ffi::aic_multi_upload_space(m.as_ptr(), layer, desc),
+            }
+        })
+    }
+    fn clear_space(self, layer: core::ffi::c_int) -> Result<(), RenderError> {
+        self.check(unsafe {
+            match self {
+                Device::One(c) => ffi::aic_clear_space(c.as_ptr(), layer),
+                Device::Many(m) => ffi::aic_multi_clear_space(m.as_ptr(), layer),
+            }
+        })
+    }
+    fn replace_blocks(
+        self,
+        layer: core::ffi::c_int,
+        indices: &[u32],
+        descs: &[ffi::aic_block_desc],
+        voxels: &[*const u16],
+        palettes: &[*const f32],
+    ) -> Result<(), RenderError> {
+        let n = indices.len() as u32;
+        self.check(unsafe {
+            match self {
+                Device::One(c) => ffi::aic_replace_blocks(c.as_ptr(), layer, n, indices.as_ptr(), descs.as_ptr(), voxels.as_ptr(), palettes.as_ptr()),
+                Device::Many(m) => ffi::aic_multi_replace_blocks(m.as_ptr(), layer, n, indices.as_ptr(), descs.as_ptr(), voxels.as_ptr(), palettes.as_ptr()),
+            }
+        })
+    }
+    /// `light` = None: block indices only (the light of these cubes is the device's business, see `set_device_light`).
+    fn update_cubes(self, layer: core::ffi::c_int, xyz: &[i32], idx: &[u16], light: Option<&[u8]>) -> Result<(), RenderError> {
+        let n = idx.len() as u32;
+        let light = light.map_or(core::ptr::null(), <[u8]>::as_ptr);
+        self.check(unsafe {
+            match self {
+                Device::One(c) => ffi::aic_update_cubes(c.as_ptr(), layer, n, xyz.as_ptr(), idx.as_ptr(), light),
+                Device::Many(m) => ffi::aic_multi_update_cubes(m.as_ptr(), layer, n, xyz.as_ptr(), idx.as_ptr(), light),
+            }
+        })
+    }
+    fn set_options(self, layer: core::ffi::c_int, options: &ffi::aic_options) -> Result<(), RenderError> {
+        self.check(unsafe {
+            match self {
+                Device::One(c) => ffi::aic_set_options(c.as_ptr(), layer, options),
+                Device::Many(m) => ffi::aic_multi_set_options(m.as_ptr(), layer, options),
+            }
+        })
+    }
+    fn render(self, frame: &ffi::aic_frame_desc, out: &mut [[u8; 4]], info: &mut ffi::aic_frame_info) -> Result<(), RenderError> {
+        self.check(unsafe {
+            match self {
+                Device::One(c) => ffi::aic_render(c.as_ptr(), frame, out.as_mut_ptr().cast(), 0, info),
+                Device::Many(m) => ffi::aic_multi_render(m.as_ptr(), frame, out.as_mut_ptr().cast(), 0, info),
+            }
+        })
+    }
+    fn evaluate_light(self, layer: core::ffi::c_int, params: &ffi::aic_light_params, info: &mut ffi::aic_light_info) -> Result<(), RenderError> {
+        self.check(unsafe {
+            match self {
+                Device::One(c) => ffi::aic_evaluate_light(c.as_ptr(), layer, params, info),
+                // runs on device 0 and hands the resulting volume to the others
+                Device::Many(m) => ffi::aic_multi_evaluate_light(m.as_ptr(), layer, params, info),
+            }
+        })
+    }
+    fn destroy(self) {
+        // SAFETY: called once, from Drop
+        unsafe {
+            match self {
+                Device::One(c) => ffi::aic_destroy(c.as_ptr()),
+                Device::Many(m) => ffi::aic_destroy_multi(m.as_ptr()),
+            }
+        }
+    }
+}
+
+/// hashbrown's `Group::WIDTH` on the host the reference's goldens came from: the order of equal-priority light updates
+const QUEUE_ORDER: core::ffi::c_int = if cfg!(target_arch = "x86_64") { 16 } else { 8 };
+
 /// The MI355X raytracer behind the reference's renderer interface.
 pub struct HipRtRenderer {
-    ctx: NonNull<ffi::aic_ctx>,
+    device: Device,
     cameras: StandardCameras,
     size_policy: Box<dyn Fn(Viewport) -> Viewport + Send + Sync>,
     layers: Layers<Option<LayerSync>>,
     had_cursor: bool,
+    /// `Some(maximum_distance)`: the world layer's light is computed on the device (see `set_device_light`)
+    device_light: Option<u8>,
 }
 
-// SAFETY: the context is only used through `&mut self`; libaic_hip keeps no thread affinity besides hipSetDevice,
+// SAFETY: the contexts are only used through `&mut self`; libaic_hip keeps no thread affinity besides hipSetDevice,
 // which every entry point performs itself.
 unsafe impl Send for HipRtRenderer {}
-
-fn check(ctx: *const ffi::aic_ctx, rc: core::ffi::c_int) -> Result<(), RenderError> {
-    if rc == ffi::AIC_OK {
-        return Ok(());
-    }
-    // SAFETY: aic_last_error returns a NUL-terminated string owned by the context
-    let message = unsafe { CStr::from_ptr(ffi::aic_last_error(ctx)) }.to_string_lossy().into_owned();
-    match rc {
-        // the reference asserts on the same conditions (e.g. output length, renderer.rs:193-197)
-        ffi::AIC_ERR_INVALID => panic!("libaic_hip rejected a call: {message}"),
-        // RenderError has no device variant yet (lib.rs:46-54 "TODO: add errors for out of memory, lost GPU");
-        // until it does, a lost device is reported the way an unreadable scene is
-        _ => {
-            log::error!("libaic_hip: {message}");
-            Err(RenderError::Read(all_is_cubes::universe::HandleError::from_message(message)))
-        }
-    }
-}
 
 fn options_of(o: &GraphicsOptions) -> ffi::aic_options {
     let (transparency, threshold) = match o.transparency {
@@ -169,16 +288,49 @@ impl HipRtRenderer {
         size_policy: Box<dyn Fn(Viewport) -> Viewport + Send + Sync>,
         device_id: i32,
     ) -> Result<Self, String> {
-        let mut status = 0;
-        // SAFETY: plain FFI call; a null return is handled below
-        let ctx = unsafe { ffi::aic_create(device_id, &mut status) };
-        let ctx = NonNull::new(ctx).ok_or_else(|| format!("aic_create failed with status {status} (no usable MI355X?)"))?;
+        Self::with_devices(cameras, size_policy, &[device_id])
+    }
+
+    /// One renderer over several GPUs of the node: the scene is replicated on each, every device traces its interleaved
+    /// 16-row strips of a frame, the strips go to `device_ids[0]` over the direct links and are assembled there
+    /// (`aic_create_multi`). With one id this is [`Self::new`].
+    ///
+    /// # Errors
+    /// Fails if any of the devices is not a usable MI355X.
+    pub fn with_devices(
+        cameras: StandardCameras,
+        size_policy: Box<dyn Fn(Viewport) -> Viewport + Send + Sync>,
+        device_ids: &[i32],
+    ) -> Result<Self, String> {
+        // SAFETY: plain FFI calls; null returns are handled
         assert_eq!(unsafe { ffi::aic_abi_version() }, ffi::AIC_ABI_VERSION);
-        Ok(Self { ctx, cameras, size_policy, layers: Layers::default(), had_cursor: false })
+        let mut status = 0;
+        let device = match device_ids {
+            [] => return Err("no device given".into()),
+            [one] => Device::One(
+                NonNull::new(unsafe { ffi::aic_create(*one, &mut status) })
+                    .ok_or_else(|| format!("aic_create failed with status {status} (no usable MI355X?)"))?,
+            ),
+            many => Device::Many(
+                NonNull::new(unsafe { ffi::aic_create_multi(many.len() as core::ffi::c_int, many.as_ptr(), &mut status) })
+                    .ok_or_else(|| format!("aic_create_multi failed with status {status}"))?,
+            ),
+        };
+        Ok(Self { device, cameras, size_policy, layers: Layers::default(), had_cursor: false, device_light: None })
+    }
+
+    /// Hands the world space's light over to the device: from now on `update` forwards block changes
+    /// WITHOUT the host's light texels and queues the changed cubes in the device's own update queue
+    /// (`LightStorage::modified_cube_needs_update`, updater.rs:135-173, as `aic_light_cubes_changed`), and
+    /// [`Self::evaluate_light_budgeted`] advances the device's light between frames. The host `Space`'s light is
+    /// neither read nor written. `None` returns to forwarding the host's light.
+    pub fn set_device_light(&mut self, maximum_distance: Option<u8>) {
+        self.device_light = maximum_distance;
     }
 
     fn sync_layer(
-        ctx: *mut ffi::aic_ctx,
+        device: Device,
+        device_light: bool,
         layer: core::ffi::c_int,
         slot: &mut Option<LayerSync>,
         space: Option<&Handle<Space>>,
@@ -198,7 +350,7 @@ impl HipRtRenderer {
             }
             (None, s) => {
                 if s.take().is_some() {
-                    check(ctx, unsafe { ffi::aic_clear_space(ctx, layer) })?;
+                    device.clear_space(layer)?;
                 }
             }
         }
@@ -213,7 +365,7 @@ impl HipRtRenderer {
         if core::mem::take(&mut todo.everything) {
             // == SpaceRaytracer::new (sr.rs:64-88)
             let flat = FlatSpace::new(&space);
-            check(ctx, unsafe { ffi::aic_upload_space(ctx, layer, &flat.desc()) })?;
+            device.upload_space(layer, &flat.desc())?;
             todo.blocks.clear();
             todo.cubes.clear();
         } else {
@@ -225,30 +377,37 @@ impl HipRtRenderer {
                 let descs: Vec<_> = flat.iter().map(|b| b.desc).collect();
                 let voxels: Vec<_> = flat.iter().map(|b| b.voxels.as_ptr()).collect();
                 let palettes: Vec<_> = flat.iter().map(|b| b.palette.as_ptr()).collect();
-                check(ctx, unsafe {
-                    ffi::aic_replace_blocks(ctx, layer, indices.len() as u32, indices.as_ptr(), descs.as_ptr(), voxels.as_ptr(), palettes.as_ptr())
-                })?;
+                device.replace_blocks(layer, &indices, &descs, &voxels, &palettes)?;
             }
             if !todo.cubes.is_empty() {
                 let (xyz, idx, light) = gather_cubes(&space, todo.cubes.drain());
-                check(ctx, unsafe { ffi::aic_update_cubes(ctx, layer, idx.len() as u32, xyz.as_ptr(), idx.as_ptr(), light.as_ptr()) })?;
+                if device_light && layer == ffi::AIC_LAYER_WORLD {
+                    // block indices only; the device relights what changed. (A CubeLight message of the host Space lands
+                    // here too and is harmless: the cube's block index is rewritten with the value it already has.)
+                    device.update_cubes(layer, &xyz, &idx, None)?;
+                    let ctx = device.first_ctx();
+                    // SAFETY: live context, `xyz` outlives the call
+                    device.check(unsafe { ffi::aic_light_cubes_changed(ctx, layer, idx.len() as u32, xyz.as_ptr(), QUEUE_ORDER) })?;
+                } else {
+                    device.update_cubes(layer, &xyz, &idx, Some(&light))?;
+                }
             }
         }
         sync.n_blocks = block_data.len();
-        check(ctx, unsafe { ffi::aic_set_options(ctx, layer, &options_of(options)) })
+        device.set_options(layer, &options_of(options))
     }
 
     /// `RtRenderer::update` (renderer.rs:96-141).
     pub fn update_scene(&mut self, read_tickets: Layers<ReadTicket<'_>>, cursor: Option<&Cursor>) -> Result<(), RenderError> {
         self.had_cursor = cursor.is_some();
         self.cameras.update(read_tickets);
-        let ctx = self.ctx.as_ptr();
+        let (device, device_light) = (self.device, self.device_light.is_some());
         let world_options = self.cameras.graphics_options().clone();
         let ui_options = self.cameras.ui_view_state().graphics_options.clone();
         let world_space = self.cameras.world_space().get();
-        Self::sync_layer(ctx, ffi::AIC_LAYER_WORLD, &mut self.layers.world, world_space.as_ref(), read_tickets.world, &world_options)?;
+        Self::sync_layer(device, device_light, ffi::AIC_LAYER_WORLD, &mut self.layers.world, world_space.as_ref(), read_tickets.world, &world_options)?;
         let ui_space = self.cameras.ui_space().cloned();
-        Self::sync_layer(ctx, ffi::AIC_LAYER_UI, &mut self.layers.ui, ui_space.as_ref(), read_tickets.ui, &ui_options)
+        Self::sync_layer(device, device_light, ffi::AIC_LAYER_UI, &mut self.layers.ui, ui_space.as_ref(), read_tickets.ui, &ui_options)
     }
 
     /// `RtRenderer::draw_rgba` (renderer.rs:282-308).
@@ -274,14 +433,17 @@ impl HipRtRenderer {
         let mut info = ffi::aic_frame_info::default();
         if !data.is_empty() {
             // zero-area viewports produce an empty image (cases viewport_zero, cases/src/lib.rs:1167-1212)
-            let ctx = self.ctx.as_ptr();
-            check(ctx, unsafe { ffi::aic_render(ctx, &frame, data.as_mut_ptr().cast(), 0, &mut info) })?;
+            self.device.render(&frame, &mut data, &mut info)?;
         }
         let options = self.cameras.graphics_options();
-        if options.debug_info_text && !info_text.is_empty() {
-            // renderer.rs:659-683: the 2-D glyph blit stays on the host; the raytracer crate's function is private, so a
-            // maintainer either exposes it or copies its 25 lines here
-            log::trace!("info text not drawn by all-is-cubes-hip: {info_text}");
+        if options.debug_info_text && !info_text.is_empty() && !data.is_empty() {
+            // renderer.rs:205-217: the encoder's black and white (exposure and tone mapping applied, as the kernel's encoder does)
+            let camera = &self.cameras.cameras().world;
+            let paint = [
+                camera.post_process_color(Rgba::BLACK).to_srgb8(),
+                camera.post_process_color(Rgba::WHITE).to_srgb8(),
+            ];
+            draw_info_text(&mut data, viewport, &paint, info_text);
         }
         let mut flaws = Flaws::empty();
         if info.flaws & ffi::AIC_FLAW_UNSUPPORTED != 0 {
@@ -301,40 +463,74 @@ impl HipRtRenderer {
         &self.cameras
     }
 
+    fn light_params(maximum_distance: u8, fast: bool, epsilon: u8, n_queue: i32, max_updates: u64) -> ffi::aic_light_params {
+        ffi::aic_light_params {
+            maximum_distance: i32::from(maximum_distance),
+            fast: i32::from(fast),
+            epsilon: i32::from(epsilon),
+            batch: 32, // update_light_from_queue's batch with feature "auto-threads" (updater.rs:212-252)
+            queue_order: QUEUE_ORDER,
+            n_queue,
+            lanes_per_cube: 0,
+            reserved: 0,
+            queue_cubes: core::ptr::null(),
+            queue_priorities: core::ptr::null(),
+            max_updates,
+        }
+    }
+
     /// Runs the light updater ON THE DEVICE against the world space as last uploaded: `Mutation::fast_evaluate_light`
     /// (if `fast`) and `Mutation::evaluate_light(epsilon, ..)` (space.rs:1496-1540) with
     /// `LightPhysics::Rays { maximum_distance }`. The device's light volume -- what the following frames trace -- is
     /// updated in place; the host `Space`'s light is not touched. Batches of 32 in the table order of the reference's
-    /// queue on x86-64, i.e. the texels `Space::evaluate_light` itself would produce with feature "auto-threads".
+    /// queue, i.e. the texels `Space::evaluate_light` itself would produce with feature "auto-threads".
     /// Returns the number of cube updates.
     ///
     /// # Errors
     /// As [`HeadlessRenderer::draw`] for device failures.
     pub fn evaluate_light(&mut self, maximum_distance: u8, fast: bool, epsilon: u8) -> Result<u64, RenderError> {
-        let params = ffi::aic_light_params {
-            maximum_distance: i32::from(maximum_distance),
-            fast: i32::from(fast),
-            epsilon: i32::from(epsilon),
-            batch: 32,
-            queue_order: if cfg!(target_arch = "x86_64") { 16 } else { 8 }, // hashbrown's Group::WIDTH on the host the goldens came from
-            n_queue: -1,
-            lanes_per_cube: 0,
-            reserved: 0,
-            queue_cubes: core::ptr::null(),
-            queue_priorities: core::ptr::null(),
-            max_updates: 0,
-        };
+        // n_queue = -1: without `fast`, start from every cube whose texel is Uninitialized (Priority::UNINIT)
+        let params = Self::light_params(maximum_distance, fast, epsilon, -1, 0);
         let mut info = ffi::aic_light_info::default();
-        // SAFETY: ctx is a live context; params and info outlive the call
-        check(self.ctx.as_ptr(), unsafe { ffi::aic_evaluate_light(self.ctx.as_ptr(), ffi::AIC_LAYER_WORLD, &params, &mut info) })?;
+        self.device.evaluate_light(ffi::AIC_LAYER_WORLD, &params, &mut info)?;
         Ok(info.updates)
     }
+
+    /// With [`Self::set_device_light`] on: continues the device's own update queue (what `update` queued for the blocks
+    /// that changed, and what earlier calls left) for at most `max_updates` cube updates -- the per-frame slice of
+    /// `Space::step`'s light update (updater.rs:181-290), on the device. Returns (updates done, queue entries left).
+    ///
+    /// # Errors
+    /// As [`HeadlessRenderer::draw`] for device failures.
+    pub fn evaluate_light_budgeted(&mut self, max_updates: u64) -> Result<(u64, u32), RenderError> {
+        let maximum_distance = self.device_light.expect("evaluate_light_budgeted needs set_device_light(Some(..))");
+        // n_queue = 0: nothing new from the caller; the layer's queue is continued
+        let params = Self::light_params(maximum_distance, false, 1, 0, max_updates);
+        let mut info = ffi::aic_light_info::default();
+        self.device.evaluate_light(ffi::AIC_LAYER_WORLD, &params, &mut info)?;
+        Ok((info.updates, info.queue_left))
+    }
+}
+
+/// `draw_info_text` of the reference (raytracer/renderer.rs:659-683, private there): the info text over the finished frame,
+/// `FontSystem16` glyphs at offset (5, 5), outline in `paint[0]`, glyph pixels in `paint[1]`.
+fn draw_info_text(output: &mut [[u8; 4]], viewport: Viewport, paint: &[[u8; 4]; 2], info_text: &str) {
+    let size = viewport.framebuffer_size;
+    let font = universe::Builtin::FontSystem16.read::<text::FontDef>();
+    font.draw_str_monospaced(info_text, |pixel, value| {
+        let (x, y) = (pixel.x + 5, pixel.y + 5);
+        if x >= 0 && y >= 0 && (x as u32) < size.width && (y as u32) < size.height {
+            output[y as usize * size.width as usize + x as usize] = paint[match value {
+                text::Value::Outline => 0,
+                text::Value::Foreground => 1,
+            }];
+        }
+    });
 }
 
 impl Drop for HipRtRenderer {
     fn drop(&mut self) {
-        // SAFETY: the context came from aic_create and is dropped exactly once
-        unsafe { ffi::aic_destroy(self.ctx.as_ptr()) }
+        self.device.destroy();
     }
 }
 
