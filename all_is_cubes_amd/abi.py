@@ -57,7 +57,7 @@ class LightParams(C.Structure):
 
 class LightInfo(C.Structure):
     _fields_ = [("updates", C.c_uint64), ("batches", C.c_uint64), ("cost", C.c_uint64), ("device_ms", C.c_double),
-                ("total_ms", C.c_double), ("queue_left", C.c_uint32), ("pad", C.c_uint32)]
+                ("total_ms", C.c_double), ("queue_left", C.c_uint32), ("pad", C.c_uint32), ("bundles_visited", C.c_uint64)]
 
 
 def light_chart():

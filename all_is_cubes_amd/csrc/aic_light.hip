@@ -694,9 +694,10 @@ __device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
         const bool origin_is_opaque = (ev_origin->flags & 63u) == 63u;
         const bool origin_emits = !(ev_origin->emission[0] == 0.f && ev_origin->emission[1] == 0.f && ev_origin->emission[2] == 0.f);
         b.cost = 0u;
+        uint32_t n_visits = 0u;  // bundles of the ray tree this thread visited (the unit of the light updater's roofline: bench.py)
 #ifdef AIC_LIGHT_TIMING
         const long long t_begin = clock64();
-        uint32_t n_rounds = 0u, n_visits = 0u;
+        uint32_t n_rounds = 0u;
 #endif
 
         if (!origin_is_opaque) {
@@ -751,11 +752,11 @@ __device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
             //    child's entry, its number of children) and the block at its cube; where that cube is, the face it is entered
             //    through and whether the walk's directions give the bundle any weight came with the entry.
             {
-                // The queue's counters. As built, the reads below go through a volatile generic pointer, which the compiler turns
-                // into system-coherent flat loads that each wait for all of the wave's outstanding memory operations.
-                // -DAIC_LIGHT_LDS_COUNTERS reads them as LDS atomics instead (`done` acquired before the appended count is
-                // read): untested on hardware when this was written, so not the default.
-#ifdef AIC_LIGHT_LDS_COUNTERS
+                // The queue's counters are read as LDS atomics (`done` acquired before the appended count is read). Round 2 read
+                // them through a volatile generic pointer, which the compiler turns into system-coherent flat loads that each
+                // wait for all of the wave's outstanding memory operations (-DAIC_LIGHT_GENERIC_COUNTERS builds that again); on
+                // hardware the difference is 1.4 % of the device time (profiles/r03_experiments.txt B), 300-seed fuzz green.
+#ifndef AIC_LIGHT_GENERIC_COUNTERS
                 struct {
                     uint32_t *c;
                     __device__ uint32_t operator[](int i) const {
@@ -852,9 +853,7 @@ __device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
                 for (uint32_t i = lane; i < got; i += nt) {
                     const uint32_t k = s_order[i];
                     float alpha;
-#ifdef AIC_LIGHT_TIMING
                     n_visits++;
-#endif
                     (void)b.visit(k, valpha[k], &alpha);
                 }
                 __syncthreads();  // s_order is written again by the next gather
@@ -868,10 +867,14 @@ __device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
         cost = 0u;
         for (uint32_t q = 0u; q < (nt >> 6); q++) cost += s_scan[q];
         __syncthreads();
+        {   // visited bundles of this cube, summed over the block like `cost`: one atomic per wave
+            uint32_t v = n_visits;
+            for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+            if ((lane & 63u) == 0u && v != 0u) atomicAdd(&J.dep_head[5], v);
+        }
 #ifdef AIC_LIGHT_TIMING
         const long long t_walk = clock64();
         if (lane == 0u) { atomicAdd(&J.dep_head[2], (uint32_t)((t_walk - t_begin) >> 6)); atomicAdd(&J.dep_head[4], n_rounds); }
-        atomicAdd(&J.dep_head[5], n_visits);
 #endif
 
         // Ordered reduction. The set bits in ascending order are the reference's order of additions. They are gathered by

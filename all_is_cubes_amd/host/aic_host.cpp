@@ -570,11 +570,21 @@ aic_frame_desc HipRtRenderer::make_frame() const {
     f.width = vp.framebuffer_width;
     f.height = vp.framebuffer_height;
     f.world = world_camera_.to_abi();
+    if (cam_override_) {
+        std::memcpy(f.world.inverse_projection_view, cam_override_inv_, sizeof(cam_override_inv_));
+        f.world.exposure = cam_override_exposure_;
+    }
     f.ui = ui_camera_.to_abi();
     std::memcpy(f.backdrop, backdrop_, sizeof(f.backdrop));
     f.partition = aic_partition{0, 1, 0, 0};
     f.flags = enable_counters ? AIC_FRAME_COUNTERS : 0;
     return f;
+}
+
+void HipRtRenderer::set_world_camera_override(const double *inverse_projection_view, float exposure) {
+    cam_override_ = inverse_projection_view != nullptr;
+    if (cam_override_) std::memcpy(cam_override_inv_, inverse_projection_view, sizeof(cam_override_inv_));
+    cam_override_exposure_ = exposure;
 }
 
 static ImageInfo to_info(const aic_frame_info &fi, uint32_t w, uint32_t h) {
@@ -771,7 +781,7 @@ HipRtRenderer::LightUpdateInfo HipRtRenderer::evaluate_light(int maximum_distanc
     p.lanes_per_cube = lanes_per_cube;
     aic_light_info info;
     check(aic_evaluate_light(ctx_, AIC_LAYER_WORLD, &p, &info), "aic_evaluate_light");
-    return LightUpdateInfo{info.updates, info.batches, info.cost, info.device_ms, info.total_ms, info.queue_left};
+    return LightUpdateInfo{info.updates, info.batches, info.cost, info.device_ms, info.total_ms, info.queue_left, info.bundles_visited};
 }
 
 void HipRtRenderer::wait_event(void *hip_event) { check(aic_wait_event(ctx_, hip_event), "aic_wait_event"); }

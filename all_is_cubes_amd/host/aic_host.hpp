@@ -306,6 +306,10 @@ class HipRtRenderer : public HeadlessRenderer {
     void update(const Cursor *cursor) override { (void)update_scene(cursor); }
     Rendering draw(const std::string &info_text) override { return draw_rgba(info_text); }
     Rendering draw_rgba(const std::string &info_text);
+    // Replaying a recorded frame (all_is_cubes_amd/replay.py, bench.py --workload replay:<file>): the world camera's
+    // inverse_projection_view and exposure exactly as the recording has them, instead of the values derived from the
+    // StandardCameras' view transform (which would be equal only up to rounding). nullptr: back to the cameras.
+    void set_world_camera_override(const double *inverse_projection_view, float exposure);
     // SpaceRaytracer::<CharacterRtData>::to_text::<CharacterBuf> (sr.rs:367-472, text.rs:52-128): one ray through each
     // pixel centre; the first block hit shows the first character of its display name ('#' if it has none), a ray that
     // entered the space and hit nothing ' ', one that never entered it '.', one that ran out of steps 'X'
@@ -327,7 +331,7 @@ class HipRtRenderer : public HeadlessRenderer {
     // Light propagation on the device (aic_evaluate_light): Mutation::fast_evaluate_light (if `fast`) then
     // Mutation::evaluate_light(epsilon) (space.rs:1496-1540) on the WORLD space as uploaded, with
     // LightPhysics::Rays { maximum_distance }; the device's light volume is updated in place (the host Space's is not).
-    struct LightUpdateInfo { uint64_t updates, batches, cost; double device_ms, total_ms; uint32_t queue_left; };
+    struct LightUpdateInfo { uint64_t updates, batches, cost; double device_ms, total_ms; uint32_t queue_left; uint64_t bundles_visited; };
     // `continue_queue`: add nothing to the layer's update queue (what update() queued through aic_light_cubes_changed is
     // drained); `max_updates`: stop after that many cube updates (a per-frame light budget), 0 = run to the end.
     LightUpdateInfo evaluate_light(int maximum_distance, bool fast = true, int epsilon = 1, int batch = 32, int queue_order = 16, int lanes_per_cube = 0,
@@ -353,6 +357,9 @@ class HipRtRenderer : public HeadlessRenderer {
     SizePolicy size_policy_;
     aic_ctx *ctx_ = nullptr;
     LayerState layers_[2];
+    bool cam_override_ = false;
+    double cam_override_inv_[16] = {0};
+    float cam_override_exposure_ = 1.0f;
     bool had_cursor_ = false;
     // snapshot taken by update(): draw() must not touch the scene objects (headless.rs:33-39)
     Camera world_camera_, ui_camera_;

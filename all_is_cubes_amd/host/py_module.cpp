@@ -220,6 +220,11 @@ PYBIND11_MODULE(_host, m) {
         .def("update", [](HipRtRenderer &r, py::object cursor) { Cursor c; return r.update_scene(cursor.is_none() ? nullptr : &c); }, py::arg("cursor") = py::none())
         .def("draw", [](HipRtRenderer &r, const std::string &t) { py::gil_scoped_release rel; return r.draw(t); }, py::arg("info_text") = "")
         .def("draw_text", [](HipRtRenderer &r, const std::string &le) { py::gil_scoped_release rel; return r.draw_text(le); }, py::arg("line_ending") = "\n")
+        .def("set_world_camera_override", [](HipRtRenderer &r, py::object inv, float exposure) {
+            if (inv.is_none()) { r.set_world_camera_override(nullptr, 1.0f); return; }
+            const auto m = inv.cast<std::array<double, 16>>();
+            r.set_world_camera_override(m.data(), exposure);
+        }, py::arg("inverse_projection_view"), py::arg("exposure") = 1.0f)
         .def("draw_rgba", [](HipRtRenderer &r, const std::string &t) { py::gil_scoped_release rel; return r.draw_rgba(t); }, py::arg("info_text") = "")
         .def("draw_rows_to_device", [](HipRtRenderer &r, uintptr_t ptr, uint32_t strip_rows, uint32_t n_parts, uint32_t part, bool counters, bool no_feedback) {
             py::gil_scoped_release rel;
@@ -243,7 +248,7 @@ PYBIND11_MODULE(_host, m) {
             const HipRtRenderer::LightUpdateInfo i = r.evaluate_light(maximum_distance, fast, epsilon, batch, queue_order, lanes_per_cube, continue_queue, max_updates);
             py::dict d;
             d["updates"] = i.updates; d["batches"] = i.batches; d["cost"] = i.cost; d["device_ms"] = i.device_ms;
-            d["total_ms"] = i.total_ms; d["queue_left"] = i.queue_left;
+            d["total_ms"] = i.total_ms; d["queue_left"] = i.queue_left; d["bundles_visited"] = i.bundles_visited;
             return d;
         }, py::arg("maximum_distance"), py::arg("fast") = true, py::arg("epsilon") = 1, py::arg("batch") = 32, py::arg("queue_order") = 16, py::arg("lanes_per_cube") = 0, py::arg("continue_queue") = false,
            py::arg("max_updates") = 0)

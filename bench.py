@@ -21,7 +21,9 @@ Abrupt fog). `--workload s256` selects configs[2] (3840x2160 synthetic 256^3 Spa
 `--workload orbit` configs[4] (60-frame orbit, light volume re-uploaded every frame),
 `--workload relight` the same loop with the light computed ON THE DEVICE (a lamp toggled, 1024 cube
 updates of the light updater and one frame per step), `--workload light-bench` the reference's own
-bench scene (all-is-cubes-render/benches/raytrace.rs: light_bench_space, 64x64), lit on the device.
+bench scene (all-is-cubes-render/benches/raytrace.rs: light_bench_space, 64x64), lit on the device,
+`--workload replay:<file.aic>` a scene recorded through the C ABI (the reference's real Atrium / DemoCity once captured with
+rust/all-is-cubes-hip/examples/capture.rs: tests/golden/README.md) with its recorded camera and options.
 
 Launch: `python bench.py --gpus 1 --steps K --warmup W`, or for N > 1
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`.
@@ -49,6 +51,9 @@ if str(ROOT) not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+# tools/ubench/issue_rate.hip on an MI355X (profiles/r03_issue_rate.txt): SIMD cycles per wave-instruction, launch-time based
+ISSUE_PEAK_CYCLES = 2.2   # the cheapest stream there is (v_mov_b32 / v_add_u32, 8 waves per SIMD)
+ISSUE_PIPE_CYCLES = 4.2   # f64 add / fma / compare, v_cndmask, v_mul_lo_u32 and every SALU instruction
 
 
 def build_workload(name: str):
@@ -79,8 +84,8 @@ def build_workload(name: str):
         size = (1920, 1080)
         eye, target = (0.5, 9.91, 10.0), (0.5, 8.0, 0.0)
         view_distance = 200.0
-        label = ("atrium-like 19x35x51 R16, 1920x1080, 60-frame orbit; each frame: a lamp block toggled, relit on the device "
-                 "(one launch of 1024 cube updates), camera moved")
+        label = ("atrium-like 19x35x51 R16, 1920x1080, 60-frame orbit; a lamp block toggled every --relight-period frames, every frame one "
+                 "launch of --light-budget cube updates of the device's light updater, camera moved")
     elif name == "s256":
         space = scenes.synthetic_space(n=256, resolution=32, n_blocks=64, seed=1)
         size = (3840, 2160)
@@ -107,9 +112,34 @@ def build_workload(name: str):
         eye, target = (16.5, 24.5, 48.0), (16.0, 8.0, 16.0)
         view_distance = 200.0
         label = "synthetic S32 R8 320x200 (plumbing)"
+    elif name.startswith("replay:"):
+        # a scene recorded through the C ABI (AIC_DUMP; rust/all-is-cubes-hip/examples/capture.rs, tests/golden/README.md): the
+        # world space, options and camera of the recording's LAST frame
+        from all_is_cubes_amd import abi, replay as rp
+        path = name.split(":", 1)[1]
+        st, frame = rp.SceneState(), None
+        for r in rp.read_dump(path):
+            if r.tag == rp.FRAME:
+                frame = r.data["frame"]
+            else:
+                st.apply(r)
+        if frame is None or st.spaces[abi.LAYER_WORLD] is None:
+            raise SystemExit(f"{path}: no frame / no world space recorded")
+        if st.spaces[abi.LAYER_UI] is not None:
+            print(f"{path}: the recorded UI layer is not replayed by the benchmark (world layer only)", file=sys.stderr)
+        space = st.spaces[abi.LAYER_WORLD]
+        size = (int(frame["width"]), int(frame["height"]))
+        o = st.options[abi.LAYER_WORLD]
+        view_distance = float(o["view_distance"]) if o is not None else 200.0
+        eye = target = None
+        label = f"recorded scene {os.path.basename(path)} ({'x'.join(str(v) for v in space.size)} cubes, {len(space.blocks)} blocks), {size[0]}x{size[1]}, recorded camera and options"
+        REPLAY.update(inv=[float(v) for v in frame["world"]["inverse_projection_view"]], exposure=float(frame["world"]["exposure"]), options=o)
     else:
         raise SystemExit(f"unknown workload {name}")
     return space, size, eye, target, view_distance, label
+
+
+REPLAY: dict = {}  # --workload replay:<file>: the recorded camera matrix, exposure and options
 
 
 def main() -> int:
@@ -117,7 +147,8 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="atrium", choices=["atrium", "s256", "small", "orbit", "light-bench", "relight"])
+    ap.add_argument("--workload", default="atrium",
+                    help="atrium | s256 | small | orbit | light-bench | relight | replay:<recording.aic> (a scene captured through the C ABI: tests/golden/README.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", dest="verify", action="store_true", default=None,
                     help="N > 1 (default there): check the assembled frame against a single-rank trace of the same frame")
@@ -132,7 +163,9 @@ def main() -> int:
     ap.add_argument("--transparency", type=int, default=None, help="experiment: 0 Surface, 1 Volumetric; default Volumetric (light-bench: Surface, the reference bench's 'linear-surface')")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed single-frame / moving-camera / read-back measurements (counter passes)")
-    ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step timed region until the regions add up to this much time")
+    ap.add_argument("--relight-period", type=int, default=4, help="relight: frames between two lamp toggles")
+    ap.add_argument("--light-budget", type=int, default=2048, help="relight: cube updates of the light updater per frame (one launch)")
+    ap.add_argument("--min-seconds", type=float, default=3.0, help="repeat the K-step timed region until the regions add up to this much time")
     args = ap.parse_args()
     default_transparency = 0 if args.workload == "light-bench" else 1
     if args.transparency is None:
@@ -187,8 +220,23 @@ def main() -> int:
     cams.graphics_options = opts
     cams.viewport = H.Viewport.with_scale(1.0, w, h)
     cams.world_space = space_from_flat(flat_space)
+    is_replay = args.workload.startswith("replay:")
+    if is_replay:
+        ro = REPLAY["options"]
+        if ro is not None:  # the recorded GraphicsOptions of the world layer
+            opts.fog = H.FogOption(int(ro["fog"]))
+            opts.transparency = H.TransparencyOption(H.TransparencyKind(int(ro["transparency"])), float(ro["threshold"]))
+            opts.lighting_display = H.LightingOption(H.LightingKind(int(ro["lighting"])))
+            opts.antialiasing = H.AntialiasingOption(int(ro["antialiasing"]))
+            opts.debug_pixel_cost = bool(ro["debug_pixel_cost"])
+            opts.tone_mapping = H.ToneMappingOperator(int(ro["tone_mapping"]))
+            opts.maximum_intensity = float(ro["maximum_intensity"])
+            cams.graphics_options = opts
+        eye, target = (0.0, 0.0, 0.0), (0.0, 0.0, -1.0)  # (unused: the recorded matrix overrides the derived camera)
     cams.world_view_transform = H.look_at_y_up(eye, target)
     renderer = H.HipRtRenderer(cams, None, local_rank)
+    if is_replay:
+        renderer.set_world_camera_override(REPLAY["inv"], REPLAY["exposure"])
     renderer.update()
     light_update = None
     relight = None
@@ -215,15 +263,29 @@ def main() -> int:
         # light.rs "both": fast_evaluate_light then evaluate_light(1), LightPhysics::Rays { maximum_distance: 30 },
         # batches of 32 in the reference's queue order -- the configuration that reproduces the reference's texels
         li = renderer.evaluate_light(30, True, 1, 32, 16)
+        def light_roofline(r):
+            # Algorithmic bytes of the light walk: per visited ray-tree bundle 16 B of the bundle's record
+            # (its only child's entry, its number of children), 2 B of the block index at its cube and 4 B of the light texel
+            # there; the kernel counts the visits (aic_light_info.bundles_visited). Against the HBM peak like the trace
+            # kernel's figure, and just as far from it: the walk is a chain of dependent L2 hits, bound by latency.
+            b = 22 * int(r["bundles_visited"])
+            return {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "bundles_visited": int(r["bundles_visited"]), "algorithmic_bytes": b,
+                    "achieved": round(b / (r["device_ms"] * 1e-3) / 1e9, 3) if r["device_ms"] > 0 else None,
+                    "frac": round(b / (r["device_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if r["device_ms"] > 0 else None,
+                    "kernel": "compute_light_wave_kernel", "kernel_ms_per_launch": round(r["device_ms"] / max(1, int(r["batches"])), 4),
+                    "bundles_per_cube": round(int(r["bundles_visited"]) / max(1, int(r["updates"])), 1)}
+
         light_update = {"mode": "fast_evaluate_light + evaluate_light(1), batch 32, hashbrown order", "updates": int(li["updates"]),
                         "launches": int(li["batches"]), "device_ms": round(li["device_ms"], 3), "total_ms": round(li["total_ms"], 3),
-                        "updates_per_s": round(li["updates"] / (li["total_ms"] * 1e-3), 1) if li["total_ms"] > 0 else None}
+                        "updates_per_s": round(li["updates"] / (li["total_ms"] * 1e-3), 1) if li["total_ms"] > 0 else None,
+                        "roofline": light_roofline(li)}
         # and the same work with whole-queue batches (order differs from the reference's in the last texel unit)
         renderer.update()
         lt = renderer.evaluate_light(30, True, 1, 8192, 0)
         light_update["throughput_mode"] = {"batch": 8192, "updates": int(lt["updates"]), "launches": int(lt["batches"]),
                                            "device_ms": round(lt["device_ms"], 3), "total_ms": round(lt["total_ms"], 3),
-                                           "updates_per_s": round(lt["updates"] / (lt["total_ms"] * 1e-3), 1) if lt["total_ms"] > 0 else None}
+                                           "updates_per_s": round(lt["updates"] / (lt["total_ms"] * 1e-3), 1) if lt["total_ms"] > 0 else None,
+                                           "roofline": light_roofline(lt)}
         li = renderer.evaluate_light(30, True, 1, 32, 16)  # leave the reference-order light in place for the traced frames
 
     strip = D.STRIP_ROWS
@@ -306,14 +368,18 @@ def main() -> int:
         frame_no[0] += 1
         if relight is not None:
             k = i % 60
-            x, y, z = relight["sites"][k % 30]
-            cams.world_space.set(x, y, z, relight["lamp"] if (i // 30) % 2 == 0 else relight["air"])
+            if i % args.relight_period == 0:   # a lamp placed (first pass over the 30 sites) or removed (second pass)
+                j = i // args.relight_period
+                x, y, z = relight["sites"][j % 30]
+                cams.world_space.set(x, y, z, relight["lamp"] if (j // 30) % 2 == 0 else relight["air"])
             cams.world_view_transform = orbit["views"][k]
             renderer.update()                                  # block delta -> aic_update_cubes + aic_light_cubes_changed
             t_l = time.perf_counter()
-            li = renderer.evaluate_light(30, False, 1, 1024, 0, 0, True, 1024)
+            li = renderer.evaluate_light(30, False, 1, args.light_budget, 0, 0, True, args.light_budget)  # one launch of that many cube updates
             relight["light_ms"] += (time.perf_counter() - t_l) * 1e3
             relight["updates"] += int(li["updates"]); relight["calls"] += 1; relight["queue_left"] = int(li["queue_left"])
+            relight["queue_max"] = max(relight.get("queue_max", 0), int(li["queue_left"]))
+            relight["drained"] = relight.get("drained", 0) + (1 if int(li["queue_left"]) == 0 else 0)
         elif orbit is not None:
             k = i % 60
             cams.world_space.load_light(orbit["lights"][k])   # SpaceChange burst -> aic_update_light_volume
@@ -419,25 +485,33 @@ def main() -> int:
         n_l = max(10, min(60, args.steps))
         tgt = render_target(0).data_ptr()
 
+        one_kernel_ms = []
+
         def one_by_one(n, **kw):
             renderer.synchronize()
             ts = []
+            one_kernel_ms.clear()
             for _ in range(n):
                 t1 = time.perf_counter()
-                renderer.draw_rows_to_device(tgt, strip, world, rank, **kw)
+                fi = renderer.draw_rows_to_device(tgt, strip, world, rank, **kw)
                 ts.append((time.perf_counter() - t1) * 1e3)
+                one_kernel_ms.append(fi.kernel_ms)
             return ts
 
         one_by_one(2)
         warm = one_by_one(n_l)
+        warm_kernel_ms = float(np.median(one_kernel_ms))  # one launch alone on the device (HIP events): the KERNEL's duration
         cold = one_by_one(n_l, no_feedback=True)
+        cold_kernel_ms = float(np.median(one_kernel_ms))
+        if is_replay:
+            eye, target = (0.0, 0.0, 1.0), (0.0, 0.0, 0.0)
         radius = float(np.hypot(eye[0] - target[0], eye[2] - target[2]))
         a0 = float(np.arctan2(eye[0] - target[0], eye[2] - target[2]))
         views = [H.look_at_y_up((target[0] + radius * np.sin(a0 + np.radians(6.0 * k)), eye[1], target[2] + radius * np.cos(a0 + np.radians(6.0 * k))), target)
                  for k in range(60)]
         moving = []
         renderer.synchronize()
-        for k in range(n_l):
+        for k in range(0 if is_replay else n_l):
             cams.world_view_transform = views[k % 60]
             renderer.update()
             t1 = time.perf_counter()
@@ -445,13 +519,13 @@ def main() -> int:
             moving.append((time.perf_counter() - t1) * 1e3)
         renderer.synchronize()
         t1 = time.perf_counter()
-        for k in range(n_l):
+        for k in range(0 if is_replay else n_l):
             cams.world_view_transform = views[k % 60]
             renderer.update()
             if k >= depth:
                 renderer.wait_rows(k % depth)
             renderer.submit_rows_to_device(render_target(k).data_ptr() if local_bufs is None else local_bufs[k % len(local_bufs)].data_ptr(), strip, world, rank, k % depth)
-        for k in range(max(0, n_l - depth), n_l):
+        for k in range(max(0, n_l - depth), 0 if is_replay else n_l):
             renderer.wait_rows(k % depth)
         moving_streamed = (time.perf_counter() - t1) / n_l * 1e3
         cams.world_view_transform = H.look_at_y_up(eye, target)
@@ -459,8 +533,10 @@ def main() -> int:
         single = {
             "single_frame_warm_ms": round(float(np.median(warm)), 4),
             "single_frame_cold_ms": round(float(np.median(cold)), 4),
-            "single_frame_moving_camera_ms": round(float(np.median(moving)), 4),
-            "streamed_moving_camera_ms": round(moving_streamed, 4),
+            "single_frame_moving_camera_ms": round(float(np.median(moving)), 4) if moving else None,
+            "streamed_moving_camera_ms": round(moving_streamed, 4) if moving else None,
+            "kernel_ms_warm": round(warm_kernel_ms, 4),
+            "kernel_ms_cold": round(cold_kernel_ms, 4),
             "frames": n_l,
             "note": "medians of one frame at a time (host submit to completion); moving camera: 6 degrees per frame about the view target",
         }
@@ -515,24 +591,31 @@ def main() -> int:
             cn = pj.get("counters", {})
             vi = cn.get("SQ_INSTS_VALU", {}).get("mean_per_launch")
             if vi and elapsed > 0:
-                # What actually bounds the kernel: instruction issue. tools/ubench/issue_rate (profiles/r02_issue_rate.txt)
-                # measures, per SIMD, one wave-instruction per 2.55 cycles for the cheapest stream there is (32-bit moves, 8
-                # waves per SIMD), 4.3-4.7 for this kernel's VALU mix (f64 compare/add, selects, integer ops) and 3.3-3.5
-                # for a VALU + SALU stream. `peak` is the first -- a ceiling no kernel can exceed; the kernel's own mix
-                # cannot get closer to it than ~0.75-0.8. The count is of ALL instructions (VALU + SALU + memory).
+                # Instruction issue, priced with tools/ubench/issue_rate.hip (residency pinned and verified per line,
+                # profiles/r03_issue_rate.txt; cycles one SIMD spends per wave-instruction at 4-8 waves per SIMD, from the launch's
+                # HIP-event time): 2.2 for the simplest VALU operations (v_mov_b32, v_add_u32), 4.0-4.45 for everything else this
+                # kernel is made of (f64 add / fma / compare, v_cndmask, v_mul_lo, v_fma_f32) and for SALU; VALU and SALU of
+                # DIFFERENT waves issue side by side (alternating stream: 2.3 per instruction). `peak` is the first figure -- a
+                # ceiling no instruction stream exceeds; `pipe_busy` prices this kernel's own VALU and SALU counts at 4.2 cycles
+                # each against the cycles its launch period offers (an upper estimate for VALU: its simple operations cost 2.2).
                 kinds = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM")
                 total = sum(float(cn.get(k, {}).get("mean_per_launch") or 0.0) for k in kinds)
-                peak = 1024 * 2.4e9 / 2.55
+                si = float(cn.get("SQ_INSTS_SALU", {}).get("mean_per_launch") or 0.0)
+                peak = 1024 * 2.4e9 / ISSUE_PEAK_CYCLES
                 rate = total / (launch_period_ms * 1e-3) if launch_period_ms > 0 else 0.0
+                simd_cycles = 1024 * 2.4e9 * launch_period_ms * 1e-3
                 tc, ai = cn.get("SQ_THREAD_CYCLES_VALU", {}).get("mean_per_launch"), cn.get("SQ_ACTIVE_INST_VALU", {}).get("mean_per_launch")
-                valu = {"wave_insts_per_launch": int(total), "valu_wave_insts_per_launch": int(vi), "issue_rate": round(rate / 1e9, 2), "peak": round(peak / 1e9, 1),
+                valu = {"wave_insts_per_launch": int(total), "valu_wave_insts_per_launch": int(vi), "salu_wave_insts_per_launch": int(si),
+                        "issue_rate": round(rate / 1e9, 2), "peak": round(peak / 1e9, 1),
                         "unit": "G wave-insts/s", "frac": round(rate / peak, 4),
                         "cycles_per_inst_per_simd": round(1024 * 2.4e9 / rate, 3) if rate else None,
+                        "pipe_busy": {"valu": round(vi * ISSUE_PIPE_CYCLES / simd_cycles, 3), "salu": round(si * ISSUE_PIPE_CYCLES / simd_cycles, 3)} if simd_cycles else None,
                         "valu_lane_utilisation": round(tc / (ai * 64.0), 4) if tc and ai else None,
                         "source": "profiles/" + os.path.basename(cands[-1]),
                         "note": "instruction counts per launch from the PMC file (one frame at a time) over this run's launch period; peak = the fastest "
-                                "instruction stream measured on this chip (32-bit moves, 2.55 cycles per instruction per SIMD, profiles/r02_issue_rate.txt); "
-                                "streams of this kernel's mix reach 3.3-4.5 there: the binding resource (DESIGN.md 6)"}
+                                f"instruction stream measured on this chip ({ISSUE_PEAK_CYCLES} cycles per instruction per SIMD: v_mov_b32 at 8 waves per SIMD, "
+                                f"profiles/r03_issue_rate.txt); pipe_busy = VALU / SALU instructions x {ISSUE_PIPE_CYCLES} cycles (what f64, compare, select and "
+                                "scalar operations cost there) / SIMD cycles of the launch period (DESIGN.md 6)"}
 
     result = None
     if rank == 0:
@@ -582,6 +665,11 @@ def main() -> int:
                                "the mean duration of one launch (HIP events on its stream; what rocprofv3's per-kernel average shows)") if streamed
                               else "one launch at a time: achieved = algorithmic bytes per launch / kernel_ms",
                 "algorithmic_bytes_per_launch": int(my_bytes),
+                # the KERNEL's own fraction: one launch alone on the device (warm tile order; HIP events), whatever the timed
+                # region above streams -- the figure to compare with rocprofv3's per-kernel duration of a --no-pipeline run
+                "kernel_ms_one_at_a_time": single["kernel_ms_warm"] if single is not None else (round(mean_kernel_ms, 4) if not streamed else None),
+                "frac_one_at_a_time": (round(my_bytes / (single["kernel_ms_warm"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if single is not None and single["kernel_ms_warm"] > 0
+                                       else (round(achieved_gbs / HBM_PEAK_GBS, 6) if not streamed else None)),
                 "gsteps_per_s": round((info.cubes_traced / (launch_period_ms * 1e-3)) / 1e9, 3) if launch_period_ms > 0 else 0.0,
                 "note": "rank-0 launch; cache-resident scene: the path is latency/ALU-bound, not HBM-bound (DESIGN.md)",
             },
@@ -598,12 +686,15 @@ def main() -> int:
             result["light_update"] = light_update
         if relight is not None and relight["calls"]:
             result["relight"] = {"light_updates_per_frame": round(relight["updates"] / relight["calls"], 1),
+                                 "light_budget_per_frame": args.light_budget, "frames_between_toggles": args.relight_period,
                                  "light_ms_per_frame": round(relight["light_ms"] / relight["calls"], 4),
-                                 "queue_left_at_end": relight["queue_left"], "frames_counted": relight["calls"]}
+                                 "queue_left_at_end": relight["queue_left"], "queue_left_max": relight.get("queue_max", 0),
+                                 "frames_ending_with_an_empty_queue": relight.get("drained", 0), "frames_counted": relight["calls"]}
         if fps_with_readback is not None:
             result["fps_with_readback"] = round(fps_with_readback, 3)
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(flat_space, opts, w, h, eye, target, view_distance, args.cpu_seconds)
+            result["cpu_baseline"] = cpu_baseline(flat_space, opts, w, h, eye, target, view_distance, args.cpu_seconds,
+                                                  inv=REPLAY.get("inv") if is_replay else None)
             if result["cpu_baseline"]["value"]:
                 result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 2)
         print(json.dumps(result), flush=True)
@@ -636,7 +727,7 @@ def usable_cpus():
     return n, note
 
 
-def cpu_baseline(flat_space, opts, w, h, eye, target, view_distance, target_seconds: float) -> dict:
+def cpu_baseline(flat_space, opts, w, h, eye, target, view_distance, target_seconds: float, inv=None) -> dict:
     """The CPU oracle (a restatement of the reference algorithm -- the reference itself is Rust and
     cannot be built here) timed on this host's cores over a bounded sample of the same workload:
     whole frames, all hardware threads, row-parallel like the reference's rayon loop
@@ -661,9 +752,10 @@ def cpu_baseline(flat_space, opts, w, h, eye, target, view_distance, target_seco
     sp = oracle.Space(flat_space)
     oo = oracle.make_options(fog=int(opts.fog), transparency=int(opts.transparency.kind), lighting=int(opts.lighting_display.kind),
                              view_distance=view_distance)
-    q = oracle.look_at_y_up(eye, target)
-    _, _, inv = oracle.camera_matrices(90.0, view_distance, w / h, q, eye)
-    cam = oracle.make_camera(inv, w, h)
+    if inv is None:
+        q = oracle.look_at_y_up(eye, target)
+        _, _, inv = oracle.camera_matrices(90.0, view_distance, w / h, q, eye)
+    cam = oracle.make_camera(np.asarray(inv, np.float64).reshape(4, 4), w, h)
     oracle.render(sp, oo, cam, threads=threads)  # warm-up frame (page-in, thread start)
     frames, t0 = 0, time.perf_counter()
     per_frame = []

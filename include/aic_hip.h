@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AIC_ABI_VERSION 1
+#define AIC_ABI_VERSION 2
 
 /* status codes */
 #define AIC_OK 0
@@ -333,6 +333,8 @@ typedef struct aic_light_info {
     double total_ms;      /* wall time of the call */
     uint32_t queue_left;  /* entries left in the queue (at or below epsilon, or cut off by max_updates) */
     uint32_t pad;
+    uint64_t bundles_visited;  /* ray-tree bundles visited by the device walk (walk_ray_tree calls that passed the weight and
+                                * distance checks, updater.rs:427-530): the unit of work of the light updater's roofline (ABI 2) */
 } aic_light_info;
 int aic_evaluate_light(aic_ctx *ctx, int layer, const aic_light_params *params, aic_light_info *info);
 /* After aic_update_cubes changed the blocks of these cubes: what LightStorage::modified_cube_needs_update (updater.rs:135-173) does

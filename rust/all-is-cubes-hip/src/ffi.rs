@@ -1,10 +1,10 @@
-//! Raw bindings to libaic_hip.so: one item per declaration of `include/aic_hip.h` (AIC_ABI_VERSION 1), same
+//! Raw bindings to libaic_hip.so: one item per declaration of `include/aic_hip.h` (AIC_ABI_VERSION 2), same
 //! names, same field order. Kept in step with the header by `tests/test_rust_shim.py` of the MI355X repository.
 #![allow(non_camel_case_types, missing_docs, clippy::missing_safety_doc)]
 
 use core::ffi::{c_char, c_int, c_void};
 
-pub const AIC_ABI_VERSION: c_int = 1;
+pub const AIC_ABI_VERSION: c_int = 2;
 pub const AIC_OK: c_int = 0;
 pub const AIC_ERR_INVALID: c_int = 1;
 pub const AIC_ERR_NO_DEVICE: c_int = 2;
@@ -174,6 +174,7 @@ pub struct aic_light_info {
     pub total_ms: f64,
     pub queue_left: u32,
     pub pad: u32,
+    pub bundles_visited: u64,
 }
 
 unsafe extern "C" {

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     lib = abi.load()
     for sym in sorted(declared):
         assert hasattr(lib, sym), sym
-    assert lib.aic_abi_version() == 1
+    assert lib.aic_abi_version() == 2
 
 
 def test_struct_layouts_match_header():

@@ -163,3 +163,23 @@ def test_recorded_sessions_replay_on_the_device(path):
     assert len(device) == len(cpu)
     for a, b in zip(cpu, device):
         assert np.abs(a.astype(np.int16) - b.astype(np.int16)).max() <= 1
+
+
+def test_bench_builds_its_workload_from_a_recording(tmp_path):
+    """bench.py --workload replay:<file>: the world space, size, options and camera matrix of the recording's last frame."""
+    import bench
+
+    path = tmp_path / "w.aic"
+    with replay.DumpWriter(path) as wr:
+        def apply(name, *args):
+            if name == "frame":
+                wr.frame(args[0])
+            else:
+                getattr(wr, name)(*args)
+        sp, _ = _session(apply)
+    space, size, eye, target, view_distance, label = bench.build_workload(f"replay:{path}")
+    assert size == (80, 56) and eye is None and target is None and view_distance == 200.0 and "w.aic" in label
+    assert space.block_index.shape == sp.block_index.shape
+    frames = [r for r in replay.read_dump(path) if r.tag == replay.FRAME]
+    assert bench.REPLAY["inv"] == [float(v) for v in frames[-1].data["frame"]["world"]["inverse_projection_view"]]
+    assert int(bench.REPLAY["options"]["lighting"]) == 4 and int(bench.REPLAY["options"]["fog"]) == 2
