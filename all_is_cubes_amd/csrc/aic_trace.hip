@@ -610,7 +610,10 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u
 #define AIC_WG_THREADS 256  // threads per persistent workgroup (a multiple of 64)
 #endif
 #ifndef AIC_STEP_REPS
-#define AIC_STEP_REPS 8  // DDA steps per scheduler trip
+#define AIC_STEP_REPS 8  // full stepping passes per scheduler trip
+#endif
+#ifndef AIC_FAST_STEPS
+#define AIC_FAST_STEPS 2  // bookkeeping-free steps a lane may take ahead of each full pass (0: none)
 #endif
 
 // Runs Raycaster::next (raycast.rs:239-284) on a freshly initialised level until it yields its
@@ -1491,6 +1494,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         mask_t m_inb = __builtin_amdgcn_ballot_w64((st & ST_IN_BLOCK) != 0u);
         mask_t m_opq = __builtin_amdgcn_ballot_w64((st & ST_OPAQUE) != 0u);
         mask_t m_hl = VOL ? __builtin_amdgcn_ballot_w64((st & ST_HAS_LAST) != 0u) : 0ull;
+        // a trip adds at most AIC_STEP_REPS * (AIC_FAST_STEPS + 2) to a lane's step count: lanes this far below the 1000-step cap
+        // (count_step_should_stop, sr.rs:639-651) cannot reach it during the trip
+        const mask_t m_far_from_cap = __builtin_amdgcn_ballot_w64(count < 1000u - (uint32_t)(AIC_STEP_REPS * (AIC_FAST_STEPS + 2)));
         // what the trip decides for each lane is collected in masks and written to the event words once, after the loop
         mask_t t_shade = 0ull, t_enter = 0ull, t_fin = 0ull, t_deadpark = 0ull;
 #define AIC_LANE(m) __builtin_amdgcn_inverse_ballot_w64(m)
@@ -1503,11 +1509,11 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
 #endif
             AIC_PROF(10, 1);
             AIC_PROF(11, __popcll(m_act));
-            const mask_t m_step = m_act & ~(m_fresh | m_dead);  // the level takes its next step
+            mask_t m_step = m_act & ~(m_fresh | m_dead);  // the level takes its next step
             // -- State::step (raycast.rs:577-626) along the axis of the smallest t_max (strict <, ties to the
             //    later axis: raycast.rs:584-596): X iff tx<ty && tx<tz, Y iff !(tx<ty) && ty<tz, else Z.
             //    One exec-masked run per axis: last_t = t; t += t_delta; steps_left -= 1; offset += stride. --
-            {
+            auto dda_step = [&](const mask_t m_who) {
                 mask_t sv, mx;
                 asm volatile(
                     "s_and_saveexec_b64 %[sv], %[m]\n\t"
@@ -1538,18 +1544,60 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     "s_mov_b64 exec, %[sv]\n\t"
                     : [tx] "+v"(tx), [ty] "+v"(ty), [tz] "+v"(tz), [lt] "+v"(last_t), [rx] "+v"(rx), [ry] "+v"(ry), [rz] "+v"(rz),
                       [bo] "+v"(boff), [lax] "+v"(lax), [sv] "=&s"(sv), [mx] "=&s"(mx)
-                    : [tdx] "v"(tdx), [tdy] "v"(tdy), [tdz] "v"(tdz), [ssx] "v"(ssx), [ssy] "v"(ssy), [ssz] "v"(ssz), [m] "s"(m_step)
+                    : [tdx] "v"(tdx), [tdy] "v"(tdy), [tdz] "v"(tdz), [ssx] "v"(ssx), [ssy] "v"(ssy), [ssz] "v"(ssz), [m] "s"(m_who)
                     : "vcc");
+            };
+            // -- Steps that cannot mean anything, taken ahead of the bookkeeping below. Four steps in five find an invisible cube
+            //    or voxel inside the bounds while the ray has no span pending (DepthIter), is not opaque yet and is far from the
+            //    1000-step cap: such a TraceStep is counted and has no other effect (sr.rs:625-656, surface.rs:453-491). A lane
+            //    in that state takes up to AIC_FAST_STEPS of them here -- step, look up, count: a third of the instructions of a
+            //    full pass -- and goes on into the full pass below with a further step; a lane whose fast step found something
+            //    or left the bounds has taken its step of this pass and joins the bookkeeping with that lookup. --
+            mask_t m_pre_exit = 0ull, m_pre_look = 0ull;  // lanes whose step of this pass was taken here: left the bounds / looked something up
+            if (!BIG && AIC_FAST_STEPS > 0) {
+                mask_t m_f = m_step & ~(m_hl | m_opq) & m_far_from_cap;
+#pragma unroll
+                for (int f = 0; f < AIC_FAST_STEPS; f++) {
+                    if (m_f == 0ull) break;
+                    dda_step(m_f);
+                    const mask_t m_fx = __builtin_amdgcn_ballot_w64(min(rx, min(ry, rz)) == 0u) & m_f;
+                    const mask_t m_fl = m_f & ~m_fx;
+                    {
+                        mask_t sv;
+                        asm volatile(
+                            "s_mov_b64 %[sv], exec\n\t"
+                            "s_mov_b64 exec, %[m]\n\t"
+                            "global_load_ushort %[raw], %[bo], %[pool]\n\t"
+                            "s_mov_b64 exec, %[sv]\n\t"
+                            : [raw] "+v"(raw), [sv] "=&s"(sv)
+                            : [bo] "v"(boff), [pool] "s"(pool_bits), [m] "s"(m_fl)
+                            : "memory");
+                    }
+                    if (DIAG) { dg.n_inner += AIC_LANE(m_fl & m_inb) ? 1u : 0u; dg.n_outer += AIC_LANE(m_fl & ~m_inb) ? 1u : 0u; }
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw));
+                    // a code >= thr is a visible voxel, or a cube whose block is visible or recursive (class bits): the full pass decides
+                    const mask_t m_fe = __builtin_amdgcn_ballot_w64(raw >= thr) & m_fl;
+                    const mask_t m_fb = m_fl & ~m_fe;  // an Invisible TraceStep: counted, nothing else
+                    asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(count) : "s"(m_fb) : "vcc");
+                    AIC_PROF(10, 1);
+                    AIC_PROF(11, __popcll(m_f));
+                    m_pre_exit |= m_fx;
+                    m_pre_look |= m_fe;
+                    m_f = m_fb;
+                }
+                m_step &= ~(m_pre_exit | m_pre_look);
             }
+            dda_step(m_step);
             // -- left the bounds? (raycast.rs:265-274) only the axis just stepped can have run out of steps --
-            const mask_t m_exit = __builtin_amdgcn_ballot_w64(min(rx, min(ry, rz)) == 0u) & m_step;
+            const mask_t m_exit = (__builtin_amdgcn_ballot_w64(min(rx, min(ry, rz)) == 0u) & m_step) | m_pre_exit;
             // -- can the level step again? valid_for_stepping (raycast.rs:563-570): "the smallest t_max is finite" held when
             //    the level was set up (lvl_first marks a level that cannot step as dead), and a step only adds the finite
             //    t_delta of an axis whose t_max was finite, so it holds for every level this loop sees: no per-step check --
             // a cube is produced by a fresh level, or by a step that stays in bounds
-            const mask_t m_lookup = m_fresh | (m_step & ~m_exit);
+            const mask_t m_load = m_fresh | (m_step & ~m_exit);  // lookups still to be made; the fast steps' hold theirs in `raw` already
+            const mask_t m_lookup = m_load | m_pre_look;
             // the level is over: it left its bounds, cannot step again, or had ended before
-            const mask_t m_over = (m_step & ~m_lookup) | m_dead;
+            const mask_t m_over = m_exit | m_dead;
             // -- the lookup: one u16 from the pool, for whichever level this is (scalar base + 32-bit byte offset) --
             {
                 mask_t sv;
@@ -1559,10 +1607,10 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     "global_load_ushort %[raw], %[bo], %[pool]\n\t"
                     "s_mov_b64 exec, %[sv]\n\t"
                     : [raw] "+v"(raw), [sv] "=&s"(sv)
-                    : [bo] "v"(boff), [pool] "s"(pool_bits), [m] "s"(m_lookup)
+                    : [bo] "v"(boff), [pool] "s"(pool_bits), [m] "s"(m_load)
                     : "memory");
             }
-            if (DIAG) { dg.n_inner += AIC_LANE(m_lookup & m_inb) ? 1u : 0u; dg.n_outer += AIC_LANE(m_lookup & ~m_inb) ? 1u : 0u; }
+            if (DIAG) { dg.n_inner += AIC_LANE(m_load & m_inb) ? 1u : 0u; dg.n_outer += AIC_LANE(m_load & ~m_inb) ? 1u : 0u; }
             const mask_t m_produced = m_lookup | m_exit;  // the include_exit step is an Invisible TraceStep
             // ---- TracingState::count_step_should_stop (sr.rs:625-656) ----
             asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(count) : "s"(m_produced) : "vcc");

@@ -155,8 +155,9 @@ def main() -> int:
     ap.add_argument("--no-verify", dest="verify", action="store_false")
     ap.add_argument("--in-flight", type=int, default=0, help="frames traced concurrently (1..8); default 4 at N < 4, 8 at N >= 4")
     ap.add_argument("--frames-per-gather", type=int, default=0,
-                    help="N > 1: consecutive frames moved to rank 0 by one collective; default 1 at N < 8, 4 at N >= 8 (a gather call costs the host about "
-                         "what an eighth of a frame costs the device)")
+                    help="N > 1: consecutive frames moved to rank 0 by one collective; default 1 (a frame is gathered as soon as it is traced). More "
+                         "frames per collective trade latency for fewer host calls: to be measured on a real 8-GPU node before it becomes a default "
+                         "(README: the SCALE commands)")
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: gather each frame before tracing the next")
     ap.add_argument("--lighting", type=int, default=3, help="experiment: LightingOption (0 None,1 Flat,2 Coarse,3 Linear,4 Smoothstep); default Linear")
     ap.add_argument("--fog", type=int, default=1, help="experiment: FogOption (0 None,1 Abrupt,...); default Abrupt")
@@ -297,7 +298,7 @@ def main() -> int:
     streamed = not args.no_pipeline
     # traces in flight (AIC_MAX_IN_FLIGHT = 8): a rank's share of a frame shrinks with N while a ray's latency does not
     depth = max(1, min(8, args.in_flight if args.in_flight > 0 else (4 if world < 4 else 8)))
-    per_gather = max(1, min(depth, args.frames_per_gather if args.frames_per_gather > 0 else (1 if world < 8 else 4))) if streamed else 1
+    per_gather = max(1, min(depth, args.frames_per_gather if args.frames_per_gather > 0 else 1)) if streamed else 1
     ring = ((depth + per_gather - 1) // per_gather + (1 if per_gather == 1 else 2)) if streamed else 1  # group slots: the groups being traced, one being gathered
     pipe = D.StripGatherPipeline(h, w, strip, "cpu" if one_gpu_test else dev, depth=ring,
                                  wait_event=None if one_gpu_test else renderer.wait_event, frames=per_gather) if world > 1 else None
