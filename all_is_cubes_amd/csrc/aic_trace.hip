@@ -604,16 +604,16 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u
 #define AIC_T_BATCH 32  // run a kind of parked work once this many lanes wait on it
 #endif
 #ifndef AIC_N_FEW
-#define AIC_N_FEW 32    // ... or once at most this many lanes can still step
+#define AIC_N_FEW 24    // ... or once at most this many lanes can still step (32 until the fast steps made stepping cheaper: r03 E)
 #endif
 #ifndef AIC_WG_THREADS
 #define AIC_WG_THREADS 256  // threads per persistent workgroup (a multiple of 64)
 #endif
 #ifndef AIC_STEP_REPS
-#define AIC_STEP_REPS 8  // full stepping passes per scheduler trip
+#define AIC_STEP_REPS 3  // full stepping passes per scheduler trip (swept together with AIC_FAST_STEPS: profiles/r03_experiments.txt D)
 #endif
 #ifndef AIC_FAST_STEPS
-#define AIC_FAST_STEPS 2  // bookkeeping-free steps a lane may take ahead of each full pass (0: none)
+#define AIC_FAST_STEPS 3  // bookkeeping-free steps a lane may take ahead of each full pass (0: none)
 #endif
 
 // Runs Raycaster::next (raycast.rs:239-284) on a freshly initialised level until it yields its
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
 #define AIC_FRAC_T 4  // eighths of the lanes alive
 #endif
 #ifndef AIC_FRAC_N
-#define AIC_FRAC_N 4
+#define AIC_FRAC_N 3
 #endif
             const int part_t = (alive * AIC_FRAC_T) >> 3, part_n = (alive * AIC_FRAC_N) >> 3;
             const int t_batch = part_t < AIC_T_BATCH ? (part_t > 0 ? part_t : 1) : AIC_T_BATCH;

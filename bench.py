@@ -164,7 +164,7 @@ def main() -> int:
     ap.add_argument("--transparency", type=int, default=None, help="experiment: 0 Surface, 1 Volumetric; default Volumetric (light-bench: Surface, the reference bench's 'linear-surface')")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample duration")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed single-frame / moving-camera / read-back measurements (counter passes)")
-    ap.add_argument("--relight-period", type=int, default=4, help="relight: frames between two lamp toggles")
+    ap.add_argument("--relight-period", type=int, default=30, help="relight: frames between two lamp toggles")
     ap.add_argument("--light-budget", type=int, default=2048, help="relight: cube updates of the light updater per frame (one launch)")
     ap.add_argument("--min-seconds", type=float, default=3.0, help="repeat the K-step timed region until the regions add up to this much time")
     args = ap.parse_args()

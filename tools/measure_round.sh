@@ -1,0 +1,42 @@
+#!/bin/bash
+# Round measurement recipe (round 3 on), run on the GPU box in TWO calls, because bench.py's `issue` / `roofline.traffic`
+# objects quote the counter file of the same round:
+#   gpurun --timeout 1500 -- 'bash tools/measure_round.sh r03 counters'   then   python tools/summarize_profile.py r03   (here)
+#   gpurun --timeout 1500 -- 'bash tools/measure_round.sh r03 bench'      then   python tools/summarize_profile.py r03   (here)
+# Raw outputs under gpurun_out/<tag>/; tools/summarize_profile.py condenses them into profiles/<tag>_*.
+TAG=${1:-r03}; PHASE=${2:-counters}
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd "$R"
+O=gpurun_out/$TAG; mkdir -p "$O"
+BENCH="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --min-seconds 1"
+if [ "$PHASE" = counters ]; then
+  python -m pytest tests -m gpu -x -q > "$O/pytest_gpu.log" 2>&1; tail -3 "$O/pytest_gpu.log"
+  python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > "$O/smoke.log" 2>&1; tail -1 "$O/smoke.log"
+  # per-kernel durations: streamed, and one frame at a time (a launch alone on the device)
+  for W in atrium s256; do
+    X=""; [ $W = s256 ] && X="--workload s256 --steps 5 --warmup 1"
+    rm -rf "$O"/stats_$W "$O"/stats_${W}_nopipe
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_$W" -- $BENCH $X --no-extras > "$O/stats_$W.log" 2>&1
+    rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_${W}_nopipe" -- $BENCH $X --no-extras --no-pipeline > "$O/stats_${W}_nopipe.log" 2>&1
+  done
+  rm -rf "$O"/stats_lightbench
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_lightbench" -- $BENCH --workload light-bench --steps 50 --no-extras > "$O/stats_lightbench.log" 2>&1
+  bash tools/measure_pmc.sh "$TAG"
+  # the light kernel's counters (same rules: separate passes, nothing else in the run that matters)
+  LB="python bench.py --workload light-bench --steps 5 --warmup 1 --no-cpu-baseline --no-extras --min-seconds 0 --no-pipeline"
+  rm -rf "$O"/pmc_light_*
+  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d "$O/pmc_light_sq1" -- $LB > /dev/null 2>&1
+  rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_ADD_F64 --output-format csv -d "$O/pmc_light_sq2" -- $LB > /dev/null 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_light_fetch" -- $LB > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_light_write" -- $LB > /dev/null 2>&1
+  ( cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o issue_rate issue_rate.hip > /dev/null 2>&1 && timeout 300 ./issue_rate ) > "$O/issue_rate.txt" 2>&1
+else
+  python bench.py > "$O/bench_atrium.json" 2> "$O/bench_atrium.err"; tail -c 400 "$O/bench_atrium.json"; echo
+  python bench.py --workload s256 --steps 10 --warmup 2 --cpu-seconds 6 > "$O/bench_s256.json" 2> "$O/bench_s256.err"; tail -c 300 "$O/bench_s256.json"; echo
+  python bench.py --workload light-bench --steps 200 --warmup 10 > "$O/bench_lightbench.json" 2> "$O/bench_lightbench.err"; tail -c 300 "$O/bench_lightbench.json"; echo
+  python bench.py --workload relight --steps 200 --warmup 10 --no-cpu-baseline > "$O/bench_relight.json" 2> "$O/bench_relight.err"; tail -c 500 "$O/bench_relight.json"; echo
+  python bench.py --workload orbit --steps 60 --warmup 5 --no-cpu-baseline > "$O/bench_orbit.json" 2> "$O/bench_orbit.err"; tail -c 300 "$O/bench_orbit.json"; echo
+fi
+find "$O" -type f -size +4M -delete
+du -sh "$O"

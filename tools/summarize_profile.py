@@ -71,7 +71,28 @@ for wl in ("atrium", "s256"):
 p = find("stats_lightbench", "kernel_stats.csv")
 if p:
     shutil.copy(p, os.path.join(dst, f"{tag}_kernel_stats_lightbench.csv"))
-for name in ("lightbench", "relight"):
+# the light kernel's counters (tools/measure_round.sh): per-launch means of compute_light_wave_kernel
+pmc = {}
+for d in ("pmc_light_sq1", "pmc_light_sq2", "pmc_light_fetch", "pmc_light_write"):
+    p = find(d, "counter_collection.csv")
+    if not p:
+        continue
+    acc = {}
+    with open(p) as f:
+        for row in csv.DictReader(f):
+            if "compute_light_wave_kernel" in row.get("Kernel_Name", ""):
+                acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    for k, v in acc.items():
+        pmc[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+if pmc:
+    out = {"workload": "light-bench (light_bench_space, batches of 32)", "kernel": "compute_light_wave_kernel", "counters": pmc}
+    if "FETCH_SIZE" in pmc:
+        out["fetch_bytes_raw"] = pmc["FETCH_SIZE"]["mean_per_launch"] * 1024.0
+        out["write_bytes_raw"] = pmc.get("WRITE_SIZE", {"mean_per_launch": 0.0})["mean_per_launch"] * 1024.0
+        out["hbm_traffic_bytes_per_launch"] = 2.0 * out["fetch_bytes_raw"] + out["write_bytes_raw"]
+    with open(os.path.join(dst, f"{tag}_pmc_lightbench.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+for name in ("lightbench", "relight", "orbit"):
     b = os.path.join(src, f"bench_{name}.json")
     if os.path.exists(b):
         lines = [l for l in open(b).read().splitlines() if l.startswith("{")]
