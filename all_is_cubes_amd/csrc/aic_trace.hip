@@ -384,6 +384,7 @@ AIC_DEV bool powf_table_domain(float x, float y) {  // 0 < x < 1 normal; y > 0 f
 // the persistent loop into VGPR pairs, runs out of registers, spills them to scratch at kernel start (every lane of every wave
 // storing the same 8 bytes: most of round 2's 46 MB of WRITE_SIZE per frame) and reloads them from memory in every SHADE event.
 AIC_DEV double KC(double v) { asm volatile("" : "+s"(v)); return v; }
+AIC_DEV float KF(float v) { asm volatile("" : "+v"(v)); return v; }
 AIC_DEV float powf_table(float x, float y, const double *s_pow) {
     const uint32_t ix = __float_as_uint(x);
     // log2_inline
@@ -577,7 +578,9 @@ AIC_DEV double fb_y_edge(uint32_t h, uint32_t y) { return -(((double)y) / (doubl
 // search; the thresholds make the result exact.
 AIC_DEV uint32_t srgb8_channel(float c, const float *__restrict__ thr) {
     if (!(c > 0.f)) return 0u;  // 0, negatives (cannot occur) and NaN encode to 0
-    float e = c <= 0.0031308f ? c * 12.92f : 1.055f * __powf(c, 0.41666666f) - 0.055f;
+    // v_log_f32 / v_exp_f32 (about 1 ulp each) are plenty for a seed that the thresholds correct
+    const float cc = fminf(c, 1.0f);
+    float e = cc <= 0.0031308f ? cc * 12.92f : 1.055f * __builtin_amdgcn_exp2f(0.41666666f * __builtin_amdgcn_logf(cc)) - 0.055f;
     int k = (int)(e * 255.f + 0.5f);
     k = k < 0 ? 0 : (k > 255 ? 255 : k);
     while (k < 255 && c >= thr[k + 1]) k++;
@@ -1393,7 +1396,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     acc.l0 = v.x; acc.l1 = v.y; acc.l2 = v.z; acc.t = v.w;
                 } else {
                     acc.l0 = acc.l1 = acc.l2 = 0.f;
-                    acc.t = 1.0f;
+                    acc.t = KF(1.0f);  // made here: as a literal it is hoisted into a register that lives across the whole loop
                 }
                 if (DIAG && sample > 0) dg.hit = dg.hit | 2;  // only the first sample's position is reported
                 if (!ui_pass && F.has_backdrop) {  // Exception::Backdrop hit: ColorBuf::from(Rgba)
