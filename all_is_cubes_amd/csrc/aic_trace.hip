@@ -615,8 +615,11 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u
 #ifndef AIC_STEP_REPS
 #define AIC_STEP_REPS 3  // full stepping passes per scheduler trip (swept together with AIC_FAST_STEPS: profiles/r03_experiments.txt D)
 #endif
+#ifndef AIC_FAST_MIN
+#define AIC_FAST_MIN 16  // ... while at least this many lanes of the wave can take one
+#endif
 #ifndef AIC_FAST_STEPS
-#define AIC_FAST_STEPS 3  // bookkeeping-free steps a lane may take ahead of each full pass (0: none)
+#define AIC_FAST_STEPS 8  // bookkeeping-free steps a lane may take ahead of each full pass (0: none) ...
 #endif
 
 // Runs Raycaster::next (raycast.rs:239-284) on a freshly initialised level until it yields its
@@ -752,11 +755,14 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
 
     uint32_t ev = EV_NEWRAY | EV_TAKE;  // every lane starts by taking a pixel
 #ifdef AIC_PROFILE
-    uint32_t prof[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // the counters live in the little LDS the kernel leaves free: as registers they would spill the stepping loop
+    __shared__ uint32_t s_prof[AIC_WG_THREADS / 64][24];
+    uint32_t *const prof = s_prof[tid >> 6];
+    if (lane < 24u) prof[lane] = 0u;
     uint32_t prof_tm = (uint32_t)__builtin_readcyclecounter();
     const uint32_t prof_t0 = prof_tm;
-#define AIC_PROF(i, v) prof[i] += (uint32_t)(v)
-#define AIC_TICK(i) { const uint32_t now_ = (uint32_t)__builtin_readcyclecounter(); prof[i] += now_ - prof_tm; prof_tm = now_; }
+#define AIC_PROF(i, v) { const uint32_t v_ = (uint32_t)(v); if (lane == 0u) prof[i] += v_; }
+#define AIC_TICK(i) { const uint32_t now_ = (uint32_t)__builtin_readcyclecounter(); if (lane == 0u) prof[i] += now_ - prof_tm; prof_tm = now_; }
 #else
 #define AIC_PROF(i, v)
 #define AIC_TICK(i)
@@ -1268,7 +1274,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                         }
                         if (t >= n_virtual) {  // image exhausted
 #ifdef AIC_PROFILE
-                            if (prof[2] == 0u) prof[2] = (uint32_t)__builtin_readcyclecounter() - prof_t0;  // wave saw the queue run dry
+                            if (lane == 0u && prof[2] == 0u) prof[2] = (uint32_t)__builtin_readcyclecounter() - prof_t0;  // wave saw the queue run dry
 #endif
                             dry = true;
                             next_idx = tile_px;
@@ -1502,6 +1508,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         const mask_t m_far_from_cap = __builtin_amdgcn_ballot_w64(count < 1000u - (uint32_t)(AIC_STEP_REPS * (AIC_FAST_STEPS + 2)));
         // what the trip decides for each lane is collected in masks and written to the event words once, after the loop
         mask_t t_shade = 0ull, t_enter = 0ull, t_fin = 0ull, t_deadpark = 0ull;
+        AIC_PROF(22, 1);
+        AIC_PROF(23, __popcll(m_act));
 #define AIC_LANE(m) __builtin_amdgcn_inverse_ballot_w64(m)
 #pragma unroll 1
 #ifdef AIC_TRIP_MIN
@@ -1518,32 +1526,31 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             //    One exec-masked run per axis: last_t = t; t += t_delta; steps_left -= 1; offset += stride. --
             auto dda_step = [&](const mask_t m_who) {
                 mask_t sv, mx;
+                // last_t = the smallest t_max, whichever axis holds it: Z iff tz is that minimum (ties go to the later axis),
+                // Y iff ty is and tz is not, X otherwise -- two v_min and two compares instead of three compares and three copies
                 asm volatile(
                     "s_and_saveexec_b64 %[sv], %[m]\n\t"
-                    "v_cmp_lt_f64 %[mx], %[tx], %[ty]\n\t"
-                    "v_cmp_lt_f64 vcc, %[tx], %[tz]\n\t"
-                    "s_and_b64 exec, %[mx], vcc\n\t"              // X
-                    "v_mov_b64 %[lt], %[tx]\n\t"
-                    "v_add_f64 %[tx], %[tx], %[tdx]\n\t"
-                    "v_add_u32 %[rx], -1, %[rx]\n\t"
-                    "v_add_u32 %[bo], %[bo], %[ssx]\n\t"
-                    "v_mov_b32 %[lax], 0\n\t"
-                    "s_andn2_b64 exec, %[m], exec\n\t"            // stepping lanes that did not take X
-                    "v_cmp_lt_f64 vcc, %[ty], %[tz]\n\t"
-                    "s_andn2_b64 %[mx], vcc, %[mx]\n\t"           // Y = (ty < tz) & !(tx < ty)   [mx held tx<ty]
-                    "s_andn2_b64 vcc, exec, %[mx]\n\t"            // Z = the rest
+                    "v_min_f64 %[lt], %[tx], %[ty]\n\t"
+                    "v_min_f64 %[lt], %[lt], %[tz]\n\t"
+                    "v_cmp_eq_f64 %[mx], %[tz], %[lt]\n\t"        // Z
+                    "v_cmp_eq_f64 vcc, %[ty], %[lt]\n\t"
+                    "s_andn2_b64 vcc, vcc, %[mx]\n\t"             // Y
                     "s_mov_b64 exec, %[mx]\n\t"
-                    "v_mov_b64 %[lt], %[ty]\n\t"
-                    "v_add_f64 %[ty], %[ty], %[tdy]\n\t"
-                    "v_add_u32 %[ry], -1, %[ry]\n\t"
-                    "v_add_u32 %[bo], %[bo], %[ssy]\n\t"
-                    "v_mov_b32 %[lax], 1\n\t"
-                    "s_mov_b64 exec, vcc\n\t"
-                    "v_mov_b64 %[lt], %[tz]\n\t"
                     "v_add_f64 %[tz], %[tz], %[tdz]\n\t"
                     "v_add_u32 %[rz], -1, %[rz]\n\t"
                     "v_add_u32 %[bo], %[bo], %[ssz]\n\t"
                     "v_mov_b32 %[lax], 2\n\t"
+                    "s_or_b64 %[mx], %[mx], vcc\n\t"
+                    "s_mov_b64 exec, vcc\n\t"
+                    "v_add_f64 %[ty], %[ty], %[tdy]\n\t"
+                    "v_add_u32 %[ry], -1, %[ry]\n\t"
+                    "v_add_u32 %[bo], %[bo], %[ssy]\n\t"
+                    "v_mov_b32 %[lax], 1\n\t"
+                    "s_andn2_b64 exec, %[m], %[mx]\n\t"           // X = stepping lanes that took neither
+                    "v_add_f64 %[tx], %[tx], %[tdx]\n\t"
+                    "v_add_u32 %[rx], -1, %[rx]\n\t"
+                    "v_add_u32 %[bo], %[bo], %[ssx]\n\t"
+                    "v_mov_b32 %[lax], 0\n\t"
                     "s_mov_b64 exec, %[sv]\n\t"
                     : [tx] "+v"(tx), [ty] "+v"(ty), [tz] "+v"(tz), [lt] "+v"(last_t), [rx] "+v"(rx), [ry] "+v"(ry), [rz] "+v"(rz),
                       [bo] "+v"(boff), [lax] "+v"(lax), [sv] "=&s"(sv), [mx] "=&s"(mx)
@@ -1561,7 +1568,13 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 mask_t m_f = m_step & ~(m_hl | m_opq) & m_far_from_cap;
 #pragma unroll
                 for (int f = 0; f < AIC_FAST_STEPS; f++) {
+#if AIC_FAST_MIN > 0
+                    // a fast step costs the same however few lanes take it: too few, and their steps are cheaper taken by
+                    // the full passes that run anyway
+                    if (__popcll(m_f) < AIC_FAST_MIN) break;
+#else
                     if (m_f == 0ull) break;
+#endif
                     dda_step(m_f);
                     const mask_t m_fx = __builtin_amdgcn_ballot_w64(min(rx, min(ry, rz)) == 0u) & m_f;
                     const mask_t m_fl = m_f & ~m_fx;
@@ -1582,8 +1595,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     const mask_t m_fe = __builtin_amdgcn_ballot_w64(raw >= thr) & m_fl;
                     const mask_t m_fb = m_fl & ~m_fe;  // an Invisible TraceStep: counted, nothing else
                     asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(count) : "s"(m_fb) : "vcc");
-                    AIC_PROF(10, 1);
-                    AIC_PROF(11, __popcll(m_f));
+                    AIC_PROF(20, 1);
+                    AIC_PROF(21, __popcll(m_f));
                     m_pre_exit |= m_fx;
                     m_pre_look |= m_fe;
                     m_f = m_fb;
@@ -1732,8 +1745,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
     }
 
 #ifdef AIC_PROFILE
-    prof[3] = (uint32_t)__builtin_readcyclecounter() - prof_t0;  // wave lifetime
     if (lane == 0) {
+        prof[3] = (uint32_t)__builtin_readcyclecounter() - prof_t0;  // wave lifetime
         const uint32_t wid = blockIdx.x * (uint32_t)(AIC_WG_THREADS / 64) + (threadIdx.x >> 6);
         if (wid < 2048u) {
             F.counters->wave_prof[wid][0] = prof_t0;
@@ -1744,8 +1757,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         atomicMax(&F.counters->prof[0], (unsigned long long)prof[3]);
         atomicMax(&F.counters->prof[1], (unsigned long long)prof[2]);
     }
-    prof[0] = 0; prof[1] = 0;
-    if (lane == 0) for (int i = 0; i < 24; i++) atomicAdd(&F.counters->prof[i], (unsigned long long)prof[i]);
+    if (lane == 0) for (int i = 2; i < 24; i++) atomicAdd(&F.counters->prof[i], (unsigned long long)prof[i]);
 #endif
     if (MIGRATE && !anchor && !donated && lane == 0u)  // (a wave that handed its rays over has signed off already)
         __hip_atomic_fetch_add(&s_mig[2], 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
