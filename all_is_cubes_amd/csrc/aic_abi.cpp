@@ -1039,8 +1039,8 @@ int wait_frame(aic_ctx *c, uint32_t slot, aic_frame_info *info) {
             info->n_light = hc.n_light;
         }
 #ifdef AIC_PROFILE
-        { static const char *names[24] = {"max_lifetime","max_until_dry","cyc_until_dry","cyc_lifetime","shade_ph","shade_ln","enter_ph","enter_ln","ray_ph","ray_ln","step_iters","step_lanes","cyc_step","cyc_shade_rest","cyc_enter","cyc_newray","cyc_finish","cyc_refill","cyc_shade_light","cyc_sched","fast_iters","fast_lanes","trips","trip_lanes"};
-          for (int i = 0; i < 24; i++) std::fprintf(stderr, "PROF %s %llu\n", names[i], hc.prof[i]);
+        { static const char *names[32] = {"max_lifetime","max_until_dry","cyc_until_dry","cyc_lifetime","shade_ph","shade_ln","enter_ph","enter_ln","ray_ph","ray_ln","step_iters","step_lanes","cyc_step","cyc_shade_rest","cyc_enter","cyc_newray","cyc_finish","cyc_refill","cyc_shade_light","cyc_sched","fast_iters","fast_lanes","trips","trip_lanes","pass_hl_lanes","pass_fast_eligible","leave_blocks","leave_lanes","apply_blocks","apply_lanes","pass_needed_lanes","-"};
+          for (int i = 0; i < 31; i++) std::fprintf(stderr, "PROF %s %llu\n", names[i], hc.prof[i]);
           if (const char *path = std::getenv("AIC_WAVE_PROF")) {
               if (FILE *fp = std::fopen(path, "w")) {
                   for (int w = 0; w < 2048; w++) std::fprintf(fp, "%u %u %u %u\n", hc.wave_prof[w][0], hc.wave_prof[w][1], hc.wave_prof[w][2], hc.wave_prof[w][3]);

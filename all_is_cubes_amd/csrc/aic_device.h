@@ -89,7 +89,7 @@ struct DevCounters {
     unsigned long long n_inner;
     unsigned long long n_hits;
     unsigned long long n_light;
-    unsigned long long prof[24];  // AIC_PROFILE builds only
+    unsigned long long prof[32];  // AIC_PROFILE builds only
     uint32_t tile_next;           // dynamic tile dispenser of the persistent trace kernel
     uint32_t pad;
 #ifdef AIC_PROFILE

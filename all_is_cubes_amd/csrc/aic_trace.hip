@@ -724,6 +724,13 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
     enum { K_SRX, K_SRY, K_SRZ, K_SBOFF,            // the suspended outer level: steps left, byte offset
            K_BLK, K_TVIEW, K_PXY, K_STEPS,          // block index; |direction| / view distance; pixel x | row << 16; step sum
            K_S0, K_S1, K_S2, K_ST, N_C32 };         // ColorBuf::mean accumulators (antialiasing)
+#ifdef AIC_LDS_PAD
+    // experiment J1 (profiles/r03_experiments.txt H): LDS claimed without being used, to price the occupancy a voxel cache in
+    // LDS would cost
+    __shared__ uint32_t s_pad[AIC_LDS_PAD / 4];
+    if (F.width == 0xffffffffu) s_pad[threadIdx.x] = 1u;
+    asm volatile("" :: "v"(&s_pad[0]) : "memory");
+#endif
     __shared__ double c64[N_C64][AIC_WG_THREADS];
     __shared__ uint32_t c32[N_C32][AIC_WG_THREADS];
     const uint32_t tid = threadIdx.x;
@@ -756,9 +763,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
     uint32_t ev = EV_NEWRAY | EV_TAKE;  // every lane starts by taking a pixel
 #ifdef AIC_PROFILE
     // the counters live in the little LDS the kernel leaves free: as registers they would spill the stepping loop
-    __shared__ uint32_t s_prof[AIC_WG_THREADS / 64][24];
+    __shared__ uint32_t s_prof[AIC_WG_THREADS / 64][32];
     uint32_t *const prof = s_prof[tid >> 6];
-    if (lane < 24u) prof[lane] = 0u;
+    if (lane < 32u) prof[lane] = 0u;
     uint32_t prof_tm = (uint32_t)__builtin_readcyclecounter();
     const uint32_t prof_t0 = prof_tm;
 #define AIC_PROF(i, v) { const uint32_t v_ = (uint32_t)(v); if (lane == 0u) prof[i] += v_; }
@@ -1563,6 +1570,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             //    in that state takes up to AIC_FAST_STEPS of them here -- step, look up, count: a third of the instructions of a
             //    full pass -- and goes on into the full pass below with a further step; a lane whose fast step found something
             //    or left the bounds has taken its step of this pass and joins the bookkeeping with that lookup. --
+            AIC_PROF(24, __popcll(m_step & m_hl));
+            AIC_PROF(25, __popcll(m_step & ~(m_hl | m_opq) & m_far_from_cap));
             mask_t m_pre_exit = 0ull, m_pre_look = 0ull;  // lanes whose step of this pass was taken here: left the bounds / looked something up
             if (!BIG && AIC_FAST_STEPS > 0) {
                 mask_t m_f = m_step & ~(m_hl | m_opq) & m_far_from_cap;
@@ -1647,6 +1656,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 m_surf = __builtin_amdgcn_ballot_w64(raw >= thr) & m_lookup & ~m_blk;
             }
             const mask_t m_some = m_blk | m_surf;
+            AIC_PROF(30, __popcll(m_some | m_exit | m_dead));  // lanes of this pass that needed its bookkeeping
             // -- the level is finished: resume the cube grid, or the ray is complete --
             // (degenerate rays only) a surface / block produced by a level that is over still needs this level's
             // state for its event: the level stays, marked dead, and is left on a later trip
@@ -1655,6 +1665,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             const mask_t m_rayover = m_over & ~m_some & ~m_inb;
             mask_t m_newdead = 0ull;
             if (m_leave != 0ull) {
+                AIC_PROF(26, 1);
+                AIC_PROF(27, __popcll(m_leave));
                 mask_t sv;
                 asm volatile(
                     "s_mov_b64 %[sv], exec\n\t"
@@ -1692,6 +1704,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             if (VOL) {
                 const mask_t m_apply = m_go & m_hl;
                 if (m_apply != 0ull) {
+                    AIC_PROF(28, 1);
+                    AIC_PROF(29, __popcll(m_apply));
                     const bool apply = AIC_LANE(m_apply);
                     acc.l0 = apply ? acc.l0 + pend0 * acc.t : acc.l0;
                     acc.l1 = apply ? acc.l1 + pend1 * acc.t : acc.l1;
@@ -1757,7 +1771,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         atomicMax(&F.counters->prof[0], (unsigned long long)prof[3]);
         atomicMax(&F.counters->prof[1], (unsigned long long)prof[2]);
     }
-    if (lane == 0) for (int i = 2; i < 24; i++) atomicAdd(&F.counters->prof[i], (unsigned long long)prof[i]);
+    if (lane == 0) for (int i = 2; i < 32; i++) atomicAdd(&F.counters->prof[i], (unsigned long long)prof[i]);
 #endif
     if (MIGRATE && !anchor && !donated && lane == 0u)  // (a wave that handed its rays over has signed off already)
         __hip_atomic_fetch_add(&s_mig[2], 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
