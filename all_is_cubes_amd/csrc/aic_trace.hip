@@ -1562,7 +1562,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     : [tx] "+v"(tx), [ty] "+v"(ty), [tz] "+v"(tz), [lt] "+v"(last_t), [rx] "+v"(rx), [ry] "+v"(ry), [rz] "+v"(rz),
                       [bo] "+v"(boff), [lax] "+v"(lax), [sv] "=&s"(sv), [mx] "=&s"(mx)
                     : [tdx] "v"(tdx), [tdy] "v"(tdy), [tdz] "v"(tdz), [ssx] "v"(ssx), [ssy] "v"(ssy), [ssz] "v"(ssz), [m] "s"(m_who)
-                    : "vcc");
+                    : "vcc", "scc");  // (the scalar mask operations write SCC)
             };
             // -- Steps that cannot mean anything, taken ahead of the bookkeeping below. Four steps in five find an invisible cube
             //    or voxel inside the bounds while the ray has no span pending (DepthIter), is not opaque yet and is far from the
