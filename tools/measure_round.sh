@@ -30,6 +30,7 @@ if [ "$PHASE" = counters ]; then
   rocprofv3 --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_ADD_F64 --output-format csv -d "$O/pmc_light_sq2" -- $LB > /dev/null 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_light_fetch" -- $LB > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_light_write" -- $LB > /dev/null 2>&1
+  python tools/reduce_pmc_csv.py "$O"/pmc_light_sq1 "$O"/pmc_light_sq2 "$O"/pmc_light_fetch "$O"/pmc_light_write  # (the per-launch CSVs of ~1800 launches exceed what is kept)
   ( cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o issue_rate issue_rate.hip > /dev/null 2>&1 && timeout 300 ./issue_rate ) > "$O/issue_rate.txt" 2>&1
 else
   python bench.py > "$O/bench_atrium.json" 2> "$O/bench_atrium.err"; tail -c 400 "$O/bench_atrium.json"; echo

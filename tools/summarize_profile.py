@@ -74,6 +74,12 @@ if p:
 # the light kernel's counters (tools/measure_round.sh): per-launch means of compute_light_wave_kernel
 pmc = {}
 for d in ("pmc_light_sq1", "pmc_light_sq2", "pmc_light_fetch", "pmc_light_write"):
+    sj = os.path.join(src, d, "pmc_summary.json")  # written on the box by tools/reduce_pmc_csv.py (the CSV itself may be too large to keep)
+    if os.path.exists(sj):
+        for kern, ctrs in json.load(open(sj)).items():
+            if "compute_light_wave_kernel" in kern and "dense" not in kern:
+                pmc.update(ctrs)
+        continue
     p = find(d, "counter_collection.csv")
     if not p:
         continue
