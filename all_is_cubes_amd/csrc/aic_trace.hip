@@ -384,6 +384,12 @@ AIC_DEV bool powf_table_domain(float x, float y) {  // 0 < x < 1 normal; y > 0 f
 // the persistent loop into VGPR pairs, runs out of registers, spills them to scratch at kernel start (every lane of every wave
 // storing the same 8 bytes: most of round 2's 46 MB of WRITE_SIZE per frame) and reloads them from memory in every SHADE event.
 AIC_DEV double KC(double v) { asm volatile("" : "+s"(v)); return v; }
+// population count of a wave mask as a 32-bit scalar (the compiler widens __popcll's result and then compares it on the VALU)
+AIC_DEV uint32_t wave_popc(unsigned long long m) {
+    uint32_t n;
+    asm volatile("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");
+    return n;
+}
 AIC_DEV float KF(float v) { asm volatile("" : "+v"(v)); return v; }
 AIC_DEV float powf_table(float x, float y, const double *s_pow) {
     const uint32_t ix = __float_as_uint(x);
@@ -702,7 +708,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
     // ---- per-lane state, hot: lives in registers across the stepping loop ----
     double tx = 0, ty = 0, tz = 0, last_t = 0;   // t_max of the current level, t of the step that entered the current cube
     double tdx = 0, tdy = 0, tdz = 0;            // t_delta
-    uint32_t rx = 1, ry = 1, rz = 1;             // steps left before leaving the bounds, per axis
+    uint32_t rx = 0, ry = 0, rz = 0;             // steps left before leaving the bounds, minus one, per axis
     uint32_t boff = 0;                           // byte offset of the current cube / voxel in the pool
     int ssx = 0, ssy = 0, ssz = 0;               // signed byte strides of the current level
     uint32_t thr = outer_thr;                    // codes >= thr are visible surfaces
@@ -792,7 +798,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         return r;
     };
     // coordinate (relative to the level's lower corner) from the steps left along an axis
-    auto coord = [](uint32_t positive, int size, uint32_t r) -> int { return positive ? size - (int)r : (int)r - 1; };
+    // (the counters hold steps left MINUS ONE, so that running out is the borrow of the decrement: see dda_step)
+    auto coord = [](uint32_t positive, int size, uint32_t r) -> int { return positive ? size - 1 - (int)r : (int)r; };
 
     for (;;) {
         // ---- wave scheduler: step, or run ONE kind of parked work for all lanes waiting on it ----
@@ -1137,9 +1144,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 const Lvl f = lvl_first(ll.s, ll.lim, rd, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz, &got);
                 tx = f.tx; ty = f.ty; tz = f.tz; last_t = f.last_t;
                 const int vcx = f.cx - ilx, vcy = f.cy - ily, vcz = f.cz - ilz;
-                rx = posx ? (uint32_t)(isx - vcx) : (uint32_t)(vcx + 1);
-                ry = posy ? (uint32_t)(isy - vcy) : (uint32_t)(vcy + 1);
-                rz = posz ? (uint32_t)(isz - vcz) : (uint32_t)(vcz + 1);
+                rx = posx ? (uint32_t)(isx - 1 - vcx) : (uint32_t)vcx;
+                ry = posy ? (uint32_t)(isy - 1 - vcy) : (uint32_t)vcy;
+                rz = posz ? (uint32_t)(isz - 1 - vcz) : (uint32_t)vcz;
                 boff = 2u * (vox_off + (uint32_t)(((uint32_t)vcx * (uint32_t)isy + (uint32_t)vcy) * (uint32_t)isz + (uint32_t)vcz));
                 ssx = posx ? 2 * isy * isz : -2 * isy * isz; ssy = posy ? 2 * isz : -2 * isz; ssz = posz ? 2 : -2;
                 thr = n_invisible;
@@ -1471,9 +1478,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     const Lvl fs = lvl_first(ll.s, ll.lim, rd, olx, oly, olz, ohx, ohy, ohz, &got);
                     tx = fs.tx; ty = fs.ty; tz = fs.tz; last_t = fs.last_t;
                     const int ccx = fs.cx - olx, ccy = fs.cy - oly, ccz = fs.cz - olz;
-                    rx = qx ? (uint32_t)(osx_i - ccx) : (uint32_t)(ccx + 1);
-                    ry = qy ? (uint32_t)(osy_i - ccy) : (uint32_t)(ccy + 1);
-                    rz = qz ? (uint32_t)(osz_i - ccz) : (uint32_t)(ccz + 1);
+                    rx = qx ? (uint32_t)(osx_i - 1 - ccx) : (uint32_t)ccx;
+                    ry = qy ? (uint32_t)(osy_i - 1 - ccy) : (uint32_t)ccy;
+                    rz = qz ? (uint32_t)(osz_i - 1 - ccz) : (uint32_t)ccz;
                     boff = 2u * (uint32_t)(((uint32_t)ccx * (uint32_t)osy_i + (uint32_t)ccy) * (uint32_t)osz_i + (uint32_t)ccz);
                     ssx = qx ? ostx : -ostx; ssy = qy ? osty : -osty; ssz = qz ? 2 : -2;
                     thr = outer_thr;
@@ -1531,10 +1538,13 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             // -- State::step (raycast.rs:577-626) along the axis of the smallest t_max (strict <, ties to the
             //    later axis: raycast.rs:584-596): X iff tx<ty && tx<tz, Y iff !(tx<ty) && ty<tz, else Z.
             //    One exec-masked run per axis: last_t = t; t += t_delta; steps_left -= 1; offset += stride. --
-            auto dda_step = [&](const mask_t m_who) {
-                mask_t sv, mx;
+            auto dda_step = [&](const mask_t m_who) -> mask_t {
+                mask_t sv, mx, bz, by, bx;
                 // last_t = the smallest t_max, whichever axis holds it: Z iff tz is that minimum (ties go to the later axis),
-                // Y iff ty is and tz is not, X otherwise -- two v_min and two compares instead of three compares and three copies
+                // Y iff ty is and tz is not, X otherwise -- two v_min and two compares instead of three compares and three copies.
+                // The steps-left counters are biased by one, so "ran out" is the borrow of the decrement (the carry-out of an
+                // exec-masked v_sub_co is zero for the lanes it does not run on). Keeping the stepped axis in wave masks instead
+                // of `lax` (3 vector instructions less, 6 scalar more) was measured and is slower: profiles/r03_experiments.txt I.
                 asm volatile(
                     "s_and_saveexec_b64 %[sv], %[m]\n\t"
                     "v_min_f64 %[lt], %[tx], %[ty]\n\t"
@@ -1544,25 +1554,29 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     "s_andn2_b64 vcc, vcc, %[mx]\n\t"             // Y
                     "s_mov_b64 exec, %[mx]\n\t"
                     "v_add_f64 %[tz], %[tz], %[tdz]\n\t"
-                    "v_add_u32 %[rz], -1, %[rz]\n\t"
+                    "v_sub_co_u32 %[rz], %[bz], %[rz], 1\n\t"
                     "v_add_u32 %[bo], %[bo], %[ssz]\n\t"
                     "v_mov_b32 %[lax], 2\n\t"
                     "s_or_b64 %[mx], %[mx], vcc\n\t"
                     "s_mov_b64 exec, vcc\n\t"
                     "v_add_f64 %[ty], %[ty], %[tdy]\n\t"
-                    "v_add_u32 %[ry], -1, %[ry]\n\t"
+                    "v_sub_co_u32 %[ry], %[by], %[ry], 1\n\t"
                     "v_add_u32 %[bo], %[bo], %[ssy]\n\t"
                     "v_mov_b32 %[lax], 1\n\t"
                     "s_andn2_b64 exec, %[m], %[mx]\n\t"           // X = stepping lanes that took neither
                     "v_add_f64 %[tx], %[tx], %[tdx]\n\t"
-                    "v_add_u32 %[rx], -1, %[rx]\n\t"
+                    "v_sub_co_u32 %[rx], %[bx], %[rx], 1\n\t"
                     "v_add_u32 %[bo], %[bo], %[ssx]\n\t"
                     "v_mov_b32 %[lax], 0\n\t"
                     "s_mov_b64 exec, %[sv]\n\t"
+                    "s_or_b64 %[bz], %[bz], %[by]\n\t"
+                    "s_or_b64 %[bz], %[bz], %[bx]\n\t"
                     : [tx] "+v"(tx), [ty] "+v"(ty), [tz] "+v"(tz), [lt] "+v"(last_t), [rx] "+v"(rx), [ry] "+v"(ry), [rz] "+v"(rz),
-                      [bo] "+v"(boff), [lax] "+v"(lax), [sv] "=&s"(sv), [mx] "=&s"(mx)
+                      [bo] "+v"(boff), [lax] "+v"(lax), [sv] "=&s"(sv), [mx] "=&s"(mx),
+                      [bz] "=&s"(bz), [by] "=&s"(by), [bx] "=&s"(bx)
                     : [tdx] "v"(tdx), [tdy] "v"(tdy), [tdz] "v"(tdz), [ssx] "v"(ssx), [ssy] "v"(ssy), [ssz] "v"(ssz), [m] "s"(m_who)
                     : "vcc", "scc");  // (the scalar mask operations write SCC)
+                return bz;  // lanes whose level ran out of steps: it left its bounds
             };
             // -- Steps that cannot mean anything, taken ahead of the bookkeeping below. Four steps in five find an invisible cube
             //    or voxel inside the bounds while the ray has no span pending (DepthIter), is not opaque yet and is far from the
@@ -1580,14 +1594,14 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
 #if AIC_FAST_MIN > 0
                     // a fast step costs the same however few lanes take it: too few, and their steps are cheaper taken by
                     // the full passes that run anyway
-                    if (__popcll(m_f) < AIC_FAST_MIN) break;
+                    if (wave_popc(m_f) < (uint32_t)AIC_FAST_MIN) break;
 #else
                     if (m_f == 0ull) break;
 #endif
-                    dda_step(m_f);
-                    const mask_t m_fx = __builtin_amdgcn_ballot_w64(min(rx, min(ry, rz)) == 0u) & m_f;
-                    const mask_t m_fl = m_f & ~m_fx;
-                    {
+                    mask_t m_fx, m_fe, m_fb;
+                    if (DIAG) {
+                        m_fx = dda_step(m_f);
+                        const mask_t m_fl = m_f & ~m_fx;
                         mask_t sv;
                         asm volatile(
                             "s_mov_b64 %[sv], exec\n\t"
@@ -1597,13 +1611,60 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                             : [raw] "+v"(raw), [sv] "=&s"(sv)
                             : [bo] "v"(boff), [pool] "s"(pool_bits), [m] "s"(m_fl)
                             : "memory");
+                        dg.n_inner += AIC_LANE(m_fl & m_inb) ? 1u : 0u; dg.n_outer += AIC_LANE(m_fl & ~m_inb) ? 1u : 0u;
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw));
+                        // a code >= thr is a visible voxel, or a cube whose block is visible or recursive (class bits): the full pass decides
+                        m_fe = __builtin_amdgcn_ballot_w64(raw >= thr) & m_fl;
+                        m_fb = m_fl & ~m_fe;  // an Invisible TraceStep: counted, nothing else
+                        asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(count) : "s"(m_fb) : "vcc");
+                    } else {
+                        // The whole fast step as one block: the DDA step of dda_step above, then -- exec narrowing as it goes instead of
+                        // being restored and set again -- the lookup under the lanes still inside their bounds, the comparison with the
+                        // level's threshold under the same mask, and the count under the lanes that found nothing. (Left to the compiler,
+                        // the pieces come with hazard nops between them, a vector compare for the loop's 64-bit population count,
+                        // and six more mask operations.)
+                        mask_t sv, mx, by, bx;
+                        asm volatile(
+                            "s_and_saveexec_b64 %[sv], %[m]\n\t"
+                            "v_min_f64 %[lt], %[tx], %[ty]\n\t"
+                            "v_min_f64 %[lt], %[lt], %[tz]\n\t"
+                            "v_cmp_eq_f64 %[mx], %[tz], %[lt]\n\t"        // Z
+                            "v_cmp_eq_f64 vcc, %[ty], %[lt]\n\t"
+                            "s_andn2_b64 vcc, vcc, %[mx]\n\t"             // Y
+                            "s_mov_b64 exec, %[mx]\n\t"
+                            "v_add_f64 %[tz], %[tz], %[tdz]\n\t"
+                            "v_sub_co_u32 %[rz], %[fx], %[rz], 1\n\t"
+                            "v_add_u32 %[bo], %[bo], %[ssz]\n\t"
+                            "v_mov_b32 %[lax], 2\n\t"
+                            "s_or_b64 %[mx], %[mx], vcc\n\t"
+                            "s_mov_b64 exec, vcc\n\t"
+                            "v_add_f64 %[ty], %[ty], %[tdy]\n\t"
+                            "v_sub_co_u32 %[ry], %[by], %[ry], 1\n\t"
+                            "v_add_u32 %[bo], %[bo], %[ssy]\n\t"
+                            "v_mov_b32 %[lax], 1\n\t"
+                            "s_andn2_b64 exec, %[m], %[mx]\n\t"           // X = stepping lanes that took neither
+                            "v_add_f64 %[tx], %[tx], %[tdx]\n\t"
+                            "v_sub_co_u32 %[rx], %[bx], %[rx], 1\n\t"
+                            "v_add_u32 %[bo], %[bo], %[ssx]\n\t"
+                            "v_mov_b32 %[lax], 0\n\t"
+                            "s_or_b64 %[fx], %[fx], %[by]\n\t"
+                            "s_or_b64 %[fx], %[fx], %[bx]\n\t"            // left the bounds
+                            "s_andn2_b64 exec, %[m], %[fx]\n\t"           // still inside: look up
+                            "global_load_ushort %[raw], %[bo], %[pool]\n\t"
+                            "s_waitcnt vmcnt(0)\n\t"
+                            "v_cmp_ge_u32 vcc, %[raw], %[thr]\n\t"        // found something (a visible voxel, a visible or recursive block)
+                            "s_mov_b64 %[fe], vcc\n\t"
+                            "s_andn2_b64 exec, exec, vcc\n\t"             // an Invisible TraceStep: counted, nothing else
+                            "s_mov_b64 %[fb], exec\n\t"
+                            "v_add_u32 %[cnt], 1, %[cnt]\n\t"
+                            "s_mov_b64 exec, %[sv]\n\t"
+                            : [tx] "+v"(tx), [ty] "+v"(ty), [tz] "+v"(tz), [lt] "+v"(last_t), [rx] "+v"(rx), [ry] "+v"(ry), [rz] "+v"(rz),
+                              [bo] "+v"(boff), [lax] "+v"(lax), [raw] "+v"(raw), [cnt] "+v"(count), [sv] "=&s"(sv), [mx] "=&s"(mx),
+                              [fx] "=&s"(m_fx), [by] "=&s"(by), [bx] "=&s"(bx), [fe] "=&s"(m_fe), [fb] "=&s"(m_fb)
+                            : [tdx] "v"(tdx), [tdy] "v"(tdy), [tdz] "v"(tdz), [ssx] "v"(ssx), [ssy] "v"(ssy), [ssz] "v"(ssz), [m] "s"(m_f),
+                              [pool] "s"(pool_bits), [thr] "v"(thr)
+                            : "memory", "vcc", "scc");
                     }
-                    if (DIAG) { dg.n_inner += AIC_LANE(m_fl & m_inb) ? 1u : 0u; dg.n_outer += AIC_LANE(m_fl & ~m_inb) ? 1u : 0u; }
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw));
-                    // a code >= thr is a visible voxel, or a cube whose block is visible or recursive (class bits): the full pass decides
-                    const mask_t m_fe = __builtin_amdgcn_ballot_w64(raw >= thr) & m_fl;
-                    const mask_t m_fb = m_fl & ~m_fe;  // an Invisible TraceStep: counted, nothing else
-                    asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(count) : "s"(m_fb) : "vcc");
                     AIC_PROF(20, 1);
                     AIC_PROF(21, __popcll(m_f));
                     m_pre_exit |= m_fx;
@@ -1612,9 +1673,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 }
                 m_step &= ~(m_pre_exit | m_pre_look);
             }
-            dda_step(m_step);
             // -- left the bounds? (raycast.rs:265-274) only the axis just stepped can have run out of steps --
-            const mask_t m_exit = (__builtin_amdgcn_ballot_w64(min(rx, min(ry, rz)) == 0u) & m_step) | m_pre_exit;
+            const mask_t m_exit = dda_step(m_step) | m_pre_exit;
             // -- can the level step again? valid_for_stepping (raycast.rs:563-570): "the smallest t_max is finite" held when
             //    the level was set up (lvl_first marks a level that cannot step as dead), and a step only adds the finite
             //    t_delta of an axis whose t_max was finite, so it holds for every level this loop sees: no per-step check --
