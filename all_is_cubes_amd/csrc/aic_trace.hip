@@ -1727,7 +1727,12 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             if (m_leave != 0ull) {
                 AIC_PROF(26, 1);
                 AIC_PROF(27, __popcll(m_leave));
+                // Everything under exec = the leaving lanes, in one block: the suspended level comes back from its LDS columns; the
+                // cube grid's strides are +-stride by the octant bits of st (bit set = the ray goes up that axis:
+                // m - (stride ^ m) with m = the bit sign-extended is +stride for m = -1, -stride for m = 0); the outer level's Face
+                // from st[16..18]; it goes on stepping if it was alive when the block was entered.
                 mask_t sv;
+                uint32_t t_;
                 asm volatile(
                     "s_mov_b64 %[sv], exec\n\t"
                     "s_mov_b64 exec, %[m]\n\t"
@@ -1739,25 +1744,33 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     "ds_read_b32 %[ry], %[a32] offset:%[p1]\n\t"
                     "ds_read_b32 %[rz], %[a32] offset:%[p2]\n\t"
                     "ds_read_b32 %[bo], %[a32] offset:%[p3]\n\t"
+                    "v_bfe_i32 %[t], %[st], 26, 1\n\t"
+                    "v_xor_b32 %[ssx], %[osx], %[t]\n\t"
+                    "v_sub_u32 %[ssx], %[t], %[ssx]\n\t"
+                    "v_bfe_i32 %[t], %[st], 25, 1\n\t"
+                    "v_xor_b32 %[ssy], %[osy], %[t]\n\t"
+                    "v_sub_u32 %[ssy], %[t], %[ssy]\n\t"
+                    "v_bfe_i32 %[t], %[st], 24, 1\n\t"
+                    "v_xor_b32 %[ssz], 2, %[t]\n\t"
+                    "v_sub_u32 %[ssz], %[t], %[ssz]\n\t"
+                    "v_mov_b32 %[thr], %[othr]\n\t"
+                    "v_bfe_u32 %[t], %[st], 16, 3\n\t"
+                    "v_or_b32 %[lax], 8, %[t]\n\t"
+                    "v_and_b32 %[t], %[alive], %[st]\n\t"
+                    "v_cmp_eq_u32 %[nd], 0, %[t]\n\t"               // the outer level had ended already (inactive lanes: 0)
+                    "v_and_b32 %[st], %[notinb], %[st]\n\t"
                     "s_waitcnt lgkmcnt(0)\n\t"
                     "s_mov_b64 exec, %[sv]\n\t"
                     : [tx] "+v"(tx), [ty] "+v"(ty), [tz] "+v"(tz), [lt] "+v"(last_t), [rx] "+v"(rx), [ry] "+v"(ry), [rz] "+v"(rz),
-                      [bo] "+v"(boff), [sv] "=&s"(sv)
-                    : [a64] "v"(lds64), [a32] "v"(lds32), [m] "s"(m_leave),
+                      [bo] "+v"(boff), [ssx] "+v"(ssx), [ssy] "+v"(ssy), [ssz] "+v"(ssz), [thr] "+v"(thr), [lax] "+v"(lax), [st] "+v"(st),
+                      [t] "=&v"(t_), [sv] "=&s"(sv), [nd] "=&s"(m_newdead)
+                    : [a64] "v"(lds64), [a32] "v"(lds32), [m] "s"(m_leave), [osx] "s"(ostx), [osy] "s"(osty), [othr] "n"(BIG ? 0x10000u : (1u << kCubeClassShift)),
+                      [alive] "n"(ST_OUTER_ALIVE), [notinb] "n"(~ST_IN_BLOCK),
                       [o0] "n"(C_STX * AIC_WG_THREADS * 8), [o1] "n"(C_STY * AIC_WG_THREADS * 8), [o2] "n"(C_STZ * AIC_WG_THREADS * 8),
                       [o3] "n"(C_SLAST * AIC_WG_THREADS * 8), [p0] "n"(K_SRX * AIC_WG_THREADS * 4), [p1] "n"(K_SRY * AIC_WG_THREADS * 4),
                       [p2] "n"(K_SRZ * AIC_WG_THREADS * 4), [p3] "n"(K_SBOFF * AIC_WG_THREADS * 4)
                     : "memory");
-                const bool leave = AIC_LANE(m_leave);
-                ssx = leave ? ((st & (1u << 26)) ? ostx : -ostx) : ssx;
-                ssy = leave ? ((st & (1u << 25)) ? osty : -osty) : ssy;
-                ssz = leave ? ((st & (1u << 24)) ? 2 : -2) : ssz;
-                thr = leave ? outer_thr : thr;
-                // outer level: its Face from st[16..18]; it goes on stepping if it was alive
-                lax = leave ? (8u | ((st >> 16) & 7u)) : lax;
-                st = leave ? (st & ~ST_IN_BLOCK) : st;
                 m_inb &= ~m_leave;
-                m_newdead = m_leave & ~__builtin_amdgcn_ballot_w64((st & ST_OUTER_ALIVE) != 0u);
             }
             // ---- DepthIter::next (surface.rs:453-491): a pending surface's span ends at this step;
             // its contribution was computed when it was shaded, apply it now ----
