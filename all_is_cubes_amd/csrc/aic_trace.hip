@@ -824,8 +824,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 only_waiting = !others;
             }
         }
-        const int n_step = __popcll(m_st);
-        const int c_shade = __popcll(b_shade), c_enter = __popcll(b_enter), c_ray = __popcll(b_ray);
+        const int n_step = (int)wave_popc(m_st);
+        const int c_shade = (int)wave_popc(b_shade), c_enter = (int)wave_popc(b_enter), c_ray = (int)wave_popc(b_ray);
         if (MIGRATE && dry && !anchor && n_step + c_shade + c_enter + c_ray <= (int)mig_k) {
             // ---- hand this wave's last rays over to the workgroup's anchor wave and leave ----
             typedef const __attribute__((address_space(4))) DevFrame KFrame;
@@ -885,7 +885,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
 #define AIC_FRAC_N 3
 #endif
             const int part_t = (alive * AIC_FRAC_T) >> 3, part_n = (alive * AIC_FRAC_N) >> 3;
-            const int t_batch = part_t < AIC_T_BATCH ? (part_t > 0 ? part_t : 1) : AIC_T_BATCH;
+            const int t_lo = opaque_s(part_t > 0 ? part_t : 1);  // (kept apart from the min: fused, the pair becomes a v_med3 and a v_readfirstlane)
+            const int t_batch = t_lo < AIC_T_BATCH ? t_lo : AIC_T_BATCH;
             const int n_few = part_n < AIC_N_FEW ? part_n : AIC_N_FEW;
 #endif
             if (best > 0 && (best >= t_batch || n_step <= n_few)) run = kind;
@@ -1302,7 +1303,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                             const uint32_t running = __hip_atomic_load(&s_mig[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
                             const uint32_t published = __hip_atomic_load(&s_mig[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
                             const uint32_t taken = __hip_atomic_load(&s_mig[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (only this wave writes it)
-                            const uint32_t n_need = (uint32_t)__popcll(need);
+                            const uint32_t n_need = wave_popc(need);
                             const uint32_t k = published - taken < n_need ? published - taken : n_need;
                             const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
                             if (want && rank < k) {
@@ -1362,7 +1363,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                             want = false;
                         }
                     }
-                    const uint32_t n_need = (uint32_t)__popcll(need);
+                    const uint32_t n_need = wave_popc(need);
                     next_idx += n_need < avail ? n_need : avail;
                 }
             }
