@@ -642,17 +642,17 @@ AIC_DEV Lvl lvl_first(Lvl s, const Lim lim, const RayDir rd, int lox, int loy, i
 // voxel volume -- use the same registers and the same stepping code):
 //   t[3]   t_max, exactly the reference's (raycast.rs:99-121)
 //   td[3]  t_delta = 1/|d|, a per-ray constant shared by both levels (a sub-ray keeps its direction)
-//   r[3]   steps the ray can still take along each axis before it leaves the level's bounds: for a
-//          coordinate c relative to the level's lower corner, r = size - c going up, c + 1 going down
-//          (direction sign = the octant bit). Stepping decrements it; r == 0 <=> the include_exit step.
-//          The coordinate is recovered when an event needs it: c = size - r or r - 1.
+//   r[3]   steps the ray can still take along each axis before it leaves the level's bounds, MINUS ONE: for a
+//          coordinate c relative to the level's lower corner, r = size - 1 - c going up, c going down
+//          (direction sign = the octant bit). Stepping decrements it; the decrement's borrow (r was 0) <=> the
+//          include_exit step. The coordinate is recovered when an event needs it: c = size - 1 - r or r.
 //   boff   BYTE offset of the current cube's / voxel's u16 in the pool; ss[3] the signed byte strides.
 //          Stepping adds ss[axis]: no index arithmetic in the loop, and the lookup is a
 //          scalar-base + 32-bit-offset load (the pool is at most 4 GiB: aic_upload_space checks).
 //   thr    a looked-up code >= thr is a visible surface (voxels: the block's first visible palette code;
 //          cubes with class bits: 0x4000, i.e. class >= 1)
-// The axis to step along is recomputed from t[] at the start of a trip (three f64 compares) instead of being
-// carried in the state: it is a pure function of t[], which nothing modifies between trips.
+// The axis to step along is recomputed from t[] at every step (two v_min_f64, two compares) instead of being
+// carried in the state: it is a pure function of t[], which nothing modifies between steps.
 
 template <bool VOL, int LMODE, bool DIAG, bool BIG>
 __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trace_image_kernel(const DevFrame F) {
@@ -1504,7 +1504,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         // volume: same registers, same code, one 2-byte lookup in the shared pool
         // (SurfaceIter::next + Raycaster::next + State::step).
         //
-        // The chip issues about one instruction per 4.4 cycles per SIMD whatever its kind (tools/ubench/issue_rate),
+        // The chip issues about one instruction per 4 cycles per SIMD, vector or scalar (tools/ubench/issue_rate; 2.2 for the simplest),
         // so the trip is written for instruction count: every decision is a 64-bit wave mask in SGPRs (a lane flag
         // costs nothing to test), per-lane state is updated IN PLACE by short exec-masked runs in inline assembly
         // (left to the compiler, the divergent branches of this loop become chains of Flow blocks with ~150 register
