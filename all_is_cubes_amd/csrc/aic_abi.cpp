@@ -161,6 +161,7 @@ struct aic_ctx {
         uint32_t cost_sig[4] = {0, 0, 0, 0};  // width, local rows, partition of the frame tile_cost describes
         double cost_cam[16] = {0};            // ... and its world camera
         bool busy = false;
+        bool diag = false;  // the slot's frame ran the aux-recording kernel variant
         const void *light_used[2] = {nullptr, nullptr};  // per layer: the light buffer the slot's frame reads
         uint32_t flaws = 0, local_rows = 0;
         size_t npix = 0;
@@ -935,6 +936,7 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
 
     const bool want_aux = allow_aux && (f->flags & AIC_FRAME_AUX) != 0;
     const bool diag = want_aux || (f->flags & AIC_FRAME_COUNTERS) != 0;
+    fs.diag = diag;
     fs.flaws = flaws;
     fs.light_used[0] = hl[0].light;
     fs.light_used[1] = hl[1].light;
@@ -1040,8 +1042,9 @@ int wait_frame(aic_ctx *c, uint32_t slot, aic_frame_info *info) {
         }
 #ifdef AIC_PROFILE
         { static const char *names[32] = {"max_lifetime","max_until_dry","cyc_until_dry","cyc_lifetime","shade_ph","shade_ln","enter_ph","enter_ln","ray_ph","ray_ln","step_iters","step_lanes","cyc_step","cyc_shade_rest","cyc_enter","cyc_newray","cyc_finish","cyc_refill","cyc_shade_light","cyc_sched","fast_iters","fast_lanes","trips","trip_lanes","pass_hl_lanes","pass_fast_eligible","leave_blocks","leave_lanes","apply_blocks","apply_lanes","pass_needed_lanes","-"};
-          for (int i = 0; i < 31; i++) std::fprintf(stderr, "PROF %s %llu\n", names[i], hc.prof[i]);
-          if (const char *path = std::getenv("AIC_WAVE_PROF")) {
+          // (only the production variant's frames: the aux-recording variant is another kernel, at half the occupancy)
+          if (!fs.diag) for (int i = 0; i < 31; i++) std::fprintf(stderr, "PROF %s %llu\n", names[i], hc.prof[i]);
+          if (const char *path = fs.diag ? nullptr : std::getenv("AIC_WAVE_PROF")) {
               if (FILE *fp = std::fopen(path, "w")) {
                   for (int w = 0; w < 2048; w++) std::fprintf(fp, "%u %u %u %u\n", hc.wave_prof[w][0], hc.wave_prof[w][1], hc.wave_prof[w][2], hc.wave_prof[w][3]);
                   std::fclose(fp);

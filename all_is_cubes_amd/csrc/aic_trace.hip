@@ -770,6 +770,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
 #ifdef AIC_PROFILE
     // the counters live in the little LDS the kernel leaves free: as registers they would spill the stepping loop
     __shared__ uint32_t s_prof[AIC_WG_THREADS / 64][32];
+    __shared__ uint32_t s_ray_t0[AIC_WG_THREADS];  // per ray: the clock when it started
+    uint32_t ray_dur_max = 0u, ray_dur_steps = 0u; // per lane: the longest ray's duration and its step count
     uint32_t *const prof = s_prof[tid >> 6];
     if (lane < 32u) prof[lane] = 0u;
     uint32_t prof_tm = (uint32_t)__builtin_readcyclecounter();
@@ -1185,6 +1187,10 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                         acc.l0 = red; acc.l1 = green; acc.l2 = blue; acc.t = 0.0f;
                     }
                     c32[K_STEPS][tid] += count;
+#ifdef AIC_PROFILE
+                    { const uint32_t dur_ = (uint32_t)__builtin_readcyclecounter() - s_ray_t0[col];
+                      if (dur_ > ray_dur_max) { ray_dur_max = dur_; ray_dur_steps = count; } }
+#endif
                     if (DIAG) px_steps += count;
                 }
                 const uint32_t x = pxy & 0xffffu, lrow = pxy >> 16;
@@ -1488,6 +1494,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     const bool dead = !got || lvl_fl(fs) != FL_INBOUNDS;
                     lax = 8u | ((fs.st >> 2) & 7u);
                     st = ST_TRACED | (octant << 24) | ((uint32_t)sample << 14);
+#ifdef AIC_PROFILE
+                    s_ray_t0[col] = (uint32_t)__builtin_readcyclecounter();
+#endif
                     if (cb_opaque(acc)) st |= ST_OPAQUE;
                     ev = (got ? EV_FRESH : 0u) | (dead ? EV_DEAD : 0u);
                 } else {
@@ -1523,6 +1532,10 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         const mask_t m_far_from_cap = __builtin_amdgcn_ballot_w64(count < 1000u - (uint32_t)(AIC_STEP_REPS * (AIC_FAST_STEPS + 2)));
         // what the trip decides for each lane is collected in masks and written to the event words once, after the loop
         mask_t t_shade = 0ull, t_enter = 0ull, t_fin = 0ull, t_deadpark = 0ull;
+        // Fast steps need AIC_FAST_MIN takers while the frame is in full swing (other waves want the issue slots); once this wave has
+        // seen the pixel queue dry it is draining its last rays and what counts is how soon the longest of them ends: a lone ray
+        // then takes its fast steps too (38 instructions a step instead of a full pass's ~180).
+        const uint32_t fast_min = (uint32_t)__builtin_amdgcn_readfirstlane(dry ? 1 : AIC_FAST_MIN);  // (`dry` is wave-uniform; the compiler cannot tell)
         AIC_PROF(22, 1);
         AIC_PROF(23, __popcll(m_act));
 #define AIC_LANE(m) __builtin_amdgcn_inverse_ballot_w64(m)
@@ -1595,7 +1608,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
 #if AIC_FAST_MIN > 0
                     // a fast step costs the same however few lanes take it: too few, and their steps are cheaper taken by
                     // the full passes that run anyway
-                    if (wave_popc(m_f) < (uint32_t)AIC_FAST_MIN) break;
+                    if (wave_popc(m_f) < fast_min) break;
 #else
                     if (m_f == 0ull) break;
 #endif
@@ -1845,6 +1858,15 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         atomicMax(&F.counters->prof[0], (unsigned long long)prof[3]);
         atomicMax(&F.counters->prof[1], (unsigned long long)prof[2]);
     }
+#ifdef AIC_RAY_PROF
+    {   // the wave's longest ray: duration in the upper bits, its step count in the lower 10
+        uint32_t best_ = (ray_dur_max & ~1023u) | (ray_dur_steps > 1023u ? 1023u : ray_dur_steps);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const uint32_t o_ = (uint32_t)__shfl_down((int)best_, off, 64); best_ = o_ > best_ ? o_ : best_; }
+        const uint32_t wid = blockIdx.x * (uint32_t)(AIC_WG_THREADS / 64) + (threadIdx.x >> 6);
+        if (lane == 0 && wid < 2048u) F.counters->wave_prof[wid][3] = best_;
+    }
+#endif
     if (lane == 0) for (int i = 2; i < 32; i++) atomicAdd(&F.counters->prof[i], (unsigned long long)prof[i]);
 #endif
     if (MIGRATE && !anchor && !donated && lane == 0u)  // (a wave that handed its rays over has signed off already)
