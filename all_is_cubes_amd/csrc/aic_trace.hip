@@ -772,12 +772,19 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
     __shared__ uint32_t s_prof[AIC_WG_THREADS / 64][32];
     __shared__ uint32_t s_ray_t0[AIC_WG_THREADS];  // per ray: the clock when it started
     uint32_t ray_dur_max = 0u, ray_dur_steps = 0u; // per lane: the longest ray's duration and its step count
+    uint32_t tail_trips = 0u, tail_events = 0u, tail_lanes = 0u;  // -DAIC_TAIL_PROF: after the wave saw the queue dry: trips, event phases, lanes stepping at trip start
     uint32_t *const prof = s_prof[tid >> 6];
     if (lane < 32u) prof[lane] = 0u;
     uint32_t prof_tm = (uint32_t)__builtin_readcyclecounter();
     const uint32_t prof_t0 = prof_tm;
 #define AIC_PROF(i, v) { const uint32_t v_ = (uint32_t)(v); if (lane == 0u) prof[i] += v_; }
+#ifdef AIC_TAIL_PROF
+// phase clocks after the wave saw the queue dry go to slots 24.. instead (12 step, 13+18 shade, 14 enter, 15-17 ray, 19 scheduler)
+#define AIC_TICK(i) { const uint32_t now_ = (uint32_t)__builtin_readcyclecounter(); const int j_ = (i) == 12 ? 24 : (i) == 13 || (i) == 18 ? 25 : (i) == 14 ? 26 : (i) == 19 ? 28 : 27; \
+                      if (lane == 0u) prof[__builtin_amdgcn_readfirstlane(dry ? 1 : 0) ? j_ : (i)] += now_ - prof_tm; prof_tm = now_; }
+#else
 #define AIC_TICK(i) { const uint32_t now_ = (uint32_t)__builtin_readcyclecounter(); if (lane == 0u) prof[i] += now_ - prof_tm; prof_tm = now_; }
+#endif
 #else
 #define AIC_PROF(i, v)
 #define AIC_TICK(i)
@@ -928,6 +935,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             };
             AIC_PROF(0, 1);
             AIC_PROF(1, c_shade + c_enter + c_ray);
+#ifdef AIC_TAIL_PROF
+            if (__builtin_amdgcn_readfirstlane(dry ? 1 : 0)) { tail_events++; AIC_PROF(30, 1); }
+#endif
             AIC_PROF(4, run == EV_SHADE ? 1 : 0); AIC_PROF(5, run == EV_SHADE ? c_shade : 0);
             AIC_PROF(6, run == EV_ENTER ? 1 : 0); AIC_PROF(7, run == EV_ENTER ? c_enter : 0);
             AIC_PROF(8, run == EV_FINISH ? 1 : 0); AIC_PROF(9, run == EV_FINISH ? c_ray : 0);
@@ -1538,6 +1548,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         const uint32_t fast_min = (uint32_t)__builtin_amdgcn_readfirstlane(dry ? 1 : AIC_FAST_MIN);  // (`dry` is wave-uniform; the compiler cannot tell)
         AIC_PROF(22, 1);
         AIC_PROF(23, __popcll(m_act));
+#ifdef AIC_TAIL_PROF
+        if (__builtin_amdgcn_readfirstlane(dry ? 1 : 0)) { tail_trips++; tail_lanes += (uint32_t)__popcll(m_act); AIC_PROF(29, 1); }
+#endif
 #define AIC_LANE(m) __builtin_amdgcn_inverse_ballot_w64(m)
 #pragma unroll 1
 #ifdef AIC_TRIP_MIN
@@ -1598,8 +1611,10 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             //    in that state takes up to AIC_FAST_STEPS of them here -- step, look up, count: a third of the instructions of a
             //    full pass -- and goes on into the full pass below with a further step; a lane whose fast step found something
             //    or left the bounds has taken its step of this pass and joins the bookkeeping with that lookup. --
+#ifndef AIC_TAIL_PROF
             AIC_PROF(24, __popcll(m_step & m_hl));
             AIC_PROF(25, __popcll(m_step & ~(m_hl | m_opq) & m_far_from_cap));
+#endif
             mask_t m_pre_exit = 0ull, m_pre_look = 0ull;  // lanes whose step of this pass was taken here: left the bounds / looked something up
             if (!BIG && AIC_FAST_STEPS > 0) {
                 mask_t m_f = m_step & ~(m_hl | m_opq) & m_far_from_cap;
@@ -1730,7 +1745,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 m_surf = __builtin_amdgcn_ballot_w64(raw >= thr) & m_lookup & ~m_blk;
             }
             const mask_t m_some = m_blk | m_surf;
+#ifndef AIC_TAIL_PROF
             AIC_PROF(30, __popcll(m_some | m_exit | m_dead));  // lanes of this pass that needed its bookkeeping
+#endif
             // -- the level is finished: resume the cube grid, or the ray is complete --
             // (degenerate rays only) a surface / block produced by a level that is over still needs this level's
             // state for its event: the level stays, marked dead, and is left on a later trip
@@ -1739,8 +1756,10 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             const mask_t m_rayover = m_over & ~m_some & ~m_inb;
             mask_t m_newdead = 0ull;
             if (m_leave != 0ull) {
+#ifndef AIC_TAIL_PROF
                 AIC_PROF(26, 1);
                 AIC_PROF(27, __popcll(m_leave));
+#endif
                 // Everything under exec = the leaving lanes, in one block: the suspended level comes back from its LDS columns; the
                 // cube grid's strides are +-stride by the octant bits of st (bit set = the ray goes up that axis:
                 // m - (stride ^ m) with m = the bit sign-extended is +stride for m = -1, -stride for m = 0); the outer level's Face
@@ -1791,8 +1810,10 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             if (VOL) {
                 const mask_t m_apply = m_go & m_hl;
                 if (m_apply != 0ull) {
+#ifndef AIC_TAIL_PROF
                     AIC_PROF(28, 1);
                     AIC_PROF(29, __popcll(m_apply));
+#endif
                     const bool apply = AIC_LANE(m_apply);
                     acc.l0 = apply ? acc.l0 + pend0 * acc.t : acc.l0;
                     acc.l1 = apply ? acc.l1 + pend1 * acc.t : acc.l1;
@@ -1858,6 +1879,13 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         atomicMax(&F.counters->prof[0], (unsigned long long)prof[3]);
         atomicMax(&F.counters->prof[1], (unsigned long long)prof[2]);
     }
+#ifdef AIC_TAIL_PROF
+    {   // trips (12 bits), event phases (10 bits) and mean lanes stepping per trip (x16, 10 bits) after the wave saw the queue dry
+        const uint32_t wid = blockIdx.x * (uint32_t)(AIC_WG_THREADS / 64) + (threadIdx.x >> 6);
+        const uint32_t ml = tail_trips ? (tail_lanes * 16u) / tail_trips : 0u;
+        if (lane == 0 && wid < 2048u) F.counters->wave_prof[wid][3] = (tail_trips > 4095u ? 4095u : tail_trips) | ((tail_events > 1023u ? 1023u : tail_events) << 12) | ((ml > 1023u ? 1023u : ml) << 22);
+    }
+#endif
 #ifdef AIC_RAY_PROF
     {   // the wave's longest ray: duration in the upper bits, its step count in the lower 10
         uint32_t best_ = (ray_dur_max & ~1023u) | (ray_dur_steps > 1023u ? 1023u : ray_dur_steps);
