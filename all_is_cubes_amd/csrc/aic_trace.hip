@@ -1108,8 +1108,24 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 if (VOL) {
                     // DepthIter.last_surface: applied when the next TraceStep is counted
                     if (will_flush) {
-                        pend0 = o0; pend1 = o1; pend2 = o2; pend_tr = tr;
-                        st |= ST_HAS_LAST;
+#ifndef AIC_EARLY_APPLY
+#define AIC_EARLY_APPLY 1
+#endif
+                        // The span is applied when the ray's next TraceStep is counted and passes the stop check (sr.rs:625-656).
+                        // For a lane whose level can step and that is below the step cap that is CERTAIN: its next step (a lookup or the
+                        // exit step) is produced, counted (count + 1 <= 1000) and not stopped (the ray is not opaque, or it would not be
+                        // shading). Nothing reads the accumulator in between, so the same additions can be made now -- unless they make
+                        // the ray opaque: the stop check of that next step still has to see it transparent, so then the span waits as
+                        // before. A lane without a pending span takes the bookkeeping-free fast steps at once.
+                        bool early = AIC_EARLY_APPLY && !DIAG && !(ev & EV_DEAD) && count <= 999u;
+                        const float n0 = acc.l0 + o0 * acc.t, n1 = acc.l1 + o1 * acc.t, n2 = acc.l2 + o2 * acc.t, nt = acc.t * tr;
+                        early = early && !(nt < 1.0f / 256.0f);
+                        if (early) {
+                            acc.l0 = n0; acc.l1 = n1; acc.l2 = n2; acc.t = nt;
+                        } else {
+                            pend0 = o0; pend1 = o1; pend2 = o2; pend_tr = tr;
+                            st |= ST_HAS_LAST;
+                        }
                         if (DIAG) { pend_d = sd; pend_t = t_enter; pend_visible = visible; }
                     }
                 } else if (visible) {
