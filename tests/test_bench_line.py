@@ -1,0 +1,71 @@
+"""The bench line's contract (the driver parses it), checked on the lines committed under profiles/ and on bench.py's own defaults.
+No GPU: the lines were produced on an MI355X by tools/measure_round.sh."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_*.json")))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline")
+
+
+def latest_round():
+    rounds = sorted({os.path.basename(p).split("_")[0] for p in LINES})
+    return rounds[-1] if rounds else None
+
+
+def test_committed_lines_exist():
+    assert LINES, "no bench lines under profiles/"
+    r = latest_round()
+    names = {os.path.basename(p) for p in LINES if os.path.basename(p).startswith(r)}
+    assert f"{r}_bench_atrium.json" in names and f"{r}_bench_s256.json" in names
+
+
+@pytest.mark.parametrize("path", [p for p in LINES if os.path.basename(p).startswith(("r03", "r04", "r05"))] or LINES[-1:])
+def test_line_has_the_contract_fields_and_is_consistent(path):
+    text = open(path).read().strip()
+    assert "\n" not in text, "one JSON line"
+    d = json.loads(text)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["metric"] == "Mrays/s" and d["unit"] == "Mrays/s" and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None  # BASELINE.md holds no published number for this metric
+    assert d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert isinstance(d["config"].get("workload"), str) and "model" not in d["config"]
+    assert d["n_gpus"] >= 1 and d["steps"] >= 1 and d["ms_per_step"] > 0
+    # value = rays per frame / ms per step
+    rays = d["config"]["rays_per_frame"]
+    assert abs(d["value"] - rays / d["ms_per_step"] / 1e3) <= 0.01 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    # achieved = algorithmic bytes per launch / launch period
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_period_ms"] * 1e-3) / 1e9) <= 0.01 * r["achieved"]
+    assert r["achieved"] < r["peak"]
+    if r.get("kernel_ms_one_at_a_time"):
+        f = r["algorithmic_bytes_per_launch"] / (r["kernel_ms_one_at_a_time"] * 1e-3) / 1e9 / r["peak"]
+        assert abs(r["frac_one_at_a_time"] - f) <= 0.01 * f
+    cb = d.get("cpu_baseline")
+    if cb is not None:
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in cb, k
+        assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+
+
+def test_bench_defaults_are_one_gpu_and_short():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--workload", "--no-pipeline", "--frames-per-gather", "--in-flight"):
+        assert flag in out.stdout, flag
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    src = open(spec.origin).read()
+    assert '"--gpus", type=int, default=1' in src.replace("'", '"')
