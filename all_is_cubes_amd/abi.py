@@ -26,7 +26,7 @@ FRAME_COUNTERS, FRAME_AUX, FRAME_PIXEL_CENTERS, FRAME_OUT_LINEAR, FRAME_OUT_COLO
 ABI_SYMBOLS = [
     "aic_abi_version", "aic_create", "aic_destroy", "aic_last_error", "aic_device_name", "aic_upload_space",
     "aic_clear_space", "aic_update_cubes", "aic_update_light_volume", "aic_replace_block", "aic_replace_blocks", "aic_compact", "aic_set_options",
-    "aic_render", "aic_render_submit", "aic_render_wait", "aic_trace_patches", "aic_partition_rows", "aic_assemble_strips", "aic_read_aux", "aic_synchronize", "aic_stream", "aic_wait_event",
+    "aic_render", "aic_render_submit", "aic_render_wait", "aic_trace_patches", "aic_partition_rows", "aic_assemble_strips", "aic_read_aux", "aic_synchronize", "aic_stream", "aic_wait_event", "aic_stream_wait_frame",
     "aic_probe_raycast", "aic_probe_light_lut", "aic_probe_powf",
     "aic_ortho_image_size", "aic_render_orthographic",
     "aic_evaluate_light", "aic_light_cubes_changed", "aic_read_light_volume", "aic_light_chart", "aic_probe_derived", "aic_probe_log2f",
@@ -436,6 +436,15 @@ class Context:
 
     def synchronize(self) -> None:
         self._check(self._lib.aic_synchronize(self._h))
+
+    def stream_wait_frame(self, slot: int, hip_stream: int) -> None:
+        """`hip_stream` (a raw hipStream_t, e.g. torch.cuda.current_stream().cuda_stream) waits on the device for the frame
+        submitted on `slot`; the host does not block (aic_stream_wait_frame)."""
+        self._check(self._lib.aic_stream_wait_frame(self._h, int(slot), C.c_void_p(hip_stream)))
+
+    def wait_event(self, hip_event: int) -> None:
+        """Everything the context queues from now on waits for the caller's hipEvent_t (aic_wait_event)."""
+        self._check(self._lib.aic_wait_event(self._h, C.c_void_p(hip_event)))
 
     # -- probes ----------------------------------------------------------------------------
     def probe_raycast(self, origin, direction, bounds=None, include_exit=True, max_steps=64):

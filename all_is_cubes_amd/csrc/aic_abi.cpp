@@ -1295,6 +1295,15 @@ int aic_wait_event(aic_ctx *c, void *hip_event) {
     return AIC_OK;
 }
 
+int aic_stream_wait_frame(aic_ctx *c, uint32_t slot, void *hip_stream) {
+    if (!c || slot >= AIC_MAX_IN_FLIGHT) return fail(c, AIC_ERR_INVALID, "aic_stream_wait_frame: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    aic_ctx::FrameSlot &fs = c->slots[slot];
+    if (!fs.busy || !fs.npix) return AIC_OK;  // nothing in flight (or an empty partition: no event was recorded)
+    HIP_TRY(c, hipStreamWaitEvent((hipStream_t)hip_stream, fs.ev1, 0));
+    return AIC_OK;
+}
+
 int aic_probe_raycast(aic_ctx *c, const double origin[3], const double direction[3], int use_bounds, const int32_t lo[3],
                       const int32_t hi[3], int include_exit, uint32_t max_steps, aic_rc_step *out, uint32_t *n_out, int *ended) {
     if (!c || !origin || !direction || !out || !n_out || !ended) return fail(c, AIC_ERR_INVALID, "aic_probe_raycast: bad argument");

@@ -627,6 +627,12 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u
 #ifndef AIC_FAST_STEPS
 #define AIC_FAST_STEPS 8  // bookkeeping-free steps a lane may take ahead of each full pass (0: none) ...
 #endif
+#ifndef AIC_SPEC_STEPS
+#define AIC_SPEC_STEPS 4  // a draining wave takes its fast steps four at a time, all four lookups in flight together (0: off)
+#endif
+#ifndef AIC_SPEC_ALWAYS
+#define AIC_SPEC_ALWAYS 0  // experiment: speculative lookups in the bulk of the frame too
+#endif
 
 // Runs Raycaster::next (raycast.rs:239-284) on a freshly initialised level until it yields its
 // first step or ends. Used by the ENTER / RAY events, so that the stepping loop only ever sees
@@ -1562,6 +1568,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         // seen the pixel queue dry it is draining its last rays and what counts is how soon the longest of them ends: a lone ray
         // then takes its fast steps too (38 instructions a step instead of a full pass's ~180).
         const uint32_t fast_min = (uint32_t)__builtin_amdgcn_readfirstlane(dry ? 1 : AIC_FAST_MIN);  // (`dry` is wave-uniform; the compiler cannot tell)
+        const bool spec_on = AIC_SPEC_ALWAYS || __builtin_amdgcn_readfirstlane(dry ? 1 : 0) != 0;
         AIC_PROF(22, 1);
         AIC_PROF(23, __popcll(m_act));
 #ifdef AIC_TAIL_PROF
@@ -1632,7 +1639,83 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             AIC_PROF(25, __popcll(m_step & ~(m_hl | m_opq) & m_far_from_cap));
 #endif
             mask_t m_pre_exit = 0ull, m_pre_look = 0ull;  // lanes whose step of this pass was taken here: left the bounds / looked something up
-            if (!BIG && AIC_FAST_STEPS > 0) {
+            if (!BIG && !DIAG && AIC_SPEC_STEPS > 0 && AIC_FAST_STEPS > 0 && spec_on) {
+                // -- Speculative lookups (a draining wave: the pixel queue is dry). What is left of the frame is the serial chain of
+                //    its last rays, one dependent L2 round trip (about 1k clocks) per step with nothing else to issue
+                //    (profiles/r03_wave_tail.txt). The DDA's geometry never depends on the code a lookup returns, so a lane in the
+                //    fast-step state takes FOUR steps back to back, each followed by its lookup, and waits ONCE. A lane whose four
+                //    lookups all find nothing has taken four counted steps for one round trip. A lane that left its bounds stopped
+                //    stepping there (its state is that step's). A lane that found something at step j < 3 went on regardless: it is put
+                //    back to the state saved before the batch and takes steps 0..j again -- the same additions in the same order,
+                //    hence the same bits -- which costs instructions the draining wave has to spare. --
+                mask_t m_f = m_step & ~(m_hl | m_opq) & m_far_from_cap;
+#pragma unroll 1
+                for (int sb = 0; sb < AIC_FAST_STEPS / 4 && m_f != 0ull; sb++) {
+                    const double v_tx = tx, v_ty = ty, v_tz = tz, v_lt = last_t;
+                    const uint32_t v_rx = rx, v_ry = ry, v_rz = rz, v_bo = boff, v_lax = lax;
+                    // The four lookups are in flight together and the ONE wait sits in the last lookup's asm statement, which takes the
+                    // first three destination registers as plain inputs and hands all four codes on as its own outputs: every later
+                    // use depends on that statement, so the compiler can neither read a code nor copy its register before the wait.
+                    uint32_t q0, q1, q2;  // written by the loads under their masks (other lanes: undefined, masked out of every use)
+                    auto spec_load = [&](uint32_t &rw, const mask_t m) {
+                        mask_t sv;
+                        asm volatile(
+                            "s_mov_b64 %[sv], exec\n\t"
+                            "s_mov_b64 exec, %[m]\n\t"
+                            "global_load_ushort %[rw], %[bo], %[pool]\n\t"
+                            "s_mov_b64 exec, %[sv]\n\t"
+                            : [rw] "=&v"(rw), [sv] "=&s"(sv)
+                            : [bo] "v"(boff), [pool] "s"(pool_bits), [m] "s"(m)
+                            : "memory");
+                    };
+                    mask_t alive = m_f;
+                    const mask_t x0 = dda_step(alive); alive &= ~x0; const mask_t l0 = alive; spec_load(q0, l0);
+                    const mask_t x1 = dda_step(alive); alive &= ~x1; const mask_t l1 = alive; spec_load(q1, l1);
+                    const mask_t x2 = dda_step(alive); alive &= ~x2; const mask_t l2 = alive; spec_load(q2, l2);
+                    const mask_t x3 = dda_step(alive); alive &= ~x3; const mask_t l3 = alive;
+                    uint32_t rw0, rw1, rw2, rw3;
+                    {
+                        mask_t sv;
+                        asm volatile(
+                            "s_mov_b64 %[sv], exec\n\t"
+                            "s_mov_b64 exec, %[m]\n\t"
+                            "global_load_ushort %[o3], %[bo], %[pool]\n\t"
+                            "s_mov_b64 exec, %[sv]\n\t"
+                            "s_waitcnt vmcnt(0)\n\t"
+                            "v_mov_b32 %[o0], %[i0]\n\t"
+                            "v_mov_b32 %[o1], %[i1]\n\t"
+                            "v_mov_b32 %[o2], %[i2]\n\t"
+                            : [o0] "=&v"(rw0), [o1] "=&v"(rw1), [o2] "=&v"(rw2), [o3] "=&v"(rw3), [sv] "=&s"(sv)
+                            : [i0] "v"(q0), [i1] "v"(q1), [i2] "v"(q2), [bo] "v"(boff), [pool] "s"(pool_bits), [m] "s"(l3)
+                            : "memory");
+                    }
+                    const mask_t f0 = __builtin_amdgcn_ballot_w64(rw0 >= thr) & l0, f1 = __builtin_amdgcn_ballot_w64(rw1 >= thr) & l1,
+                                 f2 = __builtin_amdgcn_ballot_w64(rw2 >= thr) & l2, f3 = __builtin_amdgcn_ballot_w64(rw3 >= thr) & l3;
+                    // a lane's first event: the first step that left the bounds or found something
+                    const mask_t n0 = m_f & ~(f0 | x0), n1 = n0 & ~(f1 | x1), n2 = n1 & ~(f2 | x2), n3 = n2 & ~(f3 | x3);
+                    const mask_t g0 = f0 & m_f, g1 = f1 & n0, g2 = f2 & n1, g3 = f3 & n2;   // found something first at step j
+                    const mask_t y0 = x0 & m_f, y1 = x1 & n0, y2 = x2 & n1, y3 = x3 & n2;   // left the bounds first at step j
+                    const mask_t m_back = g0 | g1 | g2;                                      // stepped past what they found
+                    if (m_back != 0ull) {
+                        const bool bk = AIC_LANE(m_back);
+                        tx = bk ? v_tx : tx; ty = bk ? v_ty : ty; tz = bk ? v_tz : tz; last_t = bk ? v_lt : last_t;
+                        rx = bk ? v_rx : rx; ry = bk ? v_ry : ry; rz = bk ? v_rz : rz; boff = bk ? v_bo : boff; lax = bk ? v_lax : lax;
+                        (void)dda_step(m_back);
+                        if ((g1 | g2) != 0ull) (void)dda_step(g1 | g2);
+                        if (g2 != 0ull) (void)dda_step(g2);
+                    }
+                    raw = AIC_LANE(g0) ? rw0 : (AIC_LANE(g1) ? rw1 : (AIC_LANE(g2) ? rw2 : (AIC_LANE(g3 | n3) ? rw3 : raw)));
+                    // the steps before a lane's first event found nothing: Invisible TraceSteps, counted and nothing else
+                    asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(count) : "s"(n0) : "vcc");
+                    asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(count) : "s"(n1) : "vcc");
+                    asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(count) : "s"(n2) : "vcc");
+                    asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(count) : "s"(n3) : "vcc");
+                    m_pre_exit |= y0 | y1 | y2 | y3;
+                    m_pre_look |= g0 | g1 | g2 | g3;
+                    m_f = n3;
+                }
+                m_step &= ~(m_pre_exit | m_pre_look);
+            } else if (!BIG && AIC_FAST_STEPS > 0) {
                 mask_t m_f = m_step & ~(m_hl | m_opq) & m_far_from_cap;
 #pragma unroll
                 for (int f = 0; f < AIC_FAST_STEPS; f++) {

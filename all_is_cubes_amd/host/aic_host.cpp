@@ -785,5 +785,6 @@ HipRtRenderer::LightUpdateInfo HipRtRenderer::evaluate_light(int maximum_distanc
 }
 
 void HipRtRenderer::wait_event(void *hip_event) { check(aic_wait_event(ctx_, hip_event), "aic_wait_event"); }
+void HipRtRenderer::stream_wait_rows(uint32_t slot, void *hip_stream) { check(aic_stream_wait_frame(ctx_, slot, hip_stream), "aic_stream_wait_frame"); }
 
 }  // namespace aic::host

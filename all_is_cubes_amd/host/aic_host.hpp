@@ -328,6 +328,7 @@ class HipRtRenderer : public HeadlessRenderer {
     std::string device_name() const;
     void *stream() const;
     void wait_event(void *hip_event);  // aic_wait_event: later frames wait for a foreign event, the host does not
+    void stream_wait_rows(uint32_t slot, void *hip_stream);  // aic_stream_wait_frame: a foreign stream waits for the slot's frame, the host does not
     // Light propagation on the device (aic_evaluate_light): Mutation::fast_evaluate_light (if `fast`) then
     // Mutation::evaluate_light(epsilon) (space.rs:1496-1540) on the WORLD space as uploaded, with
     // LightPhysics::Rays { maximum_distance }; the device's light volume is updated in place (the host Space's is not).

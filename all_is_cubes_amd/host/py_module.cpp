@@ -243,6 +243,8 @@ PYBIND11_MODULE(_host, m) {
         .def("device_name", &HipRtRenderer::device_name)
         .def("stream", [](const HipRtRenderer &r) { return reinterpret_cast<uintptr_t>(r.stream()); })
         .def("wait_event", [](HipRtRenderer &r, uintptr_t ev) { r.wait_event(reinterpret_cast<void *>(ev)); })
+        .def("stream_wait_rows", [](HipRtRenderer &r, uint32_t slot, uintptr_t stream) { r.stream_wait_rows(slot, reinterpret_cast<void *>(stream)); },
+             py::arg("slot"), py::arg("hip_stream"))
         .def("evaluate_light", [](HipRtRenderer &r, int maximum_distance, bool fast, int epsilon, int batch, int queue_order, int lanes_per_cube, bool continue_queue,
                                   uint64_t max_updates) {
             const HipRtRenderer::LightUpdateInfo i = r.evaluate_light(maximum_distance, fast, epsilon, batch, queue_order, lanes_per_cube, continue_queue, max_updates);

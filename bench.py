@@ -159,6 +159,11 @@ def main() -> int:
                          "frames per collective trade latency for fewer host calls: to be measured on a real 8-GPU node before it becomes a default "
                          "(README: the SCALE commands)")
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: gather each frame before tracing the next")
+    ap.add_argument("--gather-at-one", action="store_true",
+                    help="N = 1: run the exchange step all the same (a one-rank process group over the nccl backend, the strip ring, the gather and the "
+                         "de-interleave) -- the only way to execute the RCCL leg of the N > 1 path on a one-GPU box")
+    ap.add_argument("--host-handoff", action="store_true",
+                    help="N > 1: the round-3 hand-off (the host waits for a traced frame before it submits its gather) instead of the device-side one")
     ap.add_argument("--lighting", type=int, default=3, help="experiment: LightingOption (0 None,1 Flat,2 Coarse,3 Linear,4 Smoothstep); default Linear")
     ap.add_argument("--fog", type=int, default=1, help="experiment: FogOption (0 None,1 Abrupt,...); default Abrupt")
     ap.add_argument("--transparency", type=int, default=None, help="experiment: 0 Surface, 1 Volumetric; default Volumetric (light-bench: Surface, the reference bench's 'linear-surface')")
@@ -166,6 +171,7 @@ def main() -> int:
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed single-frame / moving-camera / read-back measurements (counter passes)")
     ap.add_argument("--relight-period", type=int, default=30, help="relight: frames between two lamp toggles")
     ap.add_argument("--light-budget", type=int, default=2048, help="relight: cube updates of the light updater per frame (one launch)")
+    ap.add_argument("--no-secondary", action="store_true", help="atrium (the default line): skip the short s256 leg reported as `secondary`")
     ap.add_argument("--min-seconds", type=float, default=3.0, help="repeat the K-step timed region until the regions add up to this much time")
     args = ap.parse_args()
     default_transparency = 0 if args.workload == "light-bench" else 1
@@ -194,8 +200,10 @@ def main() -> int:
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     one_gpu_test = os.environ.get("AIC_BENCH_ONE_GPU") == "1"
-    if world > 1:
+    exchange = world > 1 or args.gather_at_one  # the strips travel to rank 0 through a collective
+    if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if one_gpu_test:  # RCCL refuses two ranks on one device: the test hook gathers through host memory
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -301,12 +309,19 @@ def main() -> int:
     per_gather = max(1, min(depth, args.frames_per_gather if args.frames_per_gather > 0 else 1)) if streamed else 1
     ring = ((depth + per_gather - 1) // per_gather + (1 if per_gather == 1 else 2)) if streamed else 1  # group slots: the groups being traced, one being gathered
     pipe = D.StripGatherPipeline(h, w, strip, "cpu" if one_gpu_test else dev, depth=ring,
-                                 wait_event=None if one_gpu_test else renderer.wait_event, frames=per_gather) if world > 1 else None
+                                 wait_event=None if one_gpu_test else renderer.wait_event, frames=per_gather) if exchange else None
     n_local = depth if streamed else 1
     local_bufs = [torch.empty((max(local_rows, 1), w, 4), dtype=torch.uint8, device=dev) for _ in range(n_local)] if (pipe is None or one_gpu_test) else None
     stage_buf = (torch.empty((world, pipe.max_rows, w, 4) if per_gather == 1 else (world, per_gather, pipe.max_rows, w, 4), dtype=torch.uint8, device=dev)
                  if (one_gpu_test and pipe is not None and rank == 0) else None)
-    frame_buf = torch.empty((h, w, 4), dtype=torch.uint8, device=dev) if (rank == 0 and world > 1) else None
+    frame_buf = torch.empty((h, w, 4), dtype=torch.uint8, device=dev) if (rank == 0 and exchange) else None
+    # Hand-off of a traced frame to its gather. Round 3 waited for the frame on the HOST (aic_render_wait: a hipStreamSynchronize per
+    # frame in front of every collective -- at N = 8, where a rank's share is traced in 0.1 ms, a host round trip on the critical
+    # path). Now the stream the collective is issued from waits for the frame's event ON THE DEVICE (aic_stream_wait_frame) and the
+    # host goes on; the frame's report is collected just before its render slot is used again, `depth` frames later, when it has
+    # long finished (that wait is the loop's back-pressure, not part of the exchange).
+    device_handoff = pipe is not None and not one_gpu_test and not args.host_handoff
+    uncollected = {}  # render slot -> True: its frame was handed to the gather on the device, its report is still to be read
 
     kernel_ms = []
     orbit = None
@@ -353,10 +368,18 @@ def main() -> int:
             return pipe.frame_buffer(slot_of(i), i % per_gather)
         return local_bufs[i % n_local]
 
-    def complete_oldest() -> None:  # the oldest traced frame: wait for it, hand its strips to the gather
+    def collect(rslot) -> None:
+        if uncollected.pop(rslot, None):
+            kernel_ms.append(renderer.wait_rows(rslot).kernel_ms)
+
+    def complete_oldest() -> None:  # the oldest traced frame: hand its strips to the gather
         i, rslot = traced.pop(0)
-        info = renderer.wait_rows(rslot)
-        kernel_ms.append(info.kernel_ms)
+        if device_handoff:
+            renderer.stream_wait_rows(rslot, torch.cuda.current_stream(dev).cuda_stream)
+            uncollected[rslot] = True
+        else:
+            info = renderer.wait_rows(rslot)
+            kernel_ms.append(info.kernel_ms)
         if pipe is not None:
             if one_gpu_test:
                 pipe.frame_buffer(slot_of(i), i % per_gather)[:local_rows].copy_(local_bufs[i % n_local][:local_rows])
@@ -399,12 +422,15 @@ def main() -> int:
             complete_oldest()
         if pipe is not None and i % per_gather == 0:
             finish(slot_of(i))  # the gather that last used this ring slot
+        collect(i % depth)
         renderer.submit_rows_to_device(render_target(i).data_ptr(), strip, world, rank, i % depth)
         traced.append((i, i % depth))
 
     def drain() -> None:  # every frame issued so far is traced, gathered and assembled
         while traced:
             complete_oldest()
+        for rslot in list(uncollected):
+            collect(rslot)
         if pipe is not None:
             for slot in [sl for sl in filled if pipe.work[sl] is None]:  # a group the fence cut short travels as it is
                 pipe.submit(slot)
@@ -414,7 +440,7 @@ def main() -> int:
     def fence() -> None:
         drain()
         renderer.synchronize()
-        if world > 1:
+        if exchange:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -429,7 +455,7 @@ def main() -> int:
             step()
         fence()
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if one_gpu_test else dev)
-        if world > 1:
+        if exchange:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -437,7 +463,7 @@ def main() -> int:
     # --min-seconds of GPU time (every rank runs the same count: the first region's time is agreed on first). `value`
     # and `ms_per_step` are those of the MEDIAN region; min / max are reported beside them.
     regions = [timed_region()]
-    n_regions = max(1, min(200, int(np.ceil(args.min_seconds / max(regions[0], 1e-6)))))
+    n_regions = max(1, min(5000, int(np.ceil(args.min_seconds / max(regions[0], 1e-6)))))  # (capped at 200 until round 4: a 10 ms region then summed to 2.1 s, not --min-seconds)
     region_kernel_ms = [float(np.mean(kernel_ms)) if kernel_ms else 0.0]
     for _ in range(n_regions - 1):
         regions.append(timed_region())
@@ -448,7 +474,7 @@ def main() -> int:
 
     # --- untimed extras: algorithmic-byte counters, read-back rate ------------------------------
     verified = None
-    if (args.verify or args.verify is None) and world > 1:
+    if (args.verify or args.verify is None) and exchange:
         verified = True
         # the assembled frame of the last step must equal the same frame traced by one rank alone
         if rank == 0:
@@ -464,7 +490,7 @@ def main() -> int:
     info = renderer.draw_rows_to_device(cbuf.data_ptr(), strip, world, rank, True)
     counts = torch.tensor([info.cubes_traced, info.n_outer, info.n_inner, info.n_hits, info.n_light], dtype=torch.int64,
                           device="cpu" if one_gpu_test else dev)
-    if world > 1:
+    if exchange:
         dist.all_reduce(counts)
     cubes_traced, n_outer, n_inner, n_hits, n_light = (int(v) for v in counts.tolist())
     # per-launch algorithmic bytes of THIS rank's trace kernel:
@@ -618,6 +644,13 @@ def main() -> int:
                                 f"profiles/r03_issue_rate.txt); pipe_busy = VALU / SALU instructions x {ISSUE_PIPE_CYCLES} cycles (what f64, compare, select and "
                                 "scalar operations cost there) / SIMD cycles of the launch period (DESIGN.md 6)"}
 
+    secondary = None
+    if world == 1 and args.workload == "atrium" and not args.no_extras and not args.no_secondary and (args.lighting, args.fog, args.transparency) == (3, 1, 1):
+        try:
+            secondary = {"s256": secondary_workload_leg("s256", H, D, torch, dev, local_rank, space_from_flat)}
+        except Exception as exc:  # the headline line must not be lost to the extra leg
+            secondary = {"s256": {"error": repr(exc)}}
+
     result = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -647,7 +680,8 @@ def main() -> int:
                 "partition": f"interleaved {strip}-row strips over {world} GPU(s), scene replicated, RCCL gather to rank 0",
                 "steps_per_ray": round(cubes_traced / rays_per_frame, 2),
                 "frames_in_flight": depth if streamed else 1,
-                "frames_per_gather": per_gather if world > 1 else None,
+                "frames_per_gather": per_gather if exchange else None,
+                "handoff": ("device (aic_stream_wait_frame: the gather's stream waits for the trace's event)" if device_handoff else "host (aic_render_wait before each gather)") if exchange else None,
                 "assembled_frame_equals_single_rank_frame": verified,
             },
             "roofline": {
@@ -681,6 +715,16 @@ def main() -> int:
         if single is not None:
             result["single_frame"] = single
             result["streamed_ms"] = round(ms_per_step, 4) if streamed else None
+            # BASELINE.json config 2 is a SINGLE-frame raytrace: the rate of one frame alone, cold (no tile order learnt from an
+            # earlier identical frame: what the first frame of any sequence costs), beside the streamed `value`
+            if single["single_frame_cold_ms"] > 0:
+                result["value_single_frame"] = round(rays_per_frame / (single["single_frame_cold_ms"] * 1e-3) / 1e6, 3)
+                result["value_single_frame_warm"] = round(rays_per_frame / (single["single_frame_warm_ms"] * 1e-3) / 1e6, 3)
+                result["config"]["value_is"] = ("`value` = streamed frames (frames_in_flight traces overlapping, static camera: the recording loop's rate); "
+                                                "BASELINE.json config 2 names a single-frame raytrace, which is `value_single_frame` (one frame alone, cold; "
+                                                "`value_single_frame_warm` with the tile order learnt from the identical previous frame)")
+        if secondary is not None:
+            result["secondary"] = secondary
         if criterion is not None:
             result["criterion_equivalent"] = criterion
         if light_update is not None:
@@ -699,10 +743,69 @@ def main() -> int:
             if result["cpu_baseline"]["value"]:
                 result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 2)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if exchange:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def secondary_workload_leg(name, H, D, torch, dev, local_rank, space_from_flat, frames=16, one_by_one_frames=6):
+    """A short measurement of another workload inside the default run (the driver's one line then carries a C3
+    figure too): its own renderer on the same device, `frames` streamed frames (4 in flight) after a warm-up, a few frames one at
+    a time for the kernel's own duration, one counter-collecting launch for the algorithmic bytes."""
+    flat_space, (w, h), eye, target, view_distance, label = build_workload(name)
+    cams = H.StandardCameras()
+    opts = H.GraphicsOptions()
+    opts.bloom_intensity = 0.0
+    opts.view_distance = view_distance
+    opts.debug_info_text = False
+    cams.graphics_options = opts
+    cams.viewport = H.Viewport.with_scale(1.0, w, h)
+    cams.world_space = space_from_flat(flat_space)
+    cams.world_view_transform = H.look_at_y_up(eye, target)
+    r = H.HipRtRenderer(cams, None, local_rank)
+    r.update()
+    strip, depth = D.STRIP_ROWS, 4
+    bufs = [torch.empty((h, w, 4), dtype=torch.uint8, device=dev) for _ in range(depth)]
+
+    def streamed(n):
+        for i in range(n):
+            if i >= depth:
+                r.wait_rows(i % depth)
+            r.submit_rows_to_device(bufs[i % depth].data_ptr(), strip, 1, 0, i % depth)
+        for i in range(max(0, n - depth), n):
+            r.wait_rows(i % depth)
+        r.synchronize()
+
+    streamed(depth + 2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    streamed(frames)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / frames * 1e3
+    ks, ts = [], []
+    for _ in range(one_by_one_frames):
+        t1 = time.perf_counter()
+        fi = r.draw_rows_to_device(bufs[0].data_ptr(), strip, 1, 0)
+        ts.append((time.perf_counter() - t1) * 1e3)
+        ks.append(fi.kernel_ms)
+    cold = []
+    for _ in range(max(2, one_by_one_frames // 2)):
+        t1 = time.perf_counter()
+        r.draw_rows_to_device(bufs[0].data_ptr(), strip, 1, 0, no_feedback=True)
+        cold.append((time.perf_counter() - t1) * 1e3)
+    info = r.draw_rows_to_device(bufs[0].data_ptr(), strip, 1, 0, True)
+    nbytes = 2 * info.n_outer + 2 * info.n_inner + 32 * info.n_hits + 4 * info.n_light + 4 * w * h
+    k_ms = float(np.median(ks))
+    out = {"workload": label, "rays_per_frame": w * h, "frames": frames, "frames_in_flight": depth, "ms_per_step": round(ms, 4),
+           "value": round(w * h / (ms * 1e-3) / 1e6, 3), "unit": "Mrays/s", "steps_per_ray": round(info.cubes_traced / (w * h), 2),
+           "single_frame_warm_ms": round(float(np.median(ts)), 4), "single_frame_cold_ms": round(float(np.median(cold)), 4),
+           "value_single_frame": round(w * h / (float(np.median(cold)) * 1e-3) / 1e6, 3),
+           "algorithmic_bytes_per_launch": int(nbytes), "kernel_ms_one_at_a_time": round(k_ms, 4),
+           "frac_one_at_a_time": round(nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if k_ms > 0 else None,
+           "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if ms > 0 else None}
+    del r
+    return out
 
 
 def usable_cpus():

@@ -245,6 +245,13 @@ void *aic_stream(aic_ctx *ctx);
  * the caller on a stream of its own, e.g. after an RCCL gather that reads or writes buffers the next frames touch):
  * orders foreign work before the context's without blocking the host. */
 int aic_wait_event(aic_ctx *ctx, void *hip_event);
+/* The mirror of aic_wait_event: `hip_stream` (a hipStream_t of the caller's, e.g. the stream an RCCL gather of the frame's strips is
+ * issued from) waits ON THE DEVICE for the frame submitted on `slot` -- hipStreamWaitEvent on the event aic_render_submit recorded
+ * behind the slot's trace. The host does not block and the slot stays occupied (aic_render_wait still collects it, later, off
+ * the exchange step's path). A slot with no frame in flight is a no-op. Together the two calls hand a frame from the trace to
+ * the gather and the ring slot back to the trace without a host round trip (the reference has no counterpart: its image loop,
+ * renderer.rs:516-556, returns a finished image to one caller). */
+int aic_stream_wait_frame(aic_ctx *ctx, uint32_t slot, void *hip_stream);
 
 /* --- orthographic views (icons, previews) -------------------------------------------------- */
 /* replaces: raytracer::ortho::render_orthographic (all-is-cubes-render/src/raytracer/ortho.rs:30-88): five pixel-perfect

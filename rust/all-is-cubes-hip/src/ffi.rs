@@ -201,6 +201,7 @@ unsafe extern "C" {
     pub fn aic_synchronize(ctx: *mut aic_ctx) -> c_int;
     pub fn aic_stream(ctx: *mut aic_ctx) -> *mut c_void;
     pub fn aic_wait_event(ctx: *mut aic_ctx, hip_event: *mut c_void) -> c_int;
+    pub fn aic_stream_wait_frame(ctx: *mut aic_ctx, slot: u32, hip_stream: *mut c_void) -> c_int;
     pub fn aic_ortho_image_size(lo: *const i32, size: *const i32, resolution: c_int, width: *mut u32, height: *mut u32) -> c_int;
     pub fn aic_render_orthographic(ctx: *mut aic_ctx, layer: c_int, resolution: c_int, out_rgba8: *mut c_void, out_is_device: c_int, width: *mut u32, height: *mut u32, info: *mut aic_frame_info) -> c_int;
     pub fn aic_create_multi(n_devices: c_int, device_ids: *const c_int, status: *mut c_int) -> *mut aic_multi;

@@ -660,6 +660,15 @@ def test_full_size_workload_rows_and_properties(ctx, workload):
     assert first["info"].cubes_traced == again["info"].cubes_traced
     fast = ctx.render(fr)  # the production kernel variant (no per-pixel records, 4 waves per SIMD)
     assert (fast["rgba8"] == again["rgba8"]).all() and fast["info"].cubes_traced == again["info"].cubes_traced
+    # The PRODUCTION variant's per-pixel step counts: with debug_pixel_cost the pixel is
+    # rgb(0.02 n, 0.002 n, ..) (accum.rs:228-234), which the linear float output hands over unrounded, so n comes back exactly
+    # from the green channel -- no aux-recording kernel involved. Compared with the oracle's counts row by row below.
+    opt_cost = oracle.make_options(view_distance=vd, debug_pixel_cost=True)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt_cost))
+    cost = ctx.render(ctx.make_frame(w, h, world_inv=inv, flags=abi.FRAME_OUT_LINEAR))
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+    prod_counts = np.rint(cost["rgba8"][..., 1].astype(np.float64) / float(np.float32(0.002))).astype(np.int64)
+    assert cost["info"].cubes_traced == again["info"].cubes_traced and int(prod_counts.sum()) == again["info"].cubes_traced
     for k in ("cubes_traced", "hit", "cube", "voxel", "face", "block_index"):
         assert (first["aux"][k] == again["aux"][k]).all()
     # against the oracle, whole rows: steps, first hits, f64 t, RGBA8 -- EVERY row of the 1080p frame (config 2; the frame's
@@ -671,6 +680,7 @@ def test_full_size_workload_rows_and_properties(ctx, workload):
         ref = oracle.render(osp, opt, cam, rows=(y0, y1), want_aux=True, threads=min(32, os.cpu_count() or 4))
         ga, ra = again["aux"][y0:y1], ref["aux"][y0:y1]
         assert (ga["cubes_traced"] == ra["cubes_traced"]).all(), f"rows {y0}..{y1}: step counts"
+        assert (prod_counts[y0:y1] == ra["cubes_traced"]).all(), f"rows {y0}..{y1}: step counts of the production variant"
         for k in ("hit", "cube", "voxel", "resolution", "face", "block_index"):
             assert (ga[k] == ra[k]).all(), f"rows {y0}..{y1}: {k}"
         hit = ra["hit"] == 1
@@ -687,6 +697,62 @@ def test_full_size_workload_rows_and_properties(ctx, workload):
         assert (got["rgba8"] == again["rgba8"][rows]).all()
         total += got["info"].cubes_traced
     assert total == again["info"].cubes_traced
+
+
+def test_device_side_handoff_orders_a_foreign_stream_behind_the_trace():
+    """aic_stream_wait_frame: the stream an exchange step is issued from waits ON THE DEVICE for a submitted
+    frame; the host only enqueues. Two contexts on the one GPU play two ranks: each streams its strips of six frames through four
+    render slots, and after every submit a foreign (torch) stream is made to wait for the slot and copies the strips away --
+    the stand-in for the gather, issued at once, with no host wait anywhere before the end. Without the device-side wait the
+    copies run ahead of the traces (the buffers were zeroed) and the assembled frames come out wrong."""
+    import torch
+
+    import bench
+
+    sp, (w, h), eye, target, vd, _ = bench.build_workload("atrium")
+    opt = oracle.make_options(view_distance=vd)
+    _, _, inv = oracle.camera_matrices(90.0, vd, w / h, oracle.look_at_y_up(eye, target), eye)
+    dev = torch.device("cuda", 0)
+    n_ranks, n_frames, depth = 2, 6, 4
+    with abi.Context(0) as whole_ctx:
+        whole_ctx.upload_space(abi.LAYER_WORLD, sp)
+        whole_ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+        want = whole_ctx.render(whole_ctx.make_frame(w, h, world_inv=inv))["rgba8"]
+    ranks = [abi.Context(0) for _ in range(n_ranks)]
+    try:
+        side = [torch.cuda.Stream(device=dev) for _ in range(n_ranks)]
+        rows = [[y for y in range(h) if (y // 16) % n_ranks == r] for r in range(n_ranks)]
+        src = [[torch.zeros((len(rows[r]), w, 4), dtype=torch.uint8, device=dev) for _ in range(depth)] for r in range(n_ranks)]
+        dst = [[torch.zeros((len(rows[r]), w, 4), dtype=torch.uint8, device=dev) for _ in range(n_frames)] for r in range(n_ranks)]
+        torch.cuda.synchronize()
+        for r, c in enumerate(ranks):
+            c.upload_space(abi.LAYER_WORLD, sp)
+            c.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+        for k in range(n_frames):
+            for r, c in enumerate(ranks):
+                slot = k % depth
+                if k >= depth:
+                    c.render_wait(slot)  # the slot's previous frame: long finished, its copy was issued four frames ago
+                    side[r].synchronize()
+                    src[r][slot].zero_()
+                    torch.cuda.current_stream(dev).synchronize()
+                c.render_submit(c.make_frame(w, h, world_inv=inv, partition=(16, n_ranks, r)), src[r][slot].data_ptr(), slot)
+                c.stream_wait_frame(slot, side[r].cuda_stream)          # device-side: `side` waits for the trace
+                with torch.cuda.stream(side[r]):
+                    dst[r][k].copy_(src[r][slot], non_blocking=True)    # "the gather", issued at once
+        for s_ in side:
+            s_.synchronize()
+        for r, c in enumerate(ranks):
+            for slot in range(depth):
+                c.render_wait(slot)
+        for k in range(n_frames):
+            frame = np.zeros((h, w, 4), np.uint8)
+            for r in range(n_ranks):
+                frame[rows[r]] = dst[r][k].cpu().numpy()
+            assert (frame == want).all(), f"frame {k}: the copies were not ordered behind the traces"
+    finally:
+        for c in ranks:
+            c.close()
 
 
 def test_block_table_past_14_bits_uses_the_class_table(ctx):
