@@ -1575,6 +1575,12 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
         if (__builtin_amdgcn_readfirstlane(dry ? 1 : 0)) { tail_trips++; tail_lanes += (uint32_t)__popcll(m_act); AIC_PROF(29, 1); }
 #endif
 #define AIC_LANE(m) __builtin_amdgcn_inverse_ballot_w64(m)
+// Waits for a lookup issued into `raw` by an earlier asm statement. The loaded register goes in as a plain INPUT and the code comes
+// out in a fresh register, copied AFTER the wait: every later use depends on this statement. (Until round 4 this was
+// `asm("s_waitcnt vmcnt(0)" : "+v"(raw))`: a tied operand, for which the compiler may place a register copy in front of the
+// statement -- i.e. read the destination of a load still in flight. Register allocation happened never to need one; the first
+// change that gave `raw` another live range -- the speculative lookups -- made it appear, in front of the full pass's wait.)
+#define AIC_WAIT_RAW() { const uint32_t raw_in_flight_ = raw; asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %1" : "=&v"(raw) : "v"(raw_in_flight_)); }
 #pragma unroll 1
 #ifdef AIC_TRIP_MIN
         // leave the trip once no more than AIC_TRIP_MIN lanes are still stepping (the first step is always taken)
@@ -1740,7 +1746,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                             : [bo] "v"(boff), [pool] "s"(pool_bits), [m] "s"(m_fl)
                             : "memory");
                         dg.n_inner += AIC_LANE(m_fl & m_inb) ? 1u : 0u; dg.n_outer += AIC_LANE(m_fl & ~m_inb) ? 1u : 0u;
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw));
+                        AIC_WAIT_RAW();
                         // a code >= thr is a visible voxel, or a cube whose block is visible or recursive (class bits): the full pass decides
                         m_fe = __builtin_amdgcn_ballot_w64(raw >= thr) & m_fl;
                         m_fb = m_fl & ~m_fe;  // an Invisible TraceStep: counted, nothing else
@@ -1829,7 +1835,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
             asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(count) : "s"(m_produced) : "vcc");
             const mask_t m_stop = m_produced & (__builtin_amdgcn_ballot_w64(count > 1000u) | m_opq);
             const mask_t m_go = m_produced & ~m_stop;
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw));
+            AIC_WAIT_RAW();
             // TraceStep of a looked-up code: voxel -- visible iff its (re-ordered) palette code is past the invisible
             // ones; cube -- the class of its block rides in the top two bits of the grid entry (aic_device.h)
             mask_t m_blk, m_surf;
