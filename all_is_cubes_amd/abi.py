@@ -149,6 +149,8 @@ def load() -> C.CDLL:
         lib.aic_assemble_strips.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.aic_read_aux.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         lib.aic_synchronize.argtypes = [C.c_void_p]
+        lib.aic_wait_event.argtypes = [C.c_void_p, C.c_void_p]
+        lib.aic_stream_wait_frame.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         lib.aic_device_name.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
         lib.aic_probe_raycast.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                           C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]

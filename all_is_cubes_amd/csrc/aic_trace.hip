@@ -628,7 +628,9 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u
 #define AIC_FAST_STEPS 8  // bookkeeping-free steps a lane may take ahead of each full pass (0: none) ...
 #endif
 #ifndef AIC_SPEC_STEPS
-#define AIC_SPEC_STEPS 4  // a draining wave takes its fast steps four at a time, all four lookups in flight together (0: off)
+#define AIC_SPEC_STEPS 0  // experiment (-DAIC_SPEC_STEPS=4): a draining wave takes its fast steps four at a time, all four
+                          // lookups in flight together. Exact (frame hashes equal) and SLOWER: C2 one frame warm 0.776 -> 0.815 ms, cold
+                          // 1.091 -> 1.186, an eighth of the frame alone 0.491 -> 0.531 (profiles/r04_experiments.txt B): off.
 #endif
 #ifndef AIC_SPEC_ALWAYS
 #define AIC_SPEC_ALWAYS 0  // experiment: speculative lookups in the bulk of the frame too

@@ -1175,6 +1175,57 @@ Rgb get_interpolated_light(const SR &rt, const I3 &cube, const V3 &surface_point
     return Rgb{final_mix[0] / w, final_mix[1] / w, final_mix[2] / w};
 }
 
+// ---- the bounce rays' random numbers (LightingOption::Bounce, surface.rs:119-166) -------------------------------------------
+// None of this is under /root/reference: rand 0.10.1, rand_distr 0.6.0 (Cargo.lock) are registry dependencies. Restated from their
+// published algorithms; PARITY UNPINNED -- the reference holds no golden image or known-answer test for Bounce (test-renderers
+// excludes it: cases/src/lib.rs:45-50), so nothing here is checked against the reference's own output.
+//  * rand::rngs::SmallRng on 64-bit targets = Xoshiro256PlusPlus; SeedableRng::seed_from_u64 fills its four words with SplitMix64
+//    (the same seeding all_is_cubes_amd/workloads.py restates for Xoshiro256Plus, pinned there by the template-light-bench golden).
+//  * rand_distr::UnitSphere for f64 (Marsaglia 1972): x1, x2 uniform in [-1, 1) until x1^2 + x2^2 < 1; then
+//    (2 x1 sqrt(1 - s), 2 x2 sqrt(1 - s), 1 - 2 s).
+//  * Uniform::<f64>::new(-1, 1).sample: u = (next_u64 >> 12) as the mantissa of a float in [1, 2), minus 1; u * scale + low with
+//    scale = high - low = 2 (UniformFloat::new lowers the scale only while max_rand * scale + low >= high, which 2 does not).
+struct SmallRng {
+    uint64_t s[4];
+    void seed_from_u64(uint64_t state) {
+        for (int i = 0; i < 4; i++) {
+            state += 0x9e3779b97f4a7c15ull;
+            uint64_t z = state;
+            z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+            z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+            s[i] = z ^ (z >> 31);
+        }
+    }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next_u64() {  // xoshiro256++
+        const uint64_t result = rotl(s[0] + s[3], 23) + s[0];
+        const uint64_t t = s[1] << 17;
+        s[2] ^= s[0];
+        s[3] ^= s[1];
+        s[1] ^= s[2];
+        s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = rotl(s[3], 45);
+        return result;
+    }
+    f64 uniform_m1_1() {
+        const uint64_t bits = (next_u64() >> 12) | 0x3ff0000000000000ull;
+        f64 value1_2;
+        std::memcpy(&value1_2, &bits, 8);
+        const f64 value0_1 = value1_2 - 1.0;
+        return value0_1 * 2.0 + -1.0;
+    }
+    V3 unit_sphere() {
+        for (;;) {
+            const f64 x1 = uniform_m1_1(), x2 = uniform_m1_1();
+            const f64 sum = x1 * x1 + x2 * x2;
+            if (sum >= 1.0) continue;
+            const f64 factor = 2.0 * std::sqrt(1.0 - sum);
+            return v3(x1 * factor, x2 * factor, 1.0 - 2.0 * sum);
+        }
+    }
+};
+
 // sr.rs:595-622
 struct TracingState {
     f64 t_to_absolute_distance;
@@ -1183,8 +1234,12 @@ struct TracingState {
     Rgb distance_fog_light;
     f32 distance_fog_blend;
     size_t primary_cubes_traced;
+    size_t secondary_cubes_traced = 0;  // secondary_info (sr.rs:613-614): what the bounce rays traced
     Accumulate *accumulator;
     Counters *cn;
+    // ray_bounce_rng (sr.rs:165-178): rand::rngs::SmallRng, present iff allow_ray_bounce
+    bool has_rng = false;
+    SmallRng rng;
 
     // sr.rs:625-656
     bool count_step_should_stop() {
@@ -1223,6 +1278,8 @@ struct TracingState {
     }
 };
 
+size_t trace_ray_impl(const SR &rt, const Ray &ray, Accumulate *accumulator, bool include_sky, Counters *cn, bool allow_ray_bounce);
+
 // surface.rs:73-106 to_light + 113-206 compute_illumination
 bool surface_to_light(const Surface &s, const SR &rt, TracingState &ts, ColorBuf *out) {
     // graphics_options.rs:496-507 limit_alpha
@@ -1237,8 +1294,32 @@ bool surface_to_light(const Surface &s, const SR &rt, TracingState &ts, ColorBuf
     Rgb illumination;
     switch (rt.opt.lighting) {
         case 0: illumination = Rgb{1.f, 1.f, 1.f}; break;
-        case 1:
-        case 5: {  // Flat (Bounce is unsupported here and falls to Flat only when disallowed)
+        case 5:
+            // LightingOption::Bounce { samples } with an RNG and a fully opaque surface (surface.rs:85-88, 119-166): `samples`
+            // pseudorandomly directed secondary rays, each a whole trace_ray_impl with the sky included and no further bounce
+            if (ts.has_rng && diffuse.a == 1.0f) {
+                Rgb multi{0.f, 0.f, 0.f};
+                const I3 nv = face_normal(s.normal);
+                const uint32_t sample_count = (uint32_t)rt.opt.bounce_samples & 255u;  // `samples: u8`
+                for (uint32_t k = 0; k < sample_count; k++) {
+                    const V3 u = ts.rng.unit_sphere();
+                    Ray ray;
+                    // intersection_point + normal.vector(0.0001); normal.normal_vector() + UnitSphere sample
+                    ray.origin = v3(s.intersection_point[0] + (f64)nv[0] * 0.0001, s.intersection_point[1] + (f64)nv[1] * 0.0001,
+                                    s.intersection_point[2] + (f64)nv[2] * 0.0001);
+                    ray.direction = v3((f64)nv[0] + u[0], (f64)nv[1] + u[1], (f64)nv[2] + u[2]);
+                    ColorAccum light_accum_buf;  // IgnoreBlockData<D, ColorBuf>
+                    ts.secondary_cubes_traced += trace_ray_impl(rt, ray, &light_accum_buf, true, nullptr, false);
+                    const Rgba c = rgba_from_colorbuf(light_accum_buf.buf);
+                    multi.r += c.r; multi.g += c.g; multi.b += c.b;  // Rgb += (color.rs: component-wise PositiveSign add)
+                }
+                // multi_ray_accum * f32::from(sample_count).recip()  (Rgb * f32: PositiveSign::new_clamped(scalar), color.rs:912-925)
+                const f32 k = ps_new_clamped(1.0f / (f32)sample_count);
+                illumination = Rgb{ps_mul(multi.r, k), ps_mul(multi.g, k), ps_mul(multi.b, k)};
+                break;
+            }
+            [[fallthrough]];  // "if we've exceeded our bounce budget (which is always 1) we use Flat" (surface.rs:171-176)
+        case 1: {  // Flat
             I3 n = face_normal(s.normal);
             illumination = pl_value(rt.get_packed_light(i3(s.cube[0] + n[0], s.cube[1] + n[1], s.cube[2] + n[2]), ts.cn));
             break;
@@ -1296,9 +1377,16 @@ void trace_through_span(TracingState &ts, Surface surface, f64 exit_t_distance, 
 }
 
 // sr.rs:135-238 (+ finish 658-693). Returns cubes_traced.
-size_t trace_ray_impl(const SR &rt, const Ray &ray, Accumulate *accumulator, bool include_sky, Counters *cn) {
+size_t trace_ray_impl(const SR &rt, const Ray &ray, Accumulate *accumulator, bool include_sky, Counters *cn, bool allow_ray_bounce = true) {
     Rgb sky_light = sky_sample(*rt.sp, ray.direction);
     TracingState state;
+    if (allow_ray_bounce) {  // sr.rs:165-178: seeded by the bits of the ray's direction
+        uint64_t bx, by, bz;
+        const f64 dxv = ray.direction[0], dyv = ray.direction[1], dzv = ray.direction[2];
+        std::memcpy(&bx, &dxv, 8); std::memcpy(&by, &dyv, 8); std::memcpy(&bz, &dzv, 8);
+        state.has_rng = true;
+        state.rng.seed_from_u64(bx + by + bz);
+    }
     state.t_to_absolute_distance = length(ray.direction);
     state.t_to_view_distance = (f32)(state.t_to_absolute_distance / rt.opt.view_distance);
     state.has_fog_light = (rt.opt.fog != 0) && include_sky;
@@ -1348,7 +1436,7 @@ size_t trace_ray_impl(const SR &rt, const Ray &ray, Accumulate *accumulator, boo
         h.has_t = false; h.block = -1; h.has_position = false;
         accumulator->add(h);
     }
-    return state.primary_cubes_traced;
+    return state.primary_cubes_traced + state.secondary_cubes_traced;  // RaytraceInfo + secondary_info (sr.rs:690-692)
 }
 
 // ------------------------------------------------------------------------------------
@@ -1728,7 +1816,6 @@ int32_t orc_render(const orc_space *world, const orc_options *world_opt, const o
                    const float backdrop[4], uint32_t row_begin, uint32_t row_end, int32_t threads,
                    uint8_t *rgba8, float *linear, orc_pixel_aux *aux, orc_info *info) {
     if (!world_cam || !world_opt) return -1;
-    if (world_opt->lighting == 5 || (ui_opt && ui_opt->lighting == 5)) return -2;  // Bounce: unpinned
     const uint32_t w = world_cam->width, h = world_cam->height;
     if (row_end > h) row_end = h;
     SR *wrt = world ? new SR(world, world_opt) : nullptr;

@@ -22,6 +22,19 @@ def test_library_exports_every_declared_symbol():
     assert lib.aic_abi_version() == 2
 
 
+def test_every_entry_point_taking_a_context_has_its_ctypes_signature():
+    """A ctypes call without argtypes passes a Python int as a 32-bit C int: a 64-bit context handle is cut in half and the call
+    crashes on the GPU box (round 4 met this in the first GPU run of aic_stream_wait_frame). Every context-taking entry point the
+    binding calls must therefore declare its argument types."""
+    header = (ROOT / "include" / "aic_hip.h").read_text()
+    src = (ROOT / "all_is_cubes_amd" / "abi.py").read_text()
+    takers = re.findall(r"\b(aic_[a-z0-9_]+)\s*\(\s*(?:const\s+)?aic_(?:ctx|multi)\s*\*", header)
+    assert len(takers) > 30
+    for name in takers:
+        if f"_lib.{name}(" in src or f"lib.{name}(" in src:
+            assert f"lib.{name}.argtypes" in src, f"{name}: called from abi.py without argtypes"
+
+
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(abi.BlockDesc) == 48 == flat.BLOCK_DTYPE.itemsize
     assert abi.PIXEL_AUX_DTYPE.itemsize == 56
