@@ -323,11 +323,8 @@ void fill_dev_layer(const aic_ctx *c, const Layer &l, const aic_camera &cam, Dev
     d->opt.fog = o.fog;
     d->opt.transparency = o.transparency;
     d->opt.threshold = o.threshold;
-    d->opt.lighting = o.lighting;
-    if (o.lighting == 5) {  // Bounce unsupported: "the renderer should substitute Linear" (graphics_options.rs:460-467)
-        d->opt.lighting = 3;
-        *flaws |= AIC_FLAW_UNSUPPORTED;
-    }
+    d->opt.lighting = o.lighting;  // 5 = Bounce: traced as the reference does (surface.rs:119-166; aic_trace.hip bounce_secondary_ray)
+    d->opt.bounce_samples = o.bounce_samples;
     d->opt.antialiasing = o.antialiasing;
     d->opt.debug_pixel_cost = o.debug_pixel_cost;
     d->opt.tone_mapping = o.tone_mapping;

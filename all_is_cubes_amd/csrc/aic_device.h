@@ -47,11 +47,13 @@ struct DevOptions {
     int32_t fog;
     int32_t transparency;
     float threshold;
-    int32_t lighting;       // after Bounce->Linear substitution
+    int32_t lighting;       // LightingOption: 0 None, 1 Flat, 2 Coarse, 3 Linear, 4 Smoothstep, 5 Bounce
     int32_t antialiasing;
     int32_t debug_pixel_cost;
     int32_t tone_mapping;
     float maximum_intensity;
+    int32_t bounce_samples;  // LightingOption::Bounce { samples } (u8)
+    int32_t pad_;
     double view_distance;
 };
 

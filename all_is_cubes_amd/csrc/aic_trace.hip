@@ -522,6 +522,262 @@ AIC_DEV uint32_t get_packed_light(const LayerT &L, int cx, int cy, int cz, uint3
     return L.light[idx];
 }
 
+
+// ---------------------------------------------------------------------------------------
+// LightingOption::Bounce (surface.rs:119-166): the secondary rays.
+//
+// A fully opaque surface lit with Bounce { samples } sends `samples` rays in Lambert-distributed directions and averages what they
+// see; each of them is a whole SpaceRaytracer::trace_ray_impl(ray, accumulator = ColorBuf, include_sky = true,
+// allow_ray_bounce = false) under the SAME GraphicsOptions -- transparency mode, fog (with the secondary ray's own length), the
+// 1000-step cap, debug_pixel_cost -- whose surfaces are lit Flat (surface.rs:171-176: the bounce budget is one). It runs inside the
+// SHADE event of the lane that found the surface, one lane at a time through plain loops (the iterator stack of the reference
+// restated over lvl_init / lvl_next, as the oracle has it): Bounce is a quality option nobody streams frames with, so this path
+// is written for exactness and small code, not speed, and only the <.., LMODE = 3, ..> instantiations contain it.
+// The random directions: rand::rngs::SmallRng (xoshiro256++, seeded from the primary ray's direction bits through SplitMix64,
+// sr.rs:165-178) and rand_distr::UnitSphere -- rand 0.10.1 / rand_distr 0.6.0, neither under /root/reference: restated from the
+// published algorithms (the test oracle restates them separately), PARITY UNPINNED (the reference has no golden for Bounce).
+struct BounceRng {
+    unsigned long long s0, s1, s2, s3;
+};
+AIC_DEV unsigned long long rotl64(unsigned long long x, int k) { return (x << k) | (x >> (64 - k)); }
+AIC_DEV BounceRng bounce_rng_seed(unsigned long long state) {  // SeedableRng::seed_from_u64 of Xoshiro256PlusPlus
+    unsigned long long w[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        state += 0x9e3779b97f4a7c15ull;
+        unsigned long long z = state;
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        w[i] = z ^ (z >> 31);
+    }
+    return BounceRng{w[0], w[1], w[2], w[3]};
+}
+AIC_DEV unsigned long long bounce_rng_next(BounceRng &g) {
+    const unsigned long long result = rotl64(g.s0 + g.s3, 23) + g.s0;
+    const unsigned long long t = g.s1 << 17;
+    g.s2 ^= g.s0;
+    g.s3 ^= g.s1;
+    g.s1 ^= g.s2;
+    g.s0 ^= g.s3;
+    g.s2 ^= t;
+    g.s3 = rotl64(g.s3, 45);
+    return result;
+}
+AIC_DEV double bounce_uniform_m1_1(BounceRng &g) {  // Uniform::<f64>::new(-1., 1.).sample
+    const double value1_2 = __longlong_as_double((long long)((bounce_rng_next(g) >> 12) | 0x3ff0000000000000ull));
+    return (value1_2 - 1.0) * 2.0 + -1.0;
+}
+AIC_DEV void bounce_unit_sphere(BounceRng &g, double out[3]) {  // rand_distr::UnitSphere (Marsaglia)
+    for (;;) {
+        const double x1 = bounce_uniform_m1_1(g), x2 = bounce_uniform_m1_1(g);
+        const double sum = x1 * x1 + x2 * x2;
+        if (sum >= 1.0) continue;
+        const double factor = 2.0 * sqrt(1.0 - sum);
+        out[0] = x1 * factor; out[1] = x2 * factor; out[2] = 1.0 - 2.0 * sum;
+        return;
+    }
+}
+
+struct SecSurface {  // what a secondary ray's Surface needs (Flat lighting: no intersection point)
+    float r, g, b, a, e0, e1, e2;
+    int cx, cy, cz, face;
+    double t;
+};
+
+// trace_ray_impl(ray, ColorBuf, include_sky = true, allow_ray_bounce = false) -> Rgba::from(buf).to_rgb(); returns the ray's
+// cubes_traced. `sky_mem`: the layer's sky[8][3] as memory (a per-lane index into a kernel-argument array would put it in scratch).
+template <bool DIAG, class LayerT>
+AIC_DEV uint32_t bounce_secondary_ray(const LayerT &L, const float *sky_mem, const float *lut, const double *s_pow, bool big,
+                                      double ox, double oy, double oz, double dirx, double diry, double dirz, float out[3]) {
+    const auto &opt = L.opt;
+    const bool vol = opt.transparency == 1;
+    const uint32_t idx_mask = big ? 0xffffu : kCubeIndexMask;
+    const uint32_t oct = ((dirx >= 0.0) ? 4u : 0u) | ((diry >= 0.0) ? 2u : 0u) | ((dirz >= 0.0) ? 1u : 0u);  // Sky::sample (sky.rs:32-41)
+    float sky[3];
+    {
+        const float *p = sky_mem + (L.sky_kind != 0 ? 3u * oct : 0u);
+        sky[0] = p[0]; sky[1] = p[1]; sky[2] = p[2];
+    }
+    const double t_abs = sqrt(dirx * dirx + diry * diry + dirz * dirz);   // sr.rs:146
+    const float t_view = (float)(t_abs / opt.view_distance);              // sr.rs:149-151
+    const bool fog_on = opt.fog != 0;
+    const float fog_blend = opt.fog == 1 ? 1.0f : (opt.fog == 2 ? 0.5f : 0.0f);
+    const RayDir rd = raydir_init(dirx, diry, dirz);
+    const double half_over_len = 0.5 / t_abs;
+    const int olx = L.lo[0], oly = L.lo[1], olz = L.lo[2], osx = L.size[0], osy = L.size[1], osz = L.size[2];
+    const int ohx = olx + osx, ohy = oly + osy, ohz = olz + osz;
+    const LvlLim oi = lvl_init(ox, oy, oz, rd, true, olx, oly, olz, ohx, ohy, ohz, true, half_over_len);
+    Lvl os = oi.s;
+    const Lim ol = oi.lim;
+    // the block the ray is inside (VoxelSurfaceIter, surface.rs:361-411)
+    bool inb = false;
+    Lvl is = oi.s;
+    Lim il = oi.lim;
+    int ilx = 0, ily = 0, ilz = 0, isx = 1, isy = 1, isz = 1, bcx = 0, bcy = 0, bcz = 0;
+    uint32_t blk_res = 1u, vox_off = 0u, pal_off = 0u, n_inv = 0u;
+    ColorBuf acc;
+    acc.l0 = acc.l1 = acc.l2 = 0.f; acc.t = 1.0f;
+    uint32_t count = 0;
+    bool has_last = false;  // DepthIter.last_surface
+    SecSurface last;
+    last.r = last.g = last.b = last.a = last.e0 = last.e1 = last.e2 = 0.f; last.cx = last.cy = last.cz = last.face = 0; last.t = 0.0;
+
+    auto count_step_should_stop = [&]() -> bool {  // sr.rs:625-656 (the exception hits are transparent: no effect on a ColorBuf)
+        count++;
+        if (count > 1000u) return true;
+        return cb_opaque(acc);
+    };
+    // Surface::to_light with Flat illumination + trace_through_surface's accumulate (surface.rs:73-106, 171-176; sr.rs:697-717)
+    auto through_surface = [&](const SecSurface &sf) {
+        float r = sf.r, g = sf.g, b = sf.b, a = sf.a;
+        if (opt.transparency == 2) {  // limit_alpha
+            if (a > opt.threshold) a = 1.0f;
+            else { r = g = b = a = 0.f; }
+        }
+        if (a == 0.f && sf.e0 == 0.f && sf.e1 == 0.f && sf.e2 == 0.f) return;
+        int nx = 0, ny = 0, nz = 0;
+        if (sf.face == 1) nx = -1; else if (sf.face == 2) ny = -1; else if (sf.face == 3) nz = -1;
+        else if (sf.face == 4) nx = 1; else if (sf.face == 5) ny = 1; else if (sf.face == 6) nz = 1;
+        uint32_t nl = 0;
+        const uint32_t txl = get_packed_light<false>(L, sf.cx + nx, sf.cy + ny, sf.cz + nz, nl);
+        const float i0 = lut[txl & 255u], i1 = lut[(txl >> 8) & 255u], i2 = lut[(txl >> 16) & 255u];
+        float o0 = ps_mul(ps_mul(r, i0), a) + sf.e0, o1 = ps_mul(ps_mul(g, i1), a) + sf.e1, o2 = ps_mul(ps_mul(b, i2), a) + sf.e2;
+        float tr = 1.0f - a;
+        if (fog_on) {  // distance_fog (sr.rs:745-768), with THIS ray's t_to_view_distance and sky
+            float rel = (float)sf.t * t_view;
+            rel = rel < 0.0f ? 0.0f : (rel > 1.0f ? 1.0f : rel);
+            const float sq = rel * rel;
+            const float fog_exp = 1.0f - expf_table(-1.6f * rel, s_pow);
+            const float fudged = fog_exp / 0.79810348f;
+            const float amount = zo_clamped(fudged * (1.0f - fog_blend) + (sq * sq) * fog_blend);
+            const float comp = 1.0f - amount;
+            o0 = ps_mul(o0, comp) + ps_mul(sky[0], amount);
+            o1 = ps_mul(o1, comp) + ps_mul(sky[1], amount);
+            o2 = ps_mul(o2, comp) + ps_mul(sky[2], amount);
+            tr *= comp;
+        }
+        cb_add(acc, o0, o1, o2, tr);
+    };
+    // trace_through_span (sr.rs:720-740) + apply_transmittance (raytracer_components.rs:215-258)
+    auto through_span = [&](SecSurface sf, double exit_t) {
+        float thickness = (float)((exit_t - sf.t) * t_abs);
+        thickness = fmaxf(thickness, 0.0f);
+        float coeff;
+        if (thickness == 0.0f) {
+            if (sf.a == 1.0f) coeff = 1.0f;
+            else { sf.r = sf.g = sf.b = sf.a = 0.f; coeff = 0.0f; }
+        } else {
+            const float unit_t = 1.0f - sf.a;
+            float depth_t;
+            if (unit_t == 0.0f) depth_t = 0.0f;
+            else if (unit_t == 1.0f) depth_t = 1.0f;
+            else if (!(thickness < __uint_as_float(0x7f800000u))) depth_t = 0.0f;
+            else depth_t = powf_table(unit_t, thickness, s_pow);
+            sf.a = zo_clamped(1.0f - depth_t);
+            const float ec = (unit_t == 1.0f) ? thickness : (depth_t - 1.f) / (unit_t - 1.f);
+            coeff = fmaxf(ec, 0.0f);
+        }
+        const float c = ps_clamped(coeff);
+        sf.e0 = ps_mul(sf.e0, c); sf.e1 = ps_mul(sf.e1, c); sf.e2 = ps_mul(sf.e2, c);
+        through_surface(sf);
+    };
+
+    for (;;) {
+        // ---- SurfaceIter::next (surface.rs:283-354): 1 Invisible, 2 EnterSurface, 3 EnterBlock, 0 the ray is over ----
+        int kind = 0;
+        double t = 0.0;
+        SecSurface cur = last;
+        if (inb) {
+            const NextResult nr = lvl_next(is, il, rd, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz);
+            is = nr.s;
+            if (nr.got) {
+                const double as = __hiloint2double((int)((1023u - (31u - (uint32_t)__clz((int)blk_res))) << 20), 0);  // 1 / resolution
+                t = is.last_t * as;
+                kind = 1;
+                if (!nr.is_exit) {
+                    const uint32_t vi = (uint32_t)(((uint32_t)(is.cx - ilx) * (uint32_t)isy + (uint32_t)(is.cy - ily)) * (uint32_t)isz + (uint32_t)(is.cz - ilz));
+                    const uint32_t code = L.pool[(size_t)vox_off + vi];
+                    if (code >= n_inv) {
+                        const DevPaletteEntry *pe = &L.palette[pal_off + code];
+                        kind = 2;
+                        cur.r = pe->color[0]; cur.g = pe->color[1]; cur.b = pe->color[2]; cur.a = pe->color[3];
+                        cur.e0 = pe->emission[0]; cur.e1 = pe->emission[1]; cur.e2 = pe->emission[2];
+                        cur.cx = bcx; cur.cy = bcy; cur.cz = bcz; cur.face = lvl_face(is); cur.t = t;
+                    }
+                }
+            } else {
+                inb = false;
+            }
+        }
+        if (kind == 0) {
+            const NextResult nr = lvl_next(os, ol, rd, olx, oly, olz, ohx, ohy, ohz);
+            os = nr.s;
+            if (!nr.got) break;
+            t = os.last_t;
+            kind = 1;
+            if (!nr.is_exit) {
+                const size_t ci = ((size_t)(uint32_t)(os.cx - olx) * (size_t)osy + (size_t)(uint32_t)(os.cy - oly)) * (size_t)osz + (size_t)(uint32_t)(os.cz - olz);
+                const uint32_t entry = L.pool[ci];
+                const uint32_t bi = entry & idx_mask;
+                const uint32_t cls = big ? ((L.cls[bi >> 4] >> ((bi & 15u) << 1)) & 3u) : (entry >> kCubeClassShift);
+                const DevBlock *tb = &L.blocks[bi];
+                if (cls == 1u) {
+                    kind = 2;
+                    cur.r = tb->color[0]; cur.g = tb->color[1]; cur.b = tb->color[2]; cur.a = tb->color[3];
+                    cur.e0 = tb->emission[0]; cur.e1 = tb->emission[1]; cur.e2 = tb->emission[2];
+                    cur.cx = os.cx; cur.cy = os.cy; cur.cz = os.cz; cur.face = lvl_face(os); cur.t = t;
+                } else if (cls == 2u) {
+                    // RaycastStep::recursive_raycast (raycast.rs:458-476): the sub-ray keeps the direction
+                    kind = 3;
+                    blk_res = tb->kind & 255u;
+                    const uint32_t vlo = tb->vlo_packed, vsz = tb->vsize_packed;
+                    ilx = (int)(vlo & 255u); ily = (int)((vlo >> 8) & 255u); ilz = (int)((vlo >> 16) & 255u);
+                    isx = (int)(vsz & 255u); isy = (int)((vsz >> 8) & 255u); isz = (int)((vsz >> 16) & 255u);
+                    vox_off = tb->vox_off; pal_off = tb->pal_off; n_inv = tb->n_invisible;
+                    bcx = os.cx; bcy = os.cy; bcz = os.cz;
+                    const double kd = (double)blk_res;
+                    const LvlLim ii = lvl_init((ox - (double)bcx) * kd, (oy - (double)bcy) * kd, (oz - (double)bcz) * kd, rd, true, ilx, ily, ilz,
+                                               ilx + isx, ily + isy, ilz + isz, true, half_over_len);
+                    is = ii.s;
+                    il = ii.lim;
+                    inb = true;
+                }
+            }
+        }
+        // ---- the tracing loop's body (sr.rs:183-225), DepthIter (surface.rs:453-491) folded in for Volumetric ----
+        if (vol) {
+            if (count_step_should_stop()) break;
+            if (kind == 2) {
+                if (has_last) through_span(last, cur.t);
+                last = cur;
+                has_last = true;
+            } else {
+                if (has_last) { has_last = false; through_span(last, t); }
+                if (kind == 3 && count_step_should_stop()) break;  // the buffered EnterBlock step
+            }
+        } else {
+            if (count_step_should_stop()) break;
+            if (kind == 2) through_surface(cur);
+        }
+    }
+    // finish (sr.rs:658-693): the sky, then the optional cost visualisation
+    cb_add(acc, sky[0] * 1.0f, sky[1] * 1.0f, sky[2] * 1.0f, 0.0f);
+    if (opt.debug_pixel_cost) {
+        const float n = ps_clamped((float)count);
+        const float red = ps_clamped(ps_mul(0.02f, n) * 1.0f);
+        const float green = ps_clamped(ps_mul(0.002f, n) * 1.0f);
+        float cur_rgba[4];
+        cb_to_rgba(acc, cur_rgba);
+        const float blue = ps_clamped(luminance(cur_rgba[0], cur_rgba[1], cur_rgba[2]) * 0.2f);
+        acc.l0 = red; acc.l1 = green; acc.l2 = blue; acc.t = 0.0f;
+    }
+    float c[4];
+    cb_to_rgba(acc, c);
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2];
+    (void)DIAG;
+    return count;
+}
+
 // ---------------------------------------------------------------------------------------
 // The image kernel.
 //
@@ -663,7 +919,7 @@ AIC_DEV Lvl lvl_first(Lvl s, const Lim lim, const RayDir rd, int lox, int loy, i
 // carried in the state: it is a pure function of t[], which nothing modifies between steps.
 
 template <bool VOL, int LMODE, bool DIAG, bool BIG>
-__global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trace_image_kernel(const DevFrame F) {
+__global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_WAVES) void trace_image_kernel(const DevFrame F) {
     // ---- persistent waves: each wave pulls 8x8-pixel tiles from a global counter until the
     // image is exhausted, so cheap (sky) and expensive (geometry) tiles balance dynamically ----
     const uint32_t lane = threadIdx.x & 63u;
@@ -730,6 +986,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
     float pend0 = 0.f, pend1 = 0.f, pend2 = 0.f, pend_tr = 1.f;
     // the block the lane is inside: palette offset; log2(resolution) << 24 | stored-volume lower corner; stored-volume size
     uint32_t blk_pal_off = 0, blk_geo = 0, blk_vsz = 0;
+    // LightingOption::Bounce (LMODE 3 only; dead code elsewhere): the ray's SmallRng (sr.rs:165-178) and what its secondary rays traced
+    BounceRng brng{0ull, 0ull, 0ull, 0ull};
+    uint32_t sec_steps = 0;
     // ---- per-lane state, cold: only events touch it, so it lives in LDS (one column per thread: conflict-free
     //      ds_read/ds_write), not in registers -- that is what lets the kernel run at 3-4 waves per SIMD ----
     enum { C_OX, C_OY, C_OZ, C_DX, C_DY, C_DZ,      // ray origin, direction (sanitised: Parameters::new, raycast.rs:749-771)
@@ -979,16 +1238,17 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 // illumination (surface.rs:113-206)
                 float i0 = 1.0f, i1 = 1.0f, i2 = 1.0f;
                 uint32_t nl = 0;
+                double ip[3] = {0.0, 0.0, 0.0};  // the surface point in space coordinates (LMODE 2: light interpolation; 3: the bounce rays' origin)
                 if (LMODE != 0) {
                     const int face = lvl_face(ca);
-                    if (LMODE == 1) {
+                    if (LMODE == 1 || LMODE == 3) {  // Flat; Bounce falls back to it for surfaces that are not fully opaque (surface.rs:171-176)
                         int nx = 0, ny = 0, nz = 0;
                         if (face == 1) nx = -1; else if (face == 2) ny = -1; else if (face == 3) nz = -1;
                         else if (face == 4) nx = 1; else if (face == 5) ny = 1; else if (face == 6) nz = 1;
                         const uint32_t txl = get_packed_light<DIAG>(L, ocx + nx, ocy + ny, ocz + nz, nl);
                         i0 = lut[txl & 255u]; i1 = lut[(txl >> 8) & 255u]; i2 = lut[(txl >> 16) & 255u];
-                    } else {
-                        double ip[3];
+                    }
+                    if (LMODE >= 2) {
                         const double ox = c64[C_OX][col], oy = c64[C_OY][col], oz = c64[C_OZ][col];
                         const double dx = c64[C_DX][col], dy = c64[C_DY][col], dz = c64[C_DZ][col];
                         if (inb) {
@@ -1001,6 +1261,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                         } else {
                             intersection_point(ca, ox, oy, oz, dx, dy, dz, ip);
                         }
+                    }
+                    if (LMODE == 2) {
                         // get_interpolated_light (sr.rs:248-359; aic_lightmath.h), then rgb / max(weight, 0.1)
                         float fin[4];
                         lm_interpolated_light(light_view(L), lut, ocx, ocy, ocz, ip[0], ip[1], ip[2], face, opt.lighting, fin, DIAG ? &nl : nullptr);
@@ -1068,6 +1330,28 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                 if (opt.transparency == 2) {  // limit_alpha (graphics_options.rs:496-507)
                     if (a > opt.threshold) a = 1.0f;
                     else { r = g = b = a = 0.f; }
+                }
+                if (LMODE == 3 && a == 1.0f) {
+                    // compute_illumination with the RNG and a fully opaque diffuse colour (surface.rs:85-88, 119-166): `samples` secondary
+                    // rays from just above the surface, directions normal + UnitSphere sample; their mean replaces the Flat light
+                    const int face = lvl_face(ca);
+                    double nvx = 0.0, nvy = 0.0, nvz = 0.0;
+                    if (face == 1) nvx = -1.0; else if (face == 2) nvy = -1.0; else if (face == 3) nvz = -1.0;
+                    else if (face == 4) nvx = 1.0; else if (face == 5) nvy = 1.0; else if (face == 6) nvz = 1.0;
+                    const float *sky_mem = (const float *)((const char *)(const void *)Fq + offsetof(DevFrame, layer) + offsetof(DevLayer, sky));
+                    const uint32_t n_samples_b = (uint32_t)opt.bounce_samples & 255u;  // `samples: u8`
+                    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+                    for (uint32_t k = 0; k < n_samples_b; k++) {
+                        double u[3];
+                        bounce_unit_sphere(brng, u);
+                        float c3[3];
+                        sec_steps += bounce_secondary_ray<DIAG>(L, sky_mem, lut, s_pow, BIG, ip[0] + nvx * 0.0001, ip[1] + nvy * 0.0001, ip[2] + nvz * 0.0001,
+                                                                nvx + u[0], nvy + u[1], nvz + u[2], c3);
+                        m0 += c3[0]; m1 += c3[1]; m2 += c3[2];
+                    }
+                    const float kk = ps_clamped(1.0f / (float)n_samples_b);  // Rgb * f32::from(samples).recip() (color.rs:912-925)
+                    i0 = ps_mul(m0, kk); i1 = ps_mul(m1, kk); i2 = ps_mul(m2, kk);
+                    nl = 0;  // (the Flat texel read above is not a get_packed_light call of the reference's for this surface)
                 }
                 float o0 = 0.f, o1 = 0.f, o2 = 0.f, tr = 1.0f;
                 const bool visible = !(a == 0.f && e0 == 0.f && e1 == 0.f && e2 == 0.f);
@@ -1220,12 +1504,12 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                         const float blue = ps_clamped(luminance(cur_rgba[0], cur_rgba[1], cur_rgba[2]) * 0.2f);
                         acc.l0 = red; acc.l1 = green; acc.l2 = blue; acc.t = 0.0f;
                     }
-                    c32[K_STEPS][tid] += count;
+                    c32[K_STEPS][tid] += count + (LMODE == 3 ? sec_steps : 0u);  // RaytraceInfo + secondary_info (sr.rs:690-692)
 #ifdef AIC_PROFILE
                     { const uint32_t dur_ = (uint32_t)__builtin_readcyclecounter() - s_ray_t0[col];
                       if (dur_ > ray_dur_max) { ray_dur_max = dur_; ray_dur_steps = count; } }
 #endif
-                    if (DIAG) px_steps += count;
+                    if (DIAG) px_steps += count + (LMODE == 3 ? sec_steps : 0u);
                 }
                 const uint32_t x = pxy & 0xffffu, lrow = pxy >> 16;
                 if (F.tile_cost && count > 48u) {
@@ -1502,6 +1786,11 @@ __global__ __launch_bounds__(AIC_WG_THREADS, DIAG ? 2 : AIC_MIN_WAVES) void trac
                     const double ox = o[0], oy = o[1], oz = o[2];
                     c64[C_OX][col] = ox; c64[C_OY][col] = oy; c64[C_OZ][col] = oz;
                     const double dirx = dir[0], diry = dir[1], dirz = dir[2];
+                    if (LMODE == 3) {  // SmallRng::seed_from_u64(bits(dx) + bits(dy) + bits(dz)) of the ray as given (sr.rs:165-178)
+                        brng = bounce_rng_seed((unsigned long long)__double_as_longlong(dirx) + (unsigned long long)__double_as_longlong(diry) +
+                                               (unsigned long long)__double_as_longlong(dirz));
+                        sec_steps = 0;
+                    }
                     const double t_abs = sqrt(dirx * dirx + diry * diry + dirz * dirz);  // sr.rs:146
                     c64[C_TABS][col] = t_abs;
                     c32[K_TVIEW][col] = __float_as_uint((float)(t_abs / opt.view_distance));  // sr.rs:149-151
@@ -2163,7 +2452,7 @@ static void launch_trace(const DevFrame &F, hipStream_t stream) {
     // waves than tiles (each wave pulls 8x8-pixel tiles from counters->tile_next)
     const uint32_t n_tiles = F.tiles_x * F.tiles_y;
     const uint32_t wg_waves = (uint32_t)AIC_WG_THREADS / 64u;
-    const uint32_t resident_groups = F.n_cus * 4u * (uint32_t)(DIAG ? 2 : AIC_MIN_WAVES) / wg_waves;  // 4 SIMDs per CU, that many waves on each
+    const uint32_t resident_groups = F.n_cus * 4u * (uint32_t)((DIAG || LMODE == 3) ? 2 : AIC_MIN_WAVES) / wg_waves;  // 4 SIMDs per CU, that many waves on each
     // A frame smaller than the chip that is STREAMED (aic_render_submit: a rank's strips of a multi-GPU frame, several in
     // flight) gets a grid in proportion to its tiles -- four tiles per wave, so that lanes are refilled instead of waves ending
     // after one tile, and the kernels of the frames in flight are resident side by side (an eighth of a 1080p frame, 8 in
@@ -2185,10 +2474,12 @@ static void launch_trace_diag(const DevFrame &F, bool vol, int lmode, hipStream_
     if (vol) {
         if (lmode == 0) launch_trace<true, 0, DIAG, BIG>(F, stream);
         else if (lmode == 1) launch_trace<true, 1, DIAG, BIG>(F, stream);
+        else if (lmode == 3) launch_trace<true, 3, DIAG, BIG>(F, stream);
         else launch_trace<true, 2, DIAG, BIG>(F, stream);
     } else {
         if (lmode == 0) launch_trace<false, 0, DIAG, BIG>(F, stream);
         else if (lmode == 1) launch_trace<false, 1, DIAG, BIG>(F, stream);
+        else if (lmode == 3) launch_trace<false, 3, DIAG, BIG>(F, stream);
         else launch_trace<false, 2, DIAG, BIG>(F, stream);
     }
 }
@@ -2196,7 +2487,7 @@ static void launch_trace_diag(const DevFrame &F, bool vol, int lmode, hipStream_
 void launch_trace_image(const DevFrame &F, bool diag, hipStream_t stream) {
     const bool vol = F.layer_transparency == 1;
     const int l = F.layer_lighting;
-    const int lmode = l == 0 ? 0 : (l == 1 ? 1 : 2);
+    const int lmode = l == 0 ? 0 : (l == 1 ? 1 : (l == 5 ? 3 : 2));  // None, Flat, Bounce, the interpolated three
     const bool big = F.layer.cls_in_code == 0u;  // block table past 16384 entries: untagged cube grid
     if (diag) {
         if (big) launch_trace_diag<true, true>(F, vol, lmode, stream);

@@ -43,7 +43,8 @@ extern "C" {
 #define AIC_LAYER_UI 1
 
 /* Flaws bits reported in aic_frame_info.flaws (all-is-cubes-render/src/flaws.rs:20-80) */
-#define AIC_FLAW_UNSUPPORTED 1u   /* LightingOption::Bounce rendered as Linear (graphics_options.rs:460-467) */
+#define AIC_FLAW_UNSUPPORTED 1u   /* an option was substituted (Flaws::UNSUPPORTED). Reported by nothing at present: LightingOption::Bounce, which
+                                   * rounds 1-3 rendered as Linear (graphics_options.rs:460-467), is traced as the reference does since round 4 */
 #define AIC_FLAW_NO_BLOOM 2u      /* renderer.rs:293-297 */
 
 /* block descriptor flags */

@@ -1978,6 +1978,26 @@ uint32_t orc_interpolated_light(const orc_space *space, const int32_t cube[3], c
 double orc_smoothstep(double x) { return smoothstep(x); }
 double orc_coarsestep(double x) { return coarsestep(x); }
 
+
+// The bounce rays' random numbers, exposed for tests: xoshiro256++ from an explicit state (the published reference vector), from
+// seed_from_u64 (SplitMix64), and rand_distr::UnitSphere samples drawn from it.
+void orc_xoshiro256pp(const uint64_t state[4], uint32_t n, uint64_t *out) {
+    SmallRng g;
+    for (int i = 0; i < 4; i++) g.s[i] = state[i];
+    for (uint32_t k = 0; k < n; k++) out[k] = g.next_u64();
+}
+void orc_small_rng(uint64_t seed, uint32_t n, uint64_t out_state[4], uint64_t *out_u64, double *out_sphere) {
+    SmallRng g;
+    g.seed_from_u64(seed);
+    for (int i = 0; i < 4; i++) out_state[i] = g.s[i];
+    SmallRng h = g;
+    for (uint32_t k = 0; k < n; k++) out_u64[k] = h.next_u64();
+    for (uint32_t k = 0; k < n; k++) {
+        const V3 u = g.unit_sphere();
+        out_sphere[3 * k] = u[0]; out_sphere[3 * k + 1] = u[1]; out_sphere[3 * k + 2] = u[2];
+    }
+}
+
 }  // extern "C"
 
 // part 2: the light updater

@@ -186,6 +186,9 @@ double orc_coarsestep(double x);
 void orc_compute_derived(const orc_space *space, float *out, uint8_t *out_opaque);
 /* the light propagation chart (space/light/chart/generator.rs): node count; weights[n][6], children[n][6] if non-null */
 uint32_t orc_light_chart(float *weights, uint32_t *children);
+/* LightingOption::Bounce: the restated rand 0.10 SmallRng (xoshiro256++ / SplitMix64 seeding) and rand_distr UnitSphere, for tests */
+void orc_xoshiro256pp(const uint64_t state[4], uint32_t n, uint64_t *out);
+void orc_small_rng(uint64_t seed, uint32_t n, uint64_t out_state[4], uint64_t *out_u64, double *out_sphere);
 /* LightStorage::compute_light (updater.rs:368-417) for one cube against space->light; returns the cost */
 uint64_t orc_compute_light(const orc_space *space, int32_t maximum_distance, const int32_t cube[3], uint8_t out_texel[4]);
 /* Mutation::fast_evaluate_light / evaluate_light (space.rs:1496-1540); see aic_light.inc */

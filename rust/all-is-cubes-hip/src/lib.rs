@@ -251,7 +251,7 @@ fn options_of(o: &GraphicsOptions) -> ffi::aic_options {
         LightingOption::Coarse => (2, 0),
         LightingOption::Linear => (3, 0),
         LightingOption::Smoothstep => (4, 0),
-        LightingOption::Bounce { samples } => (5, i32::from(samples)), // reported as Flaws::UNSUPPORTED by the device
+        LightingOption::Bounce { samples } => (5, i32::from(samples)), // traced on the device (secondary rays inside the SHADE event)
         _ => (3, 0),
     };
     ffi::aic_options {

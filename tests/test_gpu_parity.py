@@ -359,26 +359,41 @@ def test_hip_rt_renderer_update_and_draw(ctx, synth_space):
     cams.graphics_options = o
     r.update()
     img3 = r.draw("")
-    assert img3.flaws & H.Flaws.UNSUPPORTED  # Bounce is rendered as Linear and flagged
+    # Bounce is traced as such (round 4), not substituted by Linear (the UNSUPPORTED bit left in `flaws` is NO_CURSOR's)
+    o3 = oracle.make_options(lighting=5, bounce_samples=4)
+    ref3 = oracle.render(oracle.Space(synth_space), o3, oracle.make_camera(inv, w, h))
+    assert np.abs(img3.data.astype(int) - ref3["rgba8"].astype(int)).max() <= RGBA_TOL
+    assert img3.info.cubes_traced == int(ref3["info"]["cubes_traced"])
 
 
-def test_bounce_is_flagged_and_rendered_as_linear(ctx, synth_space):
-    """LightingOption::Bounce needs the reference's RNG stream (rand 0.10 SmallRng): not reproduced. The reference says what
-    a renderer without it does -- "substitute Linear" (graphics_options.rs:460-467) -- so the frame must be the Linear
-    frame, bit for bit, and carry Flaws::UNSUPPORTED."""
-    w, h = 160, 120
-    eye = (12.5, 20.5, 40.0)
-    q = oracle.look_at_y_up(eye, (12.0, 8.0, 12.0))
-    _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, q, eye)
-    ctx.upload_space(abi.LAYER_WORLD, synth_space)
-    ctx.clear_space(abi.LAYER_UI)
-    ctx.set_options(abi.LAYER_WORLD, abi.make_options(lighting=3))
-    linear = ctx.render(ctx.make_frame(w, h, world_inv=inv))
-    ctx.set_options(abi.LAYER_WORLD, abi.make_options(lighting=5, bounce_samples=4))
-    bounce = ctx.render(ctx.make_frame(w, h, world_inv=inv))
-    assert (bounce["rgba8"] == linear["rgba8"]).all()
-    assert bounce["info"].flaws & abi.FLAW_UNSUPPORTED
-    assert not (linear["info"].flaws & abi.FLAW_UNSUPPORTED)
+@pytest.mark.parametrize("transparency,samples,fog", [(0, 1, 1), (0, 3, 2), (1, 1, 1), (1, 4, 3), (2, 2, 0)])
+def test_bounce_lighting_matches_the_oracle(ctx, synth_space, transparency, samples, fog):
+    """LightingOption::Bounce { samples } proper (surface.rs:119-166): a fully opaque surface is lit by `samples` secondary rays --
+    whole trace_ray_impl calls under the same options, Flat-lit, sky included -- in directions drawn from the primary ray's
+    SmallRng (sr.rs:165-178) through rand_distr::UnitSphere. Device == oracle per pixel: step counts INCLUDING the secondary
+    rays' (RaytraceInfo + secondary_info), first hits, t bits, counters, RGBA8. Both restate rand 0.10.1 / rand_distr 0.6.0 from
+    their published algorithms: PARITY UNPINNED against the reference (it holds no golden for Bounce, cases/src/lib.rs:45-50)."""
+    opt = oracle.make_options(fog=fog, transparency=transparency, threshold=0.6, lighting=5, bounce_samples=samples)
+    got, ref = render_both(ctx, synth_space, opt, (128, 80), SYNTH_EYE, synth_quat())
+    assert_parity(got, ref)
+    assert not (got["info"].flaws & abi.FLAW_UNSUPPORTED)
+    # the production variant of the Bounce kernel draws the same frame and counts the same steps
+    fast = ctx.render(ctx.make_frame(128, 80, world_inv=oracle.camera_matrices(90.0, opt.view_distance, 128 / 80, synth_quat(), SYNTH_EYE)[2]))
+    assert (fast["rgba8"] == got["rgba8"]).all() and fast["info"].cubes_traced == got["info"].cubes_traced
+    # ... and it is not the Flat frame: the bounce rays did something
+    flat_opt = oracle.make_options(fog=fog, transparency=transparency, threshold=0.6, lighting=1)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(flat_opt))
+    flat_frame = ctx.render(ctx.make_frame(128, 80, world_inv=oracle.camera_matrices(90.0, opt.view_distance, 128 / 80, synth_quat(), SYNTH_EYE)[2]))
+    assert fast["info"].cubes_traced > flat_frame["info"].cubes_traced
+    assert (fast["rgba8"] != flat_frame["rgba8"]).any()
+
+
+def test_bounce_with_debug_pixel_cost_and_the_step_cap(ctx, synth_space):
+    """Secondary rays run trace_ray_impl's whole tail: `finish` applies debug_pixel_cost to THEIR accumulators too (sr.rs:658-693),
+    and the cost shown for the pixel counts primary steps only (primary_cubes_traced), while cubes_traced adds the secondary ones."""
+    opt = oracle.make_options(lighting=5, bounce_samples=2, debug_pixel_cost=True)
+    got, ref = render_both(ctx, synth_space, opt, (96, 64), SYNTH_EYE, synth_quat())
+    assert_parity(got, ref)
 
 
 def test_multi_part_gather_on_one_gpu(ctx, synth_space):

@@ -14,6 +14,6 @@ def test_no_register_of_a_lookup_in_flight_is_touched_before_its_wait():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     kernels, lookups, problems = mod.scan(mod.compile_to_asm())
-    assert kernels == 24, "every <VOL, LMODE, DIAG, BIG> instantiation of trace_image_kernel"
+    assert kernels == 32, "every <VOL, LMODE, DIAG, BIG> instantiation of trace_image_kernel"
     assert lookups >= 5 * kernels
     assert not problems, problems

@@ -153,3 +153,65 @@ def test_packed_light_lut(golden_dir):
     assert got.dtype == np.float32 and (got.view(np.uint32) == ref.view(np.uint32)).all()
     for i in range(255):
         assert oracle.packed_light_scalar_in(float(ref[i])) == i
+
+
+# --- LightingOption::Bounce: the restated random numbers (rand 0.10.1 SmallRng, rand_distr 0.6.0 UnitSphere) ----------------
+def test_bounce_rng_restatement():
+    """Neither crate is under /root/reference (registry dependencies), so these pin the restatement to what IS published:
+    the xoshiro256++ reference implementation's output for the state {1, 2, 3, 4} and SplitMix64's output for the seed 0 (what
+    SeedableRng::seed_from_u64 fills the state with). Bounce as a whole stays 'parity unpinned' (no golden in the reference)."""
+    import ctypes
+
+    lib = oracle.lib()
+    out = (ctypes.c_uint64 * 6)()
+    lib.orc_xoshiro256pp((ctypes.c_uint64 * 4)(1, 2, 3, 4), 6, out)
+    # xoshiro256plusplus.c (Blackman & Vigna): result = rotl(s0 + s3, 23) + s0, first two values by hand:
+    #   rotl(5, 23) + 1 = 41943041;  then s = {7, 0, 262146, 211106232532992}
+    assert list(out)[:2] == [41943041, 58720359]
+    assert list(out)[2:] == [3588806011781223, 3591011842654386, 9228616714210784205, 9973669472204895162]
+    state = (ctypes.c_uint64 * 4)()
+    u = (ctypes.c_uint64 * 8)()
+    sph = (ctypes.c_double * 24)()
+    lib.orc_small_rng.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.orc_small_rng(0, 8, state, u, sph)
+    assert [hex(v) for v in state] == ["0xe220a8397b1dcdaf", "0x6e789e6aa1b965f4", "0x6c45d188009454f", "0xf88bb8a8724c81ec"]  # splitmix64(0)
+    s = np.array(list(sph)).reshape(8, 3)
+    assert np.allclose((s * s).sum(axis=1), 1.0, atol=1e-15)  # UnitSphere: on the sphere
+    assert len({tuple(r) for r in s}) == 8
+    lib.orc_small_rng(0, 8, state, u, sph)
+    assert np.array_equal(s, np.array(list(sph)).reshape(8, 3))  # deterministic
+
+
+def test_bounce_falls_back_to_flat_on_surfaces_that_are_not_fully_opaque():
+    """surface.rs:85-88, 171-176: the RNG is handed to compute_illumination only for a fully opaque diffuse colour; every other
+    surface -- and every surface of a secondary ray -- is lit Flat. A scene of translucent atoms therefore renders identically
+    under Bounce and Flat, and traces no secondary step; an opaque scene does not."""
+    from all_is_cubes_amd import flat
+
+    def scene(alpha):
+        sp = flat.FlatSpace((0, 0, 0), (6, 4, 6))
+        sp.set_sky_uniform((0.3, 0.5, 0.9))
+        sp.add_block(flat.air())
+        a = sp.add_block(flat.atom((0.8, 0.4, 0.2, alpha)))
+        b = sp.add_block(flat.atom((0.2, 0.7, 0.3, alpha), emission=(0.1, 0.0, 0.2)))
+        sp.block_index[:, 0, :] = a
+        sp.block_index[2, 1, 2] = b
+        sp.block_index[4, 1:3, 3] = a
+        return sp
+
+    w, h = 64, 48
+    eye = (3.0, 3.5, 9.0)
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, (3.0, 1.0, 3.0)), eye)
+    cam = oracle.make_camera(inv, w, h)
+    for transparency in (0, 1):
+        flat_o = oracle.make_options(transparency=transparency, lighting=1)
+        bounce_o = oracle.make_options(transparency=transparency, lighting=5, bounce_samples=3)
+        tr = oracle.Space(scene(0.5))
+        f, b = oracle.render(tr, flat_o, cam), oracle.render(tr, bounce_o, cam)
+        if transparency == 0:  # Surface mode: alpha stays 0.5, never fully opaque
+            assert (f["rgba8"] == b["rgba8"]).all() and int(f["info"]["cubes_traced"]) == int(b["info"]["cubes_traced"])
+        op = oracle.Space(scene(1.0))
+        f, b = oracle.render(op, flat_o, cam), oracle.render(op, bounce_o, cam)
+        assert (f["rgba8"] != b["rgba8"]).any() and int(b["info"]["cubes_traced"]) > int(f["info"]["cubes_traced"])
+        again = oracle.render(op, bounce_o, cam)
+        assert (again["rgba8"] == b["rgba8"]).all()  # the RNG is seeded from the ray: deterministic
