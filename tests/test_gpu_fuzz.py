@@ -53,6 +53,8 @@ def test_random_scene_camera_options(seed):
         lighting=int(rng.integers(0, 5)), antialiasing=int(rng.choice([0, 0, 2])), debug_pixel_cost=bool(rng.random() < 0.1),
         tone_mapping=int(rng.integers(0, 2)), maximum_intensity=float(rng.choice([np.inf, 1.0, 2.5])),
         view_distance=float(rng.choice([6.0, 30.0, 200.0])))
+    if seed % 6 == 5:  # LightingOption::Bounce (drawn after the other options, so every other seed keeps its scene and options)
+        opt.lighting, opt.bounce_samples = 5, 1 + seed % 3
     lo, hi = np.array(sp.lo, float), np.array(sp.hi, float)
     mode = seed % 4
     if mode == 0:    # outside, looking at the centre

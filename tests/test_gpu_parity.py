@@ -29,7 +29,7 @@ def ctx():
 
 
 def to_abi_options(o: oracle.OrcOptions) -> abi.Options:
-    return abi.make_options(fog=o.fog, transparency=o.transparency, threshold=o.threshold, lighting=o.lighting,
+    return abi.make_options(fog=o.fog, transparency=o.transparency, threshold=o.threshold, lighting=o.lighting, bounce_samples=o.bounce_samples,
                             antialiasing=o.antialiasing, debug_pixel_cost=bool(o.debug_pixel_cost), tone_mapping=o.tone_mapping,
                             maximum_intensity=o.maximum_intensity, bloom_intensity=0.0, view_distance=o.view_distance)
 
