@@ -26,7 +26,7 @@ FRAME_COUNTERS, FRAME_AUX, FRAME_PIXEL_CENTERS, FRAME_OUT_LINEAR, FRAME_OUT_COLO
 ABI_SYMBOLS = [
     "aic_abi_version", "aic_create", "aic_destroy", "aic_last_error", "aic_device_name", "aic_upload_space",
     "aic_clear_space", "aic_update_cubes", "aic_update_light_volume", "aic_replace_block", "aic_replace_blocks", "aic_compact", "aic_set_options",
-    "aic_render", "aic_render_submit", "aic_render_wait", "aic_trace_patches", "aic_partition_rows", "aic_assemble_strips", "aic_read_aux", "aic_synchronize", "aic_stream", "aic_wait_event", "aic_stream_wait_frame",
+    "aic_render", "aic_render_submit", "aic_render_wait", "aic_trace_patches", "aic_partition_rows", "aic_assemble_strips", "aic_assemble_strips_async", "aic_read_aux", "aic_synchronize", "aic_stream", "aic_wait_event", "aic_stream_wait_frame",
     "aic_probe_raycast", "aic_probe_light_lut", "aic_probe_powf",
     "aic_ortho_image_size", "aic_render_orthographic",
     "aic_evaluate_light", "aic_light_cubes_changed", "aic_read_light_volume", "aic_light_chart", "aic_probe_derived", "aic_probe_log2f",
@@ -147,6 +147,7 @@ def load() -> C.CDLL:
         lib.aic_render_wait.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(FrameInfo)]
         lib.aic_trace_patches.argtypes = [C.c_void_p, C.POINTER(FrameDesc), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FrameInfo)]
         lib.aic_assemble_strips.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        lib.aic_assemble_strips_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.aic_read_aux.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         lib.aic_synchronize.argtypes = [C.c_void_p]
         lib.aic_wait_event.argtypes = [C.c_void_p, C.c_void_p]

@@ -1249,8 +1249,8 @@ int aic_render_wait(aic_ctx *c, uint32_t slot, aic_frame_info *info) {
     return wait_frame(c, slot, info);
 }
 
-int aic_assemble_strips(aic_ctx *c, const void *gathered_device, void *out_device, uint32_t width, uint32_t height,
-                        uint32_t strip_rows, uint32_t n_parts) {
+int aic_assemble_strips_async(aic_ctx *c, const void *gathered_device, void *out_device, uint32_t width, uint32_t height,
+                              uint32_t strip_rows, uint32_t n_parts) {
     if (!c || !gathered_device || !out_device || !strip_rows || !n_parts) return fail(c, AIC_ERR_INVALID, "aic_assemble_strips: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     uint32_t max_rows = 0;
@@ -1261,6 +1261,13 @@ int aic_assemble_strips(aic_ctx *c, const void *gathered_device, void *out_devic
     }
     launch_assemble_strips((const uint32_t *)gathered_device, (uint32_t *)out_device, width, height, strip_rows, n_parts, max_rows, c->stream);
     HIP_TRY(c, hipGetLastError());
+    return AIC_OK;
+}
+
+int aic_assemble_strips(aic_ctx *c, const void *gathered_device, void *out_device, uint32_t width, uint32_t height,
+                        uint32_t strip_rows, uint32_t n_parts) {
+    const int rc = aic_assemble_strips_async(c, gathered_device, out_device, width, height, strip_rows, n_parts);
+    if (rc != AIC_OK) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return AIC_OK;
 }

@@ -1331,7 +1331,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                     if (a > opt.threshold) a = 1.0f;
                     else { r = g = b = a = 0.f; }
                 }
-                if (LMODE == 3 && a == 1.0f) {
+                // (Volumetric: only for a span that WILL be emitted -- the reference lights a surface when its span comes out of
+                //  DepthIter and passes the stop check, i.e. at the ray's next counted step: sr.rs:183-199)
+                if (LMODE == 3 && a == 1.0f && (!VOL || (will_flush && count <= 999u))) {
                     // compute_illumination with the RNG and a fully opaque diffuse colour (surface.rs:85-88, 119-166): `samples` secondary
                     // rays from just above the surface, directions normal + UnitSphere sample; their mean replaces the Flat light
                     const int face = lvl_face(ca);
@@ -2238,7 +2240,12 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                 asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(count) : "s"(m_second) : "vcc");
                 m_stop2 = m_second & (__builtin_amdgcn_ballot_w64(count > 1000u) | m_opq);
             }
-            const mask_t m_shade = m_go & m_surf;
+            // A surface discovered by the very step whose pending span made the ray opaque is never lit: DepthIter has emitted the
+            // span and keeps the new surface as last_surface, but the ray's next step fails count_step_should_stop and that
+            // surface's span is never produced (surface.rs:453-491, sr.rs:183-189). Until round 4 such a lane was sent to SHADE all
+            // the same -- exact, its result was never applied, and wasted: every ray that ends on a solid with something behind it
+            // paid one whole SHADE event for nothing (and, with Bounce lighting, traced secondary rays the reference never traces).
+            const mask_t m_shade = m_go & m_surf & ~m_opq;
             const mask_t m_enter = m_go & m_blk & ~m_stop2;
             const mask_t m_fin = m_stop | m_stop2 | m_rayover;
             // a lane that parks leaves the trip with its event; one whose level ended while it still owes an event keeps DEAD

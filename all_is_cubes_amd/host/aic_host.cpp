@@ -749,10 +749,14 @@ ImageInfo HipRtRenderer::draw_rows_to_device(void *device_out, uint32_t strip_ro
     check(aic_render(ctx_, &f, device_out, 1, &fi), "aic_render");
     return to_info(fi, f.width, f.height);
 }
-void HipRtRenderer::assemble_strips(const void *gathered_device, void *out_device, uint32_t strip_rows, uint32_t n_parts) {
+void HipRtRenderer::assemble_strips(const void *gathered_device, void *out_device, uint32_t strip_rows, uint32_t n_parts, bool wait) {
     const Viewport vp = world_camera_.viewport();
-    check(aic_assemble_strips(ctx_, gathered_device, out_device, vp.framebuffer_width, vp.framebuffer_height, strip_rows, n_parts),
-          "aic_assemble_strips");
+    if (wait)
+        check(aic_assemble_strips(ctx_, gathered_device, out_device, vp.framebuffer_width, vp.framebuffer_height, strip_rows, n_parts),
+              "aic_assemble_strips");
+    else
+        check(aic_assemble_strips_async(ctx_, gathered_device, out_device, vp.framebuffer_width, vp.framebuffer_height, strip_rows, n_parts),
+              "aic_assemble_strips_async");
 }
 
 void HipRtRenderer::submit_rows_to_device(void *device_out, uint32_t strip_rows, uint32_t n_parts, uint32_t part, uint32_t slot) {

@@ -318,7 +318,7 @@ class HipRtRenderer : public HeadlessRenderer {
     ImageInfo draw_rows_to_device(void *device_out, uint32_t strip_rows, uint32_t n_parts, uint32_t part, bool counters = false,
                                   bool no_feedback = false);
     uint32_t partition_rows(uint32_t strip_rows, uint32_t n_parts, uint32_t part) const;
-    void assemble_strips(const void *gathered_device, void *out_device, uint32_t strip_rows, uint32_t n_parts);
+    void assemble_strips(const void *gathered_device, void *out_device, uint32_t strip_rows, uint32_t n_parts, bool wait = true);
     // streaming pair (aic_render_submit / aic_render_wait): up to AIC_MAX_IN_FLIGHT frames in flight
     void submit_rows_to_device(void *device_out, uint32_t strip_rows, uint32_t n_parts, uint32_t part, uint32_t slot);
     ImageInfo wait_rows(uint32_t slot);

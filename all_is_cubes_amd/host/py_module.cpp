@@ -236,9 +236,9 @@ PYBIND11_MODULE(_host, m) {
         }, py::arg("device_ptr"), py::arg("strip_rows"), py::arg("n_parts"), py::arg("part"), py::arg("slot"))
         .def("wait_rows", [](HipRtRenderer &r, uint32_t slot) { py::gil_scoped_release rel; return r.wait_rows(slot); }, py::arg("slot"))
         .def("synchronize", [](HipRtRenderer &r) { py::gil_scoped_release rel; r.synchronize(); })
-        .def("assemble_strips", [](HipRtRenderer &r, uintptr_t gathered, uintptr_t out, uint32_t strip_rows, uint32_t n_parts) {
-            r.assemble_strips(reinterpret_cast<const void *>(gathered), reinterpret_cast<void *>(out), strip_rows, n_parts);
-        })
+        .def("assemble_strips", [](HipRtRenderer &r, uintptr_t gathered, uintptr_t out, uint32_t strip_rows, uint32_t n_parts, bool wait) {
+            r.assemble_strips(reinterpret_cast<const void *>(gathered), reinterpret_cast<void *>(out), strip_rows, n_parts, wait);
+        }, py::arg("gathered"), py::arg("out"), py::arg("strip_rows"), py::arg("n_parts"), py::arg("wait") = true)
         .def("modified_viewport", &HipRtRenderer::modified_viewport)
         .def("device_name", &HipRtRenderer::device_name)
         .def("stream", [](const HipRtRenderer &r) { return reinterpret_cast<uintptr_t>(r.stream()); })

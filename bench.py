@@ -358,7 +358,7 @@ def main() -> int:
                 torch.cuda.synchronize()
                 g = stage_buf
             if per_gather == 1:
-                renderer.assemble_strips(g.data_ptr(), frame_buf.data_ptr(), strip, world)
+                renderer.assemble_strips(g.data_ptr(), frame_buf.data_ptr(), strip, world, not device_handoff)  # (device hand-off: enqueue only)
             else:
                 for k in range(n_valid):
                     pipe.assemble(g, k, out=frame_buf)
@@ -742,6 +742,14 @@ def main() -> int:
                                                   inv=REPLAY.get("inv") if is_replay else None)
             if result["cpu_baseline"]["value"]:
                 result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 2)
+        # (RCCL prints a version banner through C stdio, which sits in its buffer until the process exits when stdout is a file
+        #  or a pipe: flush it now, so that the bench line is the LAST line of the output)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
         print(json.dumps(result), flush=True)
     if exchange:
         dist.barrier()

@@ -235,6 +235,11 @@ uint32_t aic_partition_rows(uint32_t height, const aic_partition *partition);
  * gathered = [n_parts][max_rows_per_part][width] pixels, out = [height][width]. */
 int aic_assemble_strips(aic_ctx *ctx, const void *gathered_device, void *out_device, uint32_t width, uint32_t height,
                         uint32_t strip_rows, uint32_t n_parts);
+/* The same de-interleave queued on the context's stream WITHOUT waiting for it: for an exchange loop that only enqueues
+ * (aic_stream_wait_frame / aic_wait_event order the device side). The image is complete once the stream is (aic_synchronize, or an
+ * event of the caller's recorded behind it through aic_stream). */
+int aic_assemble_strips_async(aic_ctx *ctx, const void *gathered_device, void *out_device, uint32_t width, uint32_t height,
+                              uint32_t strip_rows, uint32_t n_parts);
 /* read back the aux records of the last aic_render issued with AIC_FRAME_AUX
  * ([rows_rendered][width]). */
 int aic_read_aux(aic_ctx *ctx, aic_pixel_aux *out, uint64_t n_records);

@@ -197,6 +197,7 @@ unsafe extern "C" {
     pub fn aic_trace_patches(ctx: *mut aic_ctx, frame: *const aic_frame_desc, n: u32, rects: *const f64, out_rgba8: *mut c_void, aux: *mut aic_pixel_aux, info: *mut aic_frame_info) -> c_int;
     pub fn aic_partition_rows(height: u32, partition: *const aic_partition) -> u32;
     pub fn aic_assemble_strips(ctx: *mut aic_ctx, gathered_device: *const c_void, out_device: *mut c_void, width: u32, height: u32, strip_rows: u32, n_parts: u32) -> c_int;
+    pub fn aic_assemble_strips_async(ctx: *mut aic_ctx, gathered_device: *const c_void, out_device: *mut c_void, width: u32, height: u32, strip_rows: u32, n_parts: u32) -> c_int;
     pub fn aic_read_aux(ctx: *mut aic_ctx, out: *mut aic_pixel_aux, n_records: u64) -> c_int;
     pub fn aic_synchronize(ctx: *mut aic_ctx) -> c_int;
     pub fn aic_stream(ctx: *mut aic_ctx) -> *mut c_void;
