@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "aic_ortho_image_size", "aic_render_orthographic",
     "aic_evaluate_light", "aic_light_cubes_changed", "aic_read_light_volume", "aic_light_chart", "aic_probe_derived", "aic_probe_log2f",
     "aic_create_multi", "aic_destroy_multi", "aic_multi_device_count", "aic_multi_context", "aic_multi_last_error", "aic_multi_upload_space",
-    "aic_multi_clear_space", "aic_multi_update_cubes", "aic_multi_update_light_volume", "aic_multi_evaluate_light", "aic_multi_replace_blocks", "aic_multi_set_options",
+    "aic_multi_clear_space", "aic_multi_update_cubes", "aic_multi_update_light_volume", "aic_multi_evaluate_light", "aic_multi_light_cubes_changed", "aic_multi_replace_blocks", "aic_multi_set_options",
     "aic_multi_render",
 ]
 
@@ -535,6 +535,7 @@ class MultiContext:
         lib.aic_multi_set_options.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         lib.aic_multi_update_light_volume.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         lib.aic_multi_evaluate_light.argtypes = [C.c_void_p, C.c_int, C.POINTER(LightParams), C.POINTER(LightInfo)]
+        lib.aic_multi_light_cubes_changed.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_int]
         lib.aic_multi_update_cubes.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.aic_multi_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         ids = np.ascontiguousarray(device_ids, np.int32)

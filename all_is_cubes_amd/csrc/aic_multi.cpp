@@ -31,6 +31,7 @@ struct aic_multi {
     void *frame = nullptr;           // on device 0: the assembled frame when the caller wants a host copy
     size_t frame_bytes = 0;
     size_t n_cubes[2] = {0, 0};      // per layer: cubes of the uploaded space (sizes the light volume hand-over)
+    bool light_stale[2] = {false, false};  // device 0's light volume was changed (aic_multi_light_cubes_changed) and not yet handed to the others
     std::string err;
 };
 
@@ -142,14 +143,34 @@ int aic_multi_set_options(aic_multi *m, int layer, const aic_options *o) { AIC_M
 
 // The light updater is a sequential relaxation (it does not shard): it runs on the first device, and the resulting volume
 // is handed to the others, so that every device traces the same light.
-int aic_multi_evaluate_light(aic_multi *m, int layer, const aic_light_params *p, aic_light_info *info) {
-    if (!m || m->ctx.empty() || (layer != 0 && layer != 1)) return mfail(m, AIC_ERR_INVALID, "aic_multi_evaluate_light: bad argument");
-    int rc = forward(m, 0, aic_evaluate_light(m->ctx[0], layer, p, info));
-    if (rc != AIC_OK || m->ctx.size() == 1) return rc;
+namespace {
+// device 0's light volume of a layer to every other device
+int broadcast_light(aic_multi *m, int layer) {
+    m->light_stale[layer] = false;
+    if (m->ctx.size() == 1) return AIC_OK;
     std::vector<uint8_t> light(m->n_cubes[layer] * 4);
     if (light.empty()) return AIC_OK;
-    rc = forward(m, 0, aic_read_light_volume(m->ctx[0], layer, light.data()));
+    int rc = forward(m, 0, aic_read_light_volume(m->ctx[0], layer, light.data()));
     for (size_t i = 1; rc == AIC_OK && i < m->ctx.size(); i++) rc = forward(m, i, aic_update_light_volume(m->ctx[i], layer, light.data()));
+    if (rc != AIC_OK) m->light_stale[layer] = true;
+    return rc;
+}
+}  // namespace
+
+int aic_multi_evaluate_light(aic_multi *m, int layer, const aic_light_params *p, aic_light_info *info) {
+    if (!m || m->ctx.empty() || (layer != 0 && layer != 1)) return mfail(m, AIC_ERR_INVALID, "aic_multi_evaluate_light: bad argument");
+    const int rc = forward(m, 0, aic_evaluate_light(m->ctx[0], layer, p, info));
+    if (rc != AIC_OK) return rc;
+    return broadcast_light(m, layer);
+}
+
+// aic_light_cubes_changed on the device that runs the light updater. The OPAQUE texels it writes there (and its queue) are device
+// 0's alone until the volume is next handed over: the layer is marked, and aic_multi_render hands the volume over before it traces
+// if no aic_multi_evaluate_light came in between -- every device always traces the same light.
+int aic_multi_light_cubes_changed(aic_multi *m, int layer, uint32_t n, const int32_t *xyz, int queue_order) {
+    if (!m || m->ctx.empty() || (layer != 0 && layer != 1)) return mfail(m, AIC_ERR_INVALID, "aic_multi_light_cubes_changed: bad argument");
+    const int rc = forward(m, 0, aic_light_cubes_changed(m->ctx[0], layer, n, xyz, queue_order));
+    if (rc == AIC_OK && n) m->light_stale[layer] = true;
     return rc;
 }
 
@@ -161,6 +182,11 @@ int aic_multi_render(aic_multi *m, const aic_frame_desc *f, void *out_rgba8, int
     const size_t n = m->ctx.size();
     const uint32_t w = f->width, h = f->height;
     if (info) std::memset(info, 0, sizeof(*info));
+    for (int layer = 0; layer < 2; layer++)
+        if (m->light_stale[layer]) {
+            const int rc = broadcast_light(m, layer);
+            if (rc != AIC_OK) return rc;
+        }
     if (n == 1) {
         const int rc = forward(m, 0, aic_render(m->ctx[0], f, out_rgba8, out_is_device, info));
         return rc;

@@ -368,6 +368,10 @@ int aic_probe_derived(aic_ctx *ctx, int layer, float *out, uint8_t *out_opaque);
 int aic_probe_log2f(aic_ctx *ctx, const float *x, uint32_t n, float *out);
 /* aic_evaluate_light on the first device; the resulting light volume is handed to the others (the updater does not shard) */
 int aic_multi_evaluate_light(aic_multi *m, int layer, const aic_light_params *params, aic_light_info *info);
+/* aic_light_cubes_changed on the device that runs the light updater (device 0). What it writes there reaches the other devices with
+ * the next aic_multi_evaluate_light, or -- if none comes first -- at the start of the next aic_multi_render: all devices always trace
+ * the same light volume. */
+int aic_multi_light_cubes_changed(aic_multi *m, int layer, uint32_t n, const int32_t *xyz, int queue_order);
 
 #ifdef __cplusplus
 }

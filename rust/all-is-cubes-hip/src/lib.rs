@@ -133,6 +133,7 @@ impl Device {
         }
     }
     /// The context the light updater runs on (a sequential relaxation: it does not shard; csrc/aic_multi.cpp).
+    #[allow(dead_code)]
     fn first_ctx(self) -> *mut ffi::aic_ctx {
         match self {
             Device::One(c) => c.as_ptr(),
@@ -206,6 +207,16 @@ impl Device {
                 Device::One(c) => ffi::aic_evaluate_light(c.as_ptr(), layer, params, info),
                 // runs on device 0 and hands the resulting volume to the others
                 Device::Many(m) => ffi::aic_multi_evaluate_light(m.as_ptr(), layer, params, info),
+            }
+        })
+    }
+    /// `aic_light_cubes_changed` for cubes whose block `update_cubes` just changed (updater.rs:135-173).
+    fn light_cubes_changed(self, layer: core::ffi::c_int, xyz: &[i32], n: u32) -> Result<(), RenderError> {
+        // SAFETY: live handle, `xyz` holds 3 * n coordinates and outlives the call
+        self.check(unsafe {
+            match self {
+                Device::One(c) => ffi::aic_light_cubes_changed(c.as_ptr(), layer, n, xyz.as_ptr(), QUEUE_ORDER),
+                Device::Many(m) => ffi::aic_multi_light_cubes_changed(m.as_ptr(), layer, n, xyz.as_ptr(), QUEUE_ORDER),
             }
         })
     }
@@ -385,9 +396,9 @@ impl HipRtRenderer {
                     // block indices only; the device relights what changed. (A CubeLight message of the host Space lands
                     // here too and is harmless: the cube's block index is rewritten with the value it already has.)
                     device.update_cubes(layer, &xyz, &idx, None)?;
-                    let ctx = device.first_ctx();
-                    // SAFETY: live context, `xyz` outlives the call
-                    device.check(unsafe { ffi::aic_light_cubes_changed(ctx, layer, idx.len() as u32, xyz.as_ptr(), QUEUE_ORDER) })?;
+                    // (several devices: the updater runs on the first; `aic_multi_light_cubes_changed` marks the volume so that the
+                    //  next draw hands it to the others even if no evaluate_light_budgeted comes in between)
+                    device.light_cubes_changed(layer, &xyz, idx.len() as u32)?;
                 } else {
                     device.update_cubes(layer, &xyz, &idx, Some(&light))?;
                 }

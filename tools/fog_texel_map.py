@@ -73,3 +73,51 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def hysteresis():
+    """Is the converged light near a lamp a unique fixed point? A cube under a lamp sees the lamp's face lit by ITS OWN stored light
+    (updater.rs:812-826: light_from_struck_face = emission + colour.reflect(stored light of the cube in front of the face) -- the cube
+    itself), so its 8-bit log-scale texel feeds back into its own next value. For the cubes next to every lamp: lower / raise the
+    converged red texel by one unit, recompute the cube, and see whether it returns (unique fixed point) or stays (two stable states:
+    which one a run ends in depends on the side it is approached from, i.e. on the whole update history)."""
+    import copy
+    sp = fog_space()
+    oracle.evaluate_light(sp, maximum_distance=30, fast=True, epsilon=1, batch=32, hb_width=16)
+    lo = np.array(sp.lo)
+    z_length = 60
+    lamps = [((z * 19) % 60 - 30, 8, z + 1) for z in range(-z_length, 0, 2)]
+    print("\n## hysteresis of the texels next to a lamp (red channel; converged value v; recomputed after setting it to v-1 / v+1)")
+    stay_lo = stay_hi = n = 0
+    rows = []
+    for lamp in lamps:
+        for off in ((0, -1, 0), (0, 1, 0), (1, 0, 0), (-1, 0, 0), (0, 0, 1), (0, -2, 0), (0, 2, 0)):
+            c = tuple(int(a + b) for a, b in zip(lamp, off))
+            i = tuple(int(a - b) for a, b in zip(c, lo))
+            if not all(0 <= i[k] < sp.size[k] for k in range(3)) or int(sp.block_index[i]) != 0:
+                continue
+            v = int(sp.light[i][0])
+            res = []
+            for dv in (-1, +1):
+                t = copy.deepcopy(sp)
+                t.light[i][0] = max(0, min(255, v + dv))
+                out, _ = oracle.compute_light(oracle.Space(t), c, 30)
+                res.append(int(out[0]))
+            same, _ = oracle.compute_light(oracle.Space(sp), c, 30)
+            n += 1
+            stay_lo += res[0] == v - 1
+            stay_hi += res[1] == v + 1
+            rows.append((off, v, int(same[0]), res[0], res[1]))
+    by_off = {}
+    for off, v, same, lo_, hi_ in rows:
+        by_off.setdefault(off, []).append((v, same, lo_, hi_))
+    for off, lst in by_off.items():
+        a = np.array(lst)
+        print(f"   offset {off}: {len(lst):2d} cubes, converged red {a[:, 0].min()}..{a[:, 0].max()}; recomputed as is: unchanged {int((a[:, 1] == a[:, 0]).sum())}; "
+              f"from v-1: stays at v-1 {int((a[:, 2] == a[:, 0] - 1).sum())}, returns to v {int((a[:, 2] == a[:, 0]).sum())}; "
+              f"from v+1: stays at v+1 {int((a[:, 3] == a[:, 0] + 1).sum())}, returns to v {int((a[:, 3] == a[:, 0]).sum())}")
+    print(f"   total {n} texels: {stay_lo} have a second stable state one unit lower, {stay_hi} one unit higher")
+
+
+if __name__ == "__main__" and "--hysteresis" in sys.argv:
+    hysteresis()
