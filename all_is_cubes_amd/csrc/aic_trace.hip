@@ -1414,7 +1414,27 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                         bool early = AIC_EARLY_APPLY && !DIAG && !(ev & EV_DEAD) && count <= 999u;
                         const float n0 = acc.l0 + o0 * acc.t, n1 = acc.l1 + o1 * acc.t, n2 = acc.l2 + o2 * acc.t, nt = acc.t * tr;
                         early = early && !(nt < 1.0f / 256.0f);
-                        if (early) {
+#ifndef AIC_OPAQUE_SHORTCUT
+#define AIC_OPAQUE_SHORTCUT 1
+#endif
+                        // A span that makes the ray opaque decides the rest of the ray, whatever lies behind it: the ray's next step is
+                        // counted and applies the span (the accumulator is opaque from there), the step after that -- if the iterators
+                        // still yield one -- is counted and stops the ray (sr.rs:183-189, 625-656). What those two steps find is
+                        // irrelevant (a surface would never be lit, an EnterBlock's second item is that stopping step), only whether they
+                        // exist: a level that is not over always yields a next step (a cell or its exit step), and a second one unless that
+                        // next step is the exit step of the cube grid, or of a block whose enclosing grid level has ended. So the lane
+                        // finishes here: two lookups, two full stepping passes and a scheduler round trip less for every ray that ends
+                        // on a solid. (Not the aux-recording variant: its per-level lookup counters follow the reference's iterators.)
+                        const bool finish_now = AIC_OPAQUE_SHORTCUT && !DIAG && !(ev & EV_DEAD) && count <= 998u && (nt < 1.0f / 256.0f);
+                        if (finish_now) {
+                            const int pk = pick_axis(tx, ty, tz);
+                            const uint32_t r_next = pk == 0 ? rx : (pk == 1 ? ry : rz);  // steps left on that axis minus one: 0 = the exit step is next
+                            const bool second = (r_next != 0u) || (inb && (st & ST_OUTER_ALIVE));
+                            acc.l0 = n0; acc.l1 = n1; acc.l2 = n2; acc.t = nt;
+                            count += second ? 2u : 1u;
+                            st |= ST_OPAQUE;
+                            ev = (ev & EV_SHADE) | EV_FINISH;  // (EV_SHADE is cleared below)
+                        } else if (early) {
                             acc.l0 = n0; acc.l1 = n1; acc.l2 = n2; acc.t = nt;
                         } else {
                             pend0 = o0; pend1 = o1; pend2 = o2; pend_tr = tr;
@@ -1424,7 +1444,14 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                     }
                 } else if (visible) {
                     cb_add(acc, o0, o1, o2, tr);  // trace_through_surface (sr.rs:697-717)
-                    if (cb_opaque(acc)) st |= ST_OPAQUE;
+                    if (cb_opaque(acc)) {
+                        st |= ST_OPAQUE;
+                        // (as above, Surface transparency: the ray's next step is counted and stops it; a level that is not over yields one)
+                        if (AIC_OPAQUE_SHORTCUT && !DIAG && !(ev & EV_DEAD) && count <= 999u) {
+                            count += 1u;
+                            ev = (ev & EV_SHADE) | EV_FINISH;
+                        }
+                    }
                     if (DIAG) {
                         dg.n_hits++;
                         dg.n_light += sd.nlight;

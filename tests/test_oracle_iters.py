@@ -157,7 +157,7 @@ def test_packed_light_lut(golden_dir):
 
 # --- LightingOption::Bounce: the restated random numbers (rand 0.10.1 SmallRng, rand_distr 0.6.0 UnitSphere) ----------------
 def test_bounce_rng_restatement():
-    """Neither crate is under /root/reference (registry dependencies), so these pin the restatement to what IS published:
+    """Neither crate is vendored with the reference (registry dependencies), so these pin the restatement to what IS published:
     the xoshiro256++ reference implementation's output for the state {1, 2, 3, 4} and SplitMix64's output for the seed 0 (what
     SeedableRng::seed_from_u64 fills the state with). Bounce as a whole stays 'parity unpinned' (no golden in the reference)."""
     import ctypes
