@@ -243,6 +243,8 @@ int convert_block(aic_ctx *c, const aic_block_desc &d, const uint16_t *voxels, c
             return fail(c, AIC_ERR_INVALID, "block voxel bounds exceed GridAab::for_block(resolution)");
     }
     if (d.pal_len == 0 && nvox > 0) return fail(c, AIC_ERR_INVALID, "block has voxels but an empty palette");
+    if (!palette && (one || d.pal_len > 0)) return fail(c, AIC_ERR_INVALID, "block has a palette length but no palette");
+    if (!voxels && !one && nvox > 0) return fail(c, AIC_ERR_INVALID, "block has a voxel volume but no voxels");
     // Evoxel colours are the reference's Rgba = PositiveSign<f32> x 3 + ZeroOne<f32> (math/color.rs:288-314): components that type
     // cannot hold (NaN, negative, alpha above 1) are rejected here, and the kernel's powf / compositing rely on it
     for (uint32_t i = 0; i < (one ? 1u : d.pal_len) && palette; i++) {
@@ -984,10 +986,14 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         // AIC_MIGRATE_K=<n> makes a wave hand its rays over once it is down to n of them; off by default
         static const uint32_t migrate_k = [] { const char *e = std::getenv("AIC_MIGRATE_K"); const int v = e ? std::atoi(e) : 0; return (uint32_t)(v < 0 ? 0 : (v > 64 ? 64 : v)); }();
         if (migrate_k && !diag) {
-            const size_t groups = (size_t)c->n_cus * 4u;  // the persistent grid never exceeds the resident workgroups (launch_trace)
+            // room for the largest persistent grid any build launches (16 waves per CU as 64-thread workgroups), 256 columns each; the
+            // kernel is told the capacity and a workgroup beyond it simply keeps its rays (the size was duplicated from
+            // launch_trace's defaults and a build with other AIC_MIN_WAVES / AIC_WG_THREADS would have written past the buffer)
+            const size_t groups = (size_t)c->n_cus * 16u;
             if ((e = fs.orphans.ensure(groups * 256u * (kOrphanDwords / 4u))) != hipSuccess) return hip_fail(c, "alloc migration buffer", e);
             F.orphans = fs.orphans.p;
             F.migrate_k = migrate_k;
+            F.migrate_groups = (uint32_t)groups;
         }
     }
     HIP_TRY(c, hipEventRecord(fs.ev0, fs.stream));

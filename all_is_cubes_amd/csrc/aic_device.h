@@ -161,6 +161,7 @@ struct DevFrame {
     // (workgroup, LDS column); a wave hands its rays over once the tile queue is dry and it has at most migrate_k of them (0: off)
     uint4 *orphans;
     uint32_t migrate_k;
+    uint32_t migrate_groups;  // workgroups `orphans` has room for (x 256 columns x kOrphanDwords): a workgroup past that does not migrate
 };
 constexpr uint32_t kOrphanDwords = 40u;
 

@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
     c32[K_STEPS][tid] = 0u;
     c32[K_BLK][tid] = 0u;
     c32[K_PXY][tid] = 0u;
-    const uint32_t mig_k = MIGRATE ? F.migrate_k : 0u;
+    const uint32_t mig_k = (MIGRATE && blockIdx.x < F.migrate_groups && (uint32_t)AIC_WG_THREADS <= 256u) ? F.migrate_k : 0u;  // (the buffer has 256 columns per workgroup)
     const bool anchor = (threadIdx.x >> 6) == 0u;   // the wave of the workgroup that adopts, never hands over, and leaves last
     bool dry = false;                               // wave-uniform: this wave has seen the tile queue exhausted
     bool donated = false;
@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
             if ((live >> lane) & 1ull) {
                 const uint32_t rank = (uint32_t)__popcll(live & ((1ull << lane) - 1ull));
                 s_pool_col[base + rank] = (uint8_t)col;
-                uint4 *dst = Fq->orphans + ((size_t)blockIdx.x * (uint32_t)AIC_WG_THREADS + col) * (kOrphanDwords / 4u);
+                uint4 *dst = Fq->orphans + ((size_t)blockIdx.x * 256u + col) * (kOrphanDwords / 4u);
                 const unsigned long long b0 = (unsigned long long)__double_as_longlong(tx), b1 = (unsigned long long)__double_as_longlong(ty),
                                          b2 = (unsigned long long)__double_as_longlong(tz), b3 = (unsigned long long)__double_as_longlong(last_t),
                                          b4 = (unsigned long long)__double_as_longlong(tdx), b5 = (unsigned long long)__double_as_longlong(tdy),
@@ -1663,7 +1663,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                                 col = s_pool_col[taken + rank];
                                 lds64 = (uint32_t)(uintptr_t)&c64[0][col];
                                 lds32 = (uint32_t)(uintptr_t)&c32[0][col];
-                                const uint4 *src = F.orphans + ((size_t)blockIdx.x * (uint32_t)AIC_WG_THREADS + col) * (kOrphanDwords / 4u);
+                                const uint4 *src = F.orphans + ((size_t)blockIdx.x * 256u + col) * (kOrphanDwords / 4u);
                                 const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], q5 = src[5], q6 = src[6], q7 = src[7], q8 = src[8], q9 = src[9];
                                 tx = __longlong_as_double((long long)(((unsigned long long)q0.y << 32) | q0.x));
                                 ty = __longlong_as_double((long long)(((unsigned long long)q0.w << 32) | q0.z));
