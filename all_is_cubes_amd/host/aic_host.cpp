@@ -611,8 +611,10 @@ Rendering HipRtRenderer::draw_rgba(const std::string &info_text) {  // renderer.
     if (!info_text.empty() && world_camera_.options().debug_info_text && f.width && f.height) {
         uint8_t black[4], white[4];
         const float k0[3] = {0.f, 0.f, 0.f}, k1[3] = {1.f, 1.f, 1.f};
-        encode_paint(world_camera_, k0, black);
-        encode_paint(world_camera_, k1, white);
+        // (the exposure the kernel's encoder used for this frame: the recorded one when a camera override is active -- ADVICE r03)
+        const float paint_exposure = cam_override_ ? cam_override_exposure_ : world_camera_.exposure();
+        encode_paint(world_camera_, paint_exposure, k0, black);
+        encode_paint(world_camera_, paint_exposure, k1, white);
         draw_info_text(r.data.data(), f.width, f.height, black, white, info_text);
     }
     return r;
@@ -679,11 +681,11 @@ void draw_info_text(uint8_t *rgba, uint32_t width, uint32_t height, const uint8_
     }
 }
 
-void encode_paint(const Camera &camera, const float rgb_in[3], uint8_t out[4]) {
+void encode_paint(const Camera &camera, float exposure, const float rgb_in[3], uint8_t out[4]) {
     const GraphicsOptions &o = camera.options();
     float c[3];
     for (int k = 0; k < 3; k++) {  // rgb * exposure (PositiveSign: 0 * inf = 0)
-        const float v = rgb_in[k] * camera.exposure();
+        const float v = rgb_in[k] * exposure;
         c[k] = (v != v) ? 0.f : v;
     }
     if (std::isfinite(o.maximum_intensity)) {  // ToneMappingOperator::apply (graphics_options.rs:352-368)

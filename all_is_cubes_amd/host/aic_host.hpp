@@ -267,7 +267,7 @@ struct Rendering {  // headless.rs:52-67
 void draw_info_text(uint8_t *rgba, uint32_t width, uint32_t height, const uint8_t outline[4], const uint8_t foreground[4], const std::string &text);
 // Camera::post_process_color(color).to_srgb8() (camera_struct.rs:376-382, math/color.rs:669-676, 1038-1054) of an opaque
 // colour: what the reference's encoder makes of the overlay's black and white paints
-void encode_paint(const class Camera &camera, const float rgb[3], uint8_t out[4]);
+void encode_paint(const class Camera &camera, float exposure, const float rgb[3], uint8_t out[4]);
 
 struct UiViewState {  // stdcam.rs UiViewState
     std::shared_ptr<Space> space;

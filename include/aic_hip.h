@@ -74,7 +74,11 @@ typedef struct aic_space_desc {
     const aic_block_desc *blocks;
     const uint16_t *voxels;      /* pool of palette indices, Z-major per block */
     uint64_t n_voxels;
-    const float *palette;        /* pool [n_palette][8]: Evoxel color rgba, emission rgb, pad */
+    const float *palette;        /* pool [n_palette][8]: Evoxel color rgba, emission rgb, pad. Every component must be what the
+                                  * reference's Rgba / Rgb can hold (PositiveSign<f32> x 3 + ZeroOne<f32>, math/color.rs:288-314): not NaN,
+                                  * not negative, alpha <= 1 -- anything else is rejected with AIC_ERR_INVALID by aic_upload_space /
+                                  * aic_replace_block(s) (since round 3; the kernel's compositing and its table powf rely on it). A block
+                                  * with pal_len > 0 (or AIC_BLOCK_ONE) needs a non-null palette, one with voxels a non-null voxel pool. */
     uint64_t n_palette;
     int32_t sky_kind;            /* 0 Sky::Uniform(sky[0]); 1 Sky::Octants (sky.rs:16-21) */
     float sky[8][3];
