@@ -1077,6 +1077,49 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
     // (the counters hold steps left MINUS ONE, so that running out is the borrow of the decrement: see dda_step)
     auto coord = [](uint32_t positive, int size, uint32_t r) -> int { return positive ? size - 1 - (int)r : (int)r; };
 
+    // -- State::step (raycast.rs:577-626) along the axis of the smallest t_max (strict <, ties to the
+    //    later axis: raycast.rs:584-596): X iff tx<ty && tx<tz, Y iff !(tx<ty) && ty<tz, else Z.
+    //    One exec-masked run per axis: last_t = t; t += t_delta; steps_left -= 1; offset += stride. --
+    auto dda_step = [&](const unsigned long long m_who) -> unsigned long long {
+        unsigned long long sv, mx, bz, by, bx;
+        // last_t = the smallest t_max, whichever axis holds it: Z iff tz is that minimum (ties go to the later axis),
+        // Y iff ty is and tz is not, X otherwise -- two v_min and two compares instead of three compares and three copies.
+        // The steps-left counters are biased by one, so "ran out" is the borrow of the decrement (the carry-out of an
+        // exec-masked v_sub_co is zero for the lanes it does not run on). Keeping the stepped axis in wave masks instead
+        // of `lax` (3 vector instructions less, 6 scalar more) was measured and is slower: profiles/r03_experiments.txt I.
+        asm volatile(
+            "s_and_saveexec_b64 %[sv], %[m]\n\t"
+            "v_min_f64 %[lt], %[tx], %[ty]\n\t"
+            "v_min_f64 %[lt], %[lt], %[tz]\n\t"
+            "v_cmp_eq_f64 %[mx], %[tz], %[lt]\n\t"        // Z
+            "v_cmp_eq_f64 vcc, %[ty], %[lt]\n\t"
+            "s_andn2_b64 vcc, vcc, %[mx]\n\t"             // Y
+            "s_mov_b64 exec, %[mx]\n\t"
+            "v_add_f64 %[tz], %[tz], %[tdz]\n\t"
+            "v_sub_co_u32 %[rz], %[bz], %[rz], 1\n\t"
+            "v_add_u32 %[bo], %[bo], %[ssz]\n\t"
+            "v_mov_b32 %[lax], 2\n\t"
+            "s_or_b64 %[mx], %[mx], vcc\n\t"
+            "s_mov_b64 exec, vcc\n\t"
+            "v_add_f64 %[ty], %[ty], %[tdy]\n\t"
+            "v_sub_co_u32 %[ry], %[by], %[ry], 1\n\t"
+            "v_add_u32 %[bo], %[bo], %[ssy]\n\t"
+            "v_mov_b32 %[lax], 1\n\t"
+            "s_andn2_b64 exec, %[m], %[mx]\n\t"           // X = stepping lanes that took neither
+            "v_add_f64 %[tx], %[tx], %[tdx]\n\t"
+            "v_sub_co_u32 %[rx], %[bx], %[rx], 1\n\t"
+            "v_add_u32 %[bo], %[bo], %[ssx]\n\t"
+            "v_mov_b32 %[lax], 0\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
+            "s_or_b64 %[bz], %[bz], %[by]\n\t"
+            "s_or_b64 %[bz], %[bz], %[bx]\n\t"
+            : [tx] "+v"(tx), [ty] "+v"(ty), [tz] "+v"(tz), [lt] "+v"(last_t), [rx] "+v"(rx), [ry] "+v"(ry), [rz] "+v"(rz),
+              [bo] "+v"(boff), [lax] "+v"(lax), [sv] "=&s"(sv), [mx] "=&s"(mx),
+              [bz] "=&s"(bz), [by] "=&s"(by), [bx] "=&s"(bx)
+            : [tdx] "v"(tdx), [tdy] "v"(tdy), [tdz] "v"(tdz), [ssx] "v"(ssx), [ssy] "v"(ssy), [ssz] "v"(ssz), [m] "s"(m_who)
+            : "vcc", "scc");  // (the scalar mask operations write SCC)
+        return bz;  // lanes whose level ran out of steps: it left its bounds
+    };
     for (;;) {
         // ---- wave scheduler: step, or run ONE kind of parked work for all lanes waiting on it ----
         // Kinds: SHADE (light + composite a surface), ENTER (a block), RAY (finish / start a ray). A
@@ -1165,6 +1208,26 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
             const int t_batch = t_lo < AIC_T_BATCH ? t_lo : AIC_T_BATCH;
             const int n_few = part_n < AIC_N_FEW ? part_n : AIC_N_FEW;
 #endif
+#ifndef AIC_T_SHADE
+#define AIC_T_SHADE AIC_T_BATCH  // SHADE's own batching threshold (its lanes take their next step inside the event: they lose nothing by waiting)
+#endif
+#ifndef AIC_FRAC_S
+#define AIC_FRAC_S AIC_FRAC_T
+#endif
+            if (AIC_T_SHADE != AIC_T_BATCH || AIC_FRAC_S != AIC_FRAC_T) {
+                // per-kind thresholds: a kind is ready at its own count; among the ready kinds the fullest runs; with too few lanes
+                // left stepping the fullest of all runs, ready or not
+                const int part_s = (alive * AIC_FRAC_S) >> 3;
+                const int s_lo = opaque_s(part_s > 0 ? part_s : 1);
+                const int t_shade = s_lo < AIC_T_SHADE ? s_lo : AIC_T_SHADE;
+                int rbest = 0;
+                uint32_t rkind = 0u;
+                if (c_shade >= t_shade) { rbest = c_shade; rkind = EV_SHADE; }
+                if (c_enter >= t_batch && c_enter > rbest) { rbest = c_enter; rkind = EV_ENTER; }
+                if (c_ray >= t_batch && c_ray > rbest) { rbest = c_ray; rkind = EV_FINISH; }
+                if (rkind != 0u) run = rkind;
+                else if (best > 0 && n_step <= n_few) run = kind;
+            } else
             if (best > 0 && (best >= t_batch || n_step <= n_few)) run = kind;
         }
         AIC_TICK(19);
@@ -1215,6 +1278,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
             //    the surface is discovered: it is the t_max of the step the level takes next. The
             //    contribution is therefore computed here in full and merely *applied* by the stepping code
             //    when that next step is counted (so the order count -> stop-check -> accumulate is kept). --
+            bool fuse = false;  // SHADE: the lane's next step is certain to be a plain counted one -- taken in the event's tail (below)
             if (run == EV_SHADE && (ev & EV_SHADE)) {
                 const bool inb = (st & ST_IN_BLOCK) != 0;
                 const uint32_t blk_res = 1u << (blk_geo >> 24), blk_vlo = blk_geo & 0xffffffu;
@@ -1436,13 +1500,16 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                             ev = (ev & EV_SHADE) | EV_FINISH;  // (EV_SHADE is cleared below)
                         } else if (early) {
                             acc.l0 = n0; acc.l1 = n1; acc.l2 = n2; acc.t = nt;
+                            fuse = true;
                         } else {
                             pend0 = o0; pend1 = o1; pend2 = o2; pend_tr = tr;
                             st |= ST_HAS_LAST;
                         }
                         if (DIAG) { pend_d = sd; pend_t = t_enter; pend_visible = visible; }
                     }
-                } else if (visible) {
+                } else if (!visible) {
+                    fuse = !DIAG && !(ev & EV_DEAD) && count <= 999u;
+                } else {
                     cb_add(acc, o0, o1, o2, tr);  // trace_through_surface (sr.rs:697-717)
                     if (cb_opaque(acc)) {
                         st |= ST_OPAQUE;
@@ -1451,6 +1518,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                             count += 1u;
                             ev = (ev & EV_SHADE) | EV_FINISH;
                         }
+                    } else {
+                        fuse = !DIAG && !(ev & EV_DEAD) && count <= 999u;
                     }
                     if (DIAG) {
                         dg.n_hits++;
@@ -1464,6 +1533,58 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                     }
                 }
                 ev &= ~EV_SHADE;
+            }
+#ifndef AIC_SHADE_STEP
+#define AIC_SHADE_STEP 1
+#endif
+            // -- The shaded lanes' next step, taken here. A lane inside a run of translucent voxels alternates one step and one SHADE:
+            //    as a stepping lane it took that step in a full pass of a trip (its lookup finds the next voxel at once, so no fast
+            //    step serves it) and was parked again -- half of such a lane's life was spent waiting for the other half's phase,
+            //    and every SHADE phase ran at half width because the run lanes were away stepping. A lane whose span has been applied
+            //    (or that met an invisible surface) and that is not near the cap is exactly in the fast-step state: its next step is
+            //    produced, counted and passes the stop check whatever it finds. So all such lanes take it together in this event's
+            //    tail: DDA step, lookup; a lane that finds another surface stays parked for SHADE (the phase that follows serves
+            //    it again, now together with the lanes that were waiting); one that finds an invisible cube / voxel goes back to
+            //    stepping with the step counted; one that left its bounds or met a recursive block is put back as it was and takes
+            //    the step in a trip, which has the bookkeeping for those. Same steps, same order per ray: bit-identical. --
+            if (AIC_SHADE_STEP && !DIAG && !BIG && run == EV_SHADE) {
+                const unsigned long long m_fz = __builtin_amdgcn_ballot_w64(fuse);
+                if (m_fz != 0ull) {
+                    const double v_tx = tx, v_ty = ty, v_tz = tz, v_lt = last_t;
+                    const uint32_t v_rx = rx, v_ry = ry, v_rz = rz, v_bo = boff, v_lax = lax;
+                    const unsigned long long m_x = dda_step(m_fz);
+                    const unsigned long long m_lk = m_fz & ~m_x;
+                    uint32_t code, code_in_flight;
+                    {
+                        unsigned long long sv;
+                        asm volatile(
+                            "s_mov_b64 %[sv], exec\n\t"
+                            "s_mov_b64 exec, %[m]\n\t"
+                            "global_load_ushort %[q], %[bo], %[pool]\n\t"
+                            "s_mov_b64 exec, %[sv]\n\t"
+                            "s_waitcnt vmcnt(0)\n\t"
+                            "v_mov_b32 %[o], %[q]\n\t"
+                            : [o] "=&v"(code), [q] "=&v"(code_in_flight), [sv] "=&s"(sv)
+                            : [bo] "v"(boff), [pool] "s"(pool_bits), [m] "s"(m_lk)
+                            : "memory");
+                    }
+                    const unsigned long long m_ge = __builtin_amdgcn_ballot_w64(code >= thr) & m_lk;
+                    // (a cube-grid entry past 2 << kCubeClassShift is a recursive block: ENTER needs a trip's bookkeeping)
+                    const unsigned long long m_rec = __builtin_amdgcn_ballot_w64(code >= (2u << kCubeClassShift) && !(st & ST_IN_BLOCK)) & m_lk;
+                    const unsigned long long m_surf2 = m_ge & ~m_rec, m_inv2 = m_lk & ~m_ge;
+                    const unsigned long long m_took = m_surf2 | m_inv2, m_undo = m_fz & ~m_took;
+                    if (m_undo != 0ull) {
+                        const bool bk = __builtin_amdgcn_inverse_ballot_w64(m_undo);
+                        tx = bk ? v_tx : tx; ty = bk ? v_ty : ty; tz = bk ? v_tz : tz; last_t = bk ? v_lt : last_t;
+                        rx = bk ? v_rx : rx; ry = bk ? v_ry : ry; rz = bk ? v_rz : rz; boff = bk ? v_bo : boff; lax = bk ? v_lax : lax;
+                    }
+                    const bool took = __builtin_amdgcn_inverse_ballot_w64(m_took);
+                    count += took ? 1u : 0u;
+                    raw = took ? code : raw;
+                    ev = __builtin_amdgcn_inverse_ballot_w64(m_surf2) ? (ev | EV_SHADE) : ev;
+                    AIC_PROF(28, 1);
+                    AIC_PROF(29, __popcll(m_surf2));
+                }
             }
             // -- entering a recursive block: RaycastStep::recursive_raycast (raycast.rs:458-476),
             //    advanced to its first in-bounds voxel (or to its end) --
@@ -1911,49 +2032,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
             AIC_PROF(10, 1);
             AIC_PROF(11, __popcll(m_act));
             mask_t m_step = m_act & ~(m_fresh | m_dead);  // the level takes its next step
-            // -- State::step (raycast.rs:577-626) along the axis of the smallest t_max (strict <, ties to the
-            //    later axis: raycast.rs:584-596): X iff tx<ty && tx<tz, Y iff !(tx<ty) && ty<tz, else Z.
-            //    One exec-masked run per axis: last_t = t; t += t_delta; steps_left -= 1; offset += stride. --
-            auto dda_step = [&](const mask_t m_who) -> mask_t {
-                mask_t sv, mx, bz, by, bx;
-                // last_t = the smallest t_max, whichever axis holds it: Z iff tz is that minimum (ties go to the later axis),
-                // Y iff ty is and tz is not, X otherwise -- two v_min and two compares instead of three compares and three copies.
-                // The steps-left counters are biased by one, so "ran out" is the borrow of the decrement (the carry-out of an
-                // exec-masked v_sub_co is zero for the lanes it does not run on). Keeping the stepped axis in wave masks instead
-                // of `lax` (3 vector instructions less, 6 scalar more) was measured and is slower: profiles/r03_experiments.txt I.
-                asm volatile(
-                    "s_and_saveexec_b64 %[sv], %[m]\n\t"
-                    "v_min_f64 %[lt], %[tx], %[ty]\n\t"
-                    "v_min_f64 %[lt], %[lt], %[tz]\n\t"
-                    "v_cmp_eq_f64 %[mx], %[tz], %[lt]\n\t"        // Z
-                    "v_cmp_eq_f64 vcc, %[ty], %[lt]\n\t"
-                    "s_andn2_b64 vcc, vcc, %[mx]\n\t"             // Y
-                    "s_mov_b64 exec, %[mx]\n\t"
-                    "v_add_f64 %[tz], %[tz], %[tdz]\n\t"
-                    "v_sub_co_u32 %[rz], %[bz], %[rz], 1\n\t"
-                    "v_add_u32 %[bo], %[bo], %[ssz]\n\t"
-                    "v_mov_b32 %[lax], 2\n\t"
-                    "s_or_b64 %[mx], %[mx], vcc\n\t"
-                    "s_mov_b64 exec, vcc\n\t"
-                    "v_add_f64 %[ty], %[ty], %[tdy]\n\t"
-                    "v_sub_co_u32 %[ry], %[by], %[ry], 1\n\t"
-                    "v_add_u32 %[bo], %[bo], %[ssy]\n\t"
-                    "v_mov_b32 %[lax], 1\n\t"
-                    "s_andn2_b64 exec, %[m], %[mx]\n\t"           // X = stepping lanes that took neither
-                    "v_add_f64 %[tx], %[tx], %[tdx]\n\t"
-                    "v_sub_co_u32 %[rx], %[bx], %[rx], 1\n\t"
-                    "v_add_u32 %[bo], %[bo], %[ssx]\n\t"
-                    "v_mov_b32 %[lax], 0\n\t"
-                    "s_mov_b64 exec, %[sv]\n\t"
-                    "s_or_b64 %[bz], %[bz], %[by]\n\t"
-                    "s_or_b64 %[bz], %[bz], %[bx]\n\t"
-                    : [tx] "+v"(tx), [ty] "+v"(ty), [tz] "+v"(tz), [lt] "+v"(last_t), [rx] "+v"(rx), [ry] "+v"(ry), [rz] "+v"(rz),
-                      [bo] "+v"(boff), [lax] "+v"(lax), [sv] "=&s"(sv), [mx] "=&s"(mx),
-                      [bz] "=&s"(bz), [by] "=&s"(by), [bx] "=&s"(bx)
-                    : [tdx] "v"(tdx), [tdy] "v"(tdy), [tdz] "v"(tdz), [ssx] "v"(ssx), [ssy] "v"(ssy), [ssz] "v"(ssz), [m] "s"(m_who)
-                    : "vcc", "scc");  // (the scalar mask operations write SCC)
-                return bz;  // lanes whose level ran out of steps: it left its bounds
-            };
+            // (the step itself: dda_step, defined above the persistent loop -- the SHADE event's fused step uses it too)
             // -- Steps that cannot mean anything, taken ahead of the bookkeeping below. Four steps in five find an invisible cube
             //    or voxel inside the bounds while the ray has no span pending (DepthIter), is not opaque yet and is far from the
             //    1000-step cap: such a TraceStep is counted and has no other effect (sr.rs:625-656, surface.rs:453-491). A lane

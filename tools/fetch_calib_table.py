@@ -22,7 +22,7 @@ def counters(sub, name):
                     continue
                 k = row.get("Kernel_Name", "")
                 for key, label in kern.items():
-                    if re.search(re.escape(key) + r"\b|" + re.escape(key) + r"\(", k) or k.startswith("void " + key) or k.startswith(key):
+                    if k.startswith("void " + key) or k.startswith(key):
                         out.setdefault(label, []).append(float(row["Counter_Value"]) * 1024.0)
     return {k: sum(v) / len(v) for k, v in out.items()}
 
@@ -41,3 +41,24 @@ for name, p in pat.items():
         cells += [f"{'-':>14}", f"{'-':>9}", f"{'-':>14}", f"{'-':>13}"]
     cells += [f"{wv:>14.0f}" if wv is not None else f"{'-':>14}"]
     print(" ".join(cells))
+raw = {}
+for sub, names in (("calib_raw", ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_MISS_sum", "TCC_HIT_sum")), ("calib_raw2", ("TCP_TCC_READ_REQ_sum", "TCC_REQ_sum", "TCC_READ_sum"))):
+    for nm in names:
+        got = {}
+        for p in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
+            with open(p) as f:
+                for row in csv.DictReader(f):
+                    if row["Counter_Name"] != nm:
+                        continue
+                    k = row.get("Kernel_Name", "")
+                    for key, label in kern.items():
+                        if k.startswith("void " + key) or k.startswith(key):
+                            got.setdefault(label, []).append(float(row["Counter_Value"]))
+        if got:
+            raw[nm] = {k: sum(v) / len(v) for k, v in got.items()}
+if raw:
+    print("\n# raw request counters per read (the same patterns); TCC_EA0_RDREQ = L2 -> fabric read requests, _32B = those of 32 bytes")
+    names = list(raw)
+    print(f"{'pattern':<12} " + " ".join(f"{n.replace('_sum', ''):>20}" for n in names))
+    for name, p in pat.items():
+        print(f"{name:<12} " + " ".join((f"{raw[n][name] / p['reads']:>20.4f}" if name in raw[n] else f"{'-':>20}") for n in names))

@@ -10,5 +10,9 @@ O=gpurun_out/$TAG; mkdir -p "$O"
 rm -rf "$O"/calib_fetch "$O"/calib_write
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/calib_fetch" -- tools/ubench/fetch_calib > "$O/calib_patterns.csv" 2> "$O/calib_fetch.err"
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/calib_write" -- tools/ubench/fetch_calib > /dev/null 2> "$O/calib_write.err"
+# the raw request counters FETCH_SIZE is derived from (the derived metric turned out to report nothing for 2-byte loads): which of
+# them see a global_load_ushort that misses L2?
+timeout 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_MISS_sum TCC_HIT_sum --output-format csv -d "$O/calib_raw" -- tools/ubench/fetch_calib > /dev/null 2> "$O/calib_raw.err"
+timeout 300 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_READ_sum --output-format csv -d "$O/calib_raw2" -- tools/ubench/fetch_calib > /dev/null 2> "$O/calib_raw2.err"
 python tools/fetch_calib_table.py "$O" | tee "$O/fetch_calib.txt"
-find "$O"/calib_fetch "$O"/calib_write -type f -size +1M -delete
+find "$O"/calib_fetch "$O"/calib_write "$O"/calib_raw "$O"/calib_raw2 -type f -size +1M -delete

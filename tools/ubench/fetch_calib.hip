@@ -32,11 +32,13 @@ __global__ void stream16(const uint4 *p, size_t n, uint32_t *sink) {
     for (; i < n; i += (size_t)gridDim.x * blockDim.x) { const uint4 v = p[i]; a ^= v.x ^ v.y ^ v.z ^ v.w; }
     if (a == 0x12345678u) *sink = a;
 }
+// (the u16 kernels compare with a value 16 bits CAN hold: with 0x12345678 the compiler proves the store dead and drops the loads --
+//  the first run of this file "measured" 1.3 us kernels that way)
 __global__ void dense2(const uint16_t *p, size_t n, uint32_t *sink) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t a = 0;
     for (; i < n; i += (size_t)gridDim.x * blockDim.x) a ^= p[i];
-    if (a == 0x12345678u) *sink = a;
+    if (a == 0x5a5au) *sink = a;
 }
 // one u16 every `stride_elems` elements: lane i of the grid reads element i * stride_elems
 template <int STRIDE_BYTES>
@@ -44,7 +46,7 @@ __global__ void gather2_stride(const uint16_t *p, size_t n_reads, uint32_t *sink
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t a = 0;
     for (; i < n_reads; i += (size_t)gridDim.x * blockDim.x) a ^= p[i * (size_t)(STRIDE_BYTES / 2)];
-    if (a == 0x12345678u) *sink = a;
+    if (a == 0x5a5au) *sink = a;
 }
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
@@ -56,7 +58,7 @@ __global__ void gather2_rnd(const uint16_t *p, size_t n_reads, size_t n_elems, u
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t a = 0;
     for (; i < n_reads; i += (size_t)gridDim.x * blockDim.x) a ^= p[mix64(i) % n_elems];
-    if (a == 0x12345678u) *sink = a;
+    if (a == 0x5a5au) *sink = a;
 }
 __global__ void gather4_rnd(const uint32_t *p, size_t n_reads, size_t n_elems, uint32_t *sink) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
