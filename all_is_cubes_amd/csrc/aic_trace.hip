@@ -1535,7 +1535,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                 ev &= ~EV_SHADE;
             }
 #ifndef AIC_SHADE_STEP
-#define AIC_SHADE_STEP 1
+#define AIC_SHADE_STEP 0  // experiment (-DAIC_SHADE_STEP=1), exact and SLOWER: C2 0.4777 -> 0.4872 ms streamed, C3 6.817 -> 6.947; with SHADE's own
+                          // batching threshold at 40 / 48 / 56 lanes on top: 0.4935 / 0.4937 / 0.4937, 7.072 / 7.072 / 7.068 (profiles/r04_experiments.txt F)
 #endif
             // -- The shaded lanes' next step, taken here. A lane inside a run of translucent voxels alternates one step and one SHADE:
             //    as a stepping lane it took that step in a full pass of a trip (its lookup finds the next voxel at once, so no fast
