@@ -407,3 +407,49 @@ def test_light_updater_fuzz(ctx, seed):
     got = ctx.read_light_volume(abi.LAYER_WORLD, sp.size)
     assert info.updates == n_ref
     assert (got == np.asarray(ref.light).reshape(got.shape)).all(), f"seed {seed}: {(got != np.asarray(ref.light).reshape(got.shape)).any(axis=-1).sum()} texels differ"
+
+
+def test_light_update_beside_frames_in_flight(ctx):
+    """aic_evaluate_light no longer waits for the frames in flight (round 4): it works on the other half of the light double buffer.
+    A frame submitted BEFORE the update shows the old light whatever the update does meanwhile; a frame rendered after it shows the
+    new light; and the new volume is byte for byte what the same update gives with nothing in flight."""
+    import torch
+
+    sp = copy.deepcopy(lit(scenes.light_spread_space))
+    lo, size = np.array(sp.lo), np.array(sp.size)
+    cube = tuple(int(v) for v in lo + size // 2 + np.array([1, 0, 1]))
+    rel = tuple(c - l for c, l in zip(cube, sp.lo))
+    new = next(i for i in range(len(sp.blocks)) if i != int(sp.block_index[rel]))
+    queue = [(cube, 250)] + [(tuple(int(cube[a] + (d if a == k else 0)) for a in range(3)), 250) for k in range(3) for d in (-1, 1)]
+    w, h = 480, 360
+    eye = tuple(float(v) for v in lo + size * np.array([0.5, 0.5, 1.6]))
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, tuple(float(v) for v in lo + size / 2)), eye)
+    # reference run: nothing in flight
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.set_options(abi.LAYER_WORLD, abi.make_options())
+    fr = ctx.make_frame(w, h, world_inv=inv)
+    before = ctx.render(fr)["rgba8"]
+    ctx.update_cubes(abi.LAYER_WORLD, [cube], [new])
+    info0 = ctx.evaluate_light(abi.LAYER_WORLD, 30, fast=False, epsilon=1, batch=32, queue_order=16, queue=queue)
+    want_volume = ctx.read_light_volume(abi.LAYER_WORLD, sp.size)
+    after = ctx.render(fr)["rgba8"]
+    assert info0.updates > 0 and (after != before).any()
+    # the same with two frames in flight while the update runs
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.update_cubes(abi.LAYER_WORLD, [cube], [new])
+    mid = ctx.render(fr)["rgba8"]  # the block has changed, the light has not
+    bufs = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    torch.cuda.synchronize()
+    ctx.render_submit(fr, bufs[0].data_ptr(), 1)
+    ctx.render_submit(fr, bufs[1].data_ptr(), 2)
+    info1 = ctx.evaluate_light(abi.LAYER_WORLD, 30, fast=False, epsilon=1, batch=32, queue_order=16, queue=queue)
+    ctx.render_submit(fr, bufs[2].data_ptr(), 3)
+    for slot in (1, 2, 3):
+        ctx.render_wait(slot)
+    assert info1.updates == info0.updates
+    assert (bufs[0].cpu().numpy() == mid).all() and (bufs[1].cpu().numpy() == mid).all(), "a frame in flight saw the update"
+    assert (bufs[2].cpu().numpy() == after).all()
+    assert (ctx.read_light_volume(abi.LAYER_WORLD, sp.size) == want_volume).all()
+    # and once more: the halves swap back and forth
+    info2 = ctx.evaluate_light(abi.LAYER_WORLD, 30, fast=False, epsilon=1, batch=32, queue_order=16, queue=[])
+    assert info2.updates == 0 and (ctx.render(fr)["rgba8"] == after).all()
