@@ -875,13 +875,14 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u
 #define AIC_WG_THREADS 256  // threads per persistent workgroup (a multiple of 64)
 #endif
 #ifndef AIC_STEP_REPS
-#define AIC_STEP_REPS 3  // full stepping passes per scheduler trip (swept together with AIC_FAST_STEPS: profiles/r03_experiments.txt D)
+#define AIC_STEP_REPS 2  // full stepping passes per scheduler trip (3 until round 4; swept again with AIC_FAST_STEPS once no pending span kept lanes
+                         // out of the fast steps: profiles/r04_experiments.txt G)
 #endif
 #ifndef AIC_FAST_MIN
 #define AIC_FAST_MIN 16  // ... while at least this many lanes of the wave can take one
 #endif
 #ifndef AIC_FAST_STEPS
-#define AIC_FAST_STEPS 8  // bookkeeping-free steps a lane may take ahead of each full pass (0: none) ...
+#define AIC_FAST_STEPS 16  // bookkeeping-free steps a lane may take ahead of each full pass (0: none; 8 until round 4) ...
 #endif
 #ifndef AIC_SPEC_STEPS
 #define AIC_SPEC_STEPS 0  // experiment (-DAIC_SPEC_STEPS=4): a draining wave takes its fast steps four at a time, all four
