@@ -52,6 +52,20 @@ def test_line_has_the_contract_fields_and_is_consistent(path):
     if r.get("kernel_ms_one_at_a_time"):
         f = r["algorithmic_bytes_per_launch"] / (r["kernel_ms_one_at_a_time"] * 1e-3) / 1e9 / r["peak"]
         assert abs(r["frac_one_at_a_time"] - f) <= 0.01 * f
+    # round 4 on: the single-frame rate BASELINE.json's config 2 names rides beside the streamed value, and the default (atrium) line carries
+    # a short s256 leg
+    if not os.path.basename(path).startswith("r03"):
+        sf = d.get("single_frame")
+        if sf is not None:
+            assert abs(d["value_single_frame"] - rays / sf["single_frame_cold_ms"] / 1e3) <= 0.01 * d["value_single_frame"]
+            assert d["value_single_frame"] <= d["value_single_frame_warm"] * 1.02
+            assert "value_is" in d["config"]
+        if os.path.basename(path).endswith("_bench_atrium.json"):
+            s2 = d["secondary"]["s256"]
+            assert "error" not in s2, s2
+            assert s2["rays_per_frame"] == 3840 * 2160 and s2["ms_per_step"] > 0
+            f2 = s2["algorithmic_bytes_per_launch"] / (s2["kernel_ms_one_at_a_time"] * 1e-3) / 1e9 / 8000.0
+            assert abs(s2["frac_one_at_a_time"] - f2) <= 0.01 * f2
     cb = d.get("cpu_baseline")
     if cb is not None:
         for k in ("value", "unit", "cores", "kind", "sample"):

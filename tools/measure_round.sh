@@ -3,6 +3,7 @@
 # objects quote the counter file of the same round:
 #   gpurun --timeout 1500 -- 'bash tools/measure_round.sh r03 counters'   then   python tools/summarize_profile.py r03   (here)
 #   gpurun --timeout 1500 -- 'bash tools/measure_round.sh r03 bench'      then   python tools/summarize_profile.py r03   (here)
+#   gpurun --timeout 900  -- 'bash tools/measure_round.sh r04 profile'    (round 4 on: phase counters, wave tails, a rank's share; needs the prof variants)
 # Raw outputs under gpurun_out/<tag>/; tools/summarize_profile.py condenses them into profiles/<tag>_*.
 TAG=${1:-r03}; PHASE=${2:-counters}
 cd /tmp && export TMPDIR=/tmp
@@ -32,12 +33,34 @@ if [ "$PHASE" = counters ]; then
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_light_write" -- $LB > /dev/null 2>&1
   python tools/reduce_pmc_csv.py "$O"/pmc_light_sq1 "$O"/pmc_light_sq2 "$O"/pmc_light_fetch "$O"/pmc_light_write  # (the per-launch CSVs of ~1800 launches exceed what is kept)
   ( cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -o issue_rate issue_rate.hip > /dev/null 2>&1 && timeout 300 ./issue_rate ) > "$O/issue_rate.txt" 2>&1
-else
+elif [ "$PHASE" = bench ]; then
   python bench.py > "$O/bench_atrium.json" 2> "$O/bench_atrium.err"; tail -c 400 "$O/bench_atrium.json"; echo
   python bench.py --workload s256 --steps 10 --warmup 2 --cpu-seconds 6 > "$O/bench_s256.json" 2> "$O/bench_s256.err"; tail -c 300 "$O/bench_s256.json"; echo
   python bench.py --workload light-bench --steps 200 --warmup 10 > "$O/bench_lightbench.json" 2> "$O/bench_lightbench.err"; tail -c 300 "$O/bench_lightbench.json"; echo
   python bench.py --workload relight --steps 200 --warmup 10 --no-cpu-baseline > "$O/bench_relight.json" 2> "$O/bench_relight.err"; tail -c 500 "$O/bench_relight.json"; echo
   python bench.py --workload orbit --steps 60 --warmup 5 --no-cpu-baseline > "$O/bench_orbit.json" 2> "$O/bench_orbit.err"; tail -c 300 "$O/bench_orbit.json"; echo
+  # the exchange step over the nccl backend on this one GPU (a one-rank group), device-side and host-side hand-off, with the HIP API
+  # calls counted: no hipStreamSynchronize per frame may remain between a trace's submit and its gather in the first (round 4)
+  for mode in "" "--host-handoff"; do
+    rm -rf "$O/hip_gather1$mode"
+    rocprofv3 --hip-trace --stats --output-format csv -d "$O/hip_gather1$mode" -- python bench.py --no-cpu-baseline --no-extras --gather-at-one $mode --steps 30 --warmup 3 --min-seconds 1 > "$O/bench_gather1$mode.json" 2> "$O/bench_gather1$mode.err"
+    python tools/hip_handoff_summary.py "$O/hip_gather1$mode" "$O/bench_gather1$mode.json" "$mode"
+  done | tee "$O/hip_handoff.txt"
+elif [ "$PHASE" = profile ]; then
+  # in-kernel phase counters and per-wave clocks: needs variants/libaic_hip_prof.so, variants/libaic_hip_rayprof.so (tools/build_variants.sh "prof:-DAIC_PROFILE" "rayprof:-DAIC_PROFILE -DAIC_RAY_PROF")
+  cp all_is_cubes_amd/libaic_hip.so /tmp/libaic_default.so
+  cp variants/libaic_hip_prof.so all_is_cubes_amd/libaic_hip.so
+  for wl in atrium s256; do echo "== $wl"; python bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline --no-extras --no-secondary --min-seconds 0 2>&1 | grep PROF | tail -31; done > $O/prof.txt
+  cp variants/libaic_hip_rayprof.so all_is_cubes_amd/libaic_hip.so
+  for wl in atrium s256; do
+    AIC_WAVE_PROF=$O/wave_cold_$wl.txt python bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline --no-extras --no-secondary --min-seconds 0 > /dev/null 2>&1
+    python tools/wave_tail.py $O/wave_cold_$wl.txt "$wl cold"; python tools/wave_rays.py $O/wave_cold_$wl.txt "$wl cold"
+    AIC_WAVE_PROF=$O/wave_warm_$wl.txt python bench.py --workload $wl --steps 3 --warmup 2 --no-cpu-baseline --no-pipeline --no-extras --no-secondary --min-seconds 0 > /dev/null 2>&1
+    python tools/wave_tail.py $O/wave_warm_$wl.txt "$wl warm"; python tools/wave_rays.py $O/wave_warm_$wl.txt "$wl warm"
+  done > $O/wave_tail.txt
+  cp /tmp/libaic_default.so all_is_cubes_amd/libaic_hip.so
+  cat $O/prof.txt; cat $O/wave_tail.txt
+  for np in 2 4 8; do python tools/rank_share.py $np 1 atrium; python tools/rank_share.py $np 8 atrium; done 2>&1 | grep -v amdgpu | tee $O/rank_share.txt
 fi
 find "$O" -type f -size +4M -delete
 du -sh "$O"
