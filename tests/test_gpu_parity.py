@@ -213,6 +213,18 @@ def test_synthetic_octant_sky_backdrop_and_ui(ctx, synth_space):
     assert_parity(got, ref)
 
 
+def test_bounce_with_octant_sky_ui_layer_and_antialiasing(ctx):
+    """Bounce through the layer stack: the UI layer's primary rays are traced without the sky but THEIR secondary rays with it
+    (trace_ray_impl(ray, .., true, false)); each antialiasing sample seeds its own RNG from its own direction; the octant sky is sampled
+    by the secondary ray's direction."""
+    sp = scenes.synthetic_space(n=20, resolution=4, n_blocks=6, seed=5)
+    sp.set_sky_octants(np.random.default_rng(1).uniform(0.1, 1.5, (8, 3)))
+    opt = oracle.make_options(lighting=5, bounce_samples=2, antialiasing=2)
+    got, ref = render_both(ctx, sp, opt, (96, 60), (10.5, 16.5, 32.0), oracle.look_at_y_up((10.5, 16.5, 32.0), (10, 6, 10)),
+                           ui=scenes.ui_space(), backdrop=(0.2, 0.4, 0.6, 0.5))
+    assert_parity(got, ref)
+
+
 def test_step_cap_and_camera_inside_geometry(ctx):
     # a corridor of recursive blocks made only of invisible voxels: every voxel is a counted
     # step, so rays along the corridor run into the 1000-step cap (sr.rs:643)
@@ -808,6 +820,10 @@ def test_block_table_past_14_bits_uses_the_class_table(ctx):
     assert_parity(ctx.render(fr, want_aux=True), ref)
     ctx.upload_space(abi.LAYER_WORLD, sp)  # and as a fresh snapshot of 16385 blocks
     assert_parity(ctx.render(fr, want_aux=True), ref)
+    # Bounce on the untagged grid: the secondary rays classify cubes through the class table too
+    bopt = oracle.make_options(lighting=5, bounce_samples=2)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(bopt))
+    assert_parity(ctx.render(fr, want_aux=True), oracle.render(oracle.Space(sp), bopt, oracle.make_camera(inv, w, h), want_aux=True))
 
 
 # --- to_text::<CharacterBuf> through the host mirror: pixel-centre rays (sr.rs:367-472) ---------------
@@ -1088,3 +1104,22 @@ def test_render_orthographic(ctx, resolution):
     assert np.abs(got["rgba8"].astype(int) - ref["rgba8"].astype(int)).max() <= RGBA_TOL
     assert got["info"].cubes_traced == ref["cubes_traced"]
     ctx.clear_space(abi.LAYER_UI)
+
+
+def test_exchange_step_over_the_nccl_backend_on_one_gpu():
+    """bench.py --gather-at-one: the N > 1 exchange step -- strip ring, collective, retire event, de-interleave -- over torch.distributed's
+    nccl backend (RCCL) with a one-rank group, device-side hand-off; the assembled frame must equal the single-rank frame (the bench
+    exits non-zero otherwise) and the line must say which hand-off ran. The only execution of the RCCL leg a one-GPU box allows."""
+    import json
+    import subprocess
+    import sys
+
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--gather-at-one", "--workload", "small", "--steps", "6", "--warmup", "2",
+                          "--min-seconds", "0", "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["assembled_frame_equals_single_rank_frame"] is True
+    assert line["config"]["handoff"].startswith("device")
+    assert out.stdout.strip().splitlines()[-1].startswith("{"), "the bench line must be the last line of the output"
