@@ -14,12 +14,21 @@ from . import flat  # noqa: F401
 __all__ = ["flat", "abi", "host", "space_from_flat"]
 
 
+def _torch_first():
+    """One HIP runtime per process (see abi.load): PyTorch-ROCm brings its own libamdhip64; loaded before it, libaic_hip.so brings a second."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def __getattr__(name):
     import importlib
 
     if name in ("abi", "distributed"):
         return importlib.import_module("." + name, __name__)
     if name in ("host", "_host"):
+        _torch_first()
         try:
             return importlib.import_module("._host", __name__)
         except ImportError as e:  # pragma: no cover
@@ -29,6 +38,7 @@ def __getattr__(name):
 
 def space_from_flat(flat_space):
     """Builds a `_host.Space` (the C++ mirror of `Space`) from a `flat.FlatSpace`."""
+    _torch_first()
     from . import _host as H
 
     sp = H.Space(tuple(int(v) for v in flat_space.lo), tuple(int(v) for v in flat_space.size))

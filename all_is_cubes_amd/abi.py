@@ -123,6 +123,14 @@ def load() -> C.CDLL:
     if _lib is None:
         if not LIB_PATH.exists():
             raise ImportError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() (hipcc, gfx950)")
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and libaic_hip.so is linked against /opt/rocm's. Loaded
+        # after torch, this library binds to the copy already in the process; loaded BEFORE torch, the process ends up with two
+        # runtimes and the second one to initialise finds no GPU ("No HIP GPUs are available" from torch.zeros(device="cuda") --
+        # met by tests/test_gpu_light_update.py run on its own). A process that has torch gets it loaded first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(str(LIB_PATH))
         lib.aic_create.restype = C.c_void_p
         lib.aic_create.argtypes = [C.c_int, C.POINTER(C.c_int)]

@@ -67,6 +67,13 @@ struct LightJob {
     // allocator's atomics and the last block to finish copies them to `host_head` ([8], pinned); `done_count`: blocks finished.
     uint32_t *host_head;
     uint32_t *done_count;
+    // Session mode (compute_light_session_kernel: one launch serves every small batch of an aic_evaluate_light call; see LightMailbox).
+    struct LightMailbox *mailbox;  // pinned host memory; null outside a session
+    uint32_t *session_word;        // device: [0] the sequence number workgroup 0 has published, [1] that batch's cube count (0 = leave)
+    uint32_t *session_cubes;       // device: the batch's cubes, written by workgroup 0 (the same array `cubes` points to)
+    uint32_t *light_rw;            // the light volume, writable: workgroup 0 scatters the texels the previous batch changed
+    uint32_t session_seq;          // the first sequence number this launch waits for
+    uint32_t coherent_light;       // light texels are read with agent-scope loads (another XCD's L2 may hold an older line)
     uint32_t *stack;           // [max_depth][kLightFrameWords][stack_stride]
     uint32_t stack_stride;     // lanes the stack was sized for (>= n)
     uint32_t max_depth;
@@ -97,6 +104,26 @@ void launch_scatter_light(uint32_t *light, const uint32_t *index, const uint32_t
 // which is LightJob::done_count when that is in use).
 static constexpr uint32_t kLightQueueValid = 0x80000000u;
 static constexpr uint32_t kLightPrepMax = 64;
+// The hand-off page of a session, in pinned host memory. The host fills in a batch and then stores `seq` (release); workgroup 0
+// polls `seq`, scatters the texels, copies the cubes to device memory and publishes the sequence number to the other
+// workgroups through LightJob::session_word. The last workgroup out of a batch copies the counters to LightJob::host_head,
+// clears them for the next batch, and stores `done` (system-scope release): results, dependency chunks and counters are in
+// host memory by then. `n_cubes` 0 ends the session. A session whose host goes quiet for kLightSessionSpins polls ends
+// itself and says so in `exited` (the sequence number it was waiting for): nothing the host does or fails to do can leave
+// a kernel spinning for good.
+struct LightMailbox {
+    uint32_t seq, n_cubes, n_scatter, pad0;
+    uint32_t cubes[64], scatter_index[64], scatter_texel[64];
+    uint32_t pad1[12];
+    // device to host (their own cache lines)
+    uint32_t done, exited, error, pad2;
+    uint64_t t_seen, t_done;  // wall_clock64() when workgroup 0 saw the batch / when the last workgroup finished it
+    uint32_t pad3[8];
+};
+static_assert(sizeof(LightMailbox) % 64 == 0, "mailbox is whole cache lines");
+static constexpr uint32_t kLightSessionSpins = 400000u;  // polls of ~1.5 us: about half a second of silence
+void launch_compute_light_session(const LightJob &job, uint32_t n_blocks, uint32_t threads_per_cube, hipStream_t stream);
+
 struct LightPrep {
     uint32_t *light, *cubes_out, *head;
     uint32_t n_scatter, n_cubes;

@@ -417,6 +417,12 @@ __global__ void __launch_bounds__(64) compute_light_kernel(const LightJob J) {
 // adds them up, so every f32 sum is the reference's sum. Dependencies likewise (two slots per bundle), with the drop of a
 // face's light cube that repeats the previous entry (updater.rs:838-842) done in that ordered pass.
 
+#ifndef AIC_LIGHT_CHUNK
+// Bundles of a chain fetched at once by the small-batch builds of the walk (the large-batch build always takes them one by one).
+// 2, 4 and 8 were measured (profiles/r04_experiments.txt J): no faster, 8 is slower -- a step of the walk is its own ~1 k
+// dependent instructions on a SIMD that runs one wave, not the latency of its two fetches. So: 1.
+#define AIC_LIGHT_CHUNK 1
+#endif
 constexpr uint32_t kLdsFlags = 1024u;   // DevDerived.flags of the first blocks, cached in LDS
 constexpr uint32_t kOrderCap = 2048u;   // set bits gathered per pass of the ordered reduction
 constexpr uint32_t kLightBlock = 256u;  // most threads a cube's block may have (1 or 4 waves)
@@ -465,8 +471,13 @@ struct WaveCtx {
     }
     __device__ uint32_t get_light(const int c[3]) const {
         uint32_t i;
-        if (index_of(c, &i)) return J.light[i];
+        if (index_of(c, &i)) return light_texel(i);
         return light_outside(c);
+    }
+    // In a session the volume changes between batches without a kernel boundary: the texels are read past the caches that are
+    // not coherent across XCDs (agent scope), everything else (tables, grid, block records: constant during a call) stays cached.
+    __device__ uint32_t light_texel(uint32_t i) const {
+        return J.coherent_light ? __hip_atomic_load(const_cast<uint32_t *>(&J.light[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : J.light[i];
     }
     __device__ void value_of(uint32_t texel, float v[3]) const {
         v[0] = lds_lut[texel & 255u];
@@ -588,7 +599,7 @@ struct WaveCtx {
                         }
                         if (hit_alpha < 1.0f) {
                             float sl[3] = {0.f, 0.f, 0.f};
-                            if (fe >= 0) value_of(J.light[idx], sl);
+                            if (fe >= 0) value_of(light_texel(idx), sl);
                             const float a = ps_new_clamped(alpha), ww = ps_new_clamped(rbw);
                             float t[3];
                             for (int i = 0; i < 3; i++) t[i] = ps_mul(ps_mul(em[i] + ps_mul(sl[i], hit_alpha), a), ww);
@@ -661,6 +672,13 @@ __device__ uint32_t gather_set_bits(const uint32_t *bits, uint32_t n_words, uint
     return total == 0u ? 0xffffffffu : total;
 }
 
+// SESSION: the same walk, but the launch stays on the device for a whole aic_evaluate_light call and is handed one small batch
+// after another through a page of pinned host memory (LightMailbox, aic_light.h) instead of being launched once per batch:
+// in the reference's order a scene is a chain of ~1800 dependent batches of 32 cubes, and a launch per batch costs its
+// dispatch, the refill of every XCD's L2 (the caches are invalidated at a kernel boundary: 8.9 MB fetched per launch against
+// 0.57 MB algorithmic) and the host's wake-up from hipStreamSynchronize on top of the walk itself. One workgroup per cube of
+// the batch (gridDim.x >= the batch size), workgroup 0 talks to the host.
+template <bool SESSION, int CHUNK>
 __device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
     extern __shared__ uint32_t s_dyn[];  // term bitmap, candidate bitmap, visited bitmap
     __shared__ uint32_t s_flags[kLdsFlags];
@@ -684,8 +702,62 @@ __device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
     b.cslots = J.cands + (size_t)wave * 2u * J.n_tree;
     for (int f = 0; f < 6; f++) b.value_of(J.block_sky[f], b.sky_value[f]);
 
-    for (uint32_t item = wave; item < J.n; item += gridDim.x) {
-        const uint32_t ci = J.cubes[item];
+    __shared__ uint32_t s_session[3];
+    uint32_t session_seq = J.session_seq;
+    for (uint32_t item = wave; SESSION || item < J.n; item += gridDim.x) {
+        bool active = true;
+        if (SESSION) {
+            LightMailbox *const mb = J.mailbox;
+            item = wave;
+            if (wave == 0u) {
+                if (lane == 0u) {
+                    uint32_t spins = 0u, got;
+                    while ((got = __hip_atomic_load(&mb->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) != session_seq && ++spins < kLightSessionSpins)
+                        __builtin_amdgcn_s_sleep(4);
+                    const bool seen = got == session_seq;
+                    s_session[0] = seen ? __hip_atomic_load(&mb->n_cubes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+                    s_session[1] = seen ? __hip_atomic_load(&mb->n_scatter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0u;
+                    s_session[2] = seen ? 0u : 1u;
+                    if (seen) __hip_atomic_store(&mb->t_seen, (uint64_t)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                __syncthreads();
+                const uint32_t n = min(s_session[0], 64u), ns = min(s_session[1], 64u);
+                if (lane < 64u) {  // (one wave does the stores, so that its own fence below covers all of them)
+                    if (lane < ns) {
+                        const uint32_t idx = __hip_atomic_load(&mb->scatter_index[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        const uint32_t texel = __hip_atomic_load(&mb->scatter_texel[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(&J.light_rw[idx], texel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (lane < n)
+                        __hip_atomic_store(&J.session_cubes[lane], __hip_atomic_load(&mb->cubes[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    __threadfence();
+                    if (lane == 0u) {
+                        __hip_atomic_store(&J.session_word[1], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&J.session_word[0], session_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        if (s_session[2]) __hip_atomic_store(&mb->exited, session_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+                __syncthreads();
+            } else {
+                if (lane == 0u) {
+                    // (bounded far beyond workgroup 0's own patience: it always publishes something, a batch or the order to leave)
+                    uint32_t spins = 0u, got;
+                    while ((got = __hip_atomic_load(&J.session_word[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) != session_seq && ++spins < 16u * kLightSessionSpins)
+                        __builtin_amdgcn_s_sleep(2);
+                    const bool seen = got == session_seq;
+                    s_session[0] = seen ? __hip_atomic_load(&J.session_word[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    if (!seen) __hip_atomic_store(&mb->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                __syncthreads();
+            }
+            const uint32_t batch_n = min(s_session[0], 64u);
+            if (batch_n == 0u) return;  // the session is over (or the host went quiet): the same for every thread of the block
+            session_seq++;
+            active = item < batch_n;
+        }
+        if (active) {
+        const uint32_t ci = SESSION ? __hip_atomic_load(&J.session_cubes[item], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : J.cubes[item];
         const uint32_t sz = (uint32_t)J.size[2], sy = (uint32_t)J.size[1];
         b.origin[0] = J.lo[0] + (int)(ci / (sy * sz));
         b.origin[1] = J.lo[1] + (int)((ci / sz) % sy);
@@ -785,46 +857,70 @@ __device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
                         }
                     }
                     if (active) {
-                        uint4 nd = J.node[k];
-                        const int cube[3] = {b.origin[0] + (int)(off & 1023u) - 256, b.origin[1] + (int)((off >> 10) & 1023u) - 256,
-                                             b.origin[2] + (int)((off >> 20) & 1023u) - 256};
-                        uint32_t idx = 0u;
-                        const bool inside = b.index_of(cube, &idx);
-                        uint32_t block = J.grid[idx] & J.index_mask;  // cube 0's if outside: unused then
-                        asm volatile("" : "+v"(nd.z), "+v"(block));  // the two fetches stay here, ahead of the decisions
-                        float alpha;
-                        // (weight * direction_weights).sum() > 0: some weight the walk's directions select is positive
-                        if ((meta & 8u) || !inside || !(b.m0 & (meta >> 4)) || !b.alpha_behind(block, meta & 7u, alpha_in, &alpha) || nd.z == 0u) {
-                            atomicAdd(&s_count[2], 1u);
-                            active = false;
-                        } else if (nd.z == 1u) {
-                            k = nd.x & 0x3fffffu;
-                            atomicOr(&vis_bits[k >> 5], 1u << (k & 31u));
-                            valpha[k] = alpha;
-                            off = nd.y;
-                            meta = (nd.x >> 28) | (((nd.x >> 22) & 63u) << 4);
-                            alpha_in = alpha;
-                        } else {
-                            const uint2 *ce = J.child_ent + (size_t)k * 6u;
-                            uint2 ch[6];
-                            for (int f = 0; f < 6; f++) ch[f] = ce[f];
-                            const uint32_t at0 = atomicAdd(&s_count[1], nd.z);
-                            uint32_t at = at0;
-                            for (int f = 0; f < 6; f++)
-                                if (ch[f].x != 0u) {
-                                    const uint32_t ck = ch[f].x & 0x3fffffu;
-                                    atomicOr(&vis_bits[ck >> 5], 1u << (ck & 31u));
-                                    valpha[ck] = alpha;
-                                    uint32_t *const ent = reinterpret_cast<uint32_t *>(&front[at++]);
-                                    ent[0] = ck; ent[1] = __float_as_uint(alpha); ent[2] = ch[f].y;
-                                }
-                            at = at0;
-                            for (int f = 0; f < 6; f++)  // published behind the rest of the entry
-                                if (ch[f].x != 0u)
-                                    __hip_atomic_store(&front[at++].w, (ch[f].x >> 28) | (((ch[f].x >> 22) & 63u) << 4) | kLightQueueValid, __ATOMIC_RELEASE,
-                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-                            atomicAdd(&s_count[2], 1u);
-                            active = false;
+                        // Along a chain the positions are consecutive (pre-order: a bundle's only child is the next position), and
+                        // where a bundle's cube is does not depend on what the walk finds: so a lane fetches CHUNK bundles and
+                        // their CHUNK cubes' blocks in two round trips and then takes up to CHUNK steps on what it has -- a step
+                        // no longer costs a fetch's latency each. Whatever was fetched past the chain's end is not looked at.
+                        uint4 nd[CHUNK];
+_Pragma("unroll")
+                        for (int i = 0; i < CHUNK; i++) nd[i] = J.node[min(k + (uint32_t)i, J.n_tree - 1u)];
+                        uint32_t block[CHUNK];
+                        bool inside[CHUNK];
+                        {
+                            uint32_t off_i = off;
+_Pragma("unroll")
+                            for (int i = 0; i < CHUNK; i++) {
+                                if (i > 0) off_i = nd[i - 1].y;
+                                const int cube[3] = {b.origin[0] + (int)(off_i & 1023u) - 256, b.origin[1] + (int)((off_i >> 10) & 1023u) - 256,
+                                                     b.origin[2] + (int)((off_i >> 20) & 1023u) - 256};
+                                uint32_t idx = 0u;
+                                inside[i] = b.index_of(cube, &idx);
+                                block[i] = J.grid[idx] & J.index_mask;  // cube 0's if outside: unused then
+                            }
+                        }
+_Pragma("unroll")
+                        for (int i = 0; i < CHUNK; i++) asm volatile("" : "+v"(nd[i].z), "+v"(block[i]));  // the fetches stay here, ahead of the decisions
+_Pragma("unroll")
+                        for (int i = 0; i < CHUNK; i++) {
+                            float alpha;
+                            // (weight * direction_weights).sum() > 0: some weight the walk's directions select is positive
+                            if ((meta & 8u) || !inside[i] || !(b.m0 & (meta >> 4)) || !b.alpha_behind(block[i], meta & 7u, alpha_in, &alpha) || nd[i].z == 0u) {
+                                atomicAdd(&s_count[2], 1u);
+                                active = false;
+                                break;
+                            } else if (nd[i].z == 1u) {
+                                const uint32_t k_next = nd[i].x & 0x3fffffu;
+                                const bool consecutive = k_next == k + 1u;
+                                k = k_next;
+                                atomicOr(&vis_bits[k >> 5], 1u << (k & 31u));
+                                valpha[k] = alpha;
+                                off = nd[i].y;
+                                meta = (nd[i].x >> 28) | (((nd[i].x >> 22) & 63u) << 4);
+                                alpha_in = alpha;
+                                if (!consecutive) break;  // (never, in a pre-order tree: what was fetched ahead is then not this child's)
+                            } else {
+                                const uint2 *ce = J.child_ent + (size_t)k * 6u;
+                                uint2 ch[6];
+                                for (int f = 0; f < 6; f++) ch[f] = ce[f];
+                                const uint32_t at0 = atomicAdd(&s_count[1], nd[i].z);
+                                uint32_t at = at0;
+                                for (int f = 0; f < 6; f++)
+                                    if (ch[f].x != 0u) {
+                                        const uint32_t ck = ch[f].x & 0x3fffffu;
+                                        atomicOr(&vis_bits[ck >> 5], 1u << (ck & 31u));
+                                        valpha[ck] = alpha;
+                                        uint32_t *const ent = reinterpret_cast<uint32_t *>(&front[at++]);
+                                        ent[0] = ck; ent[1] = __float_as_uint(alpha); ent[2] = ch[f].y;
+                                    }
+                                at = at0;
+                                for (int f = 0; f < 6; f++)  // published behind the rest of the entry
+                                    if (ch[f].x != 0u)
+                                        __hip_atomic_store(&front[at++].w, (ch[f].x >> 28) | (((ch[f].x >> 22) & 63u) << 4) | kLightQueueValid, __ATOMIC_RELEASE,
+                                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                                atomicAdd(&s_count[2], 1u);
+                                active = false;
+                                break;
+                            }
                         }
                     }
                     if (__ballot(active) == 0ull) {  // nobody in this wave is walking
@@ -1006,9 +1102,30 @@ __device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
             atomicAdd(&J.dep_head[7], n_deps);
 #endif
         }
+        }  // active
         __syncthreads();  // LDS and the slots are reused by the wave's next cube
+        if (SESSION) {
+            // End of a batch: everything this workgroup wrote (results and dependency chunks, in host memory) is made visible to
+            // the host before it is counted; the last one out hands over the counters, clears them for the next batch (which the
+            // host posts only after it has seen `done`) and says so.
+            __threadfence_system();
+            __syncthreads();
+            if (lane == 0u) {
+                if (atomicAdd(J.done_count, 1u) == gridDim.x - 1u) {
+                    __threadfence();
+                    for (int i = 0; i < 8; i++) {
+                        J.host_head[i] = __hip_atomic_load(&J.dep_head[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&J.dep_head[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    __hip_atomic_store(J.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&J.mailbox->t_done, (uint64_t)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __threadfence_system();
+                    __hip_atomic_store(&J.mailbox->done, session_seq - 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
     }
-    if (J.host_head) {
+    if (!SESSION && J.host_head) {
         // the results went straight to host memory; the counters the host wants with them are copied by the last block out
         __syncthreads();
         if (lane == 0u) {
@@ -1024,10 +1141,11 @@ __device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
 // Two builds of the same body. A small batch (the reference's 32 cubes) is a latency problem: one block per CU at most, and
 // the register allocator is left alone (131 VGPRs). A large batch is an occupancy problem: a CU's LDS holds four cubes'
 // blocks, which needs four waves per SIMD, i.e. at most 128 VGPRs -- three fewer, at the price of a few stack slots.
-__global__ void __launch_bounds__(kLightBlock) compute_light_wave_kernel(const LightJob J) { compute_light_wave_body(J); }
+__global__ void __launch_bounds__(kLightBlock) compute_light_wave_kernel(const LightJob J) { compute_light_wave_body<false, AIC_LIGHT_CHUNK>(J); }
 __global__ void __launch_bounds__(kLightBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) compute_light_wave_kernel_dense(const LightJob J) {
-    compute_light_wave_body(J);
+    compute_light_wave_body<false, 1>(J);
 }
+__global__ void __launch_bounds__(kLightBlock) compute_light_session_kernel(const LightJob J) { compute_light_wave_body<true, AIC_LIGHT_CHUNK>(J); }
 
 __global__ void scatter_light_kernel(uint32_t *light, const uint32_t *index, const uint32_t *texel, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1053,8 +1171,8 @@ void launch_compute_light(const LightJob &job, hipStream_t stream) {
     hipLaunchKernelGGL(compute_light_kernel, dim3((job.n + 63u) / 64u), dim3(64), 0, stream, job);
 }
 
-void launch_compute_light_waves(const LightJob &job, uint32_t n_waves, uint32_t threads, hipStream_t stream) {
-    if (!job.n || !n_waves) return;
+namespace {
+uint32_t light_wave_lds(const LightJob &job) {
     const uint32_t lds = (((4u * job.n_tree + 31u) / 32u) + ((2u * job.n_tree + 31u) / 32u) + ((job.n_tree + 31u) / 32u)) * 4u;
     // more dynamic LDS than the default limit needs an opt-in, per device
     static uint32_t lds_allowed[64] = {0};
@@ -1064,8 +1182,21 @@ void launch_compute_light_waves(const LightJob &job, uint32_t n_waves, uint32_t 
     if (lds > allowed) {
         (void)hipFuncSetAttribute((const void *)compute_light_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void *)compute_light_wave_kernel_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)compute_light_session_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         allowed = lds;
     }
+    return lds;
+}
+}  // namespace
+
+void launch_compute_light_session(const LightJob &job, uint32_t n_blocks, uint32_t threads, hipStream_t stream) {
+    if (!n_blocks) return;
+    hipLaunchKernelGGL(compute_light_session_kernel, dim3(n_blocks), dim3(threads == 256u ? 256u : 64u), light_wave_lds(job), stream, job);
+}
+
+void launch_compute_light_waves(const LightJob &job, uint32_t n_waves, uint32_t threads, hipStream_t stream) {
+    if (!job.n || !n_waves) return;
+    const uint32_t lds = light_wave_lds(job);
     if (n_waves > 256u) hipLaunchKernelGGL(compute_light_wave_kernel_dense, dim3(n_waves), dim3(threads == 256u ? 256u : 64u), lds, stream, job);
     else hipLaunchKernelGGL(compute_light_wave_kernel, dim3(n_waves), dim3(threads == 256u ? 256u : 64u), lds, stream, job);
 }

@@ -58,7 +58,7 @@ def test_line_has_the_contract_fields_and_is_consistent(path):
         sf = d.get("single_frame")
         if sf is not None:
             assert abs(d["value_single_frame"] - rays / sf["single_frame_cold_ms"] / 1e3) <= 0.01 * d["value_single_frame"]
-            assert d["value_single_frame"] <= d["value_single_frame_warm"] * 1.02
+            assert d["value_single_frame"] <= d["value_single_frame_warm"] * 1.10  # (64x64 frames of 0.08 ms: cold and warm are the same thing, within noise)
             assert "value_is" in d["config"]
         if os.path.basename(path).endswith("_bench_atrium.json"):
             s2 = d["secondary"]["s256"]

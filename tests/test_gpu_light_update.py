@@ -142,6 +142,32 @@ def test_dependency_pool_grows_when_a_batch_overflows_it(batch, monkeypatch):
     assert (got == np.asarray(ref.light).reshape(got.shape)).all()
 
 
+@pytest.mark.parametrize("name,batch,lanes,pool", [("light_spread", 32, 256, None), ("light_on_slab", 7, 64, None), ("fog", 32, 256, None), ("light_spread", 32, 256, "4")])
+def test_session_kernel_gives_the_same_bytes(name, batch, lanes, pool, monkeypatch):
+    """AIC_LIGHT_SESSION=1: one launch serves every small batch of a call, fed through pinned host memory (an experiment kept
+    reproducible, csrc/aic_light.h LightMailbox). Same texels, same update count -- also when the dependency pool overflows
+    and the session has to end, grow the pool and start again, and in a relight that continues the queue."""
+    monkeypatch.setenv("AIC_LIGHT_SESSION", "1")
+    if pool:
+        monkeypatch.setenv("AIC_LIGHT_DEP_POOL_CHUNKS", pool)
+    sp = SCENES[name]()
+    ref = copy.deepcopy(sp)
+    n_ref = oracle.evaluate_light(ref, maximum_distance=30, fast=True, epsilon=1, batch=batch, hb_width=16)
+    c = abi.Context(0)
+    try:
+        c.upload_space(abi.LAYER_WORLD, sp)
+        info = c.evaluate_light(abi.LAYER_WORLD, 30, fast=True, epsilon=1, batch=batch, queue_order=16, lanes_per_cube=lanes)
+        got = c.read_light_volume(abi.LAYER_WORLD, sp.size)
+        assert info.updates == n_ref and info.device_ms > 0
+        assert (got == np.asarray(ref.light).reshape(got.shape)).all()
+        # a second call on the same context: another session, the queue continued (nothing left: no updates, no hang)
+        again = c.evaluate_light(abi.LAYER_WORLD, 30, fast=False, epsilon=1, batch=batch, queue_order=16, queue=[], lanes_per_cube=lanes)
+        assert again.updates == 0
+        assert (c.read_light_volume(abi.LAYER_WORLD, sp.size) == got).all()
+    finally:
+        c.close()
+
+
 def test_large_batches_converge_to_the_same_light(ctx):
     """Throughput mode: thousands of queue entries per launch. The order of updates differs from the reference's, so the
     converged texels may differ in their last log-scale unit (the reference's own order is unspecified, queue.rs:236-243)."""
