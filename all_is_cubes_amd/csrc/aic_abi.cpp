@@ -25,7 +25,8 @@ void launch_trace_image(const DevFrame &F, bool diag, hipStream_t stream);
 void launch_scatter_cubes(uint16_t *grid, uint32_t *light, const int32_t *xyz, const uint16_t *bi, const uint32_t *lt,
                           uint32_t n, const int lo[3], const int size[3], const uint32_t *cls, hipStream_t stream);
 void launch_probe_powf(const float *x, const float *y, float *out, uint32_t n, hipStream_t stream);
-void launch_order_tiles(const uint32_t *cost, uint32_t *order, uint32_t n_tiles, hipStream_t stream);
+void launch_order_tiles(const uint32_t *cost, uint32_t *order, uint32_t n_tiles, uint32_t macros_x, uint32_t sb_shift, uint32_t n_queues, uint32_t *queue_start,
+                        hipStream_t stream);
 void launch_tag_cubes(uint16_t *grid, size_t n, const uint32_t *cls, int from_tagged, int to_tagged, hipStream_t stream);
 void launch_assemble_strips(const uint32_t *gathered, uint32_t *out, uint32_t w, uint32_t h, uint32_t strip_rows,
                             uint32_t n_parts, uint32_t max_rows, hipStream_t stream);
@@ -156,7 +157,7 @@ struct aic_ctx {
         DevBuf<DevCounters> counters;
         DevBuf<float4> acc;  // UI pre-pass accumulators
         // cost feedback: the longest ray of every tile of the slot's last frame, and the tile order made from it
-        DevBuf<uint32_t> tile_cost, tile_order;
+        DevBuf<uint32_t> tile_cost, tile_order, queue_start;
         DevBuf<uint4> orphans;  // ray migration (aic_trace.hip): hot lane state of the rays handed over in the frame's tail
         uint32_t cost_sig[4] = {0, 0, 0, 0};  // width, local rows, partition of the frame tile_cost describes
         double cost_cam[16] = {0};            // ... and its world camera
@@ -450,7 +451,7 @@ void aic_destroy(aic_ctx *c) {
     for (uint32_t i = 0; i < AIC_MAX_IN_FLIGHT; i++) {
         aic_ctx::FrameSlot &fs = c->slots[i];
         if (fs.stream) (void)hipStreamSynchronize(fs.stream);
-        fs.counters.release(); fs.acc.release(); fs.tile_cost.release(); fs.tile_order.release(); fs.orphans.release();
+        fs.counters.release(); fs.acc.release(); fs.tile_cost.release(); fs.tile_order.release(); fs.queue_start.release(); fs.orphans.release();
         if (fs.ev0) (void)hipEventDestroy(fs.ev0);
         if (fs.ev1) (void)hipEventDestroy(fs.ev1);
         if (i > 0 && fs.stream) (void)hipStreamDestroy(fs.stream);
@@ -955,9 +956,26 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         // had the same shape (else index order); then the cost array is cleared for this frame's record
         static const bool feedback = [] { const char *e = std::getenv("AIC_TILE_FEEDBACK"); return !e || std::atoi(e) != 0; }();
         const uint32_t n_tiles = F.macros_x * F.macros_y;  // the feedback works on macro tiles
-        if (feedback && n_tiles && !patches && !ortho_n && !(f->flags & AIC_FRAME_NO_FEEDBACK)) {
+        // XCD-local tile queues (aic_trace.hip order_tiles_kernel): one per XCD (32 CUs each on this part), a macro tile in the queue of the
+        // 2^sb_shift-macro-tile super-block it lies in. AIC_TILE_QUEUES=1 is the single dispenser of rounds 1-3; AIC_SUPER_SHIFT the block edge.
+        // (both read per frame: tests switch them inside one process)
+        const int queues_env = [] { const char *e = std::getenv("AIC_TILE_QUEUES"); return e ? std::atoi(e) : 0; }();
+        const int super_env = [] { const char *e = std::getenv("AIC_SUPER_SHIFT"); return e ? std::atoi(e) : -1; }();
+        uint32_t n_queues = queues_env > 0 ? (uint32_t)queues_env : (uint32_t)c->n_cus / 32u;
+        if (n_queues > kMaxTileQueues) n_queues = kMaxTileQueues;
+        if (n_queues < 2u || patches || ortho_n || !n_tiles) n_queues = 0u;
+        const uint32_t macro_log2 = F.macro >= 16 ? 4u : (F.macro >= 8 ? 3u : (F.macro >= 4 ? 2u : (F.macro >= 2 ? 1u : 0u)));
+        const uint32_t tile_log2 = F.tile >= 16 ? 4u : 3u;
+        // default super-block edge: the largest power of two within an eighth of the (local) image height -- 128 pixels at 1080p, 256 at 4K, ~135 blocks
+        // either way: larger blocks fetch less (s256: 9.0 GB per frame with one dispenser, 5.2 at 128 pixels, 3.6 at 512) but leave a queue with too few
+        // blocks to even out a scene that is part sky (profiles/r04_experiments.txt K)
+        uint32_t sb_px_log2 = 0;
+        while ((2u << sb_px_log2) <= std::max(1u, local_rows / 8u)) sb_px_log2++;
+        const uint32_t sb_shift = super_env >= 0 ? (uint32_t)std::min(super_env, 12) : (sb_px_log2 > macro_log2 + tile_log2 ? sb_px_log2 - macro_log2 - tile_log2 : 0u);
+        const bool use_feedback = feedback && n_tiles && !patches && !ortho_n && !(f->flags & AIC_FRAME_NO_FEEDBACK);
+        if (use_feedback || n_queues) {
             const uint32_t sig[4] = {f->width, local_rows, (part.n_parts << 16) | part.part, (part.strip_rows << 8) | (F.macro << 4) | (F.tile >> 3)};
-            bool same = std::memcmp(sig, fs.cost_sig, sizeof(sig)) == 0 && fs.tile_cost.n >= n_tiles;
+            bool same = use_feedback && std::memcmp(sig, fs.cost_sig, sizeof(sig)) == 0 && fs.tile_cost.n >= n_tiles;
             if (same) {
                 // the record only predicts this frame if the camera has barely moved since: the view rays
                 // through the centre and two corners within a degree, the eye within a quarter cube.
@@ -965,14 +983,20 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
                 same = cameras_close(f->world.inverse_projection_view, fs.cost_cam);
             }
             if ((e = fs.tile_cost.ensure(n_tiles)) != hipSuccess || (e = fs.tile_order.ensure(n_tiles)) != hipSuccess) return hip_fail(c, "alloc tile feedback", e);
-            if (same) {
-                launch_order_tiles(fs.tile_cost.p, fs.tile_order.p, n_tiles, fs.stream);
+            if (n_queues && (e = fs.queue_start.ensure(kMaxTileQueues + 1)) != hipSuccess) return hip_fail(c, "alloc tile queues", e);
+            if (same || n_queues) {
+                launch_order_tiles(same ? fs.tile_cost.p : nullptr, fs.tile_order.p, n_tiles, F.macros_x, sb_shift, n_queues ? n_queues : 1u,
+                                   n_queues ? fs.queue_start.p : nullptr, fs.stream);
                 F.tile_order = fs.tile_order.p;
+                F.n_queues = n_queues;
+                F.queue_start = n_queues ? fs.queue_start.p : nullptr;
             }
-            HIP_TRY(c, hipMemsetAsync(fs.tile_cost.p, 0, (size_t)n_tiles * sizeof(uint32_t), fs.stream));
-            F.tile_cost = fs.tile_cost.p;
-            std::memcpy(fs.cost_sig, sig, sizeof(sig));
-            std::memcpy(fs.cost_cam, f->world.inverse_projection_view, sizeof(fs.cost_cam));
+            if (use_feedback) {
+                HIP_TRY(c, hipMemsetAsync(fs.tile_cost.p, 0, (size_t)n_tiles * sizeof(uint32_t), fs.stream));
+                F.tile_cost = fs.tile_cost.p;
+                std::memcpy(fs.cost_sig, sig, sizeof(sig));
+                std::memcpy(fs.cost_cam, f->world.inverse_projection_view, sizeof(fs.cost_cam));
+            }
         }
     }
     const bool ui = hl[1].present != 0;
@@ -1005,11 +1029,14 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         F.layer_lighting = hl[1].opt.lighting;
         const uint32_t *order_keep = F.tile_order;
         uint32_t *cost_keep = F.tile_cost;
+        const uint32_t queues_keep = F.n_queues;
         F.tile_order = nullptr;  // the feedback describes the world pass
         F.tile_cost = nullptr;
+        F.n_queues = 0u;
         launch_trace_image(F, diag, fs.stream);
         F.tile_order = order_keep;
         F.tile_cost = cost_keep;
+        F.n_queues = queues_keep;
         HIP_TRY(c, hipMemsetAsync(&fs.counters.p->tile_next, 0, sizeof(uint32_t), fs.stream));
         F.use_init = 1;
     }

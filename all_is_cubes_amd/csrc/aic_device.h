@@ -85,6 +85,8 @@ struct DevLayer {
 static constexpr uint32_t kCubeClassShift = 14u;
 static constexpr uint32_t kCubeIndexMask = (1u << kCubeClassShift) - 1u;
 
+constexpr uint32_t kMaxTileQueues = 8;  // one per XCD
+
 struct DevCounters {
     unsigned long long cubes_traced;
     unsigned long long n_outer;
@@ -94,6 +96,7 @@ struct DevCounters {
     unsigned long long prof[32];  // AIC_PROFILE builds only
     uint32_t tile_next;           // dynamic tile dispenser of the persistent trace kernel
     uint32_t pad;
+    uint32_t tile_next_q[kMaxTileQueues][16];  // the same per tile queue (DevFrame::n_queues), a cache line each: [q][0] counts
 #ifdef AIC_PROFILE
     uint32_t wave_prof[2048][4];  // per wave: start, first saw the queue dry, end (cycle counter), pixels taken
 #endif
@@ -155,6 +158,12 @@ struct DevFrame {
     // rays of the previous frame first (null: index order); tile_cost[macro tile] receives this frame's longest ray
     const uint32_t *tile_order;
     uint32_t *tile_cost;
+    // XCD-local tile queues (0: one queue for the whole chip, counters->tile_next). tile_order is then n_queues segments, segment q =
+    // positions queue_start[q] .. queue_start[q+1] of it (queue_start: device array of n_queues + 1), each costliest first. A macro
+    // tile belongs to the queue of the super-block it lies in (order_tiles_kernel), a workgroup starts on the queue of the XCD it runs on.
+    uint32_t n_queues;
+    uint32_t pad_q;
+    const uint32_t *queue_start;
     const float *light_lut;  // 256 floats
     const float *srgb_thr;   // 256 floats: srgb_thr[k] = smallest linear value whose sRGB8 encoding is >= k
     // ray migration in the frame's tail (aic_trace.hip): hot lane state of the rays a wave hands over, kOrphanDwords dwords per

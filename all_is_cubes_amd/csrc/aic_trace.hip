@@ -1017,6 +1017,13 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
     const uint32_t mig_k = (MIGRATE && blockIdx.x < F.migrate_groups && (uint32_t)AIC_WG_THREADS <= 256u) ? F.migrate_k : 0u;  // (the buffer has 256 columns per workgroup)
     const bool anchor = (threadIdx.x >> 6) == 0u;   // the wave of the workgroup that adopts, never hands over, and leaves last
     bool dry = false;                               // wave-uniform: this wave has seen the tile queue exhausted
+    // wave-uniform: the tile queue this wave takes from (DevFrame::n_queues > 1): its XCD's own to begin with, the next one's when that is empty
+    uint32_t my_queue = 0u, queues_tried = 0u;
+    if (F.n_queues > 1u) {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        my_queue = (xcc & 15u) % F.n_queues;
+    }
     bool donated = false;
     SurfDiag pend_d;
     double pend_t = 0.0;
@@ -1760,8 +1767,26 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                         uint32_t t = n_virtual;
                         if (!dry) {
                             const int leader = __ffsll((long long)need) - 1;
-                            if ((int)lane == leader) t = atomicAdd(&F.counters->tile_next, 1u);
-                            t = (uint32_t)__shfl((int)t, leader, 64);
+                            if (F.n_queues > 1u) {
+                                // the XCD's own queue; when it is empty, the next XCD's (for good: `my_queue` moves on), until all have been seen empty
+                                const uint32_t nq = F.n_queues;
+                                while (queues_tried < nq) {
+                                    uint32_t u = 0u;
+                                    if ((int)lane == leader) u = atomicAdd(&F.counters->tile_next_q[my_queue][0], 1u);
+                                    u = (uint32_t)__builtin_amdgcn_readlane((int)u, leader);
+                                    const uint32_t q0 = F.queue_start[my_queue], q1 = F.queue_start[my_queue + 1u];
+                                    const uint32_t j = u >> (macro_shift * 2u);
+                                    if (j < q1 - q0) {
+                                        t = ((q0 + j) << (macro_shift * 2u)) | (u & ((1u << (macro_shift * 2u)) - 1u));
+                                        break;
+                                    }
+                                    my_queue = my_queue + 1u == nq ? 0u : my_queue + 1u;
+                                    queues_tried++;
+                                }
+                            } else {
+                                if ((int)lane == leader) t = atomicAdd(&F.counters->tile_next, 1u);
+                                t = (uint32_t)__shfl((int)t, leader, 64);
+                            }
                         }
                         if (t >= n_virtual) {  // image exhausted
 #ifdef AIC_PROFILE
@@ -2466,33 +2491,54 @@ __global__ void tag_cubes_kernel(uint16_t *grid, size_t n, const uint32_t *cls, 
 // Orders the tiles of the next frame by the cost the previous frame measured for them (its longest
 // ray, in steps), costliest first: the rays most likely to be long start early instead of landing
 // in the frame's tail, where a wave with two live lanes still pays a whole event phase for each.
-// One workgroup: histogram over 1024 cost buckets, prefix sum, scatter. Order inside a bucket is
+// One workgroup: histogram over 1024 cost buckets per queue, prefix sum, scatter. Order inside a bucket is
 // whatever the atomics give -- every pixel is traced exactly once either way.
-__global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n_tiles) {
-    __shared__ uint32_t hist[1024];
+//
+// Queues (round 4): each XCD has its own L2, and with one dispenser for the chip the 4 waves' worth of rays of a macro tile and of
+// its neighbours run on all eight at once -- every L2 fetches the same lines. With n_queues > 1 the macro tiles are dealt to queues
+// by the super-block (2^sb_shift macro tiles on a side) they lie in, a workgroup serves the queue of the XCD it runs on (and helps
+// the others when its own is empty), and `order` comes out as n_queues segments, each costliest first; queue_start[q] is where
+// segment q begins. cost == nullptr: no record to go by (index order inside a queue, as far as the atomics keep it).
+__device__ __forceinline__ uint32_t tile_queue_of(uint32_t mt, uint32_t macros_x, uint32_t sb_shift, uint32_t n_queues) {
+    const uint32_t my = mt / macros_x, mx = mt - my * macros_x;
+    return ((mx >> sb_shift) + 3u * (my >> sb_shift)) % n_queues;
+}
+__global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n_tiles, uint32_t macros_x,
+                                                           uint32_t sb_shift, uint32_t n_queues, uint32_t *__restrict__ queue_start) {
+    __shared__ uint32_t hist[kMaxTileQueues * 1024];
     __shared__ uint32_t scan[1024];
     const uint32_t tid = threadIdx.x;
-    hist[tid] = 0;
+    const uint32_t n_bins = n_queues * 1024u;
+    for (uint32_t b = tid; b < n_bins; b += 1024u) hist[b] = 0;
     __syncthreads();
     for (uint32_t t = tid; t < n_tiles; t += 1024u) {
-        const uint32_t c = cost[t];
-        atomicAdd(&hist[1023u - (c < 1023u ? c : 1023u)], 1u);
+        const uint32_t c = cost ? cost[t] : 0u;
+        atomicAdd(&hist[tile_queue_of(t, macros_x, sb_shift, n_queues) * 1024u + 1023u - (c < 1023u ? c : 1023u)], 1u);
     }
     __syncthreads();
-    // exclusive prefix sum (Hillis-Steele over 1024 entries)
-    scan[tid] = hist[tid];
+    // exclusive prefix sum over the n_queues * 1024 buckets: thread `tid` owns the n_queues consecutive buckets tid * n_queues ..
+    uint32_t mine = 0;
+    for (uint32_t k = 0; k < n_queues; k++) mine += hist[tid * n_queues + k];
+    scan[tid] = mine;
     __syncthreads();
-    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {  // Hillis-Steele over the 1024 partial sums
         const uint32_t v = tid >= off ? scan[tid - off] : 0u;
         __syncthreads();
         scan[tid] += v;
         __syncthreads();
     }
-    hist[tid] = scan[tid] - hist[tid];  // start of each bucket
+    uint32_t run = scan[tid] - mine;
+    for (uint32_t k = 0; k < n_queues; k++) {
+        const uint32_t h = hist[tid * n_queues + k];
+        hist[tid * n_queues + k] = run;  // start of each bucket
+        run += h;
+    }
+    __syncthreads();
+    if (queue_start && tid <= n_queues) queue_start[tid] = tid < n_queues ? hist[tid * 1024u] : n_tiles;
     __syncthreads();
     for (uint32_t t = tid; t < n_tiles; t += 1024u) {
-        const uint32_t c = cost[t];
-        const uint32_t pos = atomicAdd(&hist[1023u - (c < 1023u ? c : 1023u)], 1u);
+        const uint32_t c = cost ? cost[t] : 0u;
+        const uint32_t pos = atomicAdd(&hist[tile_queue_of(t, macros_x, sb_shift, n_queues) * 1024u + 1023u - (c < 1023u ? c : 1023u)], 1u);
         order[pos] = t;
     }
 }
@@ -2630,9 +2676,12 @@ void launch_probe_powf(const float *x, const float *y, float *out, uint32_t n, h
     hipLaunchKernelGGL(probe_powf_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, x, y, out, n);
 }
 
-void launch_order_tiles(const uint32_t *cost, uint32_t *order, uint32_t n_tiles, hipStream_t stream) {
+void launch_order_tiles(const uint32_t *cost, uint32_t *order, uint32_t n_tiles, uint32_t macros_x, uint32_t sb_shift, uint32_t n_queues, uint32_t *queue_start,
+                        hipStream_t stream) {
     if (!n_tiles) return;
-    hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n_tiles);
+    if (n_queues < 1u) n_queues = 1u;
+    if (n_queues > kMaxTileQueues) n_queues = kMaxTileQueues;
+    hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n_tiles, macros_x ? macros_x : 1u, sb_shift, n_queues, queue_start);
 }
 
 void launch_assemble_strips(const uint32_t *gathered, uint32_t *out, uint32_t w, uint32_t h, uint32_t strip_rows,

@@ -225,6 +225,34 @@ def test_bounce_with_octant_sky_ui_layer_and_antialiasing(ctx):
     assert_parity(got, ref)
 
 
+def test_xcd_local_tile_queues_trace_every_pixel_once(ctx, synth_space, monkeypatch):
+    """The persistent kernel's waves take their tiles from one queue per XCD (macro tiles dealt to queues by super-block, a workgroup
+    starting on its XCD's queue and moving on when it is empty: csrc/aic_trace.hip order_tiles_kernel). Whatever the number of queues
+    and the block size, and with or without the previous frame's cost record, the frame is the one the single dispenser gives --
+    pixels, per-pixel step counts and totals -- and the oracle's."""
+    opt = oracle.make_options(fog=1, transparency=1, lighting=2)
+    size = (416, 232)  # not a multiple of the tile, the macro tile or any super-block
+    monkeypatch.setenv("AIC_TILE_QUEUES", "1")
+    base, ref = render_both(ctx, synth_space, opt, size, SYNTH_EYE, synth_quat())
+    assert_parity(base, ref)
+    w, h = size
+    _, _, inv = oracle.camera_matrices(90.0, opt.view_distance, w / h, synth_quat(), SYNTH_EYE)
+    for queues, shift in [("8", None), ("8", "0"), ("8", "2"), ("8", "7"), ("3", "1"), ("5", None), ("2", "12")]:
+        monkeypatch.setenv("AIC_TILE_QUEUES", queues)
+        if shift is None:
+            monkeypatch.delenv("AIC_SUPER_SHIFT", raising=False)
+        else:
+            monkeypatch.setenv("AIC_SUPER_SHIFT", shift)
+        frame = ctx.make_frame(w, h, world_inv=inv)
+        for attempt in range(2):  # the second frame of the same view is ordered by the first one's cost record
+            got = ctx.render(frame, want_aux=True)
+            assert (got["rgba8"] == base["rgba8"]).all(), (queues, shift, attempt)
+            assert (got["aux"]["cubes_traced"] == base["aux"]["cubes_traced"]).all()
+            assert got["info"].cubes_traced == base["info"].cubes_traced
+        plain = ctx.render(ctx.make_frame(w, h, world_inv=inv))  # the production variant
+        assert (plain["rgba8"] == base["rgba8"]).all() and plain["info"].cubes_traced == base["info"].cubes_traced
+
+
 def test_step_cap_and_camera_inside_geometry(ctx):
     # a corridor of recursive blocks made only of invisible voxels: every voxel is a counted
     # step, so rays along the corridor run into the 1000-step cap (sr.rs:643)
