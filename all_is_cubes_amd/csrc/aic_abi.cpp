@@ -153,8 +153,19 @@ struct aic_ctx {
     // second stream so that a submitted frame's trace can start while the previous one drains
     struct FrameSlot {
         hipStream_t stream = nullptr;
-        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the trace launch(es): the frame's kernel time
+        hipEvent_t ev2 = nullptr;                  // behind the copy of the counters to `host_counters`: what aic_render_wait waits for
         DevBuf<DevCounters> counters;
+        DevCounters *host_counters = nullptr;      // pinned
+        // What a frame needs cleared or ordered is enqueued BEHIND the previous frame of the slot, not ahead of this one (round 4): the counters
+        // are cleared again right after they were copied out, the cost record is turned into the next frame's tile order and cleared as soon as the
+        // trace that wrote it is done. A frame alone then starts with its trace launch; before, three small launches (~25 us) stood in front of it.
+        bool counters_clean = false;       // the device counters are zero (cleared behind the slot's last frame)
+        size_t cost_clean_n = 0;           // this many entries of tile_cost are zero
+        bool record_ready = false;         // tile_order / queue_start hold the cost order of the frame described by cost_sig / cost_cam / order_key
+        bool static_ready = false;         // tile_static / queue_static hold the index order for static_key
+        uint32_t order_key[6] = {0, 0, 0, 0, 0, 0}, static_key[6] = {0, 0, 0, 0, 0, 0};  // cost_sig + number of queues + super-block shift
+        DevBuf<uint32_t> tile_static, queue_static;
         DevBuf<float4> acc;  // UI pre-pass accumulators
         // cost feedback: the longest ray of every tile of the slot's last frame, and the tile order made from it
         DevBuf<uint32_t> tile_cost, tile_order, queue_start;
@@ -383,7 +394,8 @@ aic_ctx *aic_create(int device_id, int *status) {
         aic_ctx::FrameSlot &fs = c->slots[i];
         if (i == 0) fs.stream = c->stream;
         else ok = hipStreamCreateWithFlags(&fs.stream, hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipEventCreate(&fs.ev0) == hipSuccess && hipEventCreate(&fs.ev1) == hipSuccess && fs.counters.ensure(1) == hipSuccess;
+        ok = ok && hipEventCreate(&fs.ev0) == hipSuccess && hipEventCreate(&fs.ev1) == hipSuccess && hipEventCreate(&fs.ev2) == hipSuccess && fs.counters.ensure(1) == hipSuccess;
+        ok = ok && hipHostMalloc((void **)&fs.host_counters, sizeof(DevCounters), hipHostMallocDefault) == hipSuccess;
     }
     // created after the frame streams: HIP deals streams onto a few hardware queues in creation order
     // (4 by default), and two frame slots sharing a queue would serialise their kernels
@@ -454,6 +466,10 @@ void aic_destroy(aic_ctx *c) {
         fs.counters.release(); fs.acc.release(); fs.tile_cost.release(); fs.tile_order.release(); fs.queue_start.release(); fs.orphans.release();
         if (fs.ev0) (void)hipEventDestroy(fs.ev0);
         if (fs.ev1) (void)hipEventDestroy(fs.ev1);
+        if (fs.ev2) (void)hipEventDestroy(fs.ev2);
+        if (fs.host_counters) (void)hipHostFree(fs.host_counters);
+        fs.host_counters = nullptr;
+        fs.tile_static.release(); fs.queue_static.release();
         if (i > 0 && fs.stream) (void)hipStreamDestroy(fs.stream);
     }
     for (auto &l : c->layers) l.release();
@@ -950,10 +966,13 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         if ((e = c->aux.ensure(npix)) != hipSuccess) return hip_fail(c, "alloc aux", e);
         F.aux = c->aux.p;
     }
-    HIP_TRY(c, hipMemsetAsync(fs.counters.p, 0, sizeof(DevCounters), fs.stream));
+    if (!fs.counters_clean) HIP_TRY(c, hipMemsetAsync(fs.counters.p, 0, sizeof(DevCounters), fs.stream));
+    fs.counters_clean = false;
+    uint32_t order_key[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t order_tiles_n = 0, order_sb_shift = 0, order_queues = 0;
     {
         // tile order for this frame from the cost the slot's previous frame recorded, if that frame
-        // had the same shape (else index order); then the cost array is cleared for this frame's record
+        // had the same shape (else index order); the record was turned into an order, and cleared, behind that frame
         static const bool feedback = [] { const char *e = std::getenv("AIC_TILE_FEEDBACK"); return !e || std::atoi(e) != 0; }();
         const uint32_t n_tiles = F.macros_x * F.macros_y;  // the feedback works on macro tiles
         // XCD-local tile queues (aic_trace.hip order_tiles_kernel): one per XCD (32 CUs each on this part), a macro tile in the queue of the
@@ -975,27 +994,43 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         const bool use_feedback = feedback && n_tiles && !patches && !ortho_n && !(f->flags & AIC_FRAME_NO_FEEDBACK);
         if (use_feedback || n_queues) {
             const uint32_t sig[4] = {f->width, local_rows, (part.n_parts << 16) | part.part, (part.strip_rows << 8) | (F.macro << 4) | (F.tile >> 3)};
-            bool same = use_feedback && std::memcmp(sig, fs.cost_sig, sizeof(sig)) == 0 && fs.tile_cost.n >= n_tiles;
+            std::memcpy(order_key, sig, sizeof(sig));
+            order_key[4] = n_queues;
+            order_key[5] = sb_shift;
+            order_tiles_n = n_tiles; order_sb_shift = sb_shift; order_queues = n_queues;
+            bool same = use_feedback && fs.record_ready && std::memcmp(order_key, fs.order_key, sizeof(order_key)) == 0 && fs.tile_order.n >= n_tiles;
             if (same) {
                 // the record only predicts this frame if the camera has barely moved since: the view rays
                 // through the centre and two corners within a degree, the eye within a quarter cube.
                 // (A stale order is worse than none.)
                 same = cameras_close(f->world.inverse_projection_view, fs.cost_cam);
             }
-            if ((e = fs.tile_cost.ensure(n_tiles)) != hipSuccess || (e = fs.tile_order.ensure(n_tiles)) != hipSuccess) return hip_fail(c, "alloc tile feedback", e);
-            if (n_queues && (e = fs.queue_start.ensure(kMaxTileQueues + 1)) != hipSuccess) return hip_fail(c, "alloc tile queues", e);
-            if (same || n_queues) {
-                launch_order_tiles(same ? fs.tile_cost.p : nullptr, fs.tile_order.p, n_tiles, F.macros_x, sb_shift, n_queues ? n_queues : 1u,
-                                   n_queues ? fs.queue_start.p : nullptr, fs.stream);
+            if (same) {
                 F.tile_order = fs.tile_order.p;
                 F.n_queues = n_queues;
                 F.queue_start = n_queues ? fs.queue_start.p : nullptr;
+            } else if (n_queues) {
+                // no record to go by: index order inside each queue, made once per frame shape
+                if (!fs.static_ready || std::memcmp(order_key, fs.static_key, sizeof(order_key)) != 0 || fs.tile_static.n < n_tiles) {
+                    fs.static_ready = false;
+                    if ((e = fs.tile_static.ensure(n_tiles)) != hipSuccess || (e = fs.queue_static.ensure(kMaxTileQueues + 1)) != hipSuccess) return hip_fail(c, "alloc tile queues", e);
+                    launch_order_tiles(nullptr, fs.tile_static.p, n_tiles, F.macros_x, sb_shift, n_queues, fs.queue_static.p, fs.stream);
+                    HIP_TRY(c, hipGetLastError());
+                    std::memcpy(fs.static_key, order_key, sizeof(order_key));
+                    fs.static_ready = true;
+                }
+                F.tile_order = fs.tile_static.p;
+                F.n_queues = n_queues;
+                F.queue_start = fs.queue_static.p;
             }
             if (use_feedback) {
-                HIP_TRY(c, hipMemsetAsync(fs.tile_cost.p, 0, (size_t)n_tiles * sizeof(uint32_t), fs.stream));
+                const uint32_t *const before = fs.tile_cost.p;
+                if ((e = fs.tile_cost.ensure(n_tiles)) != hipSuccess) return hip_fail(c, "alloc tile feedback", e);
+                if (fs.tile_cost.p != before) fs.cost_clean_n = 0;
+                if (fs.cost_clean_n < n_tiles) HIP_TRY(c, hipMemsetAsync(fs.tile_cost.p, 0, (size_t)n_tiles * sizeof(uint32_t), fs.stream));
+                fs.cost_clean_n = 0;  // (this frame writes it)
                 F.tile_cost = fs.tile_cost.p;
                 std::memcpy(fs.cost_sig, sig, sizeof(sig));
-                std::memcpy(fs.cost_cam, f->world.inverse_projection_view, sizeof(fs.cost_cam));
             }
         }
     }
@@ -1048,20 +1083,40 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(fs.ev1, fs.stream));
     fs.busy = true;
+    // behind the trace: the counters go to pinned host memory (ev2: what a wait waits for) ...
+    HIP_TRY(c, hipMemcpyAsync(fs.host_counters, fs.counters.p, sizeof(DevCounters), hipMemcpyDeviceToHost, fs.stream));
+    HIP_TRY(c, hipEventRecord(fs.ev2, fs.stream));
+    // ... and the slot is made ready for its next frame: this frame's cost record becomes the tile order of the next frame of the same view, the
+    // record and the counters are cleared
+    if (F.tile_cost && order_tiles_n) {
+        fs.record_ready = false;
+        if ((e = fs.tile_order.ensure(order_tiles_n)) != hipSuccess || (e = fs.queue_start.ensure(kMaxTileQueues + 1)) != hipSuccess) return hip_fail(c, "alloc tile feedback", e);
+        launch_order_tiles(fs.tile_cost.p, fs.tile_order.p, order_tiles_n, F.macros_x, order_sb_shift, order_queues ? order_queues : 1u, fs.queue_start.p, fs.stream);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemsetAsync(fs.tile_cost.p, 0, (size_t)order_tiles_n * sizeof(uint32_t), fs.stream));
+        fs.cost_clean_n = order_tiles_n;
+        std::memcpy(fs.order_key, order_key, sizeof(order_key));
+        std::memcpy(fs.cost_cam, f->world.inverse_projection_view, sizeof(fs.cost_cam));
+        fs.record_ready = true;
+    }
+    HIP_TRY(c, hipMemsetAsync(fs.counters.p, 0, sizeof(DevCounters), fs.stream));
+    fs.counters_clean = true;
     if (want_aux) c->aux_records = npix;
     return AIC_OK;
 }
 
 // Waits for a slot's frame and reports it.
-int wait_frame(aic_ctx *c, uint32_t slot, aic_frame_info *info) {
+int wait_frame(aic_ctx *c, uint32_t slot, aic_frame_info *info, bool whole_stream = false) {
     aic_ctx::FrameSlot &fs = c->slots[slot];
     if (info) std::memset(info, 0, sizeof(*info));
     float kernel_ms = 0.f;
     if (fs.busy) {
         DevCounters hc;
         fs.busy = false;  // released whatever happens below: a frame that failed must not block its slot for good
-        HIP_TRY(c, hipMemcpyAsync(&hc, fs.counters.p, sizeof(hc), hipMemcpyDeviceToHost, fs.stream));
-        HIP_TRY(c, hipStreamSynchronize(fs.stream));
+        // the frame and its counters (ev2), not the slot's housekeeping behind them -- unless the caller has enqueued a copy of its own behind the frame
+        if (whole_stream) HIP_TRY(c, hipStreamSynchronize(fs.stream));
+        else HIP_TRY(c, hipEventSynchronize(fs.ev2));
+        std::memcpy(&hc, fs.host_counters, sizeof(hc));
         HIP_TRY(c, hipEventElapsedTime(&kernel_ms, fs.ev0, fs.ev1));
         if (info) {
             info->cubes_traced = hc.cubes_traced;
@@ -1112,7 +1167,7 @@ int aic_render(aic_ctx *c, const aic_frame_desc *f, void *out_rgba8, int out_is_
     if (rc != AIC_OK) return rc;
     if (!out_is_device && c->slots[0].npix)
         HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->out.p, c->slots[0].npix * px_words * 4, hipMemcpyDeviceToHost, c->slots[0].stream));
-    return wait_frame(c, 0, info);
+    return wait_frame(c, 0, info, !out_is_device);
 }
 
 namespace {
@@ -1231,7 +1286,7 @@ int aic_render_orthographic(aic_ctx *c, int layer, int resolution, void *out_rgb
     if (swap_layers) std::swap(c->layers[AIC_LAYER_WORLD], c->layers[layer]);
     if (rc != AIC_OK) return rc;
     if (!out_is_device) HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->out.p, npix * 4, hipMemcpyDeviceToHost, c->slots[0].stream));
-    return wait_frame(c, 0, info);
+    return wait_frame(c, 0, info, !out_is_device);
 }
 
 int aic_trace_patches(aic_ctx *c, const aic_frame_desc *f, uint32_t n, const double *rects, void *out_rgba8, aic_pixel_aux *aux,
@@ -1257,7 +1312,7 @@ int aic_trace_patches(aic_ctx *c, const aic_frame_desc *f, uint32_t n, const dou
     int rc = submit_frame(c, &g, c->out.p, 0, true, (const double *)c->staging.p, n);
     if (rc != AIC_OK) return rc;
     HIP_TRY(c, hipMemcpyAsync(out_rgba8, c->out.p, (size_t)n * px_words * 4, hipMemcpyDeviceToHost, c->slots[0].stream));
-    rc = wait_frame(c, 0, info);
+    rc = wait_frame(c, 0, info, true);
     if (rc != AIC_OK) return rc;
     if (aux) {
         HIP_TRY(c, hipMemcpy(aux, c->aux.p, (size_t)n * sizeof(aic_pixel_aux), hipMemcpyDeviceToHost));

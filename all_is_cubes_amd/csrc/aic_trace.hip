@@ -2500,8 +2500,14 @@ __global__ void tag_cubes_kernel(uint16_t *grid, size_t n, const uint32_t *cls, 
 // the others when its own is empty), and `order` comes out as n_queues segments, each costliest first; queue_start[q] is where
 // segment q begins. cost == nullptr: no record to go by (index order inside a queue, as far as the atomics keep it).
 __device__ __forceinline__ uint32_t tile_queue_of(uint32_t mt, uint32_t macros_x, uint32_t sb_shift, uint32_t n_queues) {
-    const uint32_t my = mt / macros_x, mx = mt - my * macros_x;
-    return ((mx >> sb_shift) + 3u * (my >> sb_shift)) % n_queues;
+    // mt / macros_x without the ~40-instruction integer division (this runs twice per macro tile on one workgroup, ahead of every frame):
+    // a float quotient is within one of the truth for these sizes (mt < 2^24), corrected exactly
+    uint32_t my = (uint32_t)((float)mt * __builtin_amdgcn_rcpf((float)macros_x));
+    if (my * macros_x > mt) my--;
+    else if ((my + 1u) * macros_x <= mt) my++;
+    const uint32_t mx = mt - my * macros_x;
+    const uint32_t v = (mx >> sb_shift) + 3u * (my >> sb_shift);
+    return (n_queues & (n_queues - 1u)) == 0u ? (v & (n_queues - 1u)) : v % n_queues;
 }
 __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n_tiles, uint32_t macros_x,
                                                            uint32_t sb_shift, uint32_t n_queues, uint32_t *__restrict__ queue_start) {
@@ -2509,11 +2515,20 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__res
     __shared__ uint32_t scan[1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t n_bins = n_queues * 1024u;
+    const uint32_t *const cp = cost ? cost : order;  // no record: any readable words, masked away
+    const uint32_t use = cost ? ~0u : 0u;
     for (uint32_t b = tid; b < n_bins; b += 1024u) hist[b] = 0;
     __syncthreads();
-    for (uint32_t t = tid; t < n_tiles; t += 1024u) {
-        const uint32_t c = cost ? cost[t] : 0u;
-        atomicAdd(&hist[tile_queue_of(t, macros_x, sb_shift, n_queues) * 1024u + 1023u - (c < 1023u ? c : 1023u)], 1u);
+    // (eight tiles per thread at a time: the eight cost fetches are issued together, not one ahead of each atomic)
+    for (uint32_t base = tid; base < n_tiles; base += 8u * 1024u) {
+        uint32_t c[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) c[k] = cp[min(base + k * 1024u, n_tiles - 1u)] & use;  // (unconditional: nothing keeps the eight fetches apart)
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) {
+            const uint32_t t = base + k * 1024u;
+            if (t < n_tiles) atomicAdd(&hist[tile_queue_of(t, macros_x, sb_shift, n_queues) * 1024u + 1023u - (c[k] < 1023u ? c[k] : 1023u)], 1u);
+        }
     }
     __syncthreads();
     // exclusive prefix sum over the n_queues * 1024 buckets: thread `tid` owns the n_queues consecutive buckets tid * n_queues ..
@@ -2536,10 +2551,18 @@ __global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__res
     __syncthreads();
     if (queue_start && tid <= n_queues) queue_start[tid] = tid < n_queues ? hist[tid * 1024u] : n_tiles;
     __syncthreads();
-    for (uint32_t t = tid; t < n_tiles; t += 1024u) {
-        const uint32_t c = cost ? cost[t] : 0u;
-        const uint32_t pos = atomicAdd(&hist[tile_queue_of(t, macros_x, sb_shift, n_queues) * 1024u + 1023u - (c < 1023u ? c : 1023u)], 1u);
-        order[pos] = t;
+    for (uint32_t base = tid; base < n_tiles; base += 8u * 1024u) {
+        uint32_t c[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) c[k] = cp[min(base + k * 1024u, n_tiles - 1u)] & use;  // (unconditional: nothing keeps the eight fetches apart)
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) {
+            const uint32_t t = base + k * 1024u;
+            if (t < n_tiles) {
+                const uint32_t pos = atomicAdd(&hist[tile_queue_of(t, macros_x, sb_shift, n_queues) * 1024u + 1023u - (c[k] < 1023u ? c[k] : 1023u)], 1u);
+                order[pos] = t;
+            }
+        }
     }
 }
 
