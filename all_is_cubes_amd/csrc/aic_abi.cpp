@@ -1114,7 +1114,8 @@ int wait_frame(aic_ctx *c, uint32_t slot, aic_frame_info *info, bool whole_strea
         DevCounters hc;
         fs.busy = false;  // released whatever happens below: a frame that failed must not block its slot for good
         // the frame and its counters (ev2), not the slot's housekeeping behind them -- unless the caller has enqueued a copy of its own behind the frame
-        if (whole_stream) HIP_TRY(c, hipStreamSynchronize(fs.stream));
+        static const bool always_whole = [] { const char *e = std::getenv("AIC_WAIT_WHOLE_STREAM"); return e && std::atoi(e) != 0; }();  // (a measurement switch: DESIGN.md 4.6)
+        if (whole_stream || always_whole) HIP_TRY(c, hipStreamSynchronize(fs.stream));
         else HIP_TRY(c, hipEventSynchronize(fs.ev2));
         std::memcpy(&hc, fs.host_counters, sizeof(hc));
         HIP_TRY(c, hipEventElapsedTime(&kernel_ms, fs.ev0, fs.ev1));
