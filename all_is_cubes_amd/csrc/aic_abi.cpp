@@ -26,7 +26,7 @@ void launch_scatter_cubes(uint16_t *grid, uint32_t *light, const int32_t *xyz, c
                           uint32_t n, const int lo[3], const int size[3], const uint32_t *cls, hipStream_t stream);
 void launch_probe_powf(const float *x, const float *y, float *out, uint32_t n, hipStream_t stream);
 void launch_order_tiles(const uint32_t *cost, uint32_t *order, uint32_t n_tiles, uint32_t macros_x, uint32_t sb_shift, uint32_t n_queues, uint32_t *queue_start,
-                        hipStream_t stream);
+                        hipStream_t stream, bool clear_cost = false, uint32_t *clear_words = nullptr, uint32_t n_clear_words = 0);
 void launch_tag_cubes(uint16_t *grid, size_t n, const uint32_t *cls, int from_tagged, int to_tagged, hipStream_t stream);
 void launch_assemble_strips(const uint32_t *gathered, uint32_t *out, uint32_t w, uint32_t h, uint32_t strip_rows,
                             uint32_t n_parts, uint32_t max_rows, hipStream_t stream);
@@ -1068,6 +1068,7 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         F.tile_order = nullptr;  // the feedback describes the world pass
         F.tile_cost = nullptr;
         F.n_queues = 0u;
+        F.host_counters = nullptr;  // (the world pass hands over the sums of both)
         launch_trace_image(F, diag, fs.stream);
         F.tile_order = order_keep;
         F.tile_cost = cost_keep;
@@ -1076,6 +1077,9 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         F.use_init = 1;
     }
     F.pass = 0;
+#ifndef AIC_PROFILE
+    F.host_counters = reinterpret_cast<unsigned long long *>(fs.host_counters);  // (DevCounters begins with the five sums)
+#endif
     F.layer = hl[0];
     F.layer_transparency = hl[0].opt.transparency;
     F.layer_lighting = hl[0].opt.lighting;
@@ -1083,23 +1087,28 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(fs.ev1, fs.stream));
     fs.busy = true;
-    // behind the trace: the counters go to pinned host memory (ev2: what a wait waits for) ...
+    // behind the trace: the frame's sums are in pinned host memory -- written by the last wave of the trace itself, or (profile builds: the whole
+    // counter block) copied there; ev2 is what a wait waits for ...
+#ifdef AIC_PROFILE
     HIP_TRY(c, hipMemcpyAsync(fs.host_counters, fs.counters.p, sizeof(DevCounters), hipMemcpyDeviceToHost, fs.stream));
+#endif
     HIP_TRY(c, hipEventRecord(fs.ev2, fs.stream));
     // ... and the slot is made ready for its next frame: this frame's cost record becomes the tile order of the next frame of the same view, the
     // record and the counters are cleared
     if (F.tile_cost && order_tiles_n) {
         fs.record_ready = false;
         if ((e = fs.tile_order.ensure(order_tiles_n)) != hipSuccess || (e = fs.queue_start.ensure(kMaxTileQueues + 1)) != hipSuccess) return hip_fail(c, "alloc tile feedback", e);
-        launch_order_tiles(fs.tile_cost.p, fs.tile_order.p, order_tiles_n, F.macros_x, order_sb_shift, order_queues ? order_queues : 1u, fs.queue_start.p, fs.stream);
+        // (one launch: orders, then clears the record it has read and the counters)
+        launch_order_tiles(fs.tile_cost.p, fs.tile_order.p, order_tiles_n, F.macros_x, order_sb_shift, order_queues ? order_queues : 1u, fs.queue_start.p, fs.stream,
+                           true, reinterpret_cast<uint32_t *>(fs.counters.p), (uint32_t)(sizeof(DevCounters) / 4));
         HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipMemsetAsync(fs.tile_cost.p, 0, (size_t)order_tiles_n * sizeof(uint32_t), fs.stream));
         fs.cost_clean_n = order_tiles_n;
         std::memcpy(fs.order_key, order_key, sizeof(order_key));
         std::memcpy(fs.cost_cam, f->world.inverse_projection_view, sizeof(fs.cost_cam));
         fs.record_ready = true;
+    } else {
+        HIP_TRY(c, hipMemsetAsync(fs.counters.p, 0, sizeof(DevCounters), fs.stream));
     }
-    HIP_TRY(c, hipMemsetAsync(fs.counters.p, 0, sizeof(DevCounters), fs.stream));
     fs.counters_clean = true;
     if (want_aux) c->aux_records = npix;
     return AIC_OK;

@@ -95,7 +95,7 @@ struct DevCounters {
     unsigned long long n_light;
     unsigned long long prof[32];  // AIC_PROFILE builds only
     uint32_t tile_next;           // dynamic tile dispenser of the persistent trace kernel
-    uint32_t pad;
+    uint32_t waves_done;          // waves of the world pass that have added their sums: the last one hands the sums to the host (DevFrame::host_counters)
     uint32_t tile_next_q[kMaxTileQueues][16];  // the same per tile queue (DevFrame::n_queues), a cache line each: [q][0] counts
 #ifdef AIC_PROFILE
     uint32_t wave_prof[2048][4];  // per wave: start, first saw the queue dry, end (cycle counter), pixels taken
@@ -164,6 +164,9 @@ struct DevFrame {
     uint32_t n_queues;
     uint32_t pad_q;
     const uint32_t *queue_start;
+    // pinned host memory for the frame's five sums (cubes_traced, n_outer, n_inner, n_hits, n_light), written by the last wave of the world pass
+    // to finish: no copy launch behind the trace (a blit kernel that, with frames streamed, waits ~0.2 ms for a CU to have room). Null: the host copies.
+    unsigned long long *host_counters;
     const float *light_lut;  // 256 floats
     const float *srgb_thr;   // 256 floats: srgb_thr[k] = smallest linear value whose sRGB8 encoding is >= k
     // ray migration in the frame's tail (aic_trace.hip): hot lane state of the rays a wave hands over, kOrphanDwords dwords per

@@ -2454,6 +2454,18 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
             if (v[3]) atomicAdd(&F.counters->n_light, v[3]);
         }
     }
+    // the last wave out hands the frame's sums to the host (pinned memory; the end of the kernel makes the stores visible)
+    // (No fences: an agent-scope release fence writes the XCD's whole L2 back -- the frame's pixels -- and 4096 waves doing that cost 10 % of a C2
+    //  frame. The sums are agent-scope atomics, performed at the memory side; the wave waits for its own to be acknowledged before it is counted, and
+    //  the last wave reads them with agent-scope loads.)
+    if (lane == 0 && F.host_counters) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (atomicAdd(&F.counters->waves_done, 1u) == gridDim.x * (blockDim.x >> 6) - 1u) {
+            unsigned long long *const src = &F.counters->cubes_traced;  // five consecutive sums (DevCounters)
+#pragma unroll
+            for (int i = 0; i < 5; i++) F.host_counters[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2509,58 +2521,68 @@ __device__ __forceinline__ uint32_t tile_queue_of(uint32_t mt, uint32_t macros_x
     const uint32_t v = (mx >> sb_shift) + 3u * (my >> sb_shift);
     return (n_queues & (n_queues - 1u)) == 0u ? (v & (n_queues - 1u)) : v % n_queues;
 }
-__global__ __launch_bounds__(1024) void order_tiles_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n_tiles, uint32_t macros_x,
-                                                           uint32_t sb_shift, uint32_t n_queues, uint32_t *__restrict__ queue_start) {
+// One workgroup of kOrderThreads = 256 threads (four waves, 33 KB of LDS): what ONE retiring workgroup of a trace kernel leaves free on a CU. With 1024
+// threads it needed a whole CU to drain, and while frames are streamed every CU is full of persistent trace workgroups: rocprofv3 showed it
+// waiting 0.14 ms (C2) / 1.6 ms (C3) for a place to run (profiles/r04_experiments.txt L).
+constexpr uint32_t kOrderThreads = 256;
+__global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n_tiles, uint32_t macros_x,
+                                                                    uint32_t sb_shift, uint32_t n_queues, uint32_t *__restrict__ queue_start, uint32_t *clear_cost,
+                                                                    uint32_t *clear_words, uint32_t n_clear_words) {
     __shared__ uint32_t hist[kMaxTileQueues * 1024];
-    __shared__ uint32_t scan[1024];
+    __shared__ uint32_t scan[kOrderThreads];
+    // (behind a frame this launch also does the slot's clearing -- the frame's counters, and below the cost record once it has been read -- instead of two
+    //  fill launches that would each wait for room on a CU)
+    for (uint32_t i = threadIdx.x; i < n_clear_words; i += kOrderThreads) clear_words[i] = 0u;
     const uint32_t tid = threadIdx.x;
     const uint32_t n_bins = n_queues * 1024u;
+    const uint32_t per_thread = n_bins / kOrderThreads;  // 4 * n_queues consecutive buckets each
     const uint32_t *const cp = cost ? cost : order;  // no record: any readable words, masked away
     const uint32_t use = cost ? ~0u : 0u;
-    for (uint32_t b = tid; b < n_bins; b += 1024u) hist[b] = 0;
+    for (uint32_t b = tid; b < n_bins; b += kOrderThreads) hist[b] = 0;
     __syncthreads();
     // (eight tiles per thread at a time: the eight cost fetches are issued together, not one ahead of each atomic)
-    for (uint32_t base = tid; base < n_tiles; base += 8u * 1024u) {
+    for (uint32_t base = tid; base < n_tiles; base += 8u * kOrderThreads) {
         uint32_t c[8];
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; k++) c[k] = cp[min(base + k * 1024u, n_tiles - 1u)] & use;  // (unconditional: nothing keeps the eight fetches apart)
+        for (uint32_t k = 0; k < 8u; k++) c[k] = cp[min(base + k * kOrderThreads, n_tiles - 1u)] & use;  // (unconditional: nothing keeps the eight fetches apart)
 #pragma unroll
         for (uint32_t k = 0; k < 8u; k++) {
-            const uint32_t t = base + k * 1024u;
+            const uint32_t t = base + k * kOrderThreads;
             if (t < n_tiles) atomicAdd(&hist[tile_queue_of(t, macros_x, sb_shift, n_queues) * 1024u + 1023u - (c[k] < 1023u ? c[k] : 1023u)], 1u);
         }
     }
     __syncthreads();
-    // exclusive prefix sum over the n_queues * 1024 buckets: thread `tid` owns the n_queues consecutive buckets tid * n_queues ..
+    // exclusive prefix sum over the n_queues * 1024 buckets: thread `tid` owns `per_thread` consecutive buckets
     uint32_t mine = 0;
-    for (uint32_t k = 0; k < n_queues; k++) mine += hist[tid * n_queues + k];
+    for (uint32_t k = 0; k < per_thread; k++) mine += hist[tid * per_thread + k];
     scan[tid] = mine;
     __syncthreads();
-    for (uint32_t off = 1; off < 1024u; off <<= 1) {  // Hillis-Steele over the 1024 partial sums
+    for (uint32_t off = 1; off < kOrderThreads; off <<= 1) {  // Hillis-Steele over the partial sums
         const uint32_t v = tid >= off ? scan[tid - off] : 0u;
         __syncthreads();
         scan[tid] += v;
         __syncthreads();
     }
     uint32_t run = scan[tid] - mine;
-    for (uint32_t k = 0; k < n_queues; k++) {
-        const uint32_t h = hist[tid * n_queues + k];
-        hist[tid * n_queues + k] = run;  // start of each bucket
+    for (uint32_t k = 0; k < per_thread; k++) {
+        const uint32_t h = hist[tid * per_thread + k];
+        hist[tid * per_thread + k] = run;  // start of each bucket
         run += h;
     }
     __syncthreads();
     if (queue_start && tid <= n_queues) queue_start[tid] = tid < n_queues ? hist[tid * 1024u] : n_tiles;
     __syncthreads();
-    for (uint32_t base = tid; base < n_tiles; base += 8u * 1024u) {
+    for (uint32_t base = tid; base < n_tiles; base += 8u * kOrderThreads) {
         uint32_t c[8];
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; k++) c[k] = cp[min(base + k * 1024u, n_tiles - 1u)] & use;  // (unconditional: nothing keeps the eight fetches apart)
+        for (uint32_t k = 0; k < 8u; k++) c[k] = cp[min(base + k * kOrderThreads, n_tiles - 1u)] & use;
 #pragma unroll
         for (uint32_t k = 0; k < 8u; k++) {
-            const uint32_t t = base + k * 1024u;
+            const uint32_t t = base + k * kOrderThreads;
             if (t < n_tiles) {
                 const uint32_t pos = atomicAdd(&hist[tile_queue_of(t, macros_x, sb_shift, n_queues) * 1024u + 1023u - (c[k] < 1023u ? c[k] : 1023u)], 1u);
                 order[pos] = t;
+                if (clear_cost) clear_cost[t] = 0u;
             }
         }
     }
@@ -2700,11 +2722,12 @@ void launch_probe_powf(const float *x, const float *y, float *out, uint32_t n, h
 }
 
 void launch_order_tiles(const uint32_t *cost, uint32_t *order, uint32_t n_tiles, uint32_t macros_x, uint32_t sb_shift, uint32_t n_queues, uint32_t *queue_start,
-                        hipStream_t stream) {
+                        hipStream_t stream, bool clear_cost, uint32_t *clear_words, uint32_t n_clear_words) {
     if (!n_tiles) return;
     if (n_queues < 1u) n_queues = 1u;
     if (n_queues > kMaxTileQueues) n_queues = kMaxTileQueues;
-    hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, stream, cost, order, n_tiles, macros_x ? macros_x : 1u, sb_shift, n_queues, queue_start);
+    hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(kOrderThreads), 0, stream, cost, order, n_tiles, macros_x ? macros_x : 1u, sb_shift, n_queues, queue_start,
+                       clear_cost ? const_cast<uint32_t *>(cost) : nullptr, clear_words, n_clear_words);
 }
 
 void launch_assemble_strips(const uint32_t *gathered, uint32_t *out, uint32_t w, uint32_t h, uint32_t strip_rows,
