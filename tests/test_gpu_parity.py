@@ -253,6 +253,42 @@ def test_xcd_local_tile_queues_trace_every_pixel_once(ctx, synth_space, monkeypa
         assert (plain["rgba8"] == base["rgba8"]).all() and plain["info"].cubes_traced == base["info"].cubes_traced
 
 
+def test_frames_of_changing_shape_on_one_slot(ctx, synth_space):
+    """A slot prepares its next frame behind the one that is done (counters and cost record cleared, the record turned into a tile order:
+    csrc/aic_abi.cpp submit_frame), keyed by the frame's shape and view. Frames of different sizes, views and feedback settings taken in turn on the
+    same slot must each be what a fresh context gives, sums included -- nothing of a neighbour's record, order or counters may leak."""
+    opt = oracle.make_options(fog=1, transparency=1, lighting=2)
+    ctx.upload_space(abi.LAYER_WORLD, synth_space)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+    views = []
+    for (w, h), eye in [((416, 232), SYNTH_EYE), ((96, 64), SYNTH_EYE), ((640, 360), (SYNTH_EYE[0] + 3.0, SYNTH_EYE[1], SYNTH_EYE[2] - 2.0)), ((416, 232), (SYNTH_EYE[0] - 2.0, SYNTH_EYE[1] + 1.0, SYNTH_EYE[2]))]:
+        _, _, inv = oracle.camera_matrices(90.0, opt.view_distance, w / h, synth_quat(), eye)
+        views.append((w, h, inv))
+    fresh = abi.Context(0)
+    try:
+        fresh.upload_space(abi.LAYER_WORLD, synth_space)
+        fresh.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+        want = []
+        for w, h, inv in views:
+            r = fresh.render(fresh.make_frame(w, h, world_inv=inv), counters=True)
+            want.append((r["rgba8"].copy(), int(r["info"].cubes_traced), int(r["info"].n_hits)))
+    finally:
+        fresh.close()
+    rng = np.random.default_rng(5)
+    for k in rng.integers(0, len(views), 40):
+        w, h, inv = views[int(k)]
+        frame = ctx.make_frame(w, h, world_inv=inv)
+        if rng.integers(0, 3) == 0:
+            frame.flags |= abi.FRAME_NO_FEEDBACK
+        counters = bool(rng.integers(0, 2))
+        r = ctx.render(frame, counters=counters)
+        assert (r["rgba8"] == want[int(k)][0]).all(), int(k)
+        assert int(r["info"].cubes_traced) == want[int(k)][1]
+        if counters:
+            assert int(r["info"].n_hits) == want[int(k)][2]
+
+
 def test_step_cap_and_camera_inside_geometry(ctx):
     # a corridor of recursive blocks made only of invisible voxels: every voxel is a counted
     # step, so rays along the corridor run into the 1000-step cap (sr.rs:643)
