@@ -884,6 +884,10 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u
 #ifndef AIC_FAST_STEPS
 #define AIC_FAST_STEPS 16  // bookkeeping-free steps a lane may take ahead of each full pass (0: none; 8 until round 4) ...
 #endif
+#ifndef AIC_PRIO_SHIFT
+#define AIC_PRIO_SHIFT 0  // experiment (-DAIC_PRIO_SHIFT=6..8): a wave hosting a ray that is n << AIC_PRIO_SHIFT steps along runs at issue priority min(n, 3) on its
+                          // SIMD (s_setprio) -- one frame alone lasts as long as its longest rays' serial lives, and those rays' waves wait their turn like any other
+#endif
 #ifndef AIC_SPEC_STEPS
 #define AIC_SPEC_STEPS 0  // experiment (-DAIC_SPEC_STEPS=4): a draining wave takes its fast steps four at a time, all four
                           // lookups in flight together. Exact (frame hashes equal) and SLOWER: C2 one frame warm 0.776 -> 0.815 ms, cold
@@ -1017,13 +1021,12 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
     const uint32_t mig_k = (MIGRATE && blockIdx.x < F.migrate_groups && (uint32_t)AIC_WG_THREADS <= 256u) ? F.migrate_k : 0u;  // (the buffer has 256 columns per workgroup)
     const bool anchor = (threadIdx.x >> 6) == 0u;   // the wave of the workgroup that adopts, never hands over, and leaves last
     bool dry = false;                               // wave-uniform: this wave has seen the tile queue exhausted
-    // wave-uniform: the tile queue this wave takes from (DevFrame::n_queues > 1): its XCD's own to begin with, the next one's when that is empty
-    uint32_t my_queue = 0u, queues_tried = 0u;
-    if (F.n_queues > 1u) {
-        uint32_t xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        my_queue = (xcc & 15u) % F.n_queues;
-    }
+    // The tile queue this wave takes from (DevFrame::n_queues > 1): its XCD's own to begin with, the next one's when that is empty. How many queues it has
+    // seen empty is a word of LDS per wave, read once per tile -- kept in a scalar register for the life of the wave it cost the production variant
+    // four spilled VGPRs (12 bytes of scratch per lane, 1.2 GB of scratch written back per C3 frame: profiles/r04_experiments.txt K).
+    __shared__ uint32_t s_queues_tried[AIC_WG_THREADS / 64];
+    if (lane == 0u) s_queues_tried[threadIdx.x >> 6] = 0u;
+    uint32_t prio_level = 0u;  // (AIC_PRIO_SHIFT) the wave's current issue priority
     bool donated = false;
     SurfDiag pend_d;
     double pend_t = 0.0;
@@ -1138,6 +1141,19 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
         const unsigned long long b_enter = __ballot((ev & EV_ENTER) != 0u);
         unsigned long long b_ray = __ballot((ev & (EV_FINISH | EV_NEWRAY)) != 0u);
         if ((m_st | b_shade | b_enter | b_ray) == 0ull) break;
+        if (AIC_PRIO_SHIFT != 0) {
+            const unsigned long long live_ = m_st | b_shade | b_enter | b_ray;
+            const uint32_t level = (__ballot(count >= (3u << AIC_PRIO_SHIFT)) & live_) != 0ull ? 3u
+                                 : (__ballot(count >= (2u << AIC_PRIO_SHIFT)) & live_) != 0ull ? 2u
+                                 : (__ballot(count >= (1u << AIC_PRIO_SHIFT)) & live_) != 0ull ? 1u : 0u;
+            if (level != prio_level) {
+                prio_level = level;
+                if (level == 3u) __builtin_amdgcn_s_setprio(3);
+                else if (level == 2u) __builtin_amdgcn_s_setprio(2);
+                else if (level == 1u) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+        }
         bool only_waiting = false;  // ray migration, anchor wave: every lane that is not done waits for a ray to adopt
         if (MIGRATE && dry && anchor && mig_k != 0u) {
             // lanes that found the queue dry wait for orphans; they ask for a ray phase only when there is one to adopt, or
@@ -1770,6 +1786,11 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                             if (F.n_queues > 1u) {
                                 // the XCD's own queue; when it is empty, the next XCD's (for good: `my_queue` moves on), until all have been seen empty
                                 const uint32_t nq = F.n_queues;
+                                uint32_t xcc;
+                                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                                uint32_t queues_tried = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_queues_tried[threadIdx.x >> 6]);
+                                uint32_t my_queue = ((xcc & 15u) + queues_tried) % nq;
+                                const uint32_t tried_before = queues_tried;
                                 while (queues_tried < nq) {
                                     uint32_t u = 0u;
                                     if ((int)lane == leader) u = atomicAdd(&F.counters->tile_next_q[my_queue][0], 1u);
@@ -1783,6 +1804,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                                     my_queue = my_queue + 1u == nq ? 0u : my_queue + 1u;
                                     queues_tried++;
                                 }
+                                if (queues_tried != tried_before && lane == 0u) s_queues_tried[threadIdx.x >> 6] = queues_tried;
                             } else {
                                 if ((int)lane == leader) t = atomicAdd(&F.counters->tile_next, 1u);
                                 t = (uint32_t)__shfl((int)t, leader, 64);

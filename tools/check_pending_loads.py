@@ -78,6 +78,27 @@ def scan(path):
     return kernels, lookups, problems
 
 
+def kernel_resources(path):
+    """{kernel symbol: dict(vgprs, scratch_bytes, lds_bytes)} from the .amdhsa_* directives of every trace_image_kernel in the assembly."""
+    out, name = {}, None
+    for line in open(path):
+        t = line.strip()
+        if t.startswith(".amdhsa_kernel "):
+            sym = t.split()[1]
+            name = sym if sym.startswith("_ZN3aic18trace_image_kernel") else None
+            if name:
+                out[name] = {}
+        elif t.startswith(".end_amdhsa_kernel"):
+            name = None
+        elif name and t.startswith(".amdhsa_"):
+            parts = t.split()
+            if len(parts) == 2 and parts[1].lstrip("-").isdigit():
+                key = {".amdhsa_next_free_vgpr": "vgprs", ".amdhsa_private_segment_fixed_size": "scratch_bytes", ".amdhsa_group_segment_fixed_size": "lds_bytes"}.get(parts[0])
+                if key:
+                    out[name][key] = int(parts[1])
+    return out
+
+
 def main():
     path = sys.argv[1] if len(sys.argv) > 1 else compile_to_asm()
     kernels, lookups, problems = scan(path)
