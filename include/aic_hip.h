@@ -221,7 +221,11 @@ int aic_render(aic_ctx *ctx, const aic_frame_desc *frame, void *out_rgba8, int o
  * `out_device` and reports it. With several frames in flight the next frame's trace starts filling the
  * GPU while the previous frame's last rays finish. out_device must be a device pointer; the
  * AIC_FRAME_AUX flag is ignored here (use aic_render). Scene updates wait for every frame in
- * flight before touching device memory. */
+ * flight before touching device memory.
+ * "The frame is in out_device" is all aic_render_wait (and aic_render with a device target) waits for: behind the frame the slot's
+ * stream still prepares the slot's next frame (the frame's cost record becomes a tile order, counters are cleared -- microseconds of
+ * work private to the slot). Work the caller orders behind the frame with aic_stream_wait_frame, or issues after the wait returns,
+ * never has to wait for that. */
 #define AIC_MAX_IN_FLIGHT 8u
 int aic_render_submit(aic_ctx *ctx, const aic_frame_desc *frame, void *out_device, uint32_t slot);
 int aic_render_wait(aic_ctx *ctx, uint32_t slot, aic_frame_info *info);
