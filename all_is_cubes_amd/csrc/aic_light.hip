@@ -1007,6 +1007,29 @@ _Pragma("unroll")
                 }
             }
             if (lane < 4u) s_sum[lane] = acc;
+            // Will the host want this cube's dependency list? It re-queues the dependencies only when the texel moves by more than one unit
+            // (apply_light_update, updater.rs:296-340: `difference_priority`), which most updates of a converging volume do not; then the list is
+            // neither built nor brought back. Decided here exactly as the host will decide it: the texel the host compares with is the one in the
+            // volume now unless it is Uninitialized (only those can be given a guess by a neighbour applied earlier in the same batch) -- for
+            // those the list is always built.
+            __syncthreads();
+            bool emit_deps = true;
+            {
+                const float tot_ = s_sum[3];
+                if (tot_ > 0.0f) {
+                    const float scale_ = ps_new_clamped(1.0f / fmaxf(tot_, 1.0f));
+                    const uint32_t new_ = packed_scalar_in(ps_mul(s_sum[0], scale_)) | (packed_scalar_in(ps_mul(s_sum[1], scale_)) << 8) |
+                                          (packed_scalar_in(ps_mul(s_sum[2], scale_)) << 16) | (255u << 24);
+                    const uint32_t old_ = b.light_texel(ci);
+                    int diff_ = 0;
+                    for (int sh = 0; sh < 24; sh += 8) {
+                        const int x_ = (int)((new_ >> sh) & 255u), y_ = (int)((old_ >> sh) & 255u);
+                        diff_ = max(diff_, x_ > y_ ? x_ - y_ : y_ - x_);
+                    }
+                    if ((new_ >> 24) != (old_ >> 24)) diff_ = min(255, diff_ + 255 / 4);  // data.rs:186-211
+                    emit_deps = (old_ >> 24) == 0u || diff_ > 1;
+                }
+            }
             // Dependencies: a candidate is dropped if it is a face cube equal to the candidate before it (`if
             // dependencies.last() != Some(&light_cube)`, updater.rs:838-842 -- "the last pushed" and "the candidate before" are
             // the same cube whenever the test can succeed) or lies outside the space (light_needs_update ignores those); the
@@ -1015,7 +1038,7 @@ _Pragma("unroll")
             uint32_t *const s_keys = reinterpret_cast<uint32_t *>(s_stage);
             const uint32_t wl = lane & 63u, wid = lane >> 6;
             word = 0u;
-            for (;;) {
+            while (emit_deps) {
                 const uint32_t got = gather_set_bits(cand_bits, cand_words, &word, s_order, lane, nt, s_scan);
                 if (got == 0u) break;
                 if (got == 0xffffffffu) continue;

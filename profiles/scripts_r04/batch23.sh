@@ -1,0 +1,13 @@
+#!/bin/bash
+# Round 4, batch 23: the host walks a cube's dependency list out of the chunks only when the update will re-queue it (texel moved by more than one unit).
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+O=gpurun_out/r04b23; mkdir -p $O
+timeout 600 python -m pytest tests/test_gpu_light_update.py tests/test_gpu_light.py -q 2>&1 | tail -2
+AIC_LIGHT_FUZZ_N=300 timeout 600 python -m pytest tests/test_gpu_light_update.py -q -k fuzz 2>&1 | tail -1
+for i in 1 2; do python bench.py --workload relight --steps 200 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('relight', d['ms_per_step'], d['relight']['light_ms_per_frame'])"; done
+python bench.py --workload light-bench --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); lu=d['light_update']; print('lightbench', lu['total_ms'], lu['device_ms'], lu['throughput_mode']['total_ms'], lu['throughput_mode']['device_ms'])"
+cp all_is_cubes_amd/libaic_hip.so /tmp/libaic_default.so
+cp variants/libaic_hip_lighttiming.so all_is_cubes_amd/libaic_hip.so
+python bench.py --workload light-bench --steps 20 --warmup 2 --no-cpu-baseline --no-extras --no-secondary --min-seconds 0 2>&1 >/dev/null | grep "light host us\|deps wanted"
+python bench.py --workload relight --steps 60 --warmup 5 --no-cpu-baseline --no-extras --no-secondary --min-seconds 0 2>&1 >/dev/null | grep "deps wanted" | awk '{w+=$4; u+=$6} END {print "relight: deps wanted", w, "of", u}'
+cp /tmp/libaic_default.so all_is_cubes_amd/libaic_hip.so
