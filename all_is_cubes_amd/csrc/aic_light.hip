@@ -678,7 +678,7 @@ __device__ uint32_t gather_set_bits(const uint32_t *bits, uint32_t n_words, uint
 // dispatch, the refill of every XCD's L2 (the caches are invalidated at a kernel boundary: 8.9 MB fetched per launch against
 // 0.57 MB algorithmic) and the host's wake-up from hipStreamSynchronize on top of the walk itself. One workgroup per cube of
 // the batch (gridDim.x >= the batch size), workgroup 0 talks to the host.
-template <bool SESSION, int CHUNK>
+template <bool SESSION, int CHUNK, bool LDSQ>
 __device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
     extern __shared__ uint32_t s_dyn[];  // term bitmap, candidate bitmap, visited bitmap
     __shared__ uint32_t s_flags[kLdsFlags];
@@ -690,6 +690,13 @@ __device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
     const uint32_t lane = threadIdx.x, wave = blockIdx.x, nt = blockDim.x;  // `lane`: thread of the cube's block (1 or 4 waves)
     const uint32_t term_words = (4u * J.n_tree + 31u) / 32u, cand_words = (2u * J.n_tree + 31u) / 32u, vis_words = (J.n_tree + 31u) / 32u;
     uint32_t *const term_bits = s_dyn, *const cand_bits = s_dyn + term_words, *const vis_bits = cand_bits + cand_words;
+    // LDSQ: the walk's work queue lives in LDS behind the bitmaps (16-byte aligned) instead of in global memory. A hand-off of a branching bundle's children
+    // to other lanes -- up to nine on a root path -- then costs LDS round trips, not a store to L2, a poll of L2 and a fetch from L2 (~4 us each at the
+    // small-batch build's one wave per SIMD). Used when the queue of this maximum_distance fits (light_wave_lds); all zero between cubes, like the global one.
+    uint4 *const lds_front = reinterpret_cast<uint4 *>(s_dyn + ((term_words + cand_words + vis_words + 3u) & ~3u));
+    if (LDSQ) {
+        for (uint32_t i = lane; i < J.n_front; i += nt) lds_front[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     for (uint32_t i = lane; i < min(J.n_blocks, kLdsFlags); i += nt) s_flags[i] = J.derived[i].flags;
     for (uint32_t i = lane; i < 256u; i += nt) s_lut[i] = J.lut[i];
     __syncthreads();
@@ -800,7 +807,7 @@ __device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
                     }
                 s_scan[0] = m0;
             }
-            uint4 *const front = J.front + (size_t)wave * J.n_front;
+            uint4 *const front = LDSQ ? lds_front : J.front + (size_t)wave * J.n_front;
             float *const valpha = J.valpha + (size_t)wave * J.n_tree;
             if (lane == 0u) {
                 front[0] = make_uint4(0u, __float_as_uint(1.0f), J.tree[0].offset, J.root_meta | kLightQueueValid);
@@ -893,7 +900,9 @@ _Pragma("unroll")
                                 const bool consecutive = k_next == k + 1u;
                                 k = k_next;
                                 atomicOr(&vis_bits[k >> 5], 1u << (k & 31u));
+#ifndef AIC_LIGHT_EXP_NOSTORE
                                 valpha[k] = alpha;
+#endif
                                 off = nd[i].y;
                                 meta = (nd[i].x >> 28) | (((nd[i].x >> 22) & 63u) << 4);
                                 alpha_in = alpha;
@@ -1164,11 +1173,12 @@ _Pragma("unroll")
 // Two builds of the same body. A small batch (the reference's 32 cubes) is a latency problem: one block per CU at most, and
 // the register allocator is left alone (131 VGPRs). A large batch is an occupancy problem: a CU's LDS holds four cubes'
 // blocks, which needs four waves per SIMD, i.e. at most 128 VGPRs -- three fewer, at the price of a few stack slots.
-__global__ void __launch_bounds__(kLightBlock) compute_light_wave_kernel(const LightJob J) { compute_light_wave_body<false, AIC_LIGHT_CHUNK>(J); }
+__global__ void __launch_bounds__(kLightBlock) compute_light_wave_kernel(const LightJob J) { compute_light_wave_body<false, AIC_LIGHT_CHUNK, false>(J); }
+__global__ void __launch_bounds__(kLightBlock) compute_light_wave_kernel_ldsq(const LightJob J) { compute_light_wave_body<false, AIC_LIGHT_CHUNK, true>(J); }
 __global__ void __launch_bounds__(kLightBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) compute_light_wave_kernel_dense(const LightJob J) {
-    compute_light_wave_body<false, 1>(J);
+    compute_light_wave_body<false, 1, false>(J);
 }
-__global__ void __launch_bounds__(kLightBlock) compute_light_session_kernel(const LightJob J) { compute_light_wave_body<true, AIC_LIGHT_CHUNK>(J); }
+__global__ void __launch_bounds__(kLightBlock) compute_light_session_kernel(const LightJob J) { compute_light_wave_body<true, AIC_LIGHT_CHUNK, false>(J); }
 
 __global__ void scatter_light_kernel(uint32_t *light, const uint32_t *index, const uint32_t *texel, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1195,18 +1205,23 @@ void launch_compute_light(const LightJob &job, hipStream_t stream) {
 }
 
 namespace {
+constexpr uint32_t kLightLdsQueueBudget = 96u << 10;  // dynamic LDS a small-batch block may take for bitmaps + queue (one block per CU; 17.5 KB are static)
+uint32_t light_wave_bitmap_words(const LightJob &job) { return ((4u * job.n_tree + 31u) / 32u) + ((2u * job.n_tree + 31u) / 32u) + ((job.n_tree + 31u) / 32u); }
+uint32_t light_wave_ldsq_bytes(const LightJob &job) { return ((light_wave_bitmap_words(job) + 3u) & ~3u) * 4u + job.n_front * 16u; }
 uint32_t light_wave_lds(const LightJob &job) {
-    const uint32_t lds = (((4u * job.n_tree + 31u) / 32u) + ((2u * job.n_tree + 31u) / 32u) + ((job.n_tree + 31u) / 32u)) * 4u;
+    const uint32_t lds = light_wave_bitmap_words(job) * 4u;
     // more dynamic LDS than the default limit needs an opt-in, per device
     static uint32_t lds_allowed[64] = {0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     uint32_t &allowed = lds_allowed[dev & 63];
-    if (lds > allowed) {
+    const uint32_t want = std::max(lds, light_wave_ldsq_bytes(job) <= kLightLdsQueueBudget ? light_wave_ldsq_bytes(job) : 0u);
+    if (want > allowed) {
         (void)hipFuncSetAttribute((const void *)compute_light_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)compute_light_wave_kernel_ldsq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
         (void)hipFuncSetAttribute((const void *)compute_light_wave_kernel_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void *)compute_light_session_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        allowed = lds;
+        allowed = want;
     }
     return lds;
 }
@@ -1220,7 +1235,10 @@ void launch_compute_light_session(const LightJob &job, uint32_t n_blocks, uint32
 void launch_compute_light_waves(const LightJob &job, uint32_t n_waves, uint32_t threads, hipStream_t stream) {
     if (!job.n || !n_waves) return;
     const uint32_t lds = light_wave_lds(job);
+    static const bool no_ldsq = std::getenv("AIC_LIGHT_GLOBAL_QUEUE") != nullptr;  // (measurement switch: the walk's queue in global memory, as until round 4)
     if (n_waves > 256u) hipLaunchKernelGGL(compute_light_wave_kernel_dense, dim3(n_waves), dim3(threads == 256u ? 256u : 64u), lds, stream, job);
+    else if (!no_ldsq && light_wave_ldsq_bytes(job) <= kLightLdsQueueBudget)
+        hipLaunchKernelGGL(compute_light_wave_kernel_ldsq, dim3(n_waves), dim3(threads == 256u ? 256u : 64u), light_wave_ldsq_bytes(job), stream, job);
     else hipLaunchKernelGGL(compute_light_wave_kernel, dim3(n_waves), dim3(threads == 256u ? 256u : 64u), lds, stream, job);
 }
 
