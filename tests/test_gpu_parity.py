@@ -1187,3 +1187,25 @@ def test_exchange_step_over_the_nccl_backend_on_one_gpu():
     assert line["config"]["assembled_frame_equals_single_rank_frame"] is True
     assert line["config"]["handoff"].startswith("device")
     assert out.stdout.strip().splitlines()[-1].startswith("{"), "the bench line must be the last line of the output"
+
+
+def test_two_ranks_launched_as_the_driver_launches_them():
+    """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...`, the driver's own command for N > 1, with the two ranks sharing the one
+    MI355X (AIC_BENCH_ONE_GPU=1: RCCL refuses two ranks on one device, so the strips are gathered through host memory over gloo). Interleaved strips,
+    the exchange pipeline, verification against a single-rank frame and the one JSON line from rank 0 are exactly what runs on a node."""
+    import json
+    import subprocess
+    import sys
+
+    root = Path(__file__).resolve().parents[1]
+    env = dict(os.environ, AIC_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29549",
+           str(root / "bench.py"), "--gpus", "2", "--workload", "small", "--steps", "6", "--warmup", "2", "--min-seconds", "0", "--no-extras", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(root))
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 alone prints the line"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["assembled_frame_equals_single_rank_frame"] is True
+    assert "2 GPU" in line["config"]["partition"] or "2 GPU(s)" in line["config"]["partition"]
