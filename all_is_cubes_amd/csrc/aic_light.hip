@@ -427,8 +427,18 @@ constexpr uint32_t kLdsFlags = 1024u;   // DevDerived.flags of the first blocks,
 constexpr uint32_t kOrderCap = 2048u;   // set bits gathered per pass of the ordered reduction
 constexpr uint32_t kLightBlock = 256u;  // most threads a cube's block may have (1 or 4 waves)
 
+// The walk's loop uses a dozen fields of the job; with ~100 scalar registers already spoken for, the compiler re-reads them from the kernel-argument
+// segment inside the loop (four s_load + wait per step of a chain: ISA of round 4). A value passed through here lives in a vector register instead --
+// the small-batch build has 370 of them to spare.
+template <class T>
+__device__ __forceinline__ T keep_in_vgpr(T x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 struct WaveCtx {
     const LightJob &J;
+    const DevDerived *derived_p;  // J.derived, held in vector registers (keep_in_vgpr)
     int origin[3];
     uint32_t m0;            // direction weights of the walk: bit per face (updater.rs:668-690)
     float sky_value[6][3];
@@ -439,8 +449,8 @@ struct WaveCtx {
     const uint32_t *lds_flags;
     const float *lds_lut;
 
-    __device__ explicit WaveCtx(const LightJob &j) : J(j) {}
-    __device__ uint32_t flags_of(uint32_t block) const { return block < kLdsFlags ? lds_flags[block] : J.derived[block].flags; }
+    __device__ explicit WaveCtx(const LightJob &j) : J(j), derived_p(j.derived) {}
+    __device__ uint32_t flags_of(uint32_t block) const { return block < kLdsFlags ? lds_flags[block] : derived_p[block].flags; }
     __device__ bool index_of(const int c[3], uint32_t *out) const {
         const uint32_t dx = (uint32_t)c[0] - (uint32_t)J.lo[0], dy = (uint32_t)c[1] - (uint32_t)J.lo[1], dz = (uint32_t)c[2] - (uint32_t)J.lo[2];
         if ((dx >= (uint32_t)J.size[0]) | (dy >= (uint32_t)J.size[1]) | (dz >= (uint32_t)J.size[2])) return false;
@@ -527,7 +537,7 @@ struct WaveCtx {
             if (hit_opaque_face && fe < 0) {
                 alpha = 0.f;
             } else {
-                const DevDerived *ev = &J.derived[block];
+                const DevDerived *ev = &derived_p[block];
                 const float hit_alpha = fe < 0 ? ev->color[3] : ev->face[fe][3];
                 if (hit_alpha > 0.f && fe >= 0) {
                     if (hit_opaque_face) alpha = 0.f;
@@ -808,7 +818,12 @@ __device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
                 s_scan[0] = m0;
             }
             uint4 *const front = LDSQ ? lds_front : J.front + (size_t)wave * J.n_front;
-            float *const valpha = J.valpha + (size_t)wave * J.n_tree;
+            float *const valpha = keep_in_vgpr(J.valpha + (size_t)wave * J.n_tree);
+            const uint4 *const node_p = keep_in_vgpr(J.node);
+            const uint16_t *const grid_p = keep_in_vgpr(J.grid);
+            const uint2 *const child_ent_p = keep_in_vgpr(J.child_ent);
+            const uint32_t index_mask_v = keep_in_vgpr(J.index_mask), n_tree_v = keep_in_vgpr(J.n_tree);
+            b.derived_p = keep_in_vgpr(J.derived);
             if (lane == 0u) {
                 front[0] = make_uint4(0u, __float_as_uint(1.0f), J.tree[0].offset, J.root_meta | kLightQueueValid);
                 valpha[0] = 1.0f;
@@ -870,7 +885,7 @@ __device__ __forceinline__ void compute_light_wave_body(const LightJob &J) {
                         // no longer costs a fetch's latency each. Whatever was fetched past the chain's end is not looked at.
                         uint4 nd[CHUNK];
 _Pragma("unroll")
-                        for (int i = 0; i < CHUNK; i++) nd[i] = J.node[min(k + (uint32_t)i, J.n_tree - 1u)];
+                        for (int i = 0; i < CHUNK; i++) nd[i] = node_p[min(k + (uint32_t)i, n_tree_v - 1u)];
                         uint32_t block[CHUNK];
                         bool inside[CHUNK];
                         {
@@ -882,7 +897,7 @@ _Pragma("unroll")
                                                      b.origin[2] + (int)((off_i >> 20) & 1023u) - 256};
                                 uint32_t idx = 0u;
                                 inside[i] = b.index_of(cube, &idx);
-                                block[i] = J.grid[idx] & J.index_mask;  // cube 0's if outside: unused then
+                                block[i] = grid_p[idx] & index_mask_v;  // cube 0's if outside: unused then
                             }
                         }
 _Pragma("unroll")
@@ -908,7 +923,7 @@ _Pragma("unroll")
                                 alpha_in = alpha;
                                 if (!consecutive) break;  // (never, in a pre-order tree: what was fetched ahead is then not this child's)
                             } else {
-                                const uint2 *ce = J.child_ent + (size_t)k * 6u;
+                                const uint2 *ce = child_ent_p + (size_t)k * 6u;
                                 uint2 ch[6];
                                 for (int f = 0; f < 6; f++) ch[f] = ce[f];
                                 const uint32_t at0 = atomicAdd(&s_count[1], nd[i].z);
