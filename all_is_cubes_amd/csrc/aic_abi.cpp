@@ -395,7 +395,6 @@ aic_ctx *aic_create(int device_id, int *status) {
         if (i == 0) fs.stream = c->stream;
         else ok = hipStreamCreateWithFlags(&fs.stream, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipEventCreate(&fs.ev0) == hipSuccess && hipEventCreate(&fs.ev1) == hipSuccess && hipEventCreate(&fs.ev2) == hipSuccess && fs.counters.ensure(1) == hipSuccess;
-        ok = ok && hipHostMalloc((void **)&fs.host_counters, sizeof(DevCounters), hipHostMallocDefault) == hipSuccess;
     }
     // created after the frame streams: HIP deals streams onto a few hardware queues in creation order
     // (4 by default), and two frame slots sharing a queue would serialise their kernels
@@ -966,6 +965,8 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         if ((e = c->aux.ensure(npix)) != hipSuccess) return hip_fail(c, "alloc aux", e);
         F.aux = c->aux.p;
     }
+    if (!fs.host_counters)  // (on a slot's first frame: most contexts only ever use slot 0, and a context is cheap to make and drop)
+        HIP_TRY(c, hipHostMalloc((void **)&fs.host_counters, sizeof(DevCounters), hipHostMallocDefault));
     if (!fs.counters_clean) HIP_TRY(c, hipMemsetAsync(fs.counters.p, 0, sizeof(DevCounters), fs.stream));
     fs.counters_clean = false;
     uint32_t order_key[6] = {0, 0, 0, 0, 0, 0};
