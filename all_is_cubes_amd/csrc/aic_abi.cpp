@@ -1087,30 +1087,34 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
     launch_trace_image(F, diag, fs.stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(fs.ev1, fs.stream));
-    fs.busy = true;
     // behind the trace: the frame's sums are in pinned host memory -- written by the last wave of the trace itself, or (profile builds: the whole
     // counter block) copied there; ev2 is what a wait waits for ...
 #ifdef AIC_PROFILE
     HIP_TRY(c, hipMemcpyAsync(fs.host_counters, fs.counters.p, sizeof(DevCounters), hipMemcpyDeviceToHost, fs.stream));
 #endif
     HIP_TRY(c, hipEventRecord(fs.ev2, fs.stream));
+    fs.busy = true;  // the frame is in flight and a wait can collect it; nothing below can fail the call any more
     // ... and the slot is made ready for its next frame: this frame's cost record becomes the tile order of the next frame of the same view, the
-    // record and the counters are cleared
+    // record and the counters are cleared. A failure here costs the next frame its head start (it clears and orders for itself), not this frame its result.
+    bool cleared = false;
     if (F.tile_cost && order_tiles_n) {
         fs.record_ready = false;
-        if ((e = fs.tile_order.ensure(order_tiles_n)) != hipSuccess || (e = fs.queue_start.ensure(kMaxTileQueues + 1)) != hipSuccess) return hip_fail(c, "alloc tile feedback", e);
-        // (one launch: orders, then clears the record it has read and the counters)
-        launch_order_tiles(fs.tile_cost.p, fs.tile_order.p, order_tiles_n, F.macros_x, order_sb_shift, order_queues ? order_queues : 1u, fs.queue_start.p, fs.stream,
-                           true, reinterpret_cast<uint32_t *>(fs.counters.p), (uint32_t)(sizeof(DevCounters) / 4));
-        HIP_TRY(c, hipGetLastError());
-        fs.cost_clean_n = order_tiles_n;
-        std::memcpy(fs.order_key, order_key, sizeof(order_key));
-        std::memcpy(fs.cost_cam, f->world.inverse_projection_view, sizeof(fs.cost_cam));
-        fs.record_ready = true;
-    } else {
-        HIP_TRY(c, hipMemsetAsync(fs.counters.p, 0, sizeof(DevCounters), fs.stream));
+        fs.cost_clean_n = 0;
+        if (fs.tile_order.ensure(order_tiles_n) == hipSuccess && fs.queue_start.ensure(kMaxTileQueues + 1) == hipSuccess) {
+            // (one launch: orders, then clears the record it has read and the counters)
+            launch_order_tiles(fs.tile_cost.p, fs.tile_order.p, order_tiles_n, F.macros_x, order_sb_shift, order_queues ? order_queues : 1u, fs.queue_start.p, fs.stream,
+                               true, reinterpret_cast<uint32_t *>(fs.counters.p), (uint32_t)(sizeof(DevCounters) / 4));
+            if (hipGetLastError() == hipSuccess) {
+                cleared = true;
+                fs.cost_clean_n = order_tiles_n;
+                std::memcpy(fs.order_key, order_key, sizeof(order_key));
+                std::memcpy(fs.cost_cam, f->world.inverse_projection_view, sizeof(fs.cost_cam));
+                fs.record_ready = true;
+            }
+        }
     }
-    fs.counters_clean = true;
+    if (!cleared) cleared = hipMemsetAsync(fs.counters.p, 0, sizeof(DevCounters), fs.stream) == hipSuccess;
+    fs.counters_clean = cleared;
     if (want_aux) c->aux_records = npix;
     return AIC_OK;
 }
