@@ -106,6 +106,30 @@ for name in ("lightbench", "relight", "orbit"):
         if lines:
             with open(os.path.join(dst, f"{tag}_bench_{name}.json"), "w") as f:
                 f.write(lines[-1] + "\n")
+# the text profiles of tools/measure_round.sh's `profile` and `bench` phases: the measured lines are replaced, the commentary of the file in profiles/
+# ('#' lines: those ahead of the first measured line stay ahead, the rest follow) is kept -- and has to be read again against the new numbers by whoever runs this
+for raw, name, default_header in (
+        ("prof.txt", "phase_cycles", "# In-kernel phase counters of trace_image_kernel<true,2,false,false> (-DAIC_PROFILE build; tools/measure_round.sh <tag> profile), one cold frame per workload"),
+        ("wave_tail.txt", "wave_tail", "# Per-wave clocks of one frame (tools/wave_tail.py, tools/wave_rays.py on the -DAIC_PROFILE -DAIC_RAY_PROF build)"),
+        ("rank_share.txt", "rank_share", "# One rank's share of the C2 frame traced on one GPU (tools/rank_share.py <n_parts> <frames in flight>)"),
+        ("hip_handoff.txt", "hip_handoff", "# bench.py --gather-at-one under rocprofv3 --hip-trace --stats (tools/measure_round.sh <tag> bench; tools/hip_handoff_summary.py)")):
+    rp = os.path.join(src, raw)
+    if not os.path.exists(rp):
+        continue
+    body = [l for l in open(rp).read().splitlines() if l.strip() and not l.startswith("#")]
+    out_path = os.path.join(dst, f"{tag}_{name}.txt")
+    head, tail = [], []
+    if os.path.exists(out_path):
+        seen_body = False
+        for l in open(out_path).read().splitlines():
+            if l.startswith("#"):
+                (tail if seen_body else head).append(l)
+            elif l.strip():
+                seen_body = True
+    if not head:
+        head = [default_header]
+    with open(out_path, "w") as f:
+        f.write("\n".join(head + body + tail) + "\n")
 if os.path.exists(os.path.join(src, "issue_rate.txt")):
     shutil.copy(os.path.join(src, "issue_rate.txt"), os.path.join(dst, f"{tag}_issue_rate.txt"))
 print(sorted(os.listdir(dst)))
