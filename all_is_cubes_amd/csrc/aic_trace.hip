@@ -888,6 +888,12 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u
 #define AIC_PRIO_SHIFT 0  // experiment (-DAIC_PRIO_SHIFT=6..8): a wave hosting a ray that is n << AIC_PRIO_SHIFT steps along runs at issue priority min(n, 3) on its
                           // SIMD (s_setprio) -- one frame alone lasts as long as its longest rays' serial lives, and those rays' waves wait their turn like any other
 #endif
+#ifndef AIC_HURRY_STEPS
+#define AIC_HURRY_STEPS 0  // experiment, BUILT BUT NOT YET MEASURED (round 4 ran out of GPU time): -DAIC_HURRY_STEPS=n makes a wave serve a ray that is
+                           // n steps along ahead of its batching -- the event such a lane waits for runs at once, whatever the thresholds, and a trip ends as soon
+                           // as such a lane has found something -- because a frame alone lasts as long as its longest ray, which advances one step per scheduler
+                           // round and waits out ~10 lookups of its neighbours in each. n belongs near the previous frame's longest ray (few waves must qualify).
+#endif
 #ifndef AIC_SPEC_STEPS
 #define AIC_SPEC_STEPS 0  // experiment (-DAIC_SPEC_STEPS=4): a draining wave takes its fast steps four at a time, all four
                           // lookups in flight together. Exact (frame hashes equal) and SLOWER: C2 one frame warm 0.776 -> 0.815 ms, cold
@@ -1254,6 +1260,17 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
             } else
             if (best > 0 && (best >= t_batch || n_step <= n_few)) run = kind;
         }
+#if AIC_HURRY_STEPS > 0
+        {   // a lane far along is waiting for an event: run that kind now
+            const unsigned long long m_far_ = __ballot(count >= (uint32_t)AIC_HURRY_STEPS);
+            const unsigned long long b_fin_ = __ballot((ev & EV_FINISH) != 0u);
+            if (run == 0u) {
+                if ((m_far_ & b_shade) != 0ull) run = EV_SHADE;
+                else if ((m_far_ & b_enter) != 0ull) run = EV_ENTER;
+                else if ((m_far_ & b_fin_) != 0ull) run = EV_FINISH;
+            }
+        }
+#endif
         AIC_TICK(19);
         if (run != 0u) {
             // ============================ event phase ======================================
@@ -2059,6 +2076,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
         // then takes its fast steps too (38 instructions a step instead of a full pass's ~180).
         const uint32_t fast_min = (uint32_t)__builtin_amdgcn_readfirstlane(dry ? 1 : AIC_FAST_MIN);  // (`dry` is wave-uniform; the compiler cannot tell)
         const bool spec_on = AIC_SPEC_ALWAYS || __builtin_amdgcn_readfirstlane(dry ? 1 : 0) != 0;
+#if AIC_HURRY_STEPS > 0
+        const mask_t m_far = __builtin_amdgcn_ballot_w64(count >= (uint32_t)AIC_HURRY_STEPS) & m_act;  // stepping lanes that are far along
+#endif
         AIC_PROF(22, 1);
         AIC_PROF(23, __popcll(m_act));
 #ifdef AIC_TAIL_PROF
@@ -2252,6 +2272,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                     m_pre_exit |= m_fx;
                     m_pre_look |= m_fe;
                     m_f = m_fb;
+#if AIC_HURRY_STEPS > 0
+                    if (((m_pre_exit | m_pre_look) & m_far) != 0ull) break;  // a lane far along has found something: on to the full pass, and out
+#endif
                 }
                 m_step &= ~(m_pre_exit | m_pre_look);
             }
@@ -2411,6 +2434,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
             m_act &= ~(m_shade | m_enter | m_fin);
             m_dead = m_newdead & m_act;
             m_fresh = 0ull;
+#if AIC_HURRY_STEPS > 0
+            if (((m_shade | m_enter | m_fin) & m_far) != 0ull) break;  // a lane far along has its event: the trip ends here, the scheduler runs that event next
+#endif
         }
         // new event words: the lanes that took part drop FRESH / DEAD, then take what the trip decided; a lane still
         // stepping whose level ended on the last step carries DEAD into the next trip
