@@ -889,7 +889,7 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u
                           // SIMD (s_setprio) -- one frame alone lasts as long as its longest rays' serial lives, and those rays' waves wait their turn like any other
 #endif
 #ifndef AIC_HURRY_STEPS
-#define AIC_HURRY_STEPS 0  // experiment, BUILT BUT NOT YET MEASURED (round 4 ran out of GPU time): -DAIC_HURRY_STEPS=n makes a wave serve a ray that is
+#define AIC_HURRY_STEPS 0  // experiment, built at the end of round 4 and measured once, in a 2.6-second run (n = 128, C2: no gain -- slower): -DAIC_HURRY_STEPS=n makes a wave serve a ray that is
                            // n steps along ahead of its batching -- the event such a lane waits for runs at once, whatever the thresholds, and a trip ends as soon
                            // as such a lane has found something -- because a frame alone lasts as long as its longest ray, which advances one step per scheduler
                            // round and waits out ~10 lookups of its neighbours in each. n belongs near the previous frame's longest ray (few waves must qualify).
