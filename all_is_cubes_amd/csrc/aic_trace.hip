@@ -884,25 +884,6 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u
 #ifndef AIC_FAST_STEPS
 #define AIC_FAST_STEPS 16  // bookkeeping-free steps a lane may take ahead of each full pass (0: none; 8 until round 4) ...
 #endif
-#ifndef AIC_PRIO_SHIFT
-#define AIC_PRIO_SHIFT 0  // experiment (-DAIC_PRIO_SHIFT=6..8): a wave hosting a ray that is n << AIC_PRIO_SHIFT steps along runs at issue priority min(n, 3) on its
-                          // SIMD (s_setprio) -- one frame alone lasts as long as its longest rays' serial lives, and those rays' waves wait their turn like any other
-#endif
-#ifndef AIC_HURRY_STEPS
-#define AIC_HURRY_STEPS 0  // experiment, built at the end of round 4 and measured once, in a 2.6-second run (n = 128, C2: no gain -- slower): -DAIC_HURRY_STEPS=n makes a wave serve a ray that is
-                           // n steps along ahead of its batching -- the event such a lane waits for runs at once, whatever the thresholds, and a trip ends as soon
-                           // as such a lane has found something -- because a frame alone lasts as long as its longest ray, which advances one step per scheduler
-                           // round and waits out ~10 lookups of its neighbours in each. n belongs near the previous frame's longest ray (few waves must qualify).
-#endif
-#ifndef AIC_SPEC_STEPS
-#define AIC_SPEC_STEPS 0  // experiment (-DAIC_SPEC_STEPS=4): a draining wave takes its fast steps four at a time, all four
-                          // lookups in flight together. Exact (frame hashes equal) and SLOWER: C2 one frame warm 0.776 -> 0.815 ms, cold
-                          // 1.091 -> 1.186, an eighth of the frame alone 0.491 -> 0.531 (profiles/r04_experiments.txt B): off.
-#endif
-#ifndef AIC_SPEC_ALWAYS
-#define AIC_SPEC_ALWAYS 0  // experiment: speculative lookups in the bulk of the frame too
-#endif
-
 // Runs Raycaster::next (raycast.rs:239-284) on a freshly initialised level until it yields its
 // first step or ends. Used by the ENTER / RAY events, so that the stepping loop only ever sees
 // levels that are already inside their bounds. On success the returned state is "emitted, step
@@ -944,23 +925,6 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
         s_lut[i] = F.light_lut[i];
         s_thr[i] = F.srgb_thr[i];
     }
-    // ---- ray migration in the frame's tail (an experiment, compiled in with -DAIC_RAY_MIGRATION=1) ----
-    // Once the tile queue is dry every wave still holds up to 64 rays at random stages and drains them at falling lane
-    // utilisation: the tail of a single frame is a quarter to a third of its duration (profiles/r03_wave_tail.txt). With this
-    // switch a wave that is down to a few rays hands them over: it parks their hot registers in global memory (`orphans`; their
-    // cold state is already in the workgroup's LDS columns, which stay valid), publishes the columns in s_pool_col and exits;
-    // the workgroup's ANCHOR wave adopts them into its own idle lanes (a lane just switches to the orphan's column). Results
-    // cannot change -- a ray is a pure function of its own state, which moves as a whole -- and do not (frame hashes and
-    // step counts equal for every threshold, 300-seed fuzz green). MEASURED: no gain (C2 one frame 0.960 ms without,
-    // 0.968 / 0.973 / 0.985 ms handing over at <= 8 / 16 / 32 rays; profiles/r03_experiments.txt): the tail is not waves
-    // competing for issue slots, it is the serial latency of the last rays themselves, which a merged wave does not shorten.
-#ifndef AIC_RAY_MIGRATION
-#define AIC_RAY_MIGRATION 0
-#endif
-    constexpr bool MIGRATE = (AIC_RAY_MIGRATION != 0) && !DIAG;
-    __shared__ uint32_t s_mig[4];  // [0] orphans published  [1] orphans adopted  [2] waves of the workgroup still running  [3] donors' lock
-    __shared__ uint8_t s_pool_col[AIC_WG_THREADS];
-    if (MIGRATE && threadIdx.x == 0) { s_mig[0] = 0u; s_mig[1] = 0u; s_mig[2] = (uint32_t)AIC_WG_THREADS / 64u; s_mig[3] = 0u; }
     __syncthreads();
     const float *lut = s_lut;
     // Kernel arguments and the persistent loop. The stepping phase needs three scalars of them (the pool pointer and the cube
@@ -1008,32 +972,21 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
     enum { K_SRX, K_SRY, K_SRZ, K_SBOFF,            // the suspended outer level: steps left, byte offset
            K_BLK, K_TVIEW, K_PXY, K_STEPS,          // block index; |direction| / view distance; pixel x | row << 16; step sum
            K_S0, K_S1, K_S2, K_ST, N_C32 };         // ColorBuf::mean accumulators (antialiasing)
-#ifdef AIC_LDS_PAD
-    // experiment J1 (profiles/r03_experiments.txt H): LDS claimed without being used, to price the occupancy a voxel cache in
-    // LDS would cost
-    __shared__ uint32_t s_pad[AIC_LDS_PAD / 4];
-    if (F.width == 0xffffffffu) s_pad[threadIdx.x] = 1u;
-    asm volatile("" :: "v"(&s_pad[0]) : "memory");
-#endif
     __shared__ double c64[N_C64][AIC_WG_THREADS];
     __shared__ uint32_t c32[N_C32][AIC_WG_THREADS];
     const uint32_t tid = threadIdx.x;
-    uint32_t col = tid;  // the LDS column holding this lane's ray: its own, or an adopted ray's (ray migration)
+    uint32_t col = tid;  // the LDS column holding this lane's ray
     // LDS byte addresses of the lane's columns (the low half of a generic LDS pointer is the LDS offset)
     uint32_t lds64 = (uint32_t)(uintptr_t)&c64[0][col], lds32 = (uint32_t)(uintptr_t)&c32[0][col];
     c32[K_STEPS][tid] = 0u;
     c32[K_BLK][tid] = 0u;
     c32[K_PXY][tid] = 0u;
-    const uint32_t mig_k = (MIGRATE && blockIdx.x < F.migrate_groups && (uint32_t)AIC_WG_THREADS <= 256u) ? F.migrate_k : 0u;  // (the buffer has 256 columns per workgroup)
-    const bool anchor = (threadIdx.x >> 6) == 0u;   // the wave of the workgroup that adopts, never hands over, and leaves last
     bool dry = false;                               // wave-uniform: this wave has seen the tile queue exhausted
     // The tile queue this wave takes from (DevFrame::n_queues > 1): its XCD's own to begin with, the next one's when that is empty. How many queues it has
     // seen empty is a word of LDS per wave, read once per tile -- kept in a scalar register for the life of the wave it cost the production variant
     // four spilled VGPRs (12 bytes of scratch per lane, 1.2 GB of scratch written back per C3 frame: profiles/r04_experiments.txt K).
     __shared__ uint32_t s_queues_tried[AIC_WG_THREADS / 64];
     if (lane == 0u) s_queues_tried[threadIdx.x >> 6] = 0u;
-    uint32_t prio_level = 0u;  // (AIC_PRIO_SHIFT) the wave's current issue priority
-    bool donated = false;
     SurfDiag pend_d;
     double pend_t = 0.0;
     bool pend_visible = false;
@@ -1145,76 +1098,10 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
         const unsigned long long m_st = __ballot(ev < 4u);
         const unsigned long long b_shade = __ballot((ev & EV_SHADE) != 0u);
         const unsigned long long b_enter = __ballot((ev & EV_ENTER) != 0u);
-        unsigned long long b_ray = __ballot((ev & (EV_FINISH | EV_NEWRAY)) != 0u);
+        const unsigned long long b_ray = __ballot((ev & (EV_FINISH | EV_NEWRAY)) != 0u);
         if ((m_st | b_shade | b_enter | b_ray) == 0ull) break;
-        if (AIC_PRIO_SHIFT != 0) {
-            const unsigned long long live_ = m_st | b_shade | b_enter | b_ray;
-            const uint32_t level = (__ballot(count >= (3u << AIC_PRIO_SHIFT)) & live_) != 0ull ? 3u
-                                 : (__ballot(count >= (2u << AIC_PRIO_SHIFT)) & live_) != 0ull ? 2u
-                                 : (__ballot(count >= (1u << AIC_PRIO_SHIFT)) & live_) != 0ull ? 1u : 0u;
-            if (level != prio_level) {
-                prio_level = level;
-                if (level == 3u) __builtin_amdgcn_s_setprio(3);
-                else if (level == 2u) __builtin_amdgcn_s_setprio(2);
-                else if (level == 1u) __builtin_amdgcn_s_setprio(1);
-                else __builtin_amdgcn_s_setprio(0);
-            }
-        }
-        bool only_waiting = false;  // ray migration, anchor wave: every lane that is not done waits for a ray to adopt
-        if (MIGRATE && dry && anchor && mig_k != 0u) {
-            // lanes that found the queue dry wait for orphans; they ask for a ray phase only when there is one to adopt, or
-            // when nothing else is left in the wave (the ray phase then decides whether anything can still come)
-            const unsigned long long b_wait = __ballot(ev == (EV_NEWRAY | EV_TAKE));
-            if (b_wait != 0ull) {
-                const bool others = (m_st | b_shade | b_enter | (b_ray & ~b_wait)) != 0ull;
-                const bool to_adopt = __hip_atomic_load(&s_mig[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) !=
-                                      __hip_atomic_load(&s_mig[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (others && !to_adopt) b_ray &= ~b_wait;
-                only_waiting = !others;
-            }
-        }
         const int n_step = (int)wave_popc(m_st);
         const int c_shade = (int)wave_popc(b_shade), c_enter = (int)wave_popc(b_enter), c_ray = (int)wave_popc(b_ray);
-        if (MIGRATE && dry && !anchor && n_step + c_shade + c_enter + c_ray <= (int)mig_k) {
-            // ---- hand this wave's last rays over to the workgroup's anchor wave and leave ----
-            typedef const __attribute__((address_space(4))) DevFrame KFrame;
-            KFrame *Fq = (KFrame *)__builtin_amdgcn_kernarg_segment_ptr();
-            asm volatile("" : "+s"(Fq));
-            const unsigned long long live = m_st | b_shade | b_enter | b_ray;
-            uint32_t base = 0u;
-            if (lane == 0u) {
-                while (atomicCAS(&s_mig[3], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(2);  // one donor at a time
-                base = __hip_atomic_load(&s_mig[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            base = (uint32_t)__shfl((int)base, 0, 64);
-            if ((live >> lane) & 1ull) {
-                const uint32_t rank = (uint32_t)__popcll(live & ((1ull << lane) - 1ull));
-                s_pool_col[base + rank] = (uint8_t)col;
-                uint4 *dst = Fq->orphans + ((size_t)blockIdx.x * 256u + col) * (kOrphanDwords / 4u);
-                const unsigned long long b0 = (unsigned long long)__double_as_longlong(tx), b1 = (unsigned long long)__double_as_longlong(ty),
-                                         b2 = (unsigned long long)__double_as_longlong(tz), b3 = (unsigned long long)__double_as_longlong(last_t),
-                                         b4 = (unsigned long long)__double_as_longlong(tdx), b5 = (unsigned long long)__double_as_longlong(tdy),
-                                         b6 = (unsigned long long)__double_as_longlong(tdz);
-                dst[0] = make_uint4((uint32_t)b0, (uint32_t)(b0 >> 32), (uint32_t)b1, (uint32_t)(b1 >> 32));
-                dst[1] = make_uint4((uint32_t)b2, (uint32_t)(b2 >> 32), (uint32_t)b3, (uint32_t)(b3 >> 32));
-                dst[2] = make_uint4((uint32_t)b4, (uint32_t)(b4 >> 32), (uint32_t)b5, (uint32_t)(b5 >> 32));
-                dst[3] = make_uint4((uint32_t)b6, (uint32_t)(b6 >> 32), rx, ry);
-                dst[4] = make_uint4(rz, boff, (uint32_t)ssx, (uint32_t)ssy);
-                dst[5] = make_uint4((uint32_t)ssz, thr, raw, lax);
-                dst[6] = make_uint4(st, count, ev, blk_pal_off);
-                dst[7] = make_uint4(blk_geo, blk_vsz, __float_as_uint(acc.l0), __float_as_uint(acc.l1));
-                dst[8] = make_uint4(__float_as_uint(acc.l2), __float_as_uint(acc.t), __float_as_uint(pend0), __float_as_uint(pend1));
-                dst[9] = make_uint4(__float_as_uint(pend2), __float_as_uint(pend_tr), 0u, 0u);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the stores above (global and LDS) before the publication below
-            if (lane == 0u) {
-                __hip_atomic_store(&s_mig[0], base + (uint32_t)__popcll(live), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(&s_mig[3], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(&s_mig[2], 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // one wave fewer
-            }
-            donated = true;
-            break;
-        }
         uint32_t run = 0u;  // kind to run this trip (an EV_* bit), 0 = step
         {
             int best = c_shade;
@@ -1223,9 +1110,6 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
             if (c_ray > best) { best = c_ray; kind = EV_FINISH; }
             // thresholds scale with the lanes still alive, so that a wave that is running out of rays
             // (the frame's tail) keeps batching instead of running every event for a lane or two
-#ifdef AIC_SCHED_SIMPLE
-            const int t_batch = AIC_T_BATCH, n_few = AIC_N_FEW;
-#else
             const int alive = n_step + c_shade + c_enter + c_ray;
 #ifndef AIC_FRAC_T
 #define AIC_FRAC_T 4  // eighths of the lanes alive
@@ -1237,40 +1121,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
             const int t_lo = opaque_s(part_t > 0 ? part_t : 1);  // (kept apart from the min: fused, the pair becomes a v_med3 and a v_readfirstlane)
             const int t_batch = t_lo < AIC_T_BATCH ? t_lo : AIC_T_BATCH;
             const int n_few = part_n < AIC_N_FEW ? part_n : AIC_N_FEW;
-#endif
-#ifndef AIC_T_SHADE
-#define AIC_T_SHADE AIC_T_BATCH  // SHADE's own batching threshold (its lanes take their next step inside the event: they lose nothing by waiting)
-#endif
-#ifndef AIC_FRAC_S
-#define AIC_FRAC_S AIC_FRAC_T
-#endif
-            if (AIC_T_SHADE != AIC_T_BATCH || AIC_FRAC_S != AIC_FRAC_T) {
-                // per-kind thresholds: a kind is ready at its own count; among the ready kinds the fullest runs; with too few lanes
-                // left stepping the fullest of all runs, ready or not
-                const int part_s = (alive * AIC_FRAC_S) >> 3;
-                const int s_lo = opaque_s(part_s > 0 ? part_s : 1);
-                const int t_shade = s_lo < AIC_T_SHADE ? s_lo : AIC_T_SHADE;
-                int rbest = 0;
-                uint32_t rkind = 0u;
-                if (c_shade >= t_shade) { rbest = c_shade; rkind = EV_SHADE; }
-                if (c_enter >= t_batch && c_enter > rbest) { rbest = c_enter; rkind = EV_ENTER; }
-                if (c_ray >= t_batch && c_ray > rbest) { rbest = c_ray; rkind = EV_FINISH; }
-                if (rkind != 0u) run = rkind;
-                else if (best > 0 && n_step <= n_few) run = kind;
-            } else
             if (best > 0 && (best >= t_batch || n_step <= n_few)) run = kind;
         }
-#if AIC_HURRY_STEPS > 0
-        {   // a lane far along is waiting for an event: run that kind now
-            const unsigned long long m_far_ = __ballot(count >= (uint32_t)AIC_HURRY_STEPS);
-            const unsigned long long b_fin_ = __ballot((ev & EV_FINISH) != 0u);
-            if (run == 0u) {
-                if ((m_far_ & b_shade) != 0ull) run = EV_SHADE;
-                else if ((m_far_ & b_enter) != 0ull) run = EV_ENTER;
-                else if ((m_far_ & b_fin_) != 0ull) run = EV_FINISH;
-            }
-        }
-#endif
         AIC_TICK(19);
         if (run != 0u) {
             // ============================ event phase ======================================
@@ -1319,7 +1171,6 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
             //    the surface is discovered: it is the t_max of the step the level takes next. The
             //    contribution is therefore computed here in full and merely *applied* by the stepping code
             //    when that next step is counted (so the order count -> stop-check -> accumulate is kept). --
-            bool fuse = false;  // SHADE: the lane's next step is certain to be a plain counted one -- taken in the event's tail (below)
             if (run == EV_SHADE && (ev & EV_SHADE)) {
                 const bool inb = (st & ST_IN_BLOCK) != 0;
                 const uint32_t blk_res = 1u << (blk_geo >> 24), blk_vlo = blk_geo & 0xffffffu;
@@ -1541,16 +1392,13 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                             ev = (ev & EV_SHADE) | EV_FINISH;  // (EV_SHADE is cleared below)
                         } else if (early) {
                             acc.l0 = n0; acc.l1 = n1; acc.l2 = n2; acc.t = nt;
-                            fuse = true;
                         } else {
                             pend0 = o0; pend1 = o1; pend2 = o2; pend_tr = tr;
                             st |= ST_HAS_LAST;
                         }
                         if (DIAG) { pend_d = sd; pend_t = t_enter; pend_visible = visible; }
                     }
-                } else if (!visible) {
-                    fuse = !DIAG && !(ev & EV_DEAD) && count <= 999u;
-                } else {
+                } else if (visible) {
                     cb_add(acc, o0, o1, o2, tr);  // trace_through_surface (sr.rs:697-717)
                     if (cb_opaque(acc)) {
                         st |= ST_OPAQUE;
@@ -1559,8 +1407,6 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                             count += 1u;
                             ev = (ev & EV_SHADE) | EV_FINISH;
                         }
-                    } else {
-                        fuse = !DIAG && !(ev & EV_DEAD) && count <= 999u;
                     }
                     if (DIAG) {
                         dg.n_hits++;
@@ -1574,59 +1420,6 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                     }
                 }
                 ev &= ~EV_SHADE;
-            }
-#ifndef AIC_SHADE_STEP
-#define AIC_SHADE_STEP 0  // experiment (-DAIC_SHADE_STEP=1), exact and SLOWER: C2 0.4777 -> 0.4872 ms streamed, C3 6.817 -> 6.947; with SHADE's own
-                          // batching threshold at 40 / 48 / 56 lanes on top: 0.4935 / 0.4937 / 0.4937, 7.072 / 7.072 / 7.068 (profiles/r04_experiments.txt F)
-#endif
-            // -- The shaded lanes' next step, taken here. A lane inside a run of translucent voxels alternates one step and one SHADE:
-            //    as a stepping lane it took that step in a full pass of a trip (its lookup finds the next voxel at once, so no fast
-            //    step serves it) and was parked again -- half of such a lane's life was spent waiting for the other half's phase,
-            //    and every SHADE phase ran at half width because the run lanes were away stepping. A lane whose span has been applied
-            //    (or that met an invisible surface) and that is not near the cap is exactly in the fast-step state: its next step is
-            //    produced, counted and passes the stop check whatever it finds. So all such lanes take it together in this event's
-            //    tail: DDA step, lookup; a lane that finds another surface stays parked for SHADE (the phase that follows serves
-            //    it again, now together with the lanes that were waiting); one that finds an invisible cube / voxel goes back to
-            //    stepping with the step counted; one that left its bounds or met a recursive block is put back as it was and takes
-            //    the step in a trip, which has the bookkeeping for those. Same steps, same order per ray: bit-identical. --
-            if (AIC_SHADE_STEP && !DIAG && !BIG && run == EV_SHADE) {
-                const unsigned long long m_fz = __builtin_amdgcn_ballot_w64(fuse);
-                if (m_fz != 0ull) {
-                    const double v_tx = tx, v_ty = ty, v_tz = tz, v_lt = last_t;
-                    const uint32_t v_rx = rx, v_ry = ry, v_rz = rz, v_bo = boff, v_lax = lax;
-                    const unsigned long long m_x = dda_step(m_fz);
-                    const unsigned long long m_lk = m_fz & ~m_x;
-                    uint32_t code, code_in_flight;
-                    {
-                        unsigned long long sv;
-                        asm volatile(
-                            "s_mov_b64 %[sv], exec\n\t"
-                            "s_mov_b64 exec, %[m]\n\t"
-                            "global_load_ushort %[q], %[bo], %[pool]\n\t"
-                            "s_mov_b64 exec, %[sv]\n\t"
-                            "s_waitcnt vmcnt(0)\n\t"
-                            "v_mov_b32 %[o], %[q]\n\t"
-                            : [o] "=&v"(code), [q] "=&v"(code_in_flight), [sv] "=&s"(sv)
-                            : [bo] "v"(boff), [pool] "s"(pool_bits), [m] "s"(m_lk)
-                            : "memory");
-                    }
-                    const unsigned long long m_ge = __builtin_amdgcn_ballot_w64(code >= thr) & m_lk;
-                    // (a cube-grid entry past 2 << kCubeClassShift is a recursive block: ENTER needs a trip's bookkeeping)
-                    const unsigned long long m_rec = __builtin_amdgcn_ballot_w64(code >= (2u << kCubeClassShift) && !(st & ST_IN_BLOCK)) & m_lk;
-                    const unsigned long long m_surf2 = m_ge & ~m_rec, m_inv2 = m_lk & ~m_ge;
-                    const unsigned long long m_took = m_surf2 | m_inv2, m_undo = m_fz & ~m_took;
-                    if (m_undo != 0ull) {
-                        const bool bk = __builtin_amdgcn_inverse_ballot_w64(m_undo);
-                        tx = bk ? v_tx : tx; ty = bk ? v_ty : ty; tz = bk ? v_tz : tz; last_t = bk ? v_lt : last_t;
-                        rx = bk ? v_rx : rx; ry = bk ? v_ry : ry; rz = bk ? v_rz : rz; boff = bk ? v_bo : boff; lax = bk ? v_lax : lax;
-                    }
-                    const bool took = __builtin_amdgcn_inverse_ballot_w64(m_took);
-                    count += took ? 1u : 0u;
-                    raw = took ? code : raw;
-                    ev = __builtin_amdgcn_inverse_ballot_w64(m_surf2) ? (ev | EV_SHADE) : ev;
-                    AIC_PROF(28, 1);
-                    AIC_PROF(29, __popcll(m_surf2));
-                }
             }
             // -- entering a recursive block: RaycastStep::recursive_raycast (raycast.rs:458-476),
             //    advanced to its first in-bounds voxel (or to its end) --
@@ -1672,7 +1465,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
             // -- finishing a ray: TracingState::finish + layer tail + (last sample) encode & store --
             uint32_t pxy = 0;
             int sample = 0;
-            bool want = false, adopted = false;
+            bool want = false;
             if (run == EV_FINISH) {
                 pxy = c32[K_PXY][col];
                 sample = (int)((st >> 14) & 3u);
@@ -1833,47 +1626,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
 #endif
                             dry = true;
                             next_idx = tile_px;
-                            if (!(MIGRATE && mig_k != 0u && anchor)) {  // these lanes are done
-                                if (want) ev = EV_DONE;
-                                break;
-                            }
-                            // ---- the anchor wave: adopt rays the workgroup's other waves handed over (ray migration) ----
-                            // `running` is read before `published`: a donor publishes before it signs off, so "no other wave
-                            // running" and then "nothing published that was not adopted" means nothing can come any more
-                            const uint32_t running = __hip_atomic_load(&s_mig[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            const uint32_t published = __hip_atomic_load(&s_mig[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            const uint32_t taken = __hip_atomic_load(&s_mig[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (only this wave writes it)
-                            const uint32_t n_need = wave_popc(need);
-                            const uint32_t k = published - taken < n_need ? published - taken : n_need;
-                            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                            if (want && rank < k) {
-                                col = s_pool_col[taken + rank];
-                                lds64 = (uint32_t)(uintptr_t)&c64[0][col];
-                                lds32 = (uint32_t)(uintptr_t)&c32[0][col];
-                                const uint4 *src = F.orphans + ((size_t)blockIdx.x * 256u + col) * (kOrphanDwords / 4u);
-                                const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4], q5 = src[5], q6 = src[6], q7 = src[7], q8 = src[8], q9 = src[9];
-                                tx = __longlong_as_double((long long)(((unsigned long long)q0.y << 32) | q0.x));
-                                ty = __longlong_as_double((long long)(((unsigned long long)q0.w << 32) | q0.z));
-                                tz = __longlong_as_double((long long)(((unsigned long long)q1.y << 32) | q1.x));
-                                last_t = __longlong_as_double((long long)(((unsigned long long)q1.w << 32) | q1.z));
-                                tdx = __longlong_as_double((long long)(((unsigned long long)q2.y << 32) | q2.x));
-                                tdy = __longlong_as_double((long long)(((unsigned long long)q2.w << 32) | q2.z));
-                                tdz = __longlong_as_double((long long)(((unsigned long long)q3.y << 32) | q3.x));
-                                rx = q3.z; ry = q3.w;
-                                rz = q4.x; boff = q4.y; ssx = (int)q4.z; ssy = (int)q4.w;
-                                ssz = (int)q5.x; thr = q5.y; raw = q5.z; lax = q5.w;
-                                st = q6.x; count = q6.y; ev = q6.z; blk_pal_off = q6.w;
-                                blk_geo = q7.x; blk_vsz = q7.y; acc.l0 = __uint_as_float(q7.z); acc.l1 = __uint_as_float(q7.w);
-                                acc.l2 = __uint_as_float(q8.x); acc.t = __uint_as_float(q8.y); pend0 = __uint_as_float(q8.z); pend1 = __uint_as_float(q8.w);
-                                pend2 = __uint_as_float(q9.x); pend_tr = __uint_as_float(q9.y);
-                                want = false;
-                                adopted = true;  // (the ray goes on from its own state at the wave's next scheduler pass)
-                            }
-                            if (k != 0u && lane == 0u) __hip_atomic_store(&s_mig[1], taken + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (want) {
-                                if (running == 1u && published == taken + k) ev = EV_DONE;  // nothing can come any more
-                                else if (only_waiting) __builtin_amdgcn_s_sleep(16);        // asked again at the wave's next ray phase
-                            }
+                            if (want) ev = EV_DONE;  // these lanes are done
                             break;
                         }
                         const uint32_t m_shift = macro_shift * 2u;
@@ -1908,7 +1661,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                 }
             }
             if (run == EV_FINISH) { AIC_TICK(17) }
-            if (run == EV_FINISH && (ev & EV_NEWRAY) && ev != EV_DONE && !want && !adopted) {  // (`want`: the anchor wave's lanes waiting for an orphan)
+            if (run == EV_FINISH && (ev & EV_NEWRAY) && ev != EV_DONE && !want) {
                 const uint32_t x = pxy & 0xffffu, lrow = pxy >> 16;
                 const size_t pix = (size_t)lrow * F.width + x;
                 if (ev & EV_TAKE) {
@@ -2042,7 +1795,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                     ev = EV_FINISH;
                 }
             }
-            if (run == EV_FINISH && !want && !adopted) c32[K_PXY][col] = pxy;
+            if (run == EV_FINISH && !want) c32[K_PXY][col] = pxy;
             if (run == EV_SHADE) { AIC_TICK(13) } else if (run == EV_ENTER) { AIC_TICK(14) } else { AIC_TICK(15) }
             continue;
         }
@@ -2075,10 +1828,6 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
         // seen the pixel queue dry it is draining its last rays and what counts is how soon the longest of them ends: a lone ray
         // then takes its fast steps too (38 instructions a step instead of a full pass's ~180).
         const uint32_t fast_min = (uint32_t)__builtin_amdgcn_readfirstlane(dry ? 1 : AIC_FAST_MIN);  // (`dry` is wave-uniform; the compiler cannot tell)
-        const bool spec_on = AIC_SPEC_ALWAYS || __builtin_amdgcn_readfirstlane(dry ? 1 : 0) != 0;
-#if AIC_HURRY_STEPS > 0
-        const mask_t m_far = __builtin_amdgcn_ballot_w64(count >= (uint32_t)AIC_HURRY_STEPS) & m_act;  // stepping lanes that are far along
-#endif
         AIC_PROF(22, 1);
         AIC_PROF(23, __popcll(m_act));
 #ifdef AIC_TAIL_PROF
@@ -2092,12 +1841,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
 // change that gave `raw` another live range -- the speculative lookups -- made it appear, in front of the full pass's wait.)
 #define AIC_WAIT_RAW() { const uint32_t raw_in_flight_ = raw; asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, %1" : "=&v"(raw) : "v"(raw_in_flight_)); }
 #pragma unroll 1
-#ifdef AIC_TRIP_MIN
-        // leave the trip once no more than AIC_TRIP_MIN lanes are still stepping (the first step is always taken)
-        for (int rep = 0; rep < AIC_STEP_REPS && (rep == 0 ? m_act != 0ull : __popcll(m_act) > AIC_TRIP_MIN); rep++) {
-#else
         for (int rep = 0; rep < AIC_STEP_REPS && m_act != 0ull; rep++) {
-#endif
             AIC_PROF(10, 1);
             AIC_PROF(11, __popcll(m_act));
             mask_t m_step = m_act & ~(m_fresh | m_dead);  // the level takes its next step
@@ -2113,83 +1857,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
             AIC_PROF(25, __popcll(m_step & ~(m_hl | m_opq) & m_far_from_cap));
 #endif
             mask_t m_pre_exit = 0ull, m_pre_look = 0ull;  // lanes whose step of this pass was taken here: left the bounds / looked something up
-            if (!BIG && !DIAG && AIC_SPEC_STEPS > 0 && AIC_FAST_STEPS > 0 && spec_on) {
-                // -- Speculative lookups (a draining wave: the pixel queue is dry). What is left of the frame is the serial chain of
-                //    its last rays, one dependent L2 round trip (about 1k clocks) per step with nothing else to issue
-                //    (profiles/r03_wave_tail.txt). The DDA's geometry never depends on the code a lookup returns, so a lane in the
-                //    fast-step state takes FOUR steps back to back, each followed by its lookup, and waits ONCE. A lane whose four
-                //    lookups all find nothing has taken four counted steps for one round trip. A lane that left its bounds stopped
-                //    stepping there (its state is that step's). A lane that found something at step j < 3 went on regardless: it is put
-                //    back to the state saved before the batch and takes steps 0..j again -- the same additions in the same order,
-                //    hence the same bits -- which costs instructions the draining wave has to spare. --
-                mask_t m_f = m_step & ~(m_hl | m_opq) & m_far_from_cap;
-#pragma unroll 1
-                for (int sb = 0; sb < AIC_FAST_STEPS / 4 && m_f != 0ull; sb++) {
-                    const double v_tx = tx, v_ty = ty, v_tz = tz, v_lt = last_t;
-                    const uint32_t v_rx = rx, v_ry = ry, v_rz = rz, v_bo = boff, v_lax = lax;
-                    // The four lookups are in flight together and the ONE wait sits in the last lookup's asm statement, which takes the
-                    // first three destination registers as plain inputs and hands all four codes on as its own outputs: every later
-                    // use depends on that statement, so the compiler can neither read a code nor copy its register before the wait.
-                    uint32_t q0, q1, q2;  // written by the loads under their masks (other lanes: undefined, masked out of every use)
-                    auto spec_load = [&](uint32_t &rw, const mask_t m) {
-                        mask_t sv;
-                        asm volatile(
-                            "s_mov_b64 %[sv], exec\n\t"
-                            "s_mov_b64 exec, %[m]\n\t"
-                            "global_load_ushort %[rw], %[bo], %[pool]\n\t"
-                            "s_mov_b64 exec, %[sv]\n\t"
-                            : [rw] "=&v"(rw), [sv] "=&s"(sv)
-                            : [bo] "v"(boff), [pool] "s"(pool_bits), [m] "s"(m)
-                            : "memory");
-                    };
-                    mask_t alive = m_f;
-                    const mask_t x0 = dda_step(alive); alive &= ~x0; const mask_t l0 = alive; spec_load(q0, l0);
-                    const mask_t x1 = dda_step(alive); alive &= ~x1; const mask_t l1 = alive; spec_load(q1, l1);
-                    const mask_t x2 = dda_step(alive); alive &= ~x2; const mask_t l2 = alive; spec_load(q2, l2);
-                    const mask_t x3 = dda_step(alive); alive &= ~x3; const mask_t l3 = alive;
-                    uint32_t rw0, rw1, rw2, rw3;
-                    {
-                        mask_t sv;
-                        asm volatile(
-                            "s_mov_b64 %[sv], exec\n\t"
-                            "s_mov_b64 exec, %[m]\n\t"
-                            "global_load_ushort %[o3], %[bo], %[pool]\n\t"
-                            "s_mov_b64 exec, %[sv]\n\t"
-                            "s_waitcnt vmcnt(0)\n\t"
-                            "v_mov_b32 %[o0], %[i0]\n\t"
-                            "v_mov_b32 %[o1], %[i1]\n\t"
-                            "v_mov_b32 %[o2], %[i2]\n\t"
-                            : [o0] "=&v"(rw0), [o1] "=&v"(rw1), [o2] "=&v"(rw2), [o3] "=&v"(rw3), [sv] "=&s"(sv)
-                            : [i0] "v"(q0), [i1] "v"(q1), [i2] "v"(q2), [bo] "v"(boff), [pool] "s"(pool_bits), [m] "s"(l3)
-                            : "memory");
-                    }
-                    const mask_t f0 = __builtin_amdgcn_ballot_w64(rw0 >= thr) & l0, f1 = __builtin_amdgcn_ballot_w64(rw1 >= thr) & l1,
-                                 f2 = __builtin_amdgcn_ballot_w64(rw2 >= thr) & l2, f3 = __builtin_amdgcn_ballot_w64(rw3 >= thr) & l3;
-                    // a lane's first event: the first step that left the bounds or found something
-                    const mask_t n0 = m_f & ~(f0 | x0), n1 = n0 & ~(f1 | x1), n2 = n1 & ~(f2 | x2), n3 = n2 & ~(f3 | x3);
-                    const mask_t g0 = f0 & m_f, g1 = f1 & n0, g2 = f2 & n1, g3 = f3 & n2;   // found something first at step j
-                    const mask_t y0 = x0 & m_f, y1 = x1 & n0, y2 = x2 & n1, y3 = x3 & n2;   // left the bounds first at step j
-                    const mask_t m_back = g0 | g1 | g2;                                      // stepped past what they found
-                    if (m_back != 0ull) {
-                        const bool bk = AIC_LANE(m_back);
-                        tx = bk ? v_tx : tx; ty = bk ? v_ty : ty; tz = bk ? v_tz : tz; last_t = bk ? v_lt : last_t;
-                        rx = bk ? v_rx : rx; ry = bk ? v_ry : ry; rz = bk ? v_rz : rz; boff = bk ? v_bo : boff; lax = bk ? v_lax : lax;
-                        (void)dda_step(m_back);
-                        if ((g1 | g2) != 0ull) (void)dda_step(g1 | g2);
-                        if (g2 != 0ull) (void)dda_step(g2);
-                    }
-                    raw = AIC_LANE(g0) ? rw0 : (AIC_LANE(g1) ? rw1 : (AIC_LANE(g2) ? rw2 : (AIC_LANE(g3 | n3) ? rw3 : raw)));
-                    // the steps before a lane's first event found nothing: Invisible TraceSteps, counted and nothing else
-                    asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(count) : "s"(n0) : "vcc");
-                    asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(count) : "s"(n1) : "vcc");
-                    asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(count) : "s"(n2) : "vcc");
-                    asm volatile("v_addc_co_u32 %0, vcc, 0, %0, %1" : "+v"(count) : "s"(n3) : "vcc");
-                    m_pre_exit |= y0 | y1 | y2 | y3;
-                    m_pre_look |= g0 | g1 | g2 | g3;
-                    m_f = n3;
-                }
-                m_step &= ~(m_pre_exit | m_pre_look);
-            } else if (!BIG && AIC_FAST_STEPS > 0) {
+            if (!BIG && AIC_FAST_STEPS > 0) {
                 mask_t m_f = m_step & ~(m_hl | m_opq) & m_far_from_cap;
 #pragma unroll
                 for (int f = 0; f < AIC_FAST_STEPS; f++) {
@@ -2272,9 +1940,6 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                     m_pre_exit |= m_fx;
                     m_pre_look |= m_fe;
                     m_f = m_fb;
-#if AIC_HURRY_STEPS > 0
-                    if (((m_pre_exit | m_pre_look) & m_far) != 0ull) break;  // a lane far along has found something: on to the full pass, and out
-#endif
                 }
                 m_step &= ~(m_pre_exit | m_pre_look);
             }
@@ -2434,9 +2099,6 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
             m_act &= ~(m_shade | m_enter | m_fin);
             m_dead = m_newdead & m_act;
             m_fresh = 0ull;
-#if AIC_HURRY_STEPS > 0
-            if (((m_shade | m_enter | m_fin) & m_far) != 0ull) break;  // a lane far along has its event: the trip ends here, the scheduler runs that event next
-#endif
         }
         // new event words: the lanes that took part drop FRESH / DEAD, then take what the trip decided; a lane still
         // stepping whose level ended on the last step carries DEAD into the next trip
@@ -2481,8 +2143,6 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
 #endif
     if (lane == 0) for (int i = 2; i < 32; i++) atomicAdd(&F.counters->prof[i], (unsigned long long)prof[i]);
 #endif
-    if (MIGRATE && !anchor && !donated && lane == 0u)  // (a wave that handed its rays over has signed off already)
-        __hip_atomic_fetch_add(&s_mig[2], 0xffffffffu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     // ---- RaytraceInfo sum (renderer.rs:555): wave reduction then one atomic per wave ----
     unsigned long long s = c32[K_STEPS][tid];
 #pragma unroll

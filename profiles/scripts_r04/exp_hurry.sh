@@ -1,7 +1,7 @@
 #!/bin/bash
 # The experiment round 4 built and could not measure (csrc/aic_trace.hip AIC_HURRY_STEPS): waves serve rays that are far along ahead of their batching.
-# Here (no GPU needed):  tools/build_variants.sh "hurry96:-DAIC_HURRY_STEPS=96" "hurry128:-DAIC_HURRY_STEPS=128" "hurry160:-DAIC_HURRY_STEPS=160" "hurry400:-DAIC_HURRY_STEPS=400" "hurry700:-DAIC_HURRY_STEPS=700"
-# On the GPU box:        gpurun --timeout 900 -- 'bash tools/exp_hurry.sh'
+# Here (no GPU needed):  AIC_PATCH=profiles/scripts_r04/experiments_r01_r04.patch tools/build_variants.sh "hurry96:-DAIC_HURRY_STEPS=96" "hurry128:-DAIC_HURRY_STEPS=128" "hurry160:-DAIC_HURRY_STEPS=160" "hurry400:-DAIC_HURRY_STEPS=400" "hurry700:-DAIC_HURRY_STEPS=700"
+# On the GPU box:        gpurun --timeout 900 -- 'bash profiles/scripts_r04/exp_hurry.sh'
 # Frames must keep their hashes (scheduling only); what to read: one frame warm / cold against the default (C2's longest rays are 154-205 steps, C3's reach the
 # 1000-step cap: 96-160 suit C2, 400-700 C3), and that the streamed figure does not pay for it.
 cd ${GRAFT_REPO_ROOT:-/root/repo}
