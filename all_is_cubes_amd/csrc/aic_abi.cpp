@@ -22,6 +22,7 @@
 
 namespace aic {
 void launch_trace_image(const DevFrame &F, bool diag, hipStream_t stream);
+size_t trace_ray_cold_bytes(uint32_t n_cus, uint32_t *groups);
 void launch_scatter_cubes(uint16_t *grid, uint32_t *light, const int32_t *xyz, const uint16_t *bi, const uint32_t *lt,
                           uint32_t n, const int lo[3], const int size[3], const uint32_t *cls, hipStream_t stream);
 void launch_probe_powf(const float *x, const float *y, float *out, uint32_t n, hipStream_t stream);
@@ -169,7 +170,7 @@ struct aic_ctx {
         DevBuf<float4> acc;  // UI pre-pass accumulators
         // cost feedback: the longest ray of every tile of the slot's last frame, and the tile order made from it
         DevBuf<uint32_t> tile_cost, tile_order, queue_start;
-        DevBuf<uint4> orphans;  // ray migration (aic_trace.hip): hot lane state of the rays handed over in the frame's tail
+        DevBuf<uint4> ray_cold;  // the production trace kernels' per-ray state in global memory (DevFrame::ray_cold)
         uint32_t cost_sig[4] = {0, 0, 0, 0};  // width, local rows, partition of the frame tile_cost describes
         double cost_cam[16] = {0};            // ... and its world camera
         bool busy = false;
@@ -462,7 +463,7 @@ void aic_destroy(aic_ctx *c) {
     for (uint32_t i = 0; i < AIC_MAX_IN_FLIGHT; i++) {
         aic_ctx::FrameSlot &fs = c->slots[i];
         if (fs.stream) (void)hipStreamSynchronize(fs.stream);
-        fs.counters.release(); fs.acc.release(); fs.tile_cost.release(); fs.tile_order.release(); fs.queue_start.release(); fs.orphans.release();
+        fs.counters.release(); fs.acc.release(); fs.tile_cost.release(); fs.tile_order.release(); fs.queue_start.release(); fs.ray_cold.release();
         if (fs.ev0) (void)hipEventDestroy(fs.ev0);
         if (fs.ev1) (void)hipEventDestroy(fs.ev1);
         if (fs.ev2) (void)hipEventDestroy(fs.ev2);
@@ -1041,19 +1042,15 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         if ((e = fs.acc.ensure(samples * npix)) != hipSuccess) return hip_fail(c, "alloc accumulators", e);
         F.acc_buf = fs.acc.p;
     }
-    {
-        // ray migration in the frame's tail (an experiment: needs a library built with -DAIC_RAY_MIGRATION=1, see aic_trace.hip):
-        // AIC_MIGRATE_K=<n> makes a wave hand its rays over once it is down to n of them; off by default
-        static const uint32_t migrate_k = [] { const char *e = std::getenv("AIC_MIGRATE_K"); const int v = e ? std::atoi(e) : 0; return (uint32_t)(v < 0 ? 0 : (v > 64 ? 64 : v)); }();
-        if (migrate_k && !diag) {
-            // room for the largest persistent grid any build launches (16 waves per CU as 64-thread workgroups), 256 columns each; the
-            // kernel is told the capacity and a workgroup beyond it simply keeps its rays (the size was duplicated from
-            // launch_trace's defaults and a build with other AIC_MIN_WAVES / AIC_WG_THREADS would have written past the buffer)
-            const size_t groups = (size_t)c->n_cus * 16u;
-            if ((e = fs.orphans.ensure(groups * 256u * (kOrphanDwords / 4u))) != hipSuccess) return hip_fail(c, "alloc migration buffer", e);
-            F.orphans = fs.orphans.p;
-            F.migrate_k = migrate_k;
-            F.migrate_groups = (uint32_t)groups;
+    if (!diag) {
+        // the production variants keep a ray's origin / direction / antialiasing sums in global memory (aic_trace.hip, lane exchange): one
+        // region per persistent workgroup, the same for the UI pre-pass and the world pass of a frame (they follow one another on the stream)
+        uint32_t groups = 0;
+        const size_t bytes = trace_ray_cold_bytes(c->n_cus, &groups);
+        if (bytes) {
+            if ((e = fs.ray_cold.ensure(bytes / sizeof(uint4))) != hipSuccess) return hip_fail(c, "alloc ray state", e);
+            F.ray_cold = fs.ray_cold.p;
+            F.ray_cold_groups = groups;
         }
     }
     HIP_TRY(c, hipEventRecord(fs.ev0, fs.stream));
@@ -1141,9 +1138,9 @@ int wait_frame(aic_ctx *c, uint32_t slot, aic_frame_info *info, bool whole_strea
             info->n_light = hc.n_light;
         }
 #ifdef AIC_PROFILE
-        { static const char *names[32] = {"max_lifetime","max_until_dry","cyc_until_dry","cyc_lifetime","shade_ph","shade_ln","enter_ph","enter_ln","ray_ph","ray_ln","step_iters","step_lanes","cyc_step","cyc_shade_rest","cyc_enter","cyc_newray","cyc_finish","cyc_refill","cyc_shade_light","cyc_sched","fast_iters","fast_lanes","trips","trip_lanes","pass_hl_lanes","pass_fast_eligible","leave_blocks","leave_lanes","apply_blocks","apply_lanes","pass_needed_lanes","-"};
+        { static const char *names[40] = {"max_lifetime","max_until_dry","cyc_until_dry","cyc_lifetime","shade_ph","shade_ln","enter_ph","enter_ln","ray_ph","ray_ln","step_iters","step_lanes","cyc_step","cyc_shade_rest","cyc_enter","cyc_newray","cyc_finish","cyc_refill","cyc_shade_light","cyc_sched","fast_iters","fast_lanes","trips","trip_lanes","pass_hl_lanes","pass_fast_eligible","leave_blocks","leave_lanes","apply_blocks","apply_lanes","pass_needed_lanes","xchg_rounds","xchg_lanes","cyc_xchg","xchg_picked","xchg_parked","idle_spins","-","-","-"};
           // (only the production variant's frames: the aux-recording variant is another kernel, at half the occupancy)
-          if (!fs.diag) for (int i = 0; i < 31; i++) std::fprintf(stderr, "PROF %s %llu\n", names[i], hc.prof[i]);
+          if (!fs.diag) for (int i = 0; i < 37; i++) std::fprintf(stderr, "PROF %s %llu\n", names[i], hc.prof[i]);
           if (const char *path = fs.diag ? nullptr : std::getenv("AIC_WAVE_PROF")) {
               if (FILE *fp = std::fopen(path, "w")) {
                   for (int w = 0; w < 2048; w++) std::fprintf(fp, "%u %u %u %u\n", hc.wave_prof[w][0], hc.wave_prof[w][1], hc.wave_prof[w][2], hc.wave_prof[w][3]);

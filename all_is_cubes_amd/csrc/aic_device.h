@@ -93,7 +93,7 @@ struct DevCounters {
     unsigned long long n_inner;
     unsigned long long n_hits;
     unsigned long long n_light;
-    unsigned long long prof[32];  // AIC_PROFILE builds only
+    unsigned long long prof[48];  // AIC_PROFILE builds only
     uint32_t tile_next;           // dynamic tile dispenser of the persistent trace kernel
     uint32_t waves_done;          // waves of the world pass that have added their sums: the last one hands the sums to the host (DevFrame::host_counters)
     uint32_t tile_next_q[kMaxTileQueues][16];  // the same per tile queue (DevFrame::n_queues), a cache line each: [q][0] counts
@@ -169,13 +169,13 @@ struct DevFrame {
     unsigned long long *host_counters;
     const float *light_lut;  // 256 floats
     const float *srgb_thr;   // 256 floats: srgb_thr[k] = smallest linear value whose sRGB8 encoding is >= k
-    // ray migration in the frame's tail (aic_trace.hip): hot lane state of the rays a wave hands over, kOrphanDwords dwords per
-    // (workgroup, LDS column); a wave hands its rays over once the tile queue is dry and it has at most migrate_k of them (0: off)
-    uint4 *orphans;
-    uint32_t migrate_k;
-    uint32_t migrate_groups;  // workgroups `orphans` has room for (x 256 columns x kOrphanDwords): a workgroup past that does not migrate
+    // Per-ray state the trace kernel keeps in global memory (production variants: aic_trace.hip "lane exchange"): 64 bytes per
+    // (workgroup, LDS column) -- the ray's origin and sanitised direction (6 f64: read by the ENTER and SHADE events) and the four
+    // antialiasing sums of its pixel. Sized by the host from trace_ray_cold_bytes(); `ray_cold_groups` workgroups fit.
+    uint4 *ray_cold;
+    uint32_t ray_cold_groups;
+    uint32_t pad_rc;
 };
-constexpr uint32_t kOrphanDwords = 40u;
 
 // Largest work tile edge in pixels (DevFrame.tile is 8 by default, 16 with AIC_TILE=16); row strips of
 // the multi-GPU partition are a multiple of it.

@@ -884,6 +884,32 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u
 #ifndef AIC_FAST_STEPS
 #define AIC_FAST_STEPS 16  // bookkeeping-free steps a lane may take ahead of each full pass (0: none; 8 until round 4) ...
 #endif
+// ---- Lane exchange between the waves of a workgroup ("regime-sorted waves"; DESIGN.md 4.2, tools/wave_sim) ----
+// A wave runs ONE kind of work per scheduler round (a stepping trip, or one kind of event) and the lanes of the other kinds idle: every phase
+// ran at 25-39 of 64 lanes (profiles/r04_phase_cycles.txt) on a kernel bound by instruction issue. The production variants therefore share a POOL
+// of parked rays per workgroup, in LDS: before a round the wave trades lanes that would idle for parked rays of the kind it is about to run
+// (compare-and-swap on a slot's tag, then a plain exchange of the ray's 40 hot dwords; the cold state stays in the ray's LDS column, whose index
+// travels with the ray), and while the pool has free slots it parks such lanes and starts new pixels in them, so that the workgroup holds more rays
+// than lanes (the reservoir the sorting needs). Nothing ever waits for another wave: a claim that fails is simply not made. A ray is a pure
+// function of its own state, which moves as a whole, so frames are bit-identical for any pool size or policy.
+#ifndef AIC_EXCHANGE
+#define AIC_EXCHANGE 1
+#endif
+#ifndef AIC_XWG_THREADS
+#define AIC_XWG_THREADS 512  // threads of a workgroup of the exchanging variants (two per CU: the pool is shared by eight waves)
+#endif
+#ifndef AIC_POOL
+#define AIC_POOL (AIC_XWG_THREADS >= 512 ? 160 : 76)  // parked rays per workgroup (<= 192: three tags per lane are scanned); what the CU's 160 KB leave room for
+#endif
+#ifndef AIC_XCHG_MIN_GAIN
+#define AIC_XCHG_MIN_GAIN 2  // a wave that has lanes of the chosen kind tops up only if the pool adds at least this many
+#endif
+#ifndef AIC_XCHG_DEPOSIT
+#define AIC_XCHG_DEPOSIT 3   // while slots are free: 0 park nothing, 2 park event lanes that do not run now, 3 stepping lanes too (tools/wave_sim: 3 > 2 > 1)
+#endif
+constexpr uint32_t TAG_FREE = 0u, TAG_STEP = 1u, TAG_SHADE = 2u, TAG_ENTER = 3u, TAG_RAY = 4u, TAG_BUSY = 7u;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 // Runs Raycaster::next (raycast.rs:239-284) on a freshly initialised level until it yields its
 // first step or ends. Used by the ENTER / RAY events, so that the stepping loop only ever sees
 // levels that are already inside their bounds. On success the returned state is "emitted, step
@@ -911,7 +937,15 @@ AIC_DEV Lvl lvl_first(Lvl s, const Lim lim, const RayDir rd, int lox, int loy, i
 // carried in the state: it is a pure function of t[], which nothing modifies between steps.
 
 template <bool VOL, int LMODE, bool DIAG, bool BIG>
-__global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_WAVES) void trace_image_kernel(const DevFrame F) {
+__global__ __launch_bounds__((AIC_EXCHANGE && !DIAG && LMODE != 3) ? AIC_XWG_THREADS : AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_WAVES) void trace_image_kernel(const DevFrame F) {
+    // XCHG: the production variants -- lanes are exchanged between the workgroup's waves through a pool of parked rays, and the part of a ray's
+    // cold state that only ENTER / SHADE / FINISH touch (origin, direction, antialiasing sums) lives in global memory to make room for it.
+    // The aux-recording and Bounce variants (more per-lane state, built for 2 waves per SIMD) keep everything in LDS and exchange nothing.
+    constexpr bool XCHG = AIC_EXCHANGE && !DIAG && LMODE != 3;
+    constexpr uint32_t WGT = XCHG ? (uint32_t)AIC_XWG_THREADS : (uint32_t)AIC_WG_THREADS;  // threads per workgroup
+    constexpr uint32_t NPOOL = XCHG ? (uint32_t)AIC_POOL : 0u;                            // pool slots
+    constexpr uint32_t NCOL = WGT + NPOOL;                                                // LDS columns: one per lane and one per slot
+    static_assert(NPOOL <= 192u, "three tags per lane are scanned");
     // ---- persistent waves: each wave pulls 8x8-pixel tiles from a global counter until the
     // image is exhausted, so cheap (sky) and expensive (geometry) tiles balance dynamically ----
     const uint32_t lane = threadIdx.x & 63u;
@@ -920,8 +954,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
     __shared__ float s_lut[256];     // PackedLight scalar decode (light/data.rs:301-354)
     __shared__ float s_thr[256];     // sRGB8 encode thresholds
     __shared__ double s_pow[64];     // powf tables (powf_table)
-    pow_tables_to_lds(s_pow, threadIdx.x, (uint32_t)AIC_WG_THREADS);
-    for (uint32_t i = threadIdx.x; i < 256u; i += (uint32_t)AIC_WG_THREADS) {
+    pow_tables_to_lds(s_pow, threadIdx.x, WGT);
+    for (uint32_t i = threadIdx.x; i < 256u; i += WGT) {
         s_lut[i] = F.light_lut[i];
         s_thr[i] = F.srgb_thr[i];
     }
@@ -966,27 +1000,45 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
     uint32_t sec_steps = 0;
     // ---- per-lane state, cold: only events touch it, so it lives in LDS (one column per thread: conflict-free
     //      ds_read/ds_write), not in registers -- that is what lets the kernel run at 3-4 waves per SIMD ----
-    enum { C_OX, C_OY, C_OZ, C_DX, C_DY, C_DZ,      // ray origin, direction (sanitised: Parameters::new, raycast.rs:749-771)
-           C_STX, C_STY, C_STZ, C_SLAST,            // the suspended outer level while inside a block: t_max, last t
-           C_TABS, C_HOLEN, N_C64 };                // |direction| (sr.rs:146); 0.5 / |direction| (raycast.rs:669)
+    //      A column belongs to a RAY, not to a lane: it travels with the ray when lanes are exchanged (`col`), and every pool slot holds a spare one.
+    //      The exchanging variants keep the rows after C_HOLEN / K_PXY in global memory instead (DevFrame::ray_cold: 64 bytes per column).
+    enum { C_STX, C_STY, C_STZ, C_SLAST,            // the suspended outer level while inside a block: t_max, last t
+           C_TABS, C_HOLEN,                         // |direction| (sr.rs:146); 0.5 / |direction| (raycast.rs:669)
+           C_OX, C_OY, C_OZ, C_DX, C_DY, C_DZ, N_C64_ALL };  // ray origin, direction (sanitised: Parameters::new, raycast.rs:749-771)
     enum { K_SRX, K_SRY, K_SRZ, K_SBOFF,            // the suspended outer level: steps left, byte offset
-           K_BLK, K_TVIEW, K_PXY, K_STEPS,          // block index; |direction| / view distance; pixel x | row << 16; step sum
-           K_S0, K_S1, K_S2, K_ST, N_C32 };         // ColorBuf::mean accumulators (antialiasing)
-    __shared__ double c64[N_C64][AIC_WG_THREADS];
-    __shared__ uint32_t c32[N_C32][AIC_WG_THREADS];
+           K_TVIEW, K_PXY,                          // |direction| / view distance; pixel x | row << 16
+           K_BLK, K_S0, K_S1, K_S2, K_ST, N_C32_ALL };  // block index (aux records); ColorBuf::mean accumulators (antialiasing)
+    constexpr int N_C64 = XCHG ? (int)C_OX : (int)N_C64_ALL, N_C32 = XCHG ? (int)K_BLK : (int)N_C32_ALL;
+    __shared__ double c64[N_C64][NCOL];
+    __shared__ uint32_t c32[N_C32][NCOL];
+    __shared__ uint32_t s_steps[WGT];               // per thread: steps of the rays it finished (RaytraceInfo)
+    // the pool of parked rays (XCHG): per slot the ray's 40 hot dwords (or, free, just the spare column in word 38), and its tag
+    __shared__ u32x4 s_pool[NPOOL ? NPOOL : 1u][10];
+    __shared__ uint32_t s_tag[NPOOL ? NPOOL : 1u];
+    __shared__ u32x4 s_census;                      // parked rays by kind: STEP, SHADE, ENTER, RAY (advisory: read without a claim)
+    __shared__ uint8_t s_pick[WGT / 64u][2][64];    // per wave: the slots a round's givers are paired with (wanted kind; free)
     const uint32_t tid = threadIdx.x;
     uint32_t col = tid;  // the LDS column holding this lane's ray
-    // LDS byte addresses of the lane's columns (the low half of a generic LDS pointer is the LDS offset)
-    uint32_t lds64 = (uint32_t)(uintptr_t)&c64[0][col], lds32 = (uint32_t)(uintptr_t)&c32[0][col];
-    c32[K_STEPS][tid] = 0u;
-    c32[K_BLK][tid] = 0u;
+    s_steps[tid] = 0u;
+    if (!XCHG) c32[XCHG ? 0 : (int)K_BLK][tid] = 0u;
     c32[K_PXY][tid] = 0u;
+    if (XCHG) {
+        for (uint32_t i = tid; i < NPOOL; i += WGT) {
+            s_tag[i] = TAG_FREE;
+            s_pool[i][9] = u32x4{0u, 0u, WGT + i, 0u};  // the slot's spare column
+            c32[K_PXY][WGT + i] = 0u;
+        }
+        if (tid == 0u) s_census = u32x4{0u, 0u, 0u, 0u};
+        __syncthreads();
+    }
     bool dry = false;                               // wave-uniform: this wave has seen the tile queue exhausted
     // The tile queue this wave takes from (DevFrame::n_queues > 1): its XCD's own to begin with, the next one's when that is empty. How many queues it has
     // seen empty is a word of LDS per wave, read once per tile -- kept in a scalar register for the life of the wave it cost the production variant
     // four spilled VGPRs (12 bytes of scratch per lane, 1.2 GB of scratch written back per C3 frame: profiles/r04_experiments.txt K).
-    __shared__ uint32_t s_queues_tried[AIC_WG_THREADS / 64];
-    if (lane == 0u) s_queues_tried[threadIdx.x >> 6] = 0u;
+    __shared__ uint32_t s_queues_tried[WGT / 64u];
+    __shared__ uint32_t s_tile_state[WGT / 64u][4];  // (XCHG) the wave's tile_x0, tile_y0, next_idx between its RAY phases (registers elsewhere)
+    __shared__ uint32_t s_idle_spins[WGT / 64u];  // (XCHG) rounds in which the wave found only rays in transit: bounded, so that nothing can hang
+    if (lane == 0u) { s_queues_tried[threadIdx.x >> 6] = 0u; s_idle_spins[threadIdx.x >> 6] = 0u; }
     SurfDiag pend_d;
     double pend_t = 0.0;
     bool pend_visible = false;
@@ -1006,12 +1058,12 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
     uint32_t ev = EV_NEWRAY | EV_TAKE;  // every lane starts by taking a pixel
 #ifdef AIC_PROFILE
     // the counters live in the little LDS the kernel leaves free: as registers they would spill the stepping loop
-    __shared__ uint32_t s_prof[AIC_WG_THREADS / 64][32];
-    __shared__ uint32_t s_ray_t0[AIC_WG_THREADS];  // per ray: the clock when it started
+    __shared__ uint32_t s_prof[WGT / 64u][40];
+    __shared__ uint32_t s_ray_t0[NCOL];  // per ray: the clock when it started
     uint32_t ray_dur_max = 0u, ray_dur_steps = 0u; // per lane: the longest ray's duration and its step count
     uint32_t tail_trips = 0u, tail_events = 0u, tail_lanes = 0u;  // -DAIC_TAIL_PROF: after the wave saw the queue dry: trips, event phases, lanes stepping at trip start
     uint32_t *const prof = s_prof[tid >> 6];
-    if (lane < 32u) prof[lane] = 0u;
+    if (lane < 40u) prof[lane] = 0u;
     uint32_t prof_tm = (uint32_t)__builtin_readcyclecounter();
     const uint32_t prof_t0 = prof_tm;
 #define AIC_PROF(i, v) { const uint32_t v_ = (uint32_t)(v); if (lane == 0u) prof[i] += v_; }
@@ -1027,6 +1079,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
 #define AIC_TICK(i)
 #endif
     uint32_t next_idx = F.tile * F.tile;  // wave-uniform: next unassigned pixel of tile_cur (tile_px = tile exhausted)
+    if (XCHG && lane == 0u) { s_tile_state[tid >> 6][0] = 0u; s_tile_state[tid >> 6][1] = 0u; s_tile_state[tid >> 6][2] = next_idx; }
 
     // FACE_TABLE (raycast.rs:618-623) applied late: the Face of the cube the level is in
     auto face_now = [&]() -> uint32_t {
@@ -1090,19 +1143,178 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
             : "vcc", "scc");  // (the scalar mask operations write SCC)
         return bz;  // lanes whose level ran out of steps: it left its bounds
     };
+    auto spun_out = [&]() -> bool {  // (XCHG) counts a round that could do nothing; true once the wave has had 2^22 of them (a bug's hang would cost the GPU box)
+        const uint32_t n_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_idle_spins[threadIdx.x >> 6]) + 1u;
+        if (lane == 0u) s_idle_spins[threadIdx.x >> 6] = n_;
+        return n_ > (1u << 22);
+    };
     for (;;) {
         // ---- wave scheduler: step, or run ONE kind of parked work for all lanes waiting on it ----
         // Kinds: SHADE (light + composite a surface), ENTER (a block), RAY (finish / start a ray). A
         // kind is run when enough lanes wait on it to fill the wave reasonably (AIC_T_BATCH), or when
         // so few lanes can still step (AIC_N_FEW) that waiting longer only idles the wave.
-        const unsigned long long m_st = __ballot(ev < 4u);
-        const unsigned long long b_shade = __ballot((ev & EV_SHADE) != 0u);
-        const unsigned long long b_enter = __ballot((ev & EV_ENTER) != 0u);
-        const unsigned long long b_ray = __ballot((ev & (EV_FINISH | EV_NEWRAY)) != 0u);
-        if ((m_st | b_shade | b_enter | b_ray) == 0ull) break;
-        const int n_step = (int)wave_popc(m_st);
-        const int c_shade = (int)wave_popc(b_shade), c_enter = (int)wave_popc(b_enter), c_ray = (int)wave_popc(b_ray);
+        unsigned long long m_st = __ballot(ev < 4u);
+        unsigned long long b_shade = __ballot((ev & EV_SHADE) != 0u);
+        unsigned long long b_enter = __ballot((ev & EV_ENTER) != 0u);
+        unsigned long long b_ray = __ballot((ev & (EV_FINISH | EV_NEWRAY)) != 0u);
+        int n_step = (int)wave_popc(m_st);
+        int c_shade = (int)wave_popc(b_shade), c_enter = (int)wave_popc(b_enter), c_ray = (int)wave_popc(b_ray);
         uint32_t run = 0u;  // kind to run this trip (an EV_* bit), 0 = step
+        if constexpr (XCHG) {
+            // ---- regime-sorted waves: run the kind that fills the wave best, own lanes plus what the workgroup's pool can add ----
+            u32x4 cs;  // parked rays by kind (advisory: a count can run a claim ahead of or behind the tags)
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cs) : "v"((uint32_t)(uintptr_t)&s_census) : "memory");
+            const int pk_step = opaque_s(__builtin_amdgcn_readfirstlane((int)cs.x)), pk_shade = opaque_s(__builtin_amdgcn_readfirstlane((int)cs.y)),
+                      pk_enter = opaque_s(__builtin_amdgcn_readfirstlane((int)cs.z)), pk_ray = opaque_s(__builtin_amdgcn_readfirstlane((int)cs.w));
+            const int parked = (pk_step > 0 ? pk_step : 0) + (pk_shade > 0 ? pk_shade : 0) + (pk_enter > 0 ? pk_enter : 0) + (pk_ray > 0 ? pk_ray : 0);
+            const int alive = n_step + c_shade + c_enter + c_ray;
+            if (alive == 0 && parked == 0) break;  // nothing of its own and nothing parked: whoever parks a ray later is running and serves it
+            // what a kind would run with: its own lanes + the parked rays that fit into the wave's other lanes (a top-up below AIC_XCHG_MIN_GAIN is not
+            // worth the exchange, unless the wave has none of that kind)
+            auto total_of = [](int mine, int pk) -> int {
+                const int room = 64 - mine;
+                int a = pk < room ? pk : room;
+                if (a < 0 || (a < AIC_XCHG_MIN_GAIN && mine > 0)) a = 0;
+                return mine + a;
+            };
+            const int t_step = total_of(n_step, pk_step), t_shade = total_of(c_shade, pk_shade), t_enter = total_of(c_enter, pk_enter), t_ray = total_of(c_ray, pk_ray);
+            int best = t_step, mine = n_step;  // (ties go to the events: a parked event lane blocks its ray, a stepping lane can wait)
+            if (t_shade >= best && t_shade > 0) { best = t_shade; mine = c_shade; run = EV_SHADE; }
+            if (t_enter >= best && t_enter > 0) { best = t_enter; mine = c_enter; run = EV_ENTER; }
+            if (t_ray >= best && t_ray > 0) { best = t_ray; mine = c_ray; run = EV_FINISH; }
+            if (best == 0) {  // only rays in transit between two waves: look again shortly (bounded: a wave never waits for another for good)
+                AIC_PROF(36, 1);
+                if (spun_out()) break;
+                __builtin_amdgcn_s_sleep(8);
+                continue;
+            }
+            AIC_TICK(19);
+            const bool dry_u = __builtin_amdgcn_readfirstlane(dry ? 1 : 0) != 0;
+            const int n_others = alive - mine - ((AIC_XCHG_DEPOSIT < 3 && run != 0u) ? n_step : 0);  // lanes holding a ray that will not run now (and may be parked)
+            const bool may_park = AIC_XCHG_DEPOSIT != 0 && !dry_u && parked < (int)NPOOL && n_others > 0;
+            if (best > mine || may_park) {
+                // ---- the exchange: lanes that would idle ("givers": empty lanes first, then rays of other kinds) are paired with parked rays of the wanted
+                // kind, and -- while the image has pixels left -- what remains of them with free slots. A pairing is a claim (compare-and-swap of the slot's
+                // tag), a plain swap of the 40 hot dwords and the column index, and the release of the slot under the tag of what it now holds. ----
+                // (the lane number through an empty asm: what is derived from it -- LDS addresses of the tags and lists, comparisons with the pool size -- is
+                //  otherwise computed before the persistent loop and kept in registers the event code needs)
+                uint32_t ln = lane;
+                asm volatile("" : "+v"(ln));
+                const uint32_t want = run == 0u ? TAG_STEP : (run == EV_SHADE ? TAG_SHADE : (run == EV_ENTER ? TAG_ENTER : TAG_RAY));
+                const bool empty = ev == EV_DONE || ev == (EV_NEWRAY | EV_TAKE);
+                const uint32_t my_tag = empty ? TAG_FREE : ((ev & EV_SHADE) ? TAG_SHADE : ((ev & EV_ENTER) ? TAG_ENTER : ((ev & (EV_FINISH | EV_NEWRAY)) ? TAG_RAY : TAG_STEP)));
+                const bool giver = empty ? (ev == EV_DONE || want != TAG_RAY) : (my_tag != want);  // (an empty lane about to take a pixel IS the RAY kind)
+                const unsigned long long m_ge = __builtin_amdgcn_ballot_w64(giver && empty), m_go = __builtin_amdgcn_ballot_w64(giver && !empty);
+                auto below = [](unsigned long long m) -> uint32_t { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+                const uint32_t n_e = wave_popc(m_ge), n_o = wave_popc(m_go);
+                const uint32_t rank = empty ? below(m_ge) : n_e + below(m_go);
+                // the slots' tags, three per lane; the first 64 slots of the wanted kind and the first 64 free ones go into the wave's pairing lists
+                const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)((tid - ln) >> 6));
+                uint32_t t0 = TAG_BUSY, t1 = TAG_BUSY, t2 = TAG_BUSY;
+                if (ln < NPOOL) t0 = __hip_atomic_load(&s_tag[ln < NPOOL ? lane : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (NPOOL > 64u && ln + 64u < NPOOL) t1 = __hip_atomic_load(&s_tag[ln + 64u < NPOOL ? ln + 64u : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (NPOOL > 128u && ln + 128u < NPOOL) t2 = __hip_atomic_load(&s_tag[ln + 128u < NPOOL ? ln + 128u : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned long long w0 = __builtin_amdgcn_ballot_w64(t0 == want), w1 = __builtin_amdgcn_ballot_w64(t1 == want), w2 = __builtin_amdgcn_ballot_w64(t2 == want);
+                const unsigned long long f0 = __builtin_amdgcn_ballot_w64(t0 == TAG_FREE), f1 = __builtin_amdgcn_ballot_w64(t1 == TAG_FREE), f2 = __builtin_amdgcn_ballot_w64(t2 == TAG_FREE);
+                const uint32_t nw0 = wave_popc(w0), nw1 = wave_popc(w1), n_w = nw0 + nw1 + wave_popc(w2);
+                const uint32_t nf0 = wave_popc(f0), nf1 = wave_popc(f1), n_f = nf0 + nf1 + wave_popc(f2);
+                if (t0 == want) s_pick[wv][0][below(w0)] = (uint8_t)ln;
+                if (t1 == want) { const uint32_t i_ = nw0 + below(w1); if (i_ < 64u) s_pick[wv][0][i_] = (uint8_t)(ln + 64u); }
+                if (t2 == want) { const uint32_t i_ = nw0 + nw1 + below(w2); if (i_ < 64u) s_pick[wv][0][i_] = (uint8_t)(ln + 128u); }
+                if (t0 == TAG_FREE) s_pick[wv][1][below(f0)] = (uint8_t)ln;
+                if (t1 == TAG_FREE) { const uint32_t i_ = nf0 + below(f1); if (i_ < 64u) s_pick[wv][1][i_] = (uint8_t)(ln + 64u); }
+                if (t2 == TAG_FREE) { const uint32_t i_ = nf0 + nf1 + below(f2); if (i_ < 64u) s_pick[wv][1][i_] = (uint8_t)(ln + 128u); }
+                const uint32_t n_giv = n_e + n_o;
+                const uint32_t n_take = n_w < n_giv ? n_w : n_giv;  // (at most 64)
+                const uint32_t n_free = n_f < 64u ? n_f : 64u;
+                uint32_t slot = 0xffffffffu, expect = TAG_FREE;
+                if (giver) {
+                    if (rank < n_take) {
+                        slot = s_pick[wv][0][rank];
+                        expect = want;
+                    } else if (may_park && !empty && (AIC_XCHG_DEPOSIT >= 3 || my_tag != TAG_STEP)) {
+                        const uint32_t j_ = rank - (n_take > n_e ? n_take : n_e);
+                        if (j_ < n_free) slot = s_pick[wv][1][j_];
+                    }
+                }
+                bool got = false;
+                if (slot != 0xffffffffu) {
+                    uint32_t seen = expect;
+                    got = __hip_atomic_compare_exchange_strong(&s_tag[slot], &seen, TAG_BUSY, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                // (this ray's stores to its global cold state -- NEWRAY, FINISH -- are in L2 before another wave can be handed the ray)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (got) {
+                    u32x4 *const sp = s_pool[slot];
+                    const u32x4 i0 = sp[0], i1 = sp[1], i2 = sp[2], i3 = sp[3], i4 = sp[4], i5 = sp[5], i6 = sp[6], i7 = sp[7], i8 = sp[8], i9 = sp[9];
+                    const unsigned long long b0 = (unsigned long long)__double_as_longlong(tx), b1 = (unsigned long long)__double_as_longlong(ty),
+                                             b2 = (unsigned long long)__double_as_longlong(tz), b3 = (unsigned long long)__double_as_longlong(last_t),
+                                             b4 = (unsigned long long)__double_as_longlong(tdx), b5 = (unsigned long long)__double_as_longlong(tdy),
+                                             b6 = (unsigned long long)__double_as_longlong(tdz);
+                    sp[0] = u32x4{(uint32_t)b0, (uint32_t)(b0 >> 32), (uint32_t)b1, (uint32_t)(b1 >> 32)};
+                    sp[1] = u32x4{(uint32_t)b2, (uint32_t)(b2 >> 32), (uint32_t)b3, (uint32_t)(b3 >> 32)};
+                    sp[2] = u32x4{(uint32_t)b4, (uint32_t)(b4 >> 32), (uint32_t)b5, (uint32_t)(b5 >> 32)};
+                    sp[3] = u32x4{(uint32_t)b6, (uint32_t)(b6 >> 32), rx, ry};
+                    sp[4] = u32x4{rz, boff, (uint32_t)ssx, (uint32_t)ssy};
+                    sp[5] = u32x4{(uint32_t)ssz, thr, raw, lax};
+                    sp[6] = u32x4{st, count, ev, blk_pal_off};
+                    sp[7] = u32x4{blk_geo, blk_vsz, __float_as_uint(acc.l0), __float_as_uint(acc.l1)};
+                    sp[8] = u32x4{__float_as_uint(acc.l2), __float_as_uint(acc.t), __float_as_uint(pend0), __float_as_uint(pend1)};
+                    sp[9] = u32x4{__float_as_uint(pend2), __float_as_uint(pend_tr), col, 0u};
+                    tx = __longlong_as_double((long long)(((unsigned long long)i0.y << 32) | i0.x));
+                    ty = __longlong_as_double((long long)(((unsigned long long)i0.w << 32) | i0.z));
+                    tz = __longlong_as_double((long long)(((unsigned long long)i1.y << 32) | i1.x));
+                    last_t = __longlong_as_double((long long)(((unsigned long long)i1.w << 32) | i1.z));
+                    tdx = __longlong_as_double((long long)(((unsigned long long)i2.y << 32) | i2.x));
+                    tdy = __longlong_as_double((long long)(((unsigned long long)i2.w << 32) | i2.z));
+                    tdz = __longlong_as_double((long long)(((unsigned long long)i3.y << 32) | i3.x));
+                    rx = i3.z; ry = i3.w;
+                    rz = i4.x; boff = i4.y; ssx = (int)i4.z; ssy = (int)i4.w;
+                    ssz = (int)i5.x; thr = i5.y; raw = i5.z; lax = i5.w;
+                    st = i6.x; count = i6.y; ev = i6.z; blk_pal_off = i6.w;
+                    blk_geo = i7.x; blk_vsz = i7.y; acc.l0 = __uint_as_float(i7.z); acc.l1 = __uint_as_float(i7.w);
+                    acc.l2 = __uint_as_float(i8.x); acc.t = __uint_as_float(i8.y); pend0 = __uint_as_float(i8.z); pend1 = __uint_as_float(i8.w);
+                    pend2 = __uint_as_float(i9.x); pend_tr = __uint_as_float(i9.y);
+                    col = i9.z;
+                    if (expect == TAG_FREE) {  // a spare column came back: the lane starts a new pixel in it
+                        ev = EV_NEWRAY | EV_TAKE;
+                        st = 0u;
+                    }
+                    __hip_atomic_store(&s_tag[slot], my_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                const unsigned long long m_got = __builtin_amdgcn_ballot_w64(got);
+                if (m_got != 0ull) {
+                    // the counts: one lane per kind adds what was parked minus what was taken
+                    const uint32_t n_picked = wave_popc(__builtin_amdgcn_ballot_w64(got && expect != TAG_FREE));
+                    const uint32_t d_step = wave_popc(__builtin_amdgcn_ballot_w64(got && my_tag == TAG_STEP)), d_shade = wave_popc(__builtin_amdgcn_ballot_w64(got && my_tag == TAG_SHADE)),
+                                   d_enter = wave_popc(__builtin_amdgcn_ballot_w64(got && my_tag == TAG_ENTER)), d_ray = wave_popc(__builtin_amdgcn_ballot_w64(got && my_tag == TAG_RAY));
+                    if (ln < 4u) {
+                        uint32_t delta = ln == 0u ? d_step : (ln == 1u ? d_shade : (ln == 2u ? d_enter : d_ray));
+                        if (ln + 1u == want) delta -= n_picked;
+                        if (delta != 0u) atomicAdd(reinterpret_cast<uint32_t *>(&s_census) + ln, delta);
+                    }
+                    AIC_PROF(31, 1);
+                    AIC_PROF(32, wave_popc(m_got));
+                    AIC_PROF(34, n_picked);
+                    AIC_PROF(35, d_step + d_shade + d_enter + d_ray);
+                    m_st = __ballot(ev < 4u);
+                    b_shade = __ballot((ev & EV_SHADE) != 0u);
+                    b_enter = __ballot((ev & EV_ENTER) != 0u);
+                    b_ray = __ballot((ev & (EV_FINISH | EV_NEWRAY)) != 0u);
+                    n_step = (int)wave_popc(m_st);
+                    c_shade = (int)wave_popc(b_shade); c_enter = (int)wave_popc(b_enter); c_ray = (int)wave_popc(b_ray);
+                }
+                AIC_TICK(33);
+                // (every claim lost to another wave, and the wave had nothing of the kind itself: choose again)
+                if ((run == 0u ? n_step : (run == EV_SHADE ? c_shade : (run == EV_ENTER ? c_enter : c_ray))) == 0) {
+                    AIC_PROF(36, 1);
+                    if (spun_out()) break;
+                    __builtin_amdgcn_s_sleep(4);
+                    continue;
+                }
+            }
+        } else {
+        if ((m_st | b_shade | b_enter | b_ray) == 0ull) break;
         {
             int best = c_shade;
             uint32_t kind = EV_SHADE;
@@ -1124,6 +1336,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
             if (best > 0 && (best >= t_batch || n_step <= n_few)) run = kind;
         }
         AIC_TICK(19);
+        }
         if (run != 0u) {
             // ============================ event phase ======================================
             // the kernel arguments, through an opaque pointer (see the top of the kernel): `F`, `L`, `opt` below shadow the
@@ -1164,6 +1377,48 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
             AIC_PROF(4, run == EV_SHADE ? 1 : 0); AIC_PROF(5, run == EV_SHADE ? c_shade : 0);
             AIC_PROF(6, run == EV_ENTER ? 1 : 0); AIC_PROF(7, run == EV_ENTER ? c_enter : 0);
             AIC_PROF(8, run == EV_FINISH ? 1 : 0); AIC_PROF(9, run == EV_FINISH ? c_ray : 0);
+            // The exchanging variants' global part of the cold state: 64 bytes per column of this workgroup -- origin and direction (6 f64), then the
+            // four antialiasing sums. Loads are agent-scope atomics: they bypass the CU's vector L1, which a store made by another wave of the
+            // workgroup does not update (the ray may have been started, or its sums last written, by a lane of another wave).
+            char *const cold_wg = XCHG ? reinterpret_cast<char *>(F.ray_cold) + (size_t)blockIdx.x * (size_t)(NCOL * 64u) : nullptr;
+            auto cold_origin = [&](double &ox, double &oy, double &oz) {
+                if constexpr (XCHG) {
+                    unsigned long long *g = reinterpret_cast<unsigned long long *>(cold_wg + col * 64u);
+                    ox = __longlong_as_double((long long)__hip_atomic_load(g + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    oy = __longlong_as_double((long long)__hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    oz = __longlong_as_double((long long)__hip_atomic_load(g + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                } else {
+                    ox = c64[XCHG ? 0 : (int)C_OX][col]; oy = c64[XCHG ? 0 : (int)C_OY][col]; oz = c64[XCHG ? 0 : (int)C_OZ][col];
+                }
+            };
+            auto cold_direction = [&](double &dx, double &dy, double &dz) {
+                if constexpr (XCHG) {
+                    unsigned long long *g = reinterpret_cast<unsigned long long *>(cold_wg + col * 64u);
+                    dx = __longlong_as_double((long long)__hip_atomic_load(g + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    dy = __longlong_as_double((long long)__hip_atomic_load(g + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    dz = __longlong_as_double((long long)__hip_atomic_load(g + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                } else {
+                    dx = c64[XCHG ? 0 : (int)C_DX][col]; dy = c64[XCHG ? 0 : (int)C_DY][col]; dz = c64[XCHG ? 0 : (int)C_DZ][col];
+                }
+            };
+            auto cold_sums_load = [&](float v[4]) {
+                if constexpr (XCHG) {
+                    unsigned long long *g = reinterpret_cast<unsigned long long *>(cold_wg + col * 64u + 48u);
+                    const unsigned long long a = __hip_atomic_load(g + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v[0] = __uint_as_float((uint32_t)a); v[1] = __uint_as_float((uint32_t)(a >> 32)); v[2] = __uint_as_float((uint32_t)b); v[3] = __uint_as_float((uint32_t)(b >> 32));
+                } else {
+                    v[0] = __uint_as_float(c32[XCHG ? 0 : (int)K_S0][col]); v[1] = __uint_as_float(c32[XCHG ? 0 : (int)K_S1][col]);
+                    v[2] = __uint_as_float(c32[XCHG ? 0 : (int)K_S2][col]); v[3] = __uint_as_float(c32[XCHG ? 0 : (int)K_ST][col]);
+                }
+            };
+            auto cold_sums_store = [&](float v0, float v1, float v2, float v3) {
+                if constexpr (XCHG) {
+                    *reinterpret_cast<float4 *>(cold_wg + col * 64u + 48u) = make_float4(v0, v1, v2, v3);
+                } else {
+                    c32[XCHG ? 0 : (int)K_S0][col] = __float_as_uint(v0); c32[XCHG ? 0 : (int)K_S1][col] = __float_as_uint(v1);
+                    c32[XCHG ? 0 : (int)K_S2][col] = __float_as_uint(v2); c32[XCHG ? 0 : (int)K_ST][col] = __float_as_uint(v3);
+                }
+            };
             const uint32_t posx = (st >> 26) & 1u, posy = (st >> 25) & 1u, posz = (st >> 24) & 1u;
             // -- shading a discovered surface: compute_illumination + trace_through_span +
             //    Surface::to_light (surface.rs:73-206; sr.rs:697-740). For Volumetric transparency the
@@ -1205,8 +1460,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                         i0 = lut[txl & 255u]; i1 = lut[(txl >> 8) & 255u]; i2 = lut[(txl >> 16) & 255u];
                     }
                     if (LMODE >= 2) {
-                        const double ox = c64[C_OX][col], oy = c64[C_OY][col], oz = c64[C_OZ][col];
-                        const double dx = c64[C_DX][col], dy = c64[C_DY][col], dz = c64[C_DZ][col];
+                        double ox, oy, oz, dx, dy, dz;
+                        cold_origin(ox, oy, oz);
+                        cold_direction(dx, dy, dz);
                         if (inb) {
                             const double kd = (double)blk_res;
                             double vp[3];
@@ -1348,7 +1604,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                     sd.cube[0] = ocx; sd.cube[1] = ocy; sd.cube[2] = ocz;
                     if (inb) {
                         sd.voxel[0] = ca.cx; sd.voxel[1] = ca.cy; sd.voxel[2] = ca.cz;
-                        sd.res = (int)blk_res; sd.block = (int)c32[K_BLK][col];
+                        sd.res = (int)blk_res; sd.block = (int)c32[XCHG ? 0 : (int)K_BLK][col];
                     } else {
                         sd.voxel[0] = sd.voxel[1] = sd.voxel[2] = 0;
                         sd.res = 1; sd.block = (int)(shade_ref & 0xffffu);
@@ -1425,14 +1681,16 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
             //    advanced to its first in-bounds voxel (or to its end) --
             if (run == EV_ENTER && (ev & EV_ENTER)) {
                 const uint32_t blk_index = raw & idx_mask;
-                c32[K_BLK][col] = blk_index;
+                if (DIAG) c32[XCHG ? 0 : (int)K_BLK][col] = blk_index;
                 const DevBlock *tb = &L.blocks[blk_index];
                 const uint32_t blk_res = tb->kind & 255u;
                 const uint32_t blk_vlo = tb->vlo_packed;
                 blk_geo = ((31u - (uint32_t)__clz((int)blk_res)) << 24) | blk_vlo;
                 blk_vsz = tb->vsize_packed;
                 blk_pal_off = tb->pal_off;
-                const double ox = c64[C_OX][col], oy = c64[C_OY][col], oz = c64[C_OZ][col];
+                double ox, oy, oz, edx, edy, edz;
+                cold_origin(ox, oy, oz);
+                cold_direction(edx, edy, edz);
                 const uint32_t n_invisible = tb->n_invisible;
                 const uint32_t vox_off = tb->vox_off;
                 const double kd = (double)blk_res;
@@ -1444,7 +1702,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                 st = (st & ~((7u << 16) | ST_OUTER_ALIVE)) | (face_now() << 16) | ((ev & EV_DEAD) ? 0u : ST_OUTER_ALIVE);
                 const int ilx = (int)(blk_vlo & 255u), ily = (int)((blk_vlo >> 8) & 255u), ilz = (int)((blk_vlo >> 16) & 255u);
                 const int isx = (int)(blk_vsz & 255u), isy = (int)((blk_vsz >> 8) & 255u), isz = (int)((blk_vsz >> 16) & 255u);
-                const RayDir rd = make_rd(c64[C_DX][col], c64[C_DY][col], c64[C_DZ][col]);
+                const RayDir rd = make_rd(edx, edy, edz);
                 const LvlLim ll = lvl_init(sx_, sy_, sz_, rd, true, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz, true, c64[C_HOLEN][col]);
                 bool got;
                 const Lvl f = lvl_first(ll.s, ll.lim, rd, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz, &got);
@@ -1489,7 +1747,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                         const float blue = ps_clamped(luminance(cur_rgba[0], cur_rgba[1], cur_rgba[2]) * 0.2f);
                         acc.l0 = red; acc.l1 = green; acc.l2 = blue; acc.t = 0.0f;
                     }
-                    c32[K_STEPS][tid] += count + (LMODE == 3 ? sec_steps : 0u);  // RaytraceInfo + secondary_info (sr.rs:690-692)
+                    { uint32_t t_ = threadIdx.x; asm volatile("" : "+v"(t_)); s_steps[t_] += count + (LMODE == 3 ? sec_steps : 0u); }  // (the address made here, not held across the loop)  // RaytraceInfo + secondary_info (sr.rs:690-692)
 #ifdef AIC_PROFILE
                     { const uint32_t dur_ = (uint32_t)__builtin_readcyclecounter() - s_ray_t0[col];
                       if (dur_ > ray_dur_max) { ray_dur_max = dur_; ray_dur_steps = count; } }
@@ -1497,6 +1755,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                     if (DIAG) px_steps += count + (LMODE == 3 ? sec_steps : 0u);
                 }
                 const uint32_t x = pxy & 0xffffu, lrow = pxy >> 16;
+                float aa_sum[4] = {0.f, 0.f, 0.f, 0.f};
                 if (F.tile_cost && count > 48u) {
                     // longest ray of the macro tile so far. Only rays long enough to matter for the frame's
                     // tail are recorded (the rest leave their tile at cost 0: handed out last, in index
@@ -1516,10 +1775,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                         acc.t = 1.0f * (1.0f - 1.0f);
                     }
                     if (n_samples == 4) {
-                        c32[K_S0][col] = __float_as_uint(__uint_as_float(c32[K_S0][col]) + acc.l0);
-                        c32[K_S1][col] = __float_as_uint(__uint_as_float(c32[K_S1][col]) + acc.l1);
-                        c32[K_S2][col] = __float_as_uint(__uint_as_float(c32[K_S2][col]) + acc.l2);
-                        c32[K_ST][col] = __float_as_uint(__uint_as_float(c32[K_ST][col]) + acc.t);
+                        cold_sums_load(aa_sum);
+                        aa_sum[0] += acc.l0; aa_sum[1] += acc.l1; aa_sum[2] += acc.l2; aa_sum[3] += acc.t;
+                        if (sample < 3) cold_sums_store(aa_sum[0], aa_sum[1], aa_sum[2], aa_sum[3]);  // (the last sample's sums are used below and dropped)
                     }
                 }
                 sample++;
@@ -1529,8 +1787,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                     if (!ui_pass) {
                         ColorBuf pixel;
                         if (n_samples == 4) {  // ColorBuf::mean (raytracer_components.rs:97-102)
-                            pixel.l0 = __uint_as_float(c32[K_S0][col]) / 4.0f; pixel.l1 = __uint_as_float(c32[K_S1][col]) / 4.0f;
-                            pixel.l2 = __uint_as_float(c32[K_S2][col]) / 4.0f; pixel.t = __uint_as_float(c32[K_ST][col]) / 4.0f;
+                            pixel.l0 = aa_sum[0] / 4.0f; pixel.l1 = aa_sum[1] / 4.0f; pixel.l2 = aa_sum[2] / 4.0f; pixel.t = aa_sum[3] / 4.0f;
                         } else {
                             pixel = acc;
                         }
@@ -1582,6 +1839,14 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                 // lanes that finished a pixel -- ballot + prefix popcount -- pulling a fresh tile
                 // from the global counter whenever the current one is used up.
                 want = (ev & (EV_NEWRAY | EV_TAKE)) == (EV_NEWRAY | EV_TAKE);
+                uint32_t wv_ = 0u;  // (XCHG) the wave's number, made here: derived before the loop, the address of its LDS words would be one more register held across it
+                if constexpr (XCHG) {
+                    wv_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+                    asm volatile("" : "+s"(wv_));
+                    tile_x0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tile_state[wv_][0]);
+                    tile_y0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tile_state[wv_][1]);
+                    next_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_tile_state[wv_][2]);
+                }
                 for (;;) {
                     const unsigned long long need = __ballot(want);
                     if (need == 0ull) break;
@@ -1659,13 +1924,16 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                     const uint32_t n_need = wave_popc(need);
                     next_idx += n_need < avail ? n_need : avail;
                 }
+                if constexpr (XCHG) {
+                    if (lane == 0u) { s_tile_state[wv_][0] = tile_x0; s_tile_state[wv_][1] = tile_y0; s_tile_state[wv_][2] = next_idx; }
+                }
             }
             if (run == EV_FINISH) { AIC_TICK(17) }
             if (run == EV_FINISH && (ev & EV_NEWRAY) && ev != EV_DONE && !want) {
                 const uint32_t x = pxy & 0xffffu, lrow = pxy >> 16;
                 const size_t pix = (size_t)lrow * F.width + x;
                 if (ev & EV_TAKE) {
-                    if (n_samples == 4) { c32[K_S0][col] = 0u; c32[K_S1][col] = 0u; c32[K_S2][col] = 0u; c32[K_ST][col] = 0u; }  // 0.f
+                    if (n_samples == 4) { const float z_ = KF(0.f); cold_sums_store(z_, z_, z_, z_); }
                     if (DIAG) {
                         dg.n_outer = dg.n_inner = dg.n_hits = dg.n_light = 0; dg.layer = 0; dg.hit = 0; dg.res = dg.face = dg.block = 0; dg.t = 0.0;
                         for (int a = 0; a < 3; a++) dg.cube[a] = dg.voxel[a] = 0;
@@ -1753,7 +2021,6 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                 }
                 if (have_ray) {
                     const double ox = o[0], oy = o[1], oz = o[2];
-                    c64[C_OX][col] = ox; c64[C_OY][col] = oy; c64[C_OZ][col] = oz;
                     const double dirx = dir[0], diry = dir[1], dirz = dir[2];
                     if (LMODE == 3) {  // SmallRng::seed_from_u64(bits(dx) + bits(dy) + bits(dz)) of the ray as given (sr.rs:165-178)
                         brng = bounce_rng_seed((unsigned long long)__double_as_longlong(dirx) + (unsigned long long)__double_as_longlong(diry) +
@@ -1764,7 +2031,13 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                     c64[C_TABS][col] = t_abs;
                     c32[K_TVIEW][col] = __float_as_uint((float)(t_abs / opt.view_distance));  // sr.rs:149-151
                     const RayDir rd = raydir_init(dirx, diry, dirz);
-                    c64[C_DX][col] = rd.dx; c64[C_DY][col] = rd.dy; c64[C_DZ][col] = rd.dz;
+                    if constexpr (XCHG) {
+                        double *g = reinterpret_cast<double *>(cold_wg + col * 64u);
+                        g[0] = ox; g[1] = oy; g[2] = oz; g[3] = rd.dx; g[4] = rd.dy; g[5] = rd.dz;
+                    } else {
+                        c64[XCHG ? 0 : (int)C_OX][col] = ox; c64[XCHG ? 0 : (int)C_OY][col] = oy; c64[XCHG ? 0 : (int)C_OZ][col] = oz;
+                        c64[XCHG ? 0 : (int)C_DX][col] = rd.dx; c64[XCHG ? 0 : (int)C_DY][col] = rd.dy; c64[XCHG ? 0 : (int)C_DZ][col] = rd.dz;
+                    }
                     tdx = rd.tdx; tdy = rd.tdy; tdz = rd.tdz;
                     const uint32_t qx = dirx >= 0.0 ? 1u : 0u, qy = diry >= 0.0 ? 1u : 0u, qz = dirz >= 0.0 ? 1u : 0u;
                     const uint32_t octant = (qx << 2) + (qy << 1) + qz;
@@ -2007,6 +2280,8 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                 // from st[16..18]; it goes on stepping if it was alive when the block was entered.
                 mask_t sv;
                 uint32_t t_;
+                // LDS byte addresses of the lane's columns (the low half of a generic LDS pointer is the LDS offset)
+                const uint32_t lds64 = (uint32_t)(uintptr_t)&c64[0][col], lds32 = (uint32_t)(uintptr_t)&c32[0][col];
                 asm volatile(
                     "s_mov_b64 %[sv], exec\n\t"
                     "s_mov_b64 exec, %[m]\n\t"
@@ -2040,9 +2315,9 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
                       [t] "=&v"(t_), [sv] "=&s"(sv), [nd] "=&s"(m_newdead)
                     : [a64] "v"(lds64), [a32] "v"(lds32), [m] "s"(m_leave), [osx] "s"(ostx), [osy] "s"(osty), [othr] "n"(BIG ? 0x10000u : (1u << kCubeClassShift)),
                       [alive] "n"(ST_OUTER_ALIVE), [notinb] "n"(~ST_IN_BLOCK),
-                      [o0] "n"(C_STX * AIC_WG_THREADS * 8), [o1] "n"(C_STY * AIC_WG_THREADS * 8), [o2] "n"(C_STZ * AIC_WG_THREADS * 8),
-                      [o3] "n"(C_SLAST * AIC_WG_THREADS * 8), [p0] "n"(K_SRX * AIC_WG_THREADS * 4), [p1] "n"(K_SRY * AIC_WG_THREADS * 4),
-                      [p2] "n"(K_SRZ * AIC_WG_THREADS * 4), [p3] "n"(K_SBOFF * AIC_WG_THREADS * 4)
+                      [o0] "n"(C_STX * NCOL * 8), [o1] "n"(C_STY * NCOL * 8), [o2] "n"(C_STZ * NCOL * 8),
+                      [o3] "n"(C_SLAST * NCOL * 8), [p0] "n"(K_SRX * NCOL * 4), [p1] "n"(K_SRY * NCOL * 4),
+                      [p2] "n"(K_SRZ * NCOL * 4), [p3] "n"(K_SBOFF * NCOL * 4)
                     : "memory");
                 m_inb &= ~m_leave;
             }
@@ -2115,7 +2390,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
 #ifdef AIC_PROFILE
     if (lane == 0) {
         prof[3] = (uint32_t)__builtin_readcyclecounter() - prof_t0;  // wave lifetime
-        const uint32_t wid = blockIdx.x * (uint32_t)(AIC_WG_THREADS / 64) + (threadIdx.x >> 6);
+        const uint32_t wid = blockIdx.x * (WGT / 64u) + (threadIdx.x >> 6);
         if (wid < 2048u) {
             F.counters->wave_prof[wid][0] = prof_t0;
             F.counters->wave_prof[wid][1] = prof_t0 + prof[2];
@@ -2127,7 +2402,7 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
     }
 #ifdef AIC_TAIL_PROF
     {   // trips (12 bits), event phases (10 bits) and mean lanes stepping per trip (x16, 10 bits) after the wave saw the queue dry
-        const uint32_t wid = blockIdx.x * (uint32_t)(AIC_WG_THREADS / 64) + (threadIdx.x >> 6);
+        const uint32_t wid = blockIdx.x * (WGT / 64u) + (threadIdx.x >> 6);
         const uint32_t ml = tail_trips ? (tail_lanes * 16u) / tail_trips : 0u;
         if (lane == 0 && wid < 2048u) F.counters->wave_prof[wid][3] = (tail_trips > 4095u ? 4095u : tail_trips) | ((tail_events > 1023u ? 1023u : tail_events) << 12) | ((ml > 1023u ? 1023u : ml) << 22);
     }
@@ -2137,14 +2412,16 @@ __global__ __launch_bounds__(AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_
         uint32_t best_ = (ray_dur_max & ~1023u) | (ray_dur_steps > 1023u ? 1023u : ray_dur_steps);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { const uint32_t o_ = (uint32_t)__shfl_down((int)best_, off, 64); best_ = o_ > best_ ? o_ : best_; }
-        const uint32_t wid = blockIdx.x * (uint32_t)(AIC_WG_THREADS / 64) + (threadIdx.x >> 6);
+        const uint32_t wid = blockIdx.x * (WGT / 64u) + (threadIdx.x >> 6);
         if (lane == 0 && wid < 2048u) F.counters->wave_prof[wid][3] = best_;
     }
 #endif
-    if (lane == 0) for (int i = 2; i < 32; i++) atomicAdd(&F.counters->prof[i], (unsigned long long)prof[i]);
+    if (lane == 0) for (int i = 2; i < 40; i++) atomicAdd(&F.counters->prof[i], (unsigned long long)prof[i]);
 #endif
     // ---- RaytraceInfo sum (renderer.rs:555): wave reduction then one atomic per wave ----
-    unsigned long long s = c32[K_STEPS][tid];
+    uint32_t t_end = threadIdx.x;
+    asm volatile("" : "+v"(t_end));  // (as above: the word's address is not a value to keep for the life of the wave)
+    unsigned long long s = s_steps[t_end];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if (lane == 0 && s) atomicAdd(&F.counters->cubes_traced, s);
@@ -2365,7 +2642,9 @@ static void launch_trace(const DevFrame &F, hipStream_t stream) {
     // persistent waves: enough workgroups to fill the chip at the kernel's occupancy, never more
     // waves than tiles (each wave pulls 8x8-pixel tiles from counters->tile_next)
     const uint32_t n_tiles = F.tiles_x * F.tiles_y;
-    const uint32_t wg_waves = (uint32_t)AIC_WG_THREADS / 64u;
+    constexpr bool XCHG = AIC_EXCHANGE && !DIAG && LMODE != 3;
+    constexpr uint32_t WGT = XCHG ? (uint32_t)AIC_XWG_THREADS : (uint32_t)AIC_WG_THREADS;
+    const uint32_t wg_waves = WGT / 64u;
     const uint32_t resident_groups = F.n_cus * 4u * (uint32_t)((DIAG || LMODE == 3) ? 2 : AIC_MIN_WAVES) / wg_waves;  // 4 SIMDs per CU, that many waves on each
     // A frame smaller than the chip that is STREAMED (aic_render_submit: a rank's strips of a multi-GPU frame, several in
     // flight) gets a grid in proportion to its tiles -- four tiles per wave, so that lanes are refilled instead of waves ending
@@ -2379,8 +2658,9 @@ static void launch_trace(const DevFrame &F, hipStream_t stream) {
     const uint32_t floor_groups = by_tiles < 128u ? by_tiles : 128u;
     if (grid < floor_groups) grid = floor_groups;
     if (grid > resident_groups) grid = resident_groups;
+    if (XCHG && grid > F.ray_cold_groups) grid = F.ray_cold_groups;  // (the host sizes the buffer for the resident grid: trace_ray_cold_bytes)
     if (grid == 0) return;
-    hipLaunchKernelGGL((trace_image_kernel<VOL, LMODE, DIAG, BIG>), dim3(grid), dim3(AIC_WG_THREADS), 0, stream, F);
+    hipLaunchKernelGGL((trace_image_kernel<VOL, LMODE, DIAG, BIG>), dim3(grid), dim3(WGT), 0, stream, F);
 }
 
 template <bool DIAG, bool BIG>
@@ -2396,6 +2676,14 @@ static void launch_trace_diag(const DevFrame &F, bool vol, int lmode, hipStream_
         else if (lmode == 3) launch_trace<false, 3, DIAG, BIG>(F, stream);
         else launch_trace<false, 2, DIAG, BIG>(F, stream);
     }
+}
+
+// DevFrame::ray_cold of the production variants: 64 bytes per LDS column (a lane's or a pool slot's) of every workgroup of the resident grid
+size_t trace_ray_cold_bytes(uint32_t n_cus, uint32_t *groups) {
+    if (!AIC_EXCHANGE) { *groups = 0; return 0; }
+    const uint32_t g = n_cus * 4u * (uint32_t)AIC_MIN_WAVES / ((uint32_t)AIC_XWG_THREADS / 64u);
+    *groups = g;
+    return (size_t)g * ((size_t)AIC_XWG_THREADS + (size_t)AIC_POOL) * 64u;
 }
 
 void launch_trace_image(const DevFrame &F, bool diag, hipStream_t stream) {

@@ -79,7 +79,7 @@ def scan(path):
 
 
 def kernel_resources(path):
-    """{kernel symbol: dict(vgprs, scratch_bytes, lds_bytes)} from the .amdhsa_* directives of every trace_image_kernel in the assembly."""
+    """{kernel symbol: dict(vgprs, scratch_bytes, lds_bytes, wg_threads)} from the .amdhsa_* directives of every trace_image_kernel in the assembly."""
     out, name = {}, None
     for line in open(path):
         t = line.strip()
@@ -96,6 +96,17 @@ def kernel_resources(path):
                 key = {".amdhsa_next_free_vgpr": "vgprs", ".amdhsa_private_segment_fixed_size": "scratch_bytes", ".amdhsa_group_segment_fixed_size": "lds_bytes"}.get(parts[0])
                 if key:
                     out[name][key] = int(parts[1])
+    # threads per workgroup (the launch bound) from the metadata block: "- .max_flat_workgroup_size: N" ... ".name: symbol"
+    size = None
+    for line in open(path):
+        t = line.strip().lstrip("- ")
+        if t.startswith(".max_flat_workgroup_size:"):
+            size = int(t.split(":")[1])
+        elif t.startswith(".name:") and size is not None:
+            sym = t.split(":", 1)[1].strip()
+            if sym in out:
+                out[sym]["wg_threads"] = size
+            size = None
     return out
 
 
