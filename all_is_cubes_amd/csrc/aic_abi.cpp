@@ -1138,9 +1138,9 @@ int wait_frame(aic_ctx *c, uint32_t slot, aic_frame_info *info, bool whole_strea
             info->n_light = hc.n_light;
         }
 #ifdef AIC_PROFILE
-        { static const char *names[40] = {"max_lifetime","max_until_dry","cyc_until_dry","cyc_lifetime","shade_ph","shade_ln","enter_ph","enter_ln","ray_ph","ray_ln","step_iters","step_lanes","cyc_step","cyc_shade_rest","cyc_enter","cyc_newray","cyc_finish","cyc_refill","cyc_shade_light","cyc_sched","fast_iters","fast_lanes","trips","trip_lanes","pass_hl_lanes","pass_fast_eligible","leave_blocks","leave_lanes","apply_blocks","apply_lanes","pass_needed_lanes","xchg_rounds","xchg_lanes","cyc_xchg","xchg_picked","xchg_parked","idle_spins","-","-","-"};
+        { static const char *names[40] = {"max_lifetime","max_until_dry","cyc_until_dry","cyc_lifetime","shade_ph","shade_ln","enter_ph","enter_ln","ray_ph","ray_ln","step_iters","step_lanes","cyc_step","cyc_shade_rest","cyc_enter","cyc_newray","cyc_finish","cyc_refill","cyc_shade_light","cyc_sched","fast_iters","fast_lanes","trips","trip_lanes","pass_hl_lanes","pass_fast_eligible","leave_blocks","leave_lanes","apply_blocks","apply_lanes","pass_needed_lanes","xchg_rounds","xchg_lanes","cyc_xchg","xchg_picked","xchg_parked","idle_spins","xchg_claims_lost","xchg_empty","-"};
           // (only the production variant's frames: the aux-recording variant is another kernel, at half the occupancy)
-          if (!fs.diag) for (int i = 0; i < 37; i++) std::fprintf(stderr, "PROF %s %llu\n", names[i], hc.prof[i]);
+          if (!fs.diag) for (int i = 0; i < 39; i++) std::fprintf(stderr, "PROF %s %llu\n", names[i], hc.prof[i]);
           if (const char *path = fs.diag ? nullptr : std::getenv("AIC_WAVE_PROF")) {
               if (FILE *fp = std::fopen(path, "w")) {
                   for (int w = 0; w < 2048; w++) std::fprintf(fp, "%u %u %u %u\n", hc.wave_prof[w][0], hc.wave_prof[w][1], hc.wave_prof[w][2], hc.wave_prof[w][3]);

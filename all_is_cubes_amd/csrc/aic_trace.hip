@@ -896,13 +896,23 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u
 #define AIC_EXCHANGE 1
 #endif
 #ifndef AIC_XWG_THREADS
-#define AIC_XWG_THREADS 512  // threads of a workgroup of the exchanging variants (two per CU: the pool is shared by eight waves)
+#define AIC_XWG_THREADS 256  // threads of a workgroup of the exchanging variants (four per CU, a pool of 72 each: measured ahead of two workgroups of 512 with a pool of 160,
+                             // whose eight waves lose more claims to one another and fill the frame's tail worse -- profiles/r05_experiments.txt B)
 #endif
 #ifndef AIC_POOL
-#define AIC_POOL (AIC_XWG_THREADS >= 512 ? 160 : 76)  // parked rays per workgroup (<= 192: three tags per lane are scanned); what the CU's 160 KB leave room for
+#define AIC_POOL (AIC_XWG_THREADS >= 512 ? 160 : 72)  // parked rays per workgroup (<= 192: three tags per lane are scanned); what the CU's 160 KB leave room for
 #endif
 #ifndef AIC_XCHG_MIN_GAIN
 #define AIC_XCHG_MIN_GAIN 2  // a wave that has lanes of the chosen kind tops up only if the pool adds at least this many
+#endif
+#ifndef AIC_COLD_SCOPE
+#define AIC_COLD_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP  // (experiment: __HIP_MEMORY_SCOPE_WAVEFRONT = plain loads the CU's L1 may serve stale -- timing only)
+#endif
+#ifndef AIC_XCHG_FULL
+#define AIC_XCHG_FULL 48     // a wave with this many lanes of one kind runs it as it is
+#endif
+#ifndef AIC_XCHG_PARK_MIN
+#define AIC_XCHG_PARK_MIN 8  // an exchange that only parks (nothing to take) is made for at least this many lanes
 #endif
 #ifndef AIC_XCHG_DEPOSIT
 #define AIC_XCHG_DEPOSIT 3   // while slots are free: 0 park nothing, 2 park event lanes that do not run now, 3 stepping lanes too (tools/wave_sim: 3 > 2 > 1)
@@ -1014,7 +1024,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && !DIAG && LMODE != 3) ? AIC_XWG_THR
     __shared__ uint32_t s_steps[WGT];               // per thread: steps of the rays it finished (RaytraceInfo)
     // the pool of parked rays (XCHG): per slot the ray's 40 hot dwords (or, free, just the spare column in word 38), and its tag
     __shared__ u32x4 s_pool[NPOOL ? NPOOL : 1u][10];
-    __shared__ uint32_t s_tag[NPOOL ? NPOOL : 1u];
+    __shared__ uint32_t s_tag[192];                 // (padded: three tags per lane are read; the entries past the pool stay BUSY)
     __shared__ u32x4 s_census;                      // parked rays by kind: STEP, SHADE, ENTER, RAY (advisory: read without a claim)
     __shared__ uint8_t s_pick[WGT / 64u][2][64];    // per wave: the slots a round's givers are paired with (wanted kind; free)
     const uint32_t tid = threadIdx.x;
@@ -1023,8 +1033,8 @@ __global__ __launch_bounds__((AIC_EXCHANGE && !DIAG && LMODE != 3) ? AIC_XWG_THR
     if (!XCHG) c32[XCHG ? 0 : (int)K_BLK][tid] = 0u;
     c32[K_PXY][tid] = 0u;
     if (XCHG) {
+        for (uint32_t i = tid; i < 192u; i += WGT) s_tag[i] = i < NPOOL ? TAG_FREE : TAG_BUSY;
         for (uint32_t i = tid; i < NPOOL; i += WGT) {
-            s_tag[i] = TAG_FREE;
             s_pool[i][9] = u32x4{0u, 0u, WGT + i, 0u};  // the slot's spare column
             c32[K_PXY][WGT + i] = 0u;
         }
@@ -1162,6 +1172,20 @@ __global__ __launch_bounds__((AIC_EXCHANGE && !DIAG && LMODE != 3) ? AIC_XWG_THR
         uint32_t run = 0u;  // kind to run this trip (an EV_* bit), 0 = step
         if constexpr (XCHG) {
             // ---- regime-sorted waves: run the kind that fills the wave best, own lanes plus what the workgroup's pool can add ----
+            // what this round's exchange (if any) decided: the lanes whose claim succeeded, those of them that took a spare column, the slot's address and
+            // index, the tag the slot is released under, the kind taken (the swap itself sits on the round's common path, below)
+            unsigned long long x_got = 0ull, x_fresh = 0ull;
+            uint32_t x_paddr = 0u, x_slot = 0u, x_tag = TAG_FREE, x_want = 0u;
+            // a wave that is full of one kind as it stands (AIC_XCHG_FULL lanes) runs it without looking at the pool
+            {
+                int cm = n_step;
+                if (c_shade >= cm) { cm = c_shade; run = EV_SHADE; }
+                if (c_enter >= cm) { cm = c_enter; run = EV_ENTER; }
+                if (c_ray >= cm) { cm = c_ray; run = EV_FINISH; }
+                if (cm < AIC_XCHG_FULL) run = 0xffffffffu;
+            }
+            if (run == 0xffffffffu) {
+            run = 0u;
             u32x4 cs;  // parked rays by kind (advisory: a count can run a claim ahead of or behind the tags)
             asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cs) : "v"((uint32_t)(uintptr_t)&s_census) : "memory");
             const int pk_step = opaque_s(__builtin_amdgcn_readfirstlane((int)cs.x)), pk_shade = opaque_s(__builtin_amdgcn_readfirstlane((int)cs.y)),
@@ -1171,11 +1195,12 @@ __global__ __launch_bounds__((AIC_EXCHANGE && !DIAG && LMODE != 3) ? AIC_XWG_THR
             if (alive == 0 && parked == 0) break;  // nothing of its own and nothing parked: whoever parks a ray later is running and serves it
             // what a kind would run with: its own lanes + the parked rays that fit into the wave's other lanes (a top-up below AIC_XCHG_MIN_GAIN is not
             // worth the exchange, unless the wave has none of that kind)
-            auto total_of = [](int mine, int pk) -> int {
+            auto total_of = [](int mine, int pk) -> int {  // (branch-free: a handful of s_min / s_max / s_cselect)
                 const int room = 64 - mine;
                 int a = pk < room ? pk : room;
-                if (a < 0 || (a < AIC_XCHG_MIN_GAIN && mine > 0)) a = 0;
-                return mine + a;
+                a = a > 0 ? a : 0;
+                const int ok = (int)(a >= AIC_XCHG_MIN_GAIN) | (int)(mine == 0);
+                return mine + a * ok;
             };
             const int t_step = total_of(n_step, pk_step), t_shade = total_of(c_shade, pk_shade), t_enter = total_of(c_enter, pk_enter), t_ray = total_of(c_ray, pk_ray);
             int best = t_step, mine = n_step;  // (ties go to the events: a parked event lane blocks its ray, a stepping lane can wait)
@@ -1192,7 +1217,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && !DIAG && LMODE != 3) ? AIC_XWG_THR
             const bool dry_u = __builtin_amdgcn_readfirstlane(dry ? 1 : 0) != 0;
             const int n_others = alive - mine - ((AIC_XCHG_DEPOSIT < 3 && run != 0u) ? n_step : 0);  // lanes holding a ray that will not run now (and may be parked)
             const bool may_park = AIC_XCHG_DEPOSIT != 0 && !dry_u && parked < (int)NPOOL && n_others > 0;
-            if (best > mine || may_park) {
+            if (best > mine || (may_park && n_others >= AIC_XCHG_PARK_MIN)) {
                 // ---- the exchange: lanes that would idle ("givers": empty lanes first, then rays of other kinds) are paired with parked rays of the wanted
                 // kind, and -- while the image has pixels left -- what remains of them with free slots. A pairing is a claim (compare-and-swap of the slot's
                 // tag), a plain swap of the 40 hot dwords and the column index, and the release of the slot under the tag of what it now holds. ----
@@ -1200,118 +1225,166 @@ __global__ __launch_bounds__((AIC_EXCHANGE && !DIAG && LMODE != 3) ? AIC_XWG_THR
                 //  otherwise computed before the persistent loop and kept in registers the event code needs)
                 uint32_t ln = lane;
                 asm volatile("" : "+v"(ln));
+                // (written as straight-line selects and exec-masked stores: per-lane `if`s and short-circuit conditions cost a saved / restored exec mask each, and
+                //  assigning the hot variables inside a branch makes the compiler copy all of them on the path that does not take it -- in every round)
                 const uint32_t want = run == 0u ? TAG_STEP : (run == EV_SHADE ? TAG_SHADE : (run == EV_ENTER ? TAG_ENTER : TAG_RAY));
-                const bool empty = ev == EV_DONE || ev == (EV_NEWRAY | EV_TAKE);
-                const uint32_t my_tag = empty ? TAG_FREE : ((ev & EV_SHADE) ? TAG_SHADE : ((ev & EV_ENTER) ? TAG_ENTER : ((ev & (EV_FINISH | EV_NEWRAY)) ? TAG_RAY : TAG_STEP)));
-                const bool giver = empty ? (ev == EV_DONE || want != TAG_RAY) : (my_tag != want);  // (an empty lane about to take a pixel IS the RAY kind)
-                const unsigned long long m_ge = __builtin_amdgcn_ballot_w64(giver && empty), m_go = __builtin_amdgcn_ballot_w64(giver && !empty);
+                const bool e_done = ev == EV_DONE, e_take = ev == (EV_NEWRAY | EV_TAKE);
+                const bool empty = e_done | e_take;
+                uint32_t my_tag = (ev & (EV_FINISH | EV_NEWRAY)) != 0u ? TAG_RAY : TAG_STEP;
+                my_tag = (ev & EV_ENTER) != 0u ? TAG_ENTER : my_tag;
+                my_tag = (ev & EV_SHADE) != 0u ? TAG_SHADE : my_tag;
+                my_tag = empty ? TAG_FREE : my_tag;
+                const bool giver = (my_tag != want) & (!e_take | (want != TAG_RAY));  // (an empty lane about to take a pixel IS the RAY kind)
+                const unsigned long long m_giv = __builtin_amdgcn_ballot_w64(giver);
                 auto below = [](unsigned long long m) -> uint32_t { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
-                const uint32_t n_e = wave_popc(m_ge), n_o = wave_popc(m_go);
-                const uint32_t rank = empty ? below(m_ge) : n_e + below(m_go);
-                // the slots' tags, three per lane; the first 64 slots of the wanted kind and the first 64 free ones go into the wave's pairing lists
+                const uint32_t n_giv = wave_popc(m_giv);
+                const uint32_t rank = below(m_giv);  // (givers in lane order)
+                // the slots' tags, three per lane (the array is padded to 192 with BUSY); the first 64 slots of the wanted kind and the first 64 free ones go
+                // into the wave's pairing lists
                 const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)((tid - ln) >> 6));
-                uint32_t t0 = TAG_BUSY, t1 = TAG_BUSY, t2 = TAG_BUSY;
-                if (ln < NPOOL) t0 = __hip_atomic_load(&s_tag[ln < NPOOL ? lane : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (NPOOL > 64u && ln + 64u < NPOOL) t1 = __hip_atomic_load(&s_tag[ln + 64u < NPOOL ? ln + 64u : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (NPOOL > 128u && ln + 128u < NPOOL) t2 = __hip_atomic_load(&s_tag[ln + 128u < NPOOL ? ln + 128u : 0u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t t0 = __hip_atomic_load(&s_tag[ln], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t t1 = NPOOL > 64u ? __hip_atomic_load(&s_tag[ln + 64u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : TAG_BUSY;
+                const uint32_t t2 = NPOOL > 128u ? __hip_atomic_load(&s_tag[ln + 128u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : TAG_BUSY;
                 const unsigned long long w0 = __builtin_amdgcn_ballot_w64(t0 == want), w1 = __builtin_amdgcn_ballot_w64(t1 == want), w2 = __builtin_amdgcn_ballot_w64(t2 == want);
-                const unsigned long long f0 = __builtin_amdgcn_ballot_w64(t0 == TAG_FREE), f1 = __builtin_amdgcn_ballot_w64(t1 == TAG_FREE), f2 = __builtin_amdgcn_ballot_w64(t2 == TAG_FREE);
-                const uint32_t nw0 = wave_popc(w0), nw1 = wave_popc(w1), n_w = nw0 + nw1 + wave_popc(w2);
-                const uint32_t nf0 = wave_popc(f0), nf1 = wave_popc(f1), n_f = nf0 + nf1 + wave_popc(f2);
-                if (t0 == want) s_pick[wv][0][below(w0)] = (uint8_t)ln;
-                if (t1 == want) { const uint32_t i_ = nw0 + below(w1); if (i_ < 64u) s_pick[wv][0][i_] = (uint8_t)(ln + 64u); }
-                if (t2 == want) { const uint32_t i_ = nw0 + nw1 + below(w2); if (i_ < 64u) s_pick[wv][0][i_] = (uint8_t)(ln + 128u); }
-                if (t0 == TAG_FREE) s_pick[wv][1][below(f0)] = (uint8_t)ln;
-                if (t1 == TAG_FREE) { const uint32_t i_ = nf0 + below(f1); if (i_ < 64u) s_pick[wv][1][i_] = (uint8_t)(ln + 64u); }
-                if (t2 == TAG_FREE) { const uint32_t i_ = nf0 + nf1 + below(f2); if (i_ < 64u) s_pick[wv][1][i_] = (uint8_t)(ln + 128u); }
-                const uint32_t n_giv = n_e + n_o;
+                // (every wave would otherwise list the same lowest slots first, and two waves exchanging at the same moment would fight over them: odd waves
+                //  list from the top down)
+                const uint32_t nw0 = wave_popc(w0), nw1 = wave_popc(w1), nw2 = wave_popc(w2), n_w = nw0 + nw1 + nw2;
+                const bool down = (wv & 1u) != 0u;
+                uint8_t *const pick_w = s_pick[wv][0], *const pick_f = s_pick[wv][1];
+                { const uint32_t u_ = below(w0), i_ = down ? n_w - 1u - u_ : u_; if ((t0 == want) & (i_ < 64u)) pick_w[i_] = (uint8_t)ln; }
+                if (NPOOL > 64u) { const uint32_t u_ = nw0 + below(w1), i_ = down ? n_w - 1u - u_ : u_; if ((t1 == want) & (i_ < 64u)) pick_w[i_] = (uint8_t)(ln + 64u); }
+                if (NPOOL > 128u) { const uint32_t u_ = nw0 + nw1 + below(w2), i_ = down ? n_w - 1u - u_ : u_; if ((t2 == want) & (i_ < 64u)) pick_w[i_] = (uint8_t)(ln + 128u); }
+                uint32_t n_f = 0u;
+                if (may_park) {  // (uniform) the free slots, for the lanes that park
+                    const unsigned long long f0 = __builtin_amdgcn_ballot_w64(t0 == TAG_FREE), f1 = __builtin_amdgcn_ballot_w64(t1 == TAG_FREE), f2 = __builtin_amdgcn_ballot_w64(t2 == TAG_FREE);
+                    const uint32_t nf0 = wave_popc(f0), nf1 = wave_popc(f1);
+                    n_f = nf0 + nf1 + wave_popc(f2);
+                    { const uint32_t u_ = below(f0), i_ = down ? n_f - 1u - u_ : u_; if ((t0 == TAG_FREE) & (i_ < 64u)) pick_f[i_] = (uint8_t)ln; }
+                    if (NPOOL > 64u) { const uint32_t u_ = nf0 + below(f1), i_ = down ? n_f - 1u - u_ : u_; if ((t1 == TAG_FREE) & (i_ < 64u)) pick_f[i_] = (uint8_t)(ln + 64u); }
+                    if (NPOOL > 128u) { const uint32_t u_ = nf0 + nf1 + below(f2), i_ = down ? n_f - 1u - u_ : u_; if ((t2 == TAG_FREE) & (i_ < 64u)) pick_f[i_] = (uint8_t)(ln + 128u); }
+                }
                 const uint32_t n_take = n_w < n_giv ? n_w : n_giv;  // (at most 64)
                 const uint32_t n_free = n_f < 64u ? n_f : 64u;
-                uint32_t slot = 0xffffffffu, expect = TAG_FREE;
-                if (giver) {
-                    if (rank < n_take) {
-                        slot = s_pick[wv][0][rank];
-                        expect = want;
-                    } else if (may_park && !empty && (AIC_XCHG_DEPOSIT >= 3 || my_tag != TAG_STEP)) {
-                        const uint32_t j_ = rank - (n_take > n_e ? n_take : n_e);
-                        if (j_ < n_free) slot = s_pick[wv][1][j_];
-                    }
-                }
+                // a giver of rank < n_take takes a parked ray; the rays of the ranks after that are parked while slots are free
+                const bool takes = giver & (rank < n_take);
+                const uint32_t j_ = rank - n_take;
+                const bool parks = giver & !empty & (AIC_XCHG_DEPOSIT >= 3 || my_tag != TAG_STEP) & (rank >= n_take) & (j_ < n_free);  // (n_free is 0 unless may_park)
+                const uint32_t expect = takes ? want : TAG_FREE;
+                const uint32_t slot = (takes | parks) ? (uint32_t)(takes ? pick_w : pick_f)[takes ? rank : (j_ & 63u)] : 0u;
                 bool got = false;
-                if (slot != 0xffffffffu) {
+                if (takes | parks) {
                     uint32_t seen = expect;
                     got = __hip_atomic_compare_exchange_strong(&s_tag[slot], &seen, TAG_BUSY, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 // (this ray's stores to its global cold state -- NEWRAY, FINISH -- are in L2 before another wave can be handed the ray)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (got) {
-                    u32x4 *const sp = s_pool[slot];
-                    const u32x4 i0 = sp[0], i1 = sp[1], i2 = sp[2], i3 = sp[3], i4 = sp[4], i5 = sp[5], i6 = sp[6], i7 = sp[7], i8 = sp[8], i9 = sp[9];
-                    const unsigned long long b0 = (unsigned long long)__double_as_longlong(tx), b1 = (unsigned long long)__double_as_longlong(ty),
-                                             b2 = (unsigned long long)__double_as_longlong(tz), b3 = (unsigned long long)__double_as_longlong(last_t),
-                                             b4 = (unsigned long long)__double_as_longlong(tdx), b5 = (unsigned long long)__double_as_longlong(tdy),
-                                             b6 = (unsigned long long)__double_as_longlong(tdz);
-                    sp[0] = u32x4{(uint32_t)b0, (uint32_t)(b0 >> 32), (uint32_t)b1, (uint32_t)(b1 >> 32)};
-                    sp[1] = u32x4{(uint32_t)b2, (uint32_t)(b2 >> 32), (uint32_t)b3, (uint32_t)(b3 >> 32)};
-                    sp[2] = u32x4{(uint32_t)b4, (uint32_t)(b4 >> 32), (uint32_t)b5, (uint32_t)(b5 >> 32)};
-                    sp[3] = u32x4{(uint32_t)b6, (uint32_t)(b6 >> 32), rx, ry};
-                    sp[4] = u32x4{rz, boff, (uint32_t)ssx, (uint32_t)ssy};
-                    sp[5] = u32x4{(uint32_t)ssz, thr, raw, lax};
-                    sp[6] = u32x4{st, count, ev, blk_pal_off};
-                    sp[7] = u32x4{blk_geo, blk_vsz, __float_as_uint(acc.l0), __float_as_uint(acc.l1)};
-                    sp[8] = u32x4{__float_as_uint(acc.l2), __float_as_uint(acc.t), __float_as_uint(pend0), __float_as_uint(pend1)};
-                    sp[9] = u32x4{__float_as_uint(pend2), __float_as_uint(pend_tr), col, 0u};
-                    tx = __longlong_as_double((long long)(((unsigned long long)i0.y << 32) | i0.x));
-                    ty = __longlong_as_double((long long)(((unsigned long long)i0.w << 32) | i0.z));
-                    tz = __longlong_as_double((long long)(((unsigned long long)i1.y << 32) | i1.x));
-                    last_t = __longlong_as_double((long long)(((unsigned long long)i1.w << 32) | i1.z));
-                    tdx = __longlong_as_double((long long)(((unsigned long long)i2.y << 32) | i2.x));
-                    tdy = __longlong_as_double((long long)(((unsigned long long)i2.w << 32) | i2.z));
-                    tdz = __longlong_as_double((long long)(((unsigned long long)i3.y << 32) | i3.x));
-                    rx = i3.z; ry = i3.w;
-                    rz = i4.x; boff = i4.y; ssx = (int)i4.z; ssy = (int)i4.w;
-                    ssz = (int)i5.x; thr = i5.y; raw = i5.z; lax = i5.w;
-                    st = i6.x; count = i6.y; ev = i6.z; blk_pal_off = i6.w;
-                    blk_geo = i7.x; blk_vsz = i7.y; acc.l0 = __uint_as_float(i7.z); acc.l1 = __uint_as_float(i7.w);
-                    acc.l2 = __uint_as_float(i8.x); acc.t = __uint_as_float(i8.y); pend0 = __uint_as_float(i8.z); pend1 = __uint_as_float(i8.w);
-                    pend2 = __uint_as_float(i9.x); pend_tr = __uint_as_float(i9.y);
-                    col = i9.z;
-                    if (expect == TAG_FREE) {  // a spare column came back: the lane starts a new pixel in it
-                        ev = EV_NEWRAY | EV_TAKE;
-                        st = 0u;
-                    }
-                    __hip_atomic_store(&s_tag[slot], my_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                const unsigned long long m_got = __builtin_amdgcn_ballot_w64(got);
-                if (m_got != 0ull) {
-                    // the counts: one lane per kind adds what was parked minus what was taken
-                    const uint32_t n_picked = wave_popc(__builtin_amdgcn_ballot_w64(got && expect != TAG_FREE));
-                    const uint32_t d_step = wave_popc(__builtin_amdgcn_ballot_w64(got && my_tag == TAG_STEP)), d_shade = wave_popc(__builtin_amdgcn_ballot_w64(got && my_tag == TAG_SHADE)),
-                                   d_enter = wave_popc(__builtin_amdgcn_ballot_w64(got && my_tag == TAG_ENTER)), d_ray = wave_popc(__builtin_amdgcn_ballot_w64(got && my_tag == TAG_RAY));
-                    if (ln < 4u) {
-                        uint32_t delta = ln == 0u ? d_step : (ln == 1u ? d_shade : (ln == 2u ? d_enter : d_ray));
-                        if (ln + 1u == want) delta -= n_picked;
-                        if (delta != 0u) atomicAdd(reinterpret_cast<uint32_t *>(&s_census) + ln, delta);
-                    }
-                    AIC_PROF(31, 1);
-                    AIC_PROF(32, wave_popc(m_got));
-                    AIC_PROF(34, n_picked);
-                    AIC_PROF(35, d_step + d_shade + d_enter + d_ray);
-                    m_st = __ballot(ev < 4u);
-                    b_shade = __ballot((ev & EV_SHADE) != 0u);
-                    b_enter = __ballot((ev & EV_ENTER) != 0u);
-                    b_ray = __ballot((ev & (EV_FINISH | EV_NEWRAY)) != 0u);
-                    n_step = (int)wave_popc(m_st);
-                    c_shade = (int)wave_popc(b_shade); c_enter = (int)wave_popc(b_enter); c_ray = (int)wave_popc(b_ray);
-                }
+                x_got = __builtin_amdgcn_ballot_w64(got);
+                x_fresh = x_got & ~__builtin_amdgcn_ballot_w64(takes);
+                x_paddr = (uint32_t)(uintptr_t)&s_pool[0][0] + slot * 160u;
+                x_slot = slot; x_tag = my_tag; x_want = want;
+                AIC_PROF(37, wave_popc(__builtin_amdgcn_ballot_w64(takes | parks)) - wave_popc(x_got));  // claims lost to another wave
+                if (x_got == 0ull) { AIC_PROF(38, 1); }  // an exchange that moved nothing
+            }
+            }
+            else { AIC_TICK(19); }
+            // ---- The swap proper, under exec = the lanes whose claim succeeded (none in a round without an exchange: the three blocks are then skipped): one
+            // LDS exchange (`ds_wrxchg_rtn`: write the register, return what was there) per hot variable, IN PLACE and on the round's common path -- like the
+            // stepping code's asm blocks. (Inside the exchange's own branch, or assigned from loaded values in C++, the compiler renames the hot variables
+            // and copies all 38 registers: at the branch in every round, or around each block.) ----
+            {
+                unsigned long long sv;
+                asm volatile(
+                    "s_and_saveexec_b64 %[sv], %[m]\n\t"
+                    "s_cbranch_execz .Lxa%=\n\t"
+                    "ds_wrxchg_rtn_b64 %[x0], %[p], %[x0]\n\t"
+                    "ds_wrxchg_rtn_b64 %[x1], %[p], %[x1] offset:8\n\t"
+                    "ds_wrxchg_rtn_b64 %[x2], %[p], %[x2] offset:16\n\t"
+                    "ds_wrxchg_rtn_b64 %[x3], %[p], %[x3] offset:24\n\t"
+                    "ds_wrxchg_rtn_b64 %[x4], %[p], %[x4] offset:32\n\t"
+                    "ds_wrxchg_rtn_b64 %[x5], %[p], %[x5] offset:40\n\t"
+                    "ds_wrxchg_rtn_b64 %[x6], %[p], %[x6] offset:48\n\t"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    ".Lxa%=:\n\t"
+                    "s_mov_b64 exec, %[sv]\n\t"
+                    : [x0] "+v"(tx), [x1] "+v"(ty), [x2] "+v"(tz), [x3] "+v"(last_t), [x4] "+v"(tdx), [x5] "+v"(tdy), [x6] "+v"(tdz), [sv] "=&s"(sv)
+                    : [p] "v"(x_paddr), [m] "s"(x_got)
+                    : "memory", "scc");
+                asm volatile(
+                    "s_and_saveexec_b64 %[sv], %[m]\n\t"
+                    "s_cbranch_execz .Lxb%=\n\t"
+                    "ds_wrxchg_rtn_b32 %[w0], %[p], %[w0] offset:56\n\t"
+                    "ds_wrxchg_rtn_b32 %[w1], %[p], %[w1] offset:60\n\t"
+                    "ds_wrxchg_rtn_b32 %[w2], %[p], %[w2] offset:64\n\t"
+                    "ds_wrxchg_rtn_b32 %[w3], %[p], %[w3] offset:68\n\t"
+                    "ds_wrxchg_rtn_b32 %[w4], %[p], %[w4] offset:72\n\t"
+                    "ds_wrxchg_rtn_b32 %[w5], %[p], %[w5] offset:76\n\t"
+                    "ds_wrxchg_rtn_b32 %[w6], %[p], %[w6] offset:80\n\t"
+                    "ds_wrxchg_rtn_b32 %[w7], %[p], %[w7] offset:84\n\t"
+                    "ds_wrxchg_rtn_b32 %[w8], %[p], %[w8] offset:88\n\t"
+                    "ds_wrxchg_rtn_b32 %[w9], %[p], %[w9] offset:92\n\t"
+                    "ds_wrxchg_rtn_b32 %[wa], %[p], %[wa] offset:96\n\t"
+                    "ds_wrxchg_rtn_b32 %[wb], %[p], %[wb] offset:100\n\t"
+                    "s_waitcnt lgkmcnt(0)\n"
+                    ".Lxb%=:\n\t"
+                    "s_mov_b64 exec, %[sv]\n\t"
+                    : [w0] "+v"(rx), [w1] "+v"(ry), [w2] "+v"(rz), [w3] "+v"(boff), [w4] "+v"(ssx), [w5] "+v"(ssy), [w6] "+v"(ssz), [w7] "+v"(thr), [w8] "+v"(raw),
+                      [w9] "+v"(lax), [wa] "+v"(st), [wb] "+v"(count), [sv] "=&s"(sv)
+                    : [p] "v"(x_paddr), [m] "s"(x_got)
+                    : "memory", "scc");
+                asm volatile(
+                    "s_and_saveexec_b64 %[sv], %[m]\n\t"
+                    "s_cbranch_execz .Lxc%=\n\t"
+                    "ds_wrxchg_rtn_b32 %[w0], %[p], %[w0] offset:104\n\t"
+                    "ds_wrxchg_rtn_b32 %[w1], %[p], %[w1] offset:108\n\t"
+                    "ds_wrxchg_rtn_b32 %[w2], %[p], %[w2] offset:112\n\t"
+                    "ds_wrxchg_rtn_b32 %[w3], %[p], %[w3] offset:116\n\t"
+                    "ds_wrxchg_rtn_b32 %[w4], %[p], %[w4] offset:120\n\t"
+                    "ds_wrxchg_rtn_b32 %[w5], %[p], %[w5] offset:124\n\t"
+                    "ds_wrxchg_rtn_b32 %[w6], %[p], %[w6] offset:128\n\t"
+                    "ds_wrxchg_rtn_b32 %[w7], %[p], %[w7] offset:132\n\t"
+                    "ds_wrxchg_rtn_b32 %[w8], %[p], %[w8] offset:136\n\t"
+                    "ds_wrxchg_rtn_b32 %[w9], %[p], %[w9] offset:140\n\t"
+                    "ds_wrxchg_rtn_b32 %[wa], %[p], %[wa] offset:144\n\t"
+                    "ds_wrxchg_rtn_b32 %[wb], %[p], %[wb] offset:148\n\t"
+                    "ds_wrxchg_rtn_b32 %[wc], %[p], %[wc] offset:152\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    "s_mov_b64 exec, %[f]\n\t"            // the lanes that took a spare column: an empty lane about to take a pixel
+                    "v_mov_b32 %[w0], 0xa0\n"             // ev = EV_NEWRAY | EV_TAKE
+                    ".Lxc%=:\n\t"
+                    "s_mov_b64 exec, %[sv]\n\t"
+                    : [w0] "+v"(ev), [w1] "+v"(blk_pal_off), [w2] "+v"(blk_geo), [w3] "+v"(blk_vsz), [w4] "+v"(acc.l0), [w5] "+v"(acc.l1), [w6] "+v"(acc.l2), [w7] "+v"(acc.t),
+                      [w8] "+v"(pend0), [w9] "+v"(pend1), [wa] "+v"(pend2), [wb] "+v"(pend_tr), [wc] "+v"(col), [sv] "=&s"(sv)
+                    : [p] "v"(x_paddr), [m] "s"(x_got), [f] "s"(x_fresh)
+                    : "memory", "scc");
+                static_assert((EV_NEWRAY | EV_TAKE) == 0xa0u, "the literal in the asm above");
+            }
+            if (x_got != 0ull) {
+                const bool got = __builtin_amdgcn_inverse_ballot_w64(x_got), fresh = __builtin_amdgcn_inverse_ballot_w64(x_fresh);
+                if (got) __hip_atomic_store(&s_tag[x_slot], x_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // the slot is released under the tag of what it now holds
+                // the counts: every lane that parked a ray adds it to its kind (LDS atomics on one word each: a few cycles per lane, two instructions),
+                // one lane takes off what was taken
+                const uint32_t n_picked = wave_popc(x_got & ~x_fresh);
+                if (got && x_tag != TAG_FREE) atomicAdd(reinterpret_cast<uint32_t *>(&s_census) + (x_tag - 1u), 1u);
+                if (lane == 0u && n_picked != 0u) atomicSub(reinterpret_cast<uint32_t *>(&s_census) + (x_want - 1u), n_picked);
+                (void)fresh;
+                AIC_PROF(31, 1);
+                AIC_PROF(32, wave_popc(x_got));
+                AIC_PROF(34, n_picked);
+                AIC_PROF(35, wave_popc(__builtin_amdgcn_ballot_w64(got && x_tag != TAG_FREE)));
+                m_st = __ballot(ev < 4u);
+                b_shade = __ballot((ev & EV_SHADE) != 0u);
+                b_enter = __ballot((ev & EV_ENTER) != 0u);
+                b_ray = __ballot((ev & (EV_FINISH | EV_NEWRAY)) != 0u);
+                n_step = (int)wave_popc(m_st);
+                c_shade = (int)wave_popc(b_shade); c_enter = (int)wave_popc(b_enter); c_ray = (int)wave_popc(b_ray);
                 AIC_TICK(33);
-                // (every claim lost to another wave, and the wave had nothing of the kind itself: choose again)
-                if ((run == 0u ? n_step : (run == EV_SHADE ? c_shade : (run == EV_ENTER ? c_enter : c_ray))) == 0) {
-                    AIC_PROF(36, 1);
-                    if (spun_out()) break;
-                    __builtin_amdgcn_s_sleep(4);
-                    continue;
-                }
+            }
+            if ((run == 0u ? n_step : (run == EV_SHADE ? c_shade : (run == EV_ENTER ? c_enter : c_ray))) == 0) {
+                // (the kind was chosen for what the pool holds, and every claim was lost to another wave -- or only rays in transit were found)
+                AIC_PROF(36, 1);
+                if (spun_out()) break;
+                __builtin_amdgcn_s_sleep(4);
+                continue;
             }
         } else {
         if ((m_st | b_shade | b_enter | b_ray) == 0ull) break;
@@ -1378,34 +1451,37 @@ __global__ __launch_bounds__((AIC_EXCHANGE && !DIAG && LMODE != 3) ? AIC_XWG_THR
             AIC_PROF(6, run == EV_ENTER ? 1 : 0); AIC_PROF(7, run == EV_ENTER ? c_enter : 0);
             AIC_PROF(8, run == EV_FINISH ? 1 : 0); AIC_PROF(9, run == EV_FINISH ? c_ray : 0);
             // The exchanging variants' global part of the cold state: 64 bytes per column of this workgroup -- origin and direction (6 f64), then the
-            // four antialiasing sums. Loads are agent-scope atomics: they bypass the CU's vector L1, which a store made by another wave of the
-            // workgroup does not update (the ray may have been started, or its sums last written, by a lane of another wave).
+            // four antialiasing sums. Loads are workgroup-scope atomics (`sc0`: past the CU's vector L1, which a store made by another wave of the
+            // workgroup does not update -- the ray may have been started, or its sums last written, by a lane of another wave -- and served by the L2; agent
+            // scope, `sc1`, goes past the XCD's L2 as well: 6 k cycles per SHADE phase, measured).
+            // Layout: per workgroup six arrays of NCOL doubles (origin x y z, direction x y z), then four of NCOL floats: a wave's lanes read neighbouring words
+            // (columns stay mostly in lane order), 8 cache lines per load instead of the 64 of a 64-byte record per column.
             char *const cold_wg = XCHG ? reinterpret_cast<char *>(F.ray_cold) + (size_t)blockIdx.x * (size_t)(NCOL * 64u) : nullptr;
             auto cold_origin = [&](double &ox, double &oy, double &oz) {
                 if constexpr (XCHG) {
-                    unsigned long long *g = reinterpret_cast<unsigned long long *>(cold_wg + col * 64u);
-                    ox = __longlong_as_double((long long)__hip_atomic_load(g + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    oy = __longlong_as_double((long long)__hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    oz = __longlong_as_double((long long)__hip_atomic_load(g + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    unsigned long long *g = reinterpret_cast<unsigned long long *>(cold_wg) + col;
+                    ox = __longlong_as_double((long long)__hip_atomic_load(g + 0u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE));
+                    oy = __longlong_as_double((long long)__hip_atomic_load(g + 1u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE));
+                    oz = __longlong_as_double((long long)__hip_atomic_load(g + 2u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE));
                 } else {
                     ox = c64[XCHG ? 0 : (int)C_OX][col]; oy = c64[XCHG ? 0 : (int)C_OY][col]; oz = c64[XCHG ? 0 : (int)C_OZ][col];
                 }
             };
             auto cold_direction = [&](double &dx, double &dy, double &dz) {
                 if constexpr (XCHG) {
-                    unsigned long long *g = reinterpret_cast<unsigned long long *>(cold_wg + col * 64u);
-                    dx = __longlong_as_double((long long)__hip_atomic_load(g + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    dy = __longlong_as_double((long long)__hip_atomic_load(g + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    dz = __longlong_as_double((long long)__hip_atomic_load(g + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    unsigned long long *g = reinterpret_cast<unsigned long long *>(cold_wg) + col;
+                    dx = __longlong_as_double((long long)__hip_atomic_load(g + 3u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE));
+                    dy = __longlong_as_double((long long)__hip_atomic_load(g + 4u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE));
+                    dz = __longlong_as_double((long long)__hip_atomic_load(g + 5u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE));
                 } else {
                     dx = c64[XCHG ? 0 : (int)C_DX][col]; dy = c64[XCHG ? 0 : (int)C_DY][col]; dz = c64[XCHG ? 0 : (int)C_DZ][col];
                 }
             };
             auto cold_sums_load = [&](float v[4]) {
                 if constexpr (XCHG) {
-                    unsigned long long *g = reinterpret_cast<unsigned long long *>(cold_wg + col * 64u + 48u);
-                    const unsigned long long a = __hip_atomic_load(g + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    v[0] = __uint_as_float((uint32_t)a); v[1] = __uint_as_float((uint32_t)(a >> 32)); v[2] = __uint_as_float((uint32_t)b); v[3] = __uint_as_float((uint32_t)(b >> 32));
+                    uint32_t *g = reinterpret_cast<uint32_t *>(cold_wg + NCOL * 48u) + col;
+                    v[0] = __uint_as_float(__hip_atomic_load(g + 0u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE)); v[1] = __uint_as_float(__hip_atomic_load(g + 1u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE));
+                    v[2] = __uint_as_float(__hip_atomic_load(g + 2u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE)); v[3] = __uint_as_float(__hip_atomic_load(g + 3u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE));
                 } else {
                     v[0] = __uint_as_float(c32[XCHG ? 0 : (int)K_S0][col]); v[1] = __uint_as_float(c32[XCHG ? 0 : (int)K_S1][col]);
                     v[2] = __uint_as_float(c32[XCHG ? 0 : (int)K_S2][col]); v[3] = __uint_as_float(c32[XCHG ? 0 : (int)K_ST][col]);
@@ -1413,7 +1489,8 @@ __global__ __launch_bounds__((AIC_EXCHANGE && !DIAG && LMODE != 3) ? AIC_XWG_THR
             };
             auto cold_sums_store = [&](float v0, float v1, float v2, float v3) {
                 if constexpr (XCHG) {
-                    *reinterpret_cast<float4 *>(cold_wg + col * 64u + 48u) = make_float4(v0, v1, v2, v3);
+                    float *g = reinterpret_cast<float *>(cold_wg + NCOL * 48u) + col;
+                    g[0u * NCOL] = v0; g[1u * NCOL] = v1; g[2u * NCOL] = v2; g[3u * NCOL] = v3;
                 } else {
                     c32[XCHG ? 0 : (int)K_S0][col] = __float_as_uint(v0); c32[XCHG ? 0 : (int)K_S1][col] = __float_as_uint(v1);
                     c32[XCHG ? 0 : (int)K_S2][col] = __float_as_uint(v2); c32[XCHG ? 0 : (int)K_ST][col] = __float_as_uint(v3);
@@ -1726,7 +1803,8 @@ __global__ __launch_bounds__((AIC_EXCHANGE && !DIAG && LMODE != 3) ? AIC_XWG_THR
             bool want = false;
             if (run == EV_FINISH) {
                 pxy = c32[K_PXY][col];
-                sample = (int)((st >> 14) & 3u);
+                sample = (ev & EV_TAKE) ? 0 : (int)((st >> 14) & 3u);  // (a lane about to take a pixel starts at sample 0 whatever its state word holds: a lane
+                                                                         //  that parked its ray keeps the word of the slot's previous content)
             }
             if (run == EV_FINISH && (ev & EV_FINISH)) {
                 if (st & ST_TRACED) {
@@ -1909,7 +1987,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && !DIAG && LMODE != 3) ? AIC_XWG_THR
                         if (tile_x0 >= F.width || tile_y0 >= F.local_rows) continue;  // a macro tile's overhang past the image edge
                         next_idx = 0;
                     }
-                    const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));  // lanes of `need` below this one (v_mbcnt: no mask of the lanes below to keep in registers)
                     const uint32_t avail = tile_px - next_idx;
                     if (want && rank < avail) {
                         const uint32_t pidx = next_idx + rank;
@@ -2032,8 +2110,8 @@ __global__ __launch_bounds__((AIC_EXCHANGE && !DIAG && LMODE != 3) ? AIC_XWG_THR
                     c32[K_TVIEW][col] = __float_as_uint((float)(t_abs / opt.view_distance));  // sr.rs:149-151
                     const RayDir rd = raydir_init(dirx, diry, dirz);
                     if constexpr (XCHG) {
-                        double *g = reinterpret_cast<double *>(cold_wg + col * 64u);
-                        g[0] = ox; g[1] = oy; g[2] = oz; g[3] = rd.dx; g[4] = rd.dy; g[5] = rd.dz;
+                        double *g = reinterpret_cast<double *>(cold_wg) + col;
+                        g[0u * NCOL] = ox; g[1u * NCOL] = oy; g[2u * NCOL] = oz; g[3u * NCOL] = rd.dx; g[4u * NCOL] = rd.dy; g[5u * NCOL] = rd.dz;
                     } else {
                         c64[XCHG ? 0 : (int)C_OX][col] = ox; c64[XCHG ? 0 : (int)C_OY][col] = oy; c64[XCHG ? 0 : (int)C_OZ][col] = oz;
                         c64[XCHG ? 0 : (int)C_DX][col] = rd.dx; c64[XCHG ? 0 : (int)C_DY][col] = rd.dy; c64[XCHG ? 0 : (int)C_DZ][col] = rd.dz;
