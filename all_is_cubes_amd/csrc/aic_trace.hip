@@ -903,7 +903,7 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u
 #define AIC_POOL (AIC_XWG_THREADS >= 512 ? 160 : 72)  // parked rays per workgroup (<= 192: three tags per lane are scanned); what the CU's 160 KB leave room for
 #endif
 #ifndef AIC_XCHG_MIN_GAIN
-#define AIC_XCHG_MIN_GAIN 2  // a wave that has lanes of the chosen kind tops up only if the pool adds at least this many
+#define AIC_XCHG_MIN_GAIN 8  // a wave that has lanes of the chosen kind tops up only if the pool adds at least this many
 #endif
 #ifndef AIC_COLD_SCOPE
 #define AIC_COLD_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP  // (experiment: __HIP_MEMORY_SCOPE_WAVEFRONT = plain loads the CU's L1 may serve stale -- timing only)
@@ -1193,14 +1193,10 @@ __global__ __launch_bounds__((AIC_EXCHANGE && !DIAG && LMODE != 3) ? AIC_XWG_THR
             const int parked = (pk_step > 0 ? pk_step : 0) + (pk_shade > 0 ? pk_shade : 0) + (pk_enter > 0 ? pk_enter : 0) + (pk_ray > 0 ? pk_ray : 0);
             const int alive = n_step + c_shade + c_enter + c_ray;
             if (alive == 0 && parked == 0) break;  // nothing of its own and nothing parked: whoever parks a ray later is running and serves it
-            // what a kind would run with: its own lanes + the parked rays that fit into the wave's other lanes (a top-up below AIC_XCHG_MIN_GAIN is not
-            // worth the exchange, unless the wave has none of that kind)
-            auto total_of = [](int mine, int pk) -> int {  // (branch-free: a handful of s_min / s_max / s_cselect)
-                const int room = 64 - mine;
-                int a = pk < room ? pk : room;
-                a = a > 0 ? a : 0;
-                const int ok = (int)(a >= AIC_XCHG_MIN_GAIN) | (int)(mine == 0);
-                return mine + a * ok;
+            // what a kind would run with: its own lanes + the parked rays that fit into the wave's other lanes
+            auto total_of = [](int mine, int pk) -> int {  // (three scalar instructions)
+                const int all = mine + (pk > 0 ? pk : 0);
+                return all < 64 ? all : 64;
             };
             const int t_step = total_of(n_step, pk_step), t_shade = total_of(c_shade, pk_shade), t_enter = total_of(c_enter, pk_enter), t_ray = total_of(c_ray, pk_ray);
             int best = t_step, mine = n_step;  // (ties go to the events: a parked event lane blocks its ray, a stepping lane can wait)
@@ -1217,7 +1213,9 @@ __global__ __launch_bounds__((AIC_EXCHANGE && !DIAG && LMODE != 3) ? AIC_XWG_THR
             const bool dry_u = __builtin_amdgcn_readfirstlane(dry ? 1 : 0) != 0;
             const int n_others = alive - mine - ((AIC_XCHG_DEPOSIT < 3 && run != 0u) ? n_step : 0);  // lanes holding a ray that will not run now (and may be parked)
             const bool may_park = AIC_XCHG_DEPOSIT != 0 && !dry_u && parked < (int)NPOOL && n_others > 0;
-            if (best > mine || (may_park && n_others >= AIC_XCHG_PARK_MIN)) {
+            // (an exchange costs a few hundred instructions: it is made for a top-up of at least AIC_XCHG_MIN_GAIN lanes, for a kind the wave has none of, or to
+            //  park at least AIC_XCHG_PARK_MIN lanes)
+            if (best - mine >= AIC_XCHG_MIN_GAIN || (mine == 0 && best > 0) || (may_park && n_others >= AIC_XCHG_PARK_MIN)) {
                 // ---- the exchange: lanes that would idle ("givers": empty lanes first, then rays of other kinds) are paired with parked rays of the wanted
                 // kind, and -- while the image has pixels left -- what remains of them with free slots. A pairing is a claim (compare-and-swap of the slot's
                 // tag), a plain swap of the 40 hot dwords and the column index, and the release of the slot under the tag of what it now holds. ----
