@@ -18,7 +18,7 @@ LIB_PATH = _PKG / "libaic_hip.so"
 AIC_OK = 0
 ERR_NAMES = {1: "AIC_ERR_INVALID", 2: "AIC_ERR_NO_DEVICE", 3: "AIC_ERR_OOM", 4: "AIC_ERR_DEVICE", 5: "AIC_ERR_UNSUPPORTED"}
 LAYER_WORLD, LAYER_UI = 0, 1
-MAX_IN_FLIGHT = 8  # AIC_MAX_IN_FLIGHT
+MAX_IN_FLIGHT = 32  # AIC_MAX_IN_FLIGHT
 FLAW_UNSUPPORTED, FLAW_NO_BLOOM = 1, 2
 FRAME_COUNTERS, FRAME_AUX, FRAME_PIXEL_CENTERS, FRAME_OUT_LINEAR, FRAME_OUT_COLORBUF, FRAME_NO_FEEDBACK = 1, 2, 4, 8, 16, 32
 

@@ -391,7 +391,9 @@ aic_ctx *aic_create(int device_id, int *status) {
         if (c->dump) std::fwrite("AICDUMP1", 1, 8, c->dump);
     }
     bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-    for (uint32_t i = 0; ok && i < AIC_MAX_IN_FLIGHT; i++) {
+    // the first eight slots are made with the context (as AIC_MAX_IN_FLIGHT = 8 always was: HIP deals streams onto its hardware queues in creation order); slots
+    // 8..31 -- a rank's many small shares of a multi-GPU frame -- get their stream and events on first use (ensure_slot)
+    for (uint32_t i = 0; ok && i < 8u && i < AIC_MAX_IN_FLIGHT; i++) {
         aic_ctx::FrameSlot &fs = c->slots[i];
         if (i == 0) fs.stream = c->stream;
         else ok = hipStreamCreateWithFlags(&fs.stream, hipStreamNonBlocking) == hipSuccess;
@@ -1051,6 +1053,14 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
             if ((e = fs.ray_cold.ensure(bytes / sizeof(uint4))) != hipSuccess) return hip_fail(c, "alloc ray state", e);
             F.ray_cold = fs.ray_cold.p;
             F.ray_cold_groups = groups;
+            // the exchange (a pool of parked rays per workgroup: more rays in flight than lanes, lanes traded between waves) pays when a wave refills its lanes
+            // several times over: from AIC_XCHG_TILES tiles per resident wave (default 5: the whole 1080p frame has 7.9 and gains 6.5 %, a rank's share at
+            // N = 2 has 4 and gains nothing, at N = 4 / 8 two / one and loses 3-6 % -- profiles/r05_rank_share.txt); the UI pre-pass follows the world pass
+            // -- and from 3 for frames that are streamed (aic_render_submit), where a share of C3 at N = 8 (4 tiles per wave) gains 9 % by it)
+            static const double x_tiles = [] { const char *e = std::getenv("AIC_XCHG_TILES"); return e ? std::atof(e) : -1.0; }();
+            const double resident_waves = (double)c->n_cus * 16.0;
+            const double need = x_tiles >= 0.0 ? x_tiles : (c->streaming_submit ? 3.0 : 5.0);
+            F.exchange = ((double)F.tiles_x * (double)F.tiles_y >= need * resident_waves) ? 1u : 0u;
         }
     }
     HIP_TRY(c, hipEventRecord(fs.ev0, fs.stream));
@@ -1333,10 +1343,24 @@ int aic_trace_patches(aic_ctx *c, const aic_frame_desc *f, uint32_t n, const dou
     return AIC_OK;
 }
 
+// a frame slot's stream, events and counter block (slots past the eighth: on first use)
+static int ensure_slot(aic_ctx *c, uint32_t slot) {
+    aic_ctx::FrameSlot &fs = c->slots[slot];
+    if (fs.stream && fs.ev0 && fs.ev1 && fs.ev2 && fs.counters.p) return AIC_OK;
+    if (!fs.stream) HIP_TRY(c, hipStreamCreateWithFlags(&fs.stream, hipStreamNonBlocking));
+    if (!fs.ev0) HIP_TRY(c, hipEventCreate(&fs.ev0));
+    if (!fs.ev1) HIP_TRY(c, hipEventCreate(&fs.ev1));
+    if (!fs.ev2) HIP_TRY(c, hipEventCreate(&fs.ev2));
+    hipError_t e = fs.counters.ensure(1);
+    if (e != hipSuccess) return hip_fail(c, "alloc frame counters", e);
+    return AIC_OK;
+}
+
 int aic_render_submit(aic_ctx *c, const aic_frame_desc *f, void *out_device, uint32_t slot) {
     if (!c || !f || slot >= AIC_MAX_IN_FLIGHT) return fail(c, AIC_ERR_INVALID, "aic_render_submit: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->slots[slot].busy) return fail(c, AIC_ERR_INVALID, "aic_render_submit: slot busy (aic_render_wait it first)");
+    { const int rs = ensure_slot(c, slot); if (rs != AIC_OK) return rs; }
     c->streaming_submit = true;
     const int rc = submit_frame(c, f, (uint32_t *)out_device, slot, false);
     c->streaming_submit = false;
@@ -1384,7 +1408,8 @@ int aic_synchronize(aic_ctx *c) {
     if (!c) return AIC_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (uint32_t i = 1; i < AIC_MAX_IN_FLIGHT; i++) HIP_TRY(c, hipStreamSynchronize(c->slots[i].stream));
+    for (uint32_t i = 1; i < AIC_MAX_IN_FLIGHT; i++)
+        if (c->slots[i].stream) HIP_TRY(c, hipStreamSynchronize(c->slots[i].stream));
     return AIC_OK;
 }
 

@@ -174,7 +174,8 @@ struct DevFrame {
     // antialiasing sums of its pixel. Sized by the host from trace_ray_cold_bytes(); `ray_cold_groups` workgroups fit.
     uint4 *ray_cold;
     uint32_t ray_cold_groups;
-    uint32_t pad_rc;
+    uint32_t exchange;       // host-side: launch the exchanging variant (aic_trace.hip "lane exchange") -- a frame with several tiles per persistent wave; a frame of
+                             // about one tile per wave (a rank's share at N >= 4, small images) runs the variant without the pool, which it would only pay for
 };
 
 // Largest work tile edge in pixels (DevFrame.tile is 8 by default, 16 with AIC_TILE=16); row strips of

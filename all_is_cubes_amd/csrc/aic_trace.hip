@@ -946,12 +946,13 @@ AIC_DEV Lvl lvl_first(Lvl s, const Lim lim, const RayDir rd, int lox, int loy, i
 // The axis to step along is recomputed from t[] at every step (two v_min_f64, two compares) instead of being
 // carried in the state: it is a pure function of t[], which nothing modifies between steps.
 
-template <bool VOL, int LMODE, bool DIAG, bool BIG>
-__global__ __launch_bounds__((AIC_EXCHANGE && !DIAG && LMODE != 3) ? AIC_XWG_THREADS : AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_WAVES) void trace_image_kernel(const DevFrame F) {
+template <bool VOL, int LMODE, bool DIAG, bool BIG, bool XC>
+__global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_XWG_THREADS : AIC_WG_THREADS, (DIAG || LMODE == 3) ? 2 : AIC_MIN_WAVES) void trace_image_kernel(const DevFrame F) {
     // XCHG: the production variants -- lanes are exchanged between the workgroup's waves through a pool of parked rays, and the part of a ray's
     // cold state that only ENTER / SHADE / FINISH touch (origin, direction, antialiasing sums) lives in global memory to make room for it.
     // The aux-recording and Bounce variants (more per-lane state, built for 2 waves per SIMD) keep everything in LDS and exchange nothing.
-    constexpr bool XCHG = AIC_EXCHANGE && !DIAG && LMODE != 3;
+    // (XC: the production variants exist with and without the exchange; the launcher picks by the frame's size -- DevFrame::exchange)
+    constexpr bool XCHG = AIC_EXCHANGE && XC && !DIAG && LMODE != 3;
     constexpr uint32_t WGT = XCHG ? (uint32_t)AIC_XWG_THREADS : (uint32_t)AIC_WG_THREADS;  // threads per workgroup
     constexpr uint32_t NPOOL = XCHG ? (uint32_t)AIC_POOL : 0u;                            // pool slots
     constexpr uint32_t NCOL = WGT + NPOOL;                                                // LDS columns: one per lane and one per slot
@@ -2713,12 +2714,12 @@ __global__ void probe_powf_kernel(const float *x, const float *y, float *out, ui
 // ---------------------------------------------------------------------------------------
 // host-callable launchers (used by aic_abi.cpp)
 
-template <bool VOL, int LMODE, bool DIAG, bool BIG>
-static void launch_trace(const DevFrame &F, hipStream_t stream) {
+template <bool VOL, int LMODE, bool DIAG, bool BIG, bool XC>
+static void launch_trace_x(const DevFrame &F, hipStream_t stream) {
     // persistent waves: enough workgroups to fill the chip at the kernel's occupancy, never more
     // waves than tiles (each wave pulls 8x8-pixel tiles from counters->tile_next)
     const uint32_t n_tiles = F.tiles_x * F.tiles_y;
-    constexpr bool XCHG = AIC_EXCHANGE && !DIAG && LMODE != 3;
+    constexpr bool XCHG = AIC_EXCHANGE && XC && !DIAG && LMODE != 3;
     constexpr uint32_t WGT = XCHG ? (uint32_t)AIC_XWG_THREADS : (uint32_t)AIC_WG_THREADS;
     const uint32_t wg_waves = WGT / 64u;
     const uint32_t resident_groups = F.n_cus * 4u * (uint32_t)((DIAG || LMODE == 3) ? 2 : AIC_MIN_WAVES) / wg_waves;  // 4 SIMDs per CU, that many waves on each
@@ -2736,7 +2737,17 @@ static void launch_trace(const DevFrame &F, hipStream_t stream) {
     if (grid > resident_groups) grid = resident_groups;
     if (XCHG && grid > F.ray_cold_groups) grid = F.ray_cold_groups;  // (the host sizes the buffer for the resident grid: trace_ray_cold_bytes)
     if (grid == 0) return;
-    hipLaunchKernelGGL((trace_image_kernel<VOL, LMODE, DIAG, BIG>), dim3(grid), dim3(WGT), 0, stream, F);
+    hipLaunchKernelGGL((trace_image_kernel<VOL, LMODE, DIAG, BIG, XC>), dim3(grid), dim3(WGT), 0, stream, F);
+}
+
+// The production variants (no per-pixel records, not Bounce) exist twice: with the lane exchange (a frame of many tiles per persistent wave) and without
+// (DevFrame::exchange == 0: a frame of a tile or two per wave -- a rank's share of a multi-GPU frame, the test images -- which the pool only costs).
+template <bool VOL, int LMODE, bool DIAG, bool BIG>
+static void launch_trace(const DevFrame &F, hipStream_t stream) {
+    if constexpr (AIC_EXCHANGE && !DIAG && LMODE != 3) {
+        if (F.exchange && F.ray_cold) { launch_trace_x<VOL, LMODE, DIAG, BIG, true>(F, stream); return; }
+    }
+    launch_trace_x<VOL, LMODE, DIAG, BIG, false>(F, stream);
 }
 
 template <bool DIAG, bool BIG>

@@ -153,7 +153,7 @@ def main() -> int:
     ap.add_argument("--verify", dest="verify", action="store_true", default=None,
                     help="N > 1 (default there): check the assembled frame against a single-rank trace of the same frame")
     ap.add_argument("--no-verify", dest="verify", action="store_false")
-    ap.add_argument("--in-flight", type=int, default=0, help="frames traced concurrently (1..8); default 4 at N < 4, 8 at N >= 4")
+    ap.add_argument("--in-flight", type=int, default=0, help="frames traced concurrently (1..32); default 4 at N < 4, 8 at N = 4, 16 at N >= 8")
     ap.add_argument("--frames-per-gather", type=int, default=0,
                     help="N > 1: consecutive frames moved to rank 0 by one collective; default 1 (a frame is gathered as soon as it is traced). More "
                          "frames per collective trade latency for fewer host calls: to be measured on a real 8-GPU node before it becomes a default "
@@ -304,8 +304,9 @@ def main() -> int:
     # frame i's last rays finish) and, for N > 1, frame i-2's RCCL gather running under them.
     # --no-pipeline: one frame at a time, gathered before the next is traced.
     streamed = not args.no_pipeline
-    # traces in flight (AIC_MAX_IN_FLIGHT = 8): a rank's share of a frame shrinks with N while a ray's latency does not
-    depth = max(1, min(8, args.in_flight if args.in_flight > 0 else (4 if world < 4 else 8)))
+    # traces in flight (AIC_MAX_IN_FLIGHT = 32): a rank's share of a frame shrinks with N while a ray's latency does not -- the default keeps about four
+    # frames' worth of rays on each device (profiles/r05_rank_share.txt)
+    depth = max(1, min(32, args.in_flight if args.in_flight > 0 else (4 if world < 4 else (8 if world < 8 else 16))))
     per_gather = max(1, min(depth, args.frames_per_gather if args.frames_per_gather > 0 else 1)) if streamed else 1
     ring = ((depth + per_gather - 1) // per_gather + (1 if per_gather == 1 else 2)) if streamed else 1  # group slots: the groups being traced, one being gathered
     pipe = D.StripGatherPipeline(h, w, strip, "cpu" if one_gpu_test else dev, depth=ring,

@@ -220,13 +220,18 @@ int aic_render(aic_ctx *ctx, const aic_frame_desc *frame, void *out_rgba8, int o
  * 0..AIC_MAX_IN_FLIGHT-1 and returns at once; aic_render_wait blocks until that slot's frame is in
  * `out_device` and reports it. With several frames in flight the next frame's trace starts filling the
  * GPU while the previous frame's last rays finish. out_device must be a device pointer; the
- * AIC_FRAME_AUX flag is ignored here (use aic_render). Scene updates wait for every frame in
- * flight before touching device memory.
+ * AIC_FRAME_AUX flag is ignored here (use aic_render). Scene updates that change what a frame in flight
+ * reads (aic_upload_space, aic_update_cubes, aic_replace_blocks, aic_set_options, aic_compact) wait for every
+ * frame in flight first; aic_update_light_volume and aic_evaluate_light do NOT: they write the other half of the
+ * light double buffer beside the frames in flight (which keep the half they were given) and only wait for a frame
+ * still reading that other half.
+ * Slots 0..7 are made with the context; a higher slot gets its stream and events when it is first used.
  * "The frame is in out_device" is all aic_render_wait (and aic_render with a device target) waits for: behind the frame the slot's
  * stream still prepares the slot's next frame (the frame's cost record becomes a tile order, counters are cleared -- microseconds of
  * work private to the slot). Work the caller orders behind the frame with aic_stream_wait_frame, or issues after the wait returns,
- * never has to wait for that. */
-#define AIC_MAX_IN_FLIGHT 8u
+ * never has to wait for that. aic_render_wait does NOT drain the slot's stream: call aic_synchronize before handing aic_stream() to
+ * other code that assumes it idle. */
+#define AIC_MAX_IN_FLIGHT 32u
 int aic_render_submit(aic_ctx *ctx, const aic_frame_desc *frame, void *out_device, uint32_t slot);
 int aic_render_wait(aic_ctx *ctx, uint32_t slot, aic_frame_info *info);
 /* replaces: RtScene::trace_patch (renderer.rs:418-451) for a batch of pixel rectangles -- the call

@@ -23,7 +23,7 @@ pub const AIC_FRAME_PIXEL_CENTERS: u32 = 4;
 pub const AIC_FRAME_OUT_LINEAR: u32 = 8;
 pub const AIC_FRAME_OUT_COLORBUF: u32 = 16;
 pub const AIC_FRAME_NO_FEEDBACK: u32 = 32;
-pub const AIC_MAX_IN_FLIGHT: u32 = 8;
+pub const AIC_MAX_IN_FLIGHT: u32 = 32;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]

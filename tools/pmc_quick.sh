@@ -15,7 +15,7 @@ for d in ("sq1_$W", "sq2_$W"):
     acc = collections.defaultdict(list)
     for f in glob.glob("$O/%s/**/*counter_collection.csv" % d, recursive=True):
         for r in csv.DictReader(open(f)):
-            if "trace_image_kernel" in r["Kernel_Name"] and ", false, false>" in r["Kernel_Name"]:
+            if "trace_image_kernel" in r["Kernel_Name"] and (", false, false>" in r["Kernel_Name"] or ", false, false, " in r["Kernel_Name"]):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in sorted(acc.items()):
         # one row per dispatch (and per dimension instance): sum per dispatch
