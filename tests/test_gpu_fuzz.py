@@ -3,6 +3,8 @@ random scenes, cameras and options -- mixed block resolutions, partial voxel vol
 (all statuses), octant skies, backdrops, eyes inside and outside the space, axis-parallel views,
 narrow and wide fields of view. Same bar as tests/test_gpu_parity.py: per-pixel step counts, first
 hit (cube, voxel, face, block), f64 distance bit for bit; RGBA8 within one level."""
+import os
+
 import numpy as np
 import pytest
 
@@ -78,8 +80,16 @@ def test_random_scene_camera_options(seed):
         ctx.upload_space(abi.LAYER_WORLD, sp)
         ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
         got = ctx.render(ctx.make_frame(w, h, world_inv=inv, backdrop=backdrop), want_aux=True)
-        # the production kernel variant (no per-pixel records; built for 4 waves per SIMD)
+        # the production kernel variants (no per-pixel records; built for 4 waves per SIMD): the plain one an image this small gets, and the one that
+        # exchanges lanes between the waves of a workgroup (round 5; AIC_XCHG_TILES=0: for every frame, read per frame) -- parked rays, spare columns,
+        # claims lost to other waves and the drain at the frame's end all happen at this size too
         fast = ctx.render(ctx.make_frame(w, h, world_inv=inv, backdrop=backdrop))
+        os.environ["AIC_XCHG_TILES"] = "0"
+        try:
+            exchanged = ctx.render(ctx.make_frame(w, h, world_inv=inv, backdrop=backdrop))
+        finally:
+            del os.environ["AIC_XCHG_TILES"]
     assert (fast["rgba8"] == got["rgba8"]).all() and fast["info"].cubes_traced == got["info"].cubes_traced
+    assert (exchanged["rgba8"] == got["rgba8"]).all() and exchanged["info"].cubes_traced == got["info"].cubes_traced
     ref = oracle.render(oracle.Space(sp), opt, oracle.make_camera(inv, w, h), backdrop=backdrop, want_aux=True)
     assert_parity(got, ref)
