@@ -1286,6 +1286,15 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
             }
             }
             else { AIC_TICK(19); }
+            // (the two masks through v_readfirstlane: they are wave-uniform by construction, but a build in which the compiler's divergence analysis loses that --
+            //  the -DAIC_PROFILE one did -- would hand vector registers to the scalar operands below, and to every mask of the stepping phase after them)
+            {
+                auto uniform64 = [](unsigned long long m) -> unsigned long long {
+                    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(m >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)m);
+                };
+                x_got = uniform64(x_got);
+                x_fresh = uniform64(x_fresh);
+            }
             // ---- The swap proper, under exec = the lanes whose claim succeeded (none in a round without an exchange: the three blocks are then skipped): one
             // LDS exchange (`ds_wrxchg_rtn`: write the register, return what was there) per hot variable, IN PLACE and on the round's common path -- like the
             // stepping code's asm blocks. (Inside the exchange's own branch, or assigned from loaded values in C++, the compiler renames the hot variables
@@ -1456,31 +1465,33 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
             // Layout: per workgroup six arrays of NCOL doubles (origin x y z, direction x y z), then four of NCOL floats: a wave's lanes read neighbouring words
             // (columns stay mostly in lane order), 8 cache lines per load instead of the 64 of a 64-byte record per column.
             char *const cold_wg = XCHG ? reinterpret_cast<char *>(F.ray_cold) + (size_t)blockIdx.x * (size_t)(NCOL * 64u) : nullptr;
+#ifndef AIC_COLD_SOA
+#define AIC_COLD_SOA 1
+#endif
+            // byte offset of the ray's k-th double (k = 0..5) / k-th float sum (k = 0..3) inside the workgroup's region
+            auto off64 = [&](uint32_t k) -> uint32_t { return AIC_COLD_SOA ? (k * NCOL + col) * 8u : col * 64u + k * 8u; };
+            auto off32 = [&](uint32_t k) -> uint32_t { return AIC_COLD_SOA ? NCOL * 48u + (k * NCOL + col) * 4u : col * 64u + 48u + k * 4u; };
             auto cold_origin = [&](double &ox, double &oy, double &oz) {
                 if constexpr (XCHG) {
-                    unsigned long long *g = reinterpret_cast<unsigned long long *>(cold_wg) + col;
-                    ox = __longlong_as_double((long long)__hip_atomic_load(g + 0u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE));
-                    oy = __longlong_as_double((long long)__hip_atomic_load(g + 1u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE));
-                    oz = __longlong_as_double((long long)__hip_atomic_load(g + 2u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE));
+                    ox = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(cold_wg + off64(0u)), __ATOMIC_RELAXED, AIC_COLD_SCOPE));
+                    oy = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(cold_wg + off64(1u)), __ATOMIC_RELAXED, AIC_COLD_SCOPE));
+                    oz = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(cold_wg + off64(2u)), __ATOMIC_RELAXED, AIC_COLD_SCOPE));
                 } else {
                     ox = c64[XCHG ? 0 : (int)C_OX][col]; oy = c64[XCHG ? 0 : (int)C_OY][col]; oz = c64[XCHG ? 0 : (int)C_OZ][col];
                 }
             };
             auto cold_direction = [&](double &dx, double &dy, double &dz) {
                 if constexpr (XCHG) {
-                    unsigned long long *g = reinterpret_cast<unsigned long long *>(cold_wg) + col;
-                    dx = __longlong_as_double((long long)__hip_atomic_load(g + 3u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE));
-                    dy = __longlong_as_double((long long)__hip_atomic_load(g + 4u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE));
-                    dz = __longlong_as_double((long long)__hip_atomic_load(g + 5u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE));
+                    dx = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(cold_wg + off64(3u)), __ATOMIC_RELAXED, AIC_COLD_SCOPE));
+                    dy = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(cold_wg + off64(4u)), __ATOMIC_RELAXED, AIC_COLD_SCOPE));
+                    dz = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(cold_wg + off64(5u)), __ATOMIC_RELAXED, AIC_COLD_SCOPE));
                 } else {
                     dx = c64[XCHG ? 0 : (int)C_DX][col]; dy = c64[XCHG ? 0 : (int)C_DY][col]; dz = c64[XCHG ? 0 : (int)C_DZ][col];
                 }
             };
             auto cold_sums_load = [&](float v[4]) {
                 if constexpr (XCHG) {
-                    uint32_t *g = reinterpret_cast<uint32_t *>(cold_wg + NCOL * 48u) + col;
-                    v[0] = __uint_as_float(__hip_atomic_load(g + 0u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE)); v[1] = __uint_as_float(__hip_atomic_load(g + 1u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE));
-                    v[2] = __uint_as_float(__hip_atomic_load(g + 2u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE)); v[3] = __uint_as_float(__hip_atomic_load(g + 3u * NCOL, __ATOMIC_RELAXED, AIC_COLD_SCOPE));
+                    for (uint32_t k = 0; k < 4u; k++) v[k] = __uint_as_float(__hip_atomic_load(reinterpret_cast<uint32_t *>(cold_wg + off32(k)), __ATOMIC_RELAXED, AIC_COLD_SCOPE));
                 } else {
                     v[0] = __uint_as_float(c32[XCHG ? 0 : (int)K_S0][col]); v[1] = __uint_as_float(c32[XCHG ? 0 : (int)K_S1][col]);
                     v[2] = __uint_as_float(c32[XCHG ? 0 : (int)K_S2][col]); v[3] = __uint_as_float(c32[XCHG ? 0 : (int)K_ST][col]);
@@ -1488,8 +1499,8 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
             };
             auto cold_sums_store = [&](float v0, float v1, float v2, float v3) {
                 if constexpr (XCHG) {
-                    float *g = reinterpret_cast<float *>(cold_wg + NCOL * 48u) + col;
-                    g[0u * NCOL] = v0; g[1u * NCOL] = v1; g[2u * NCOL] = v2; g[3u * NCOL] = v3;
+                    *reinterpret_cast<float *>(cold_wg + off32(0u)) = v0; *reinterpret_cast<float *>(cold_wg + off32(1u)) = v1;
+                    *reinterpret_cast<float *>(cold_wg + off32(2u)) = v2; *reinterpret_cast<float *>(cold_wg + off32(3u)) = v3;
                 } else {
                     c32[XCHG ? 0 : (int)K_S0][col] = __float_as_uint(v0); c32[XCHG ? 0 : (int)K_S1][col] = __float_as_uint(v1);
                     c32[XCHG ? 0 : (int)K_S2][col] = __float_as_uint(v2); c32[XCHG ? 0 : (int)K_ST][col] = __float_as_uint(v3);
@@ -1536,9 +1547,14 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                         i0 = lut[txl & 255u]; i1 = lut[(txl >> 8) & 255u]; i2 = lut[(txl >> 16) & 255u];
                     }
                     if (LMODE >= 2) {
-                        double ox, oy, oz, dx, dy, dz;
-                        cold_origin(ox, oy, oz);
+                        // (the origin enters intersection_point only for a lane whose step is Face7::Within or whose ray does not move along some axis --
+                        //  raycast.rs:409-439 -- : it is fetched for those lanes, i.e. hardly ever; half of the SHADE event's cold-state traffic)
+                        double ox = 0.0, oy = 0.0, oz = 0.0, dx, dy, dz;
                         cold_direction(dx, dy, dz);
+                        const bool need_o = (face == FACE_WITHIN) | (dx == 0.0) | (dy == 0.0) | (dz == 0.0);
+                        if (__ballot(need_o) != 0ull) {
+                            if (need_o) cold_origin(ox, oy, oz);
+                        }
                         if (inb) {
                             const double kd = (double)blk_res;
                             double vp[3];
@@ -2109,8 +2125,8 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                     c32[K_TVIEW][col] = __float_as_uint((float)(t_abs / opt.view_distance));  // sr.rs:149-151
                     const RayDir rd = raydir_init(dirx, diry, dirz);
                     if constexpr (XCHG) {
-                        double *g = reinterpret_cast<double *>(cold_wg) + col;
-                        g[0u * NCOL] = ox; g[1u * NCOL] = oy; g[2u * NCOL] = oz; g[3u * NCOL] = rd.dx; g[4u * NCOL] = rd.dy; g[5u * NCOL] = rd.dz;
+                        *reinterpret_cast<double *>(cold_wg + off64(0u)) = ox; *reinterpret_cast<double *>(cold_wg + off64(1u)) = oy; *reinterpret_cast<double *>(cold_wg + off64(2u)) = oz;
+                        *reinterpret_cast<double *>(cold_wg + off64(3u)) = rd.dx; *reinterpret_cast<double *>(cold_wg + off64(4u)) = rd.dy; *reinterpret_cast<double *>(cold_wg + off64(5u)) = rd.dz;
                     } else {
                         c64[XCHG ? 0 : (int)C_OX][col] = ox; c64[XCHG ? 0 : (int)C_OY][col] = oy; c64[XCHG ? 0 : (int)C_OZ][col] = oz;
                         c64[XCHG ? 0 : (int)C_DX][col] = rd.dx; c64[XCHG ? 0 : (int)C_DY][col] = rd.dy; c64[XCHG ? 0 : (int)C_DZ][col] = rd.dz;
