@@ -85,11 +85,23 @@ def test_random_scene_camera_options(seed):
         # claims lost to other waves and the drain at the frame's end all happen at this size too
         fast = ctx.render(ctx.make_frame(w, h, world_inv=inv, backdrop=backdrop))
         os.environ["AIC_XCHG_TILES"] = "0"
+        cost = None
         try:
             exchanged = ctx.render(ctx.make_frame(w, h, world_inv=inv, backdrop=backdrop))
+            if opt.antialiasing == 0 and opt.lighting != 5:  # (a mean of four samples / secondary rays' steps do not come back from one channel)
+                was = opt.debug_pixel_cost
+                opt.debug_pixel_cost = 1
+                ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+                cost = ctx.render(ctx.make_frame(w, h, world_inv=inv, backdrop=backdrop, flags=abi.FRAME_OUT_LINEAR))
+                opt.debug_pixel_cost = was
         finally:
             del os.environ["AIC_XCHG_TILES"]
     assert (fast["rgba8"] == got["rgba8"]).all() and fast["info"].cubes_traced == got["info"].cubes_traced
     assert (exchanged["rgba8"] == got["rgba8"]).all() and exchanged["info"].cubes_traced == got["info"].cubes_traced
+    if cost is not None:
+        # the production variants' PER-PIXEL step counts (the opaque shortcut works the reference's remaining counted steps out instead of taking
+        # them): with debug_pixel_cost the pixel is rgb(0.02 n, 0.002 n, ..) and the linear float output hands it over unrounded
+        counts = np.rint(cost["rgba8"][..., 1].astype(np.float64) / float(np.float32(0.002))).astype(np.int64)
+        assert (counts == got["aux"]["cubes_traced"]).all(), "per-pixel step counts of the production (exchanging) variant"
     ref = oracle.render(oracle.Space(sp), opt, oracle.make_camera(inv, w, h), backdrop=backdrop, want_aux=True)
     assert_parity(got, ref)
