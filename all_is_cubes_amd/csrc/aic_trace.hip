@@ -1171,6 +1171,8 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
         int n_step = (int)wave_popc(m_st);
         int c_shade = (int)wave_popc(b_shade), c_enter = (int)wave_popc(b_enter), c_ray = (int)wave_popc(b_ray);
         uint32_t run = 0u;  // kind to run this trip (an EV_* bit), 0 = step
+        u32x4 cs_early = u32x4{0u, 0u, 0u, 0u};
+        if constexpr (XCHG) cs_early = *reinterpret_cast<volatile u32x4 *>(&s_census);  // (issued here, waited for where the counts are used: behind the ballots and counts above)
         if constexpr (XCHG) {
             // ---- regime-sorted waves: run the kind that fills the wave best, own lanes plus what the workgroup's pool can add ----
             // what this round's exchange (if any) decided: the lanes whose claim succeeded, those of them that took a spare column, the slot's address and
@@ -1187,8 +1189,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
             }
             if (run == 0xffffffffu) {
             run = 0u;
-            u32x4 cs;  // parked rays by kind (advisory: a count can run a claim ahead of or behind the tags)
-            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(cs) : "v"((uint32_t)(uintptr_t)&s_census) : "memory");
+            const u32x4 cs = cs_early;  // parked rays by kind (advisory: a count can run a claim ahead of or behind the tags), read at the top of the round
             const int pk_step = opaque_s(__builtin_amdgcn_readfirstlane((int)cs.x)), pk_shade = opaque_s(__builtin_amdgcn_readfirstlane((int)cs.y)),
                       pk_enter = opaque_s(__builtin_amdgcn_readfirstlane((int)cs.z)), pk_ray = opaque_s(__builtin_amdgcn_readfirstlane((int)cs.w));
             const int parked = (pk_step > 0 ? pk_step : 0) + (pk_shade > 0 ? pk_shade : 0) + (pk_enter > 0 ? pk_enter : 0) + (pk_ray > 0 ? pk_ray : 0);
@@ -1199,11 +1200,15 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 const int all = mine + (pk > 0 ? pk : 0);
                 return all < 64 ? all : 64;
             };
-            const int t_step = total_of(n_step, pk_step), t_shade = total_of(c_shade, pk_shade), t_enter = total_of(c_enter, pk_enter), t_ray = total_of(c_ray, pk_ray);
-            int best = t_step, mine = n_step;  // (ties go to the events: a parked event lane blocks its ray, a stepping lane can wait)
-            if (t_shade >= best && t_shade > 0) { best = t_shade; mine = c_shade; run = EV_SHADE; }
-            if (t_enter >= best && t_enter > 0) { best = t_enter; mine = c_enter; run = EV_ENTER; }
-            if (t_ray >= best && t_ray > 0) { best = t_ray; mine = c_ray; run = EV_FINISH; }
+            // the kind with the most lanes; ties go to the events, the later kind first (a parked event lane blocks its ray, a stepping lane can wait): the
+            // four totals as keys  total << 2 | kind  and one maximum (kind: 0 stepping, 1 SHADE, 2 ENTER, 3 RAY; EV_SHADE / EV_ENTER / EV_FINISH = 2 << kind)
+            const int key0 = total_of(n_step, pk_step) << 2, key1 = (total_of(c_shade, pk_shade) << 2) | 1, key2 = (total_of(c_enter, pk_enter) << 2) | 2,
+                      key3 = (total_of(c_ray, pk_ray) << 2) | 3;
+            const int ka = key0 > key1 ? key0 : key1, kb = key2 > key3 ? key2 : key3, kmax = ka > kb ? ka : kb;
+            const int best = kmax >> 2, kind = kmax & 3;
+            const int mine = kind == 0 ? n_step : (kind == 1 ? c_shade : (kind == 2 ? c_enter : c_ray));
+            run = kind == 0 ? 0u : (2u << kind);
+            static_assert(EV_SHADE == (2u << 1) && EV_ENTER == (2u << 2) && EV_FINISH == (2u << 3), "the kinds' event bits");
             if (best == 0) {  // only rays in transit between two waves: look again shortly (bounded: a wave never waits for another for good)
                 AIC_PROF(36, 1);
                 if (spun_out()) break;

@@ -793,7 +793,9 @@ def test_full_size_workload_rows_and_properties(ctx, workload):
 # Other production variants at BASELINE's full sizes: the test above runs <Volumetric, interpolated light>; these run
 # <Surface, Flat> on C2 and <Threshold, None> on C3 -- the production kernels (no per-pixel records; lanes exchanged between waves since
 # round 5), checked per pixel through the same trick: debug_pixel_cost + the linear float output give every pixel's step count exactly.
-@pytest.mark.parametrize("workload,transparency,lighting", [("atrium", 0, 1), ("s256", 2, 0)])
+# (<VOL, LMODE> of the kernel: transparency 1 = Volumetric; lighting 0 None, 1 Flat, 2-4 interpolated. With the default <Volumetric, Linear> above these are all six
+#  combinations the two scenes can reach -- the other six production kernels are the BIG ones, for block tables past 16 384 entries)
+@pytest.mark.parametrize("workload,transparency,lighting", [("atrium", 0, 1), ("s256", 2, 0), ("atrium", 1, 0), ("s256", 1, 1), ("atrium", 2, 4)])
 def test_full_size_other_production_variants(ctx, workload, transparency, lighting):
     import bench
 
