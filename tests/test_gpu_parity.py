@@ -52,6 +52,17 @@ def render_both(ctx, space, opt: oracle.OrcOptions, size, eye, quat=(0, 0, 0, 1)
     opt.exposure = 1.0
     frame = ctx.make_frame(w, h, world_inv=inv, ui_inv=ui_inv, backdrop=backdrop)
     got = ctx.render(frame, want_aux=True)
+    # the production kernel variants of the same frame -- the plain one an image this small gets and the lane-exchanging one (forced: AIC_XCHG_TILES is read per
+    # frame) -- must give the aux-recording variant's bytes and step total: every scene that goes through this helper (goldens, options matrix, layers,
+    # antialiasing, UI pre-pass + world pass) covers all three
+    fast = ctx.render(frame)
+    os.environ["AIC_XCHG_TILES"] = "0"
+    try:
+        exchanged = ctx.render(frame)
+    finally:
+        del os.environ["AIC_XCHG_TILES"]
+    for name, other in (("plain", fast), ("exchanging", exchanged)):
+        assert (other["rgba8"] == got["rgba8"]).all() and other["info"].cubes_traced == got["info"].cubes_traced, f"production variant ({name}) differs from the aux-recording one"
     ref = oracle.render(
         oracle.Space(space) if space is not None else None, opt, oracle.make_camera(inv, w, h),
         ui=oracle.Space(ui) if ui is not None else None, ui_opt=opt if ui is not None else None,
