@@ -34,6 +34,19 @@ def to_abi_options(o: oracle.OrcOptions) -> abi.Options:
                             maximum_intensity=o.maximum_intensity, bloom_intensity=0.0, view_distance=o.view_distance)
 
 
+def assert_production_variants(ctx, frame, got):
+    """The production kernel variants of `frame` -- the plain one an image this small gets and the lane-exchanging one (forced: AIC_XCHG_TILES is read per
+    frame) -- must give the aux-recording variant's bytes and step total."""
+    fast = ctx.render(frame)
+    os.environ["AIC_XCHG_TILES"] = "0"
+    try:
+        exchanged = ctx.render(frame)
+    finally:
+        del os.environ["AIC_XCHG_TILES"]
+    for name, other in (("plain", fast), ("exchanging", exchanged)):
+        assert (other["rgba8"] == got["rgba8"]).all() and other["info"].cubes_traced == got["info"].cubes_traced, f"production variant ({name}) differs from the aux-recording one"
+
+
 def render_both(ctx, space, opt: oracle.OrcOptions, size, eye, quat=(0, 0, 0, 1), fov=90.0, ui=None, ui_eye=(0, 0, 0), backdrop=(0, 0, 0, 0)):
     w, h = size
     _, _, inv = oracle.camera_matrices(fov, opt.view_distance, w / h, quat, eye)
@@ -52,17 +65,8 @@ def render_both(ctx, space, opt: oracle.OrcOptions, size, eye, quat=(0, 0, 0, 1)
     opt.exposure = 1.0
     frame = ctx.make_frame(w, h, world_inv=inv, ui_inv=ui_inv, backdrop=backdrop)
     got = ctx.render(frame, want_aux=True)
-    # the production kernel variants of the same frame -- the plain one an image this small gets and the lane-exchanging one (forced: AIC_XCHG_TILES is read per
-    # frame) -- must give the aux-recording variant's bytes and step total: every scene that goes through this helper (goldens, options matrix, layers,
-    # antialiasing, UI pre-pass + world pass) covers all three
-    fast = ctx.render(frame)
-    os.environ["AIC_XCHG_TILES"] = "0"
-    try:
-        exchanged = ctx.render(frame)
-    finally:
-        del os.environ["AIC_XCHG_TILES"]
-    for name, other in (("plain", fast), ("exchanging", exchanged)):
-        assert (other["rgba8"] == got["rgba8"]).all() and other["info"].cubes_traced == got["info"].cubes_traced, f"production variant ({name}) differs from the aux-recording one"
+    # every scene that goes through this helper (goldens, options matrix, layers, antialiasing, UI pre-pass + world pass) covers the production variants too
+    assert_production_variants(ctx, frame, got)
     ref = oracle.render(
         oracle.Space(space) if space is not None else None, opt, oracle.make_camera(inv, w, h),
         ui=oracle.Space(ui) if ui is not None else None, ui_opt=opt if ui is not None else None,
@@ -948,6 +952,12 @@ def test_block_table_past_14_bits_uses_the_class_table(ctx):
     assert_parity(ctx.render(fr, want_aux=True), ref)
     ctx.upload_space(abi.LAYER_WORLD, sp)  # and as a fresh snapshot of 16385 blocks
     assert_parity(ctx.render(fr, want_aux=True), ref)
+    # the BIG production kernels (no per-pixel records; plain and lane-exchanging), all six <VOL, LMODE> of them, against the aux-recording variant
+    for transparency, lighting in ((1, 3), (1, 0), (1, 1), (0, 3), (2, 0), (0, 1)):
+        vopt = oracle.make_options(transparency=transparency, lighting=lighting)
+        ctx.set_options(abi.LAYER_WORLD, to_abi_options(vopt))
+        assert_production_variants(ctx, fr, ctx.render(fr, want_aux=True))
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
     # Bounce on the untagged grid: the secondary rays classify cubes through the class table too
     bopt = oracle.make_options(lighting=5, bounce_samples=2)
     ctx.set_options(abi.LAYER_WORLD, to_abi_options(bopt))
