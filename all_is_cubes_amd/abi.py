@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "aic_render", "aic_render_submit", "aic_render_wait", "aic_trace_patches", "aic_partition_rows", "aic_assemble_strips", "aic_assemble_strips_async", "aic_read_aux", "aic_synchronize", "aic_stream", "aic_wait_event", "aic_stream_wait_frame",
     "aic_probe_raycast", "aic_probe_light_lut", "aic_probe_powf",
     "aic_ortho_image_size", "aic_render_orthographic",
-    "aic_evaluate_light", "aic_light_cubes_changed", "aic_read_light_volume", "aic_light_chart", "aic_probe_derived", "aic_probe_log2f",
+    "aic_evaluate_light", "aic_light_cubes_changed", "aic_read_light_volume", "aic_read_light_cubes", "aic_light_chart", "aic_probe_derived", "aic_probe_log2f",
     "aic_create_multi", "aic_destroy_multi", "aic_multi_device_count", "aic_multi_context", "aic_multi_last_error", "aic_multi_upload_space",
     "aic_multi_clear_space", "aic_multi_update_cubes", "aic_multi_update_light_volume", "aic_multi_evaluate_light", "aic_multi_light_cubes_changed", "aic_multi_replace_blocks", "aic_multi_set_options",
     "aic_multi_render",
@@ -167,6 +167,7 @@ def load() -> C.CDLL:
         lib.aic_probe_powf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.aic_evaluate_light.argtypes = [C.c_void_p, C.c_int, C.POINTER(LightParams), C.POINTER(LightInfo)]
         lib.aic_read_light_volume.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.aic_read_light_cubes.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
         lib.aic_light_cubes_changed.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_int]
         lib.aic_probe_derived.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         lib.aic_probe_log2f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
@@ -507,6 +508,13 @@ class Context:
         self._check(self._lib.aic_read_light_volume(self._h, layer, out.ctypes.data))
         return out
 
+    def read_light_cubes(self, layer: int, xyz) -> np.ndarray:
+        """The texels of the listed cubes, [n][4] (`LightStorage::get`, light/data.rs, over a list)."""
+        xyz = np.ascontiguousarray(xyz, np.int32).reshape(-1, 3)
+        out = np.zeros((len(xyz), 4), np.uint8)
+        self._check(self._lib.aic_read_light_cubes(self._h, layer, len(xyz), _ptr(xyz), out.ctypes.data))
+        return out
+
     def probe_derived(self, layer: int, n_blocks: int):
         out = np.zeros((n_blocks, 32), np.float32)
         opq = np.zeros((n_blocks, 6), np.uint8)
@@ -590,6 +598,11 @@ class MultiContext:
         info = LightInfo()
         self._check(self._lib.aic_multi_evaluate_light(self._h, layer, C.byref(p), C.byref(info)))
         return info
+
+    def light_cubes_changed(self, layer: int, xyz, queue_order: int = 16) -> None:
+        """`Context.light_cubes_changed` on the device that runs the updater; the texels it writes reach the others at once."""
+        xyz = np.ascontiguousarray(xyz, np.int32).reshape(-1, 3)
+        self._check(self._lib.aic_multi_light_cubes_changed(self._h, layer, len(xyz), _ptr(xyz), queue_order))
 
     def update_cubes(self, layer: int, xyz, block_index=None, light=None) -> None:
         xyz = np.ascontiguousarray(xyz, np.int32).reshape(-1, 3)

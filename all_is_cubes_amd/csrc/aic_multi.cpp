@@ -164,14 +164,21 @@ int aic_multi_evaluate_light(aic_multi *m, int layer, const aic_light_params *p,
     return broadcast_light(m, layer);
 }
 
-// aic_light_cubes_changed on the device that runs the light updater. The OPAQUE texels it writes there (and its queue) are device
-// 0's alone until the volume is next handed over: the layer is marked, and aic_multi_render hands the volume over before it traces
-// if no aic_multi_evaluate_light came in between -- every device always traces the same light.
+// aic_light_cubes_changed on the device that runs the light updater. Its queue is device 0's alone; the texels it writes there
+// (PackedLight::OPAQUE at the cubes that are now opaque, nothing else) are read back from device 0's host mirror and scattered
+// into the other devices' volumes at once -- n texels, not the volume -- so every device always traces the same
+// light. Should that hand-over fail, the layer is marked and aic_multi_render hands the whole volume over before it traces.
 int aic_multi_light_cubes_changed(aic_multi *m, int layer, uint32_t n, const int32_t *xyz, int queue_order) {
     if (!m || m->ctx.empty() || (layer != 0 && layer != 1)) return mfail(m, AIC_ERR_INVALID, "aic_multi_light_cubes_changed: bad argument");
-    const int rc = forward(m, 0, aic_light_cubes_changed(m->ctx[0], layer, n, xyz, queue_order));
-    if (rc == AIC_OK && n) m->light_stale[layer] = true;
-    return rc;
+    int rc = forward(m, 0, aic_light_cubes_changed(m->ctx[0], layer, n, xyz, queue_order));
+    if (rc != AIC_OK || !n || m->ctx.size() == 1) return rc;
+    if (m->light_stale[layer]) return AIC_OK;  // the whole volume is owed already
+    m->light_stale[layer] = true;
+    std::vector<uint8_t> texels((size_t)n * 4);
+    rc = forward(m, 0, aic_read_light_cubes(m->ctx[0], layer, n, xyz, texels.data()));
+    for (size_t i = 1; rc == AIC_OK && i < m->ctx.size(); i++) rc = forward(m, i, aic_update_cubes(m->ctx[i], layer, n, xyz, nullptr, texels.data()));
+    if (rc == AIC_OK) m->light_stale[layer] = false;
+    return AIC_OK;  // device 0 has taken the change; what the others lack is owed (light_stale) and paid by aic_multi_render
 }
 
 int aic_multi_render(aic_multi *m, const aic_frame_desc *f, void *out_rgba8, int out_is_device, aic_frame_info *info) {

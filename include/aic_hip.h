@@ -371,6 +371,9 @@ int aic_evaluate_light(aic_ctx *ctx, int layer, const aic_light_params *params, 
 int aic_light_cubes_changed(aic_ctx *ctx, int layer, uint32_t n, const int32_t *xyz, int queue_order);
 /* the layer's current light volume, [n cubes][4] PackedLight texels, Z-major */
 int aic_read_light_volume(aic_ctx *ctx, int layer, uint8_t *out);
+/* the texels of n cubes, out[n][4] (LightStorage::get, all-is-cubes/src/space/light/data.rs, over a list): served from the
+ * updater's host mirror of the volume when that is current. AIC_ERR_INVALID for a cube outside the space. */
+int aic_read_light_cubes(aic_ctx *ctx, int layer, uint32_t n, const int32_t *xyz, uint8_t *out);
 /* The propagation chart (chart/generator.rs): returns the node count; fills weights[n][6] and children[n][6] when both
  * are non-null, and the depth of the tree. Host-only: needs no device or context. */
 uint32_t aic_light_chart(float *weights, uint32_t *children, uint32_t *depth);
@@ -381,9 +384,10 @@ int aic_probe_derived(aic_ctx *ctx, int layer, float *out, uint8_t *out_opaque);
 int aic_probe_log2f(aic_ctx *ctx, const float *x, uint32_t n, float *out);
 /* aic_evaluate_light on the first device; the resulting light volume is handed to the others (the updater does not shard) */
 int aic_multi_evaluate_light(aic_multi *m, int layer, const aic_light_params *params, aic_light_info *info);
-/* aic_light_cubes_changed on the device that runs the light updater (device 0). What it writes there reaches the other devices with
- * the next aic_multi_evaluate_light, or -- if none comes first -- at the start of the next aic_multi_render: all devices always trace
- * the same light volume. */
+/* aic_light_cubes_changed on the device that runs the light updater (device 0). The texels it writes there (PackedLight::OPAQUE at
+ * the cubes that are now opaque) are scattered into the other devices' volumes before it returns -- n texels, not the volume -- so
+ * all devices always trace the same light volume; if that hand-over fails, the whole volume goes over at the next
+ * aic_multi_evaluate_light or aic_multi_render, whichever comes first. */
 int aic_multi_light_cubes_changed(aic_multi *m, int layer, uint32_t n, const int32_t *xyz, int queue_order);
 
 #ifdef __cplusplus

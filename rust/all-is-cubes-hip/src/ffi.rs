@@ -224,6 +224,7 @@ unsafe extern "C" {
     pub fn aic_evaluate_light(ctx: *mut aic_ctx, layer: c_int, params: *const aic_light_params, info: *mut aic_light_info) -> c_int;
     pub fn aic_light_cubes_changed(ctx: *mut aic_ctx, layer: c_int, n: u32, xyz: *const i32, queue_order: c_int) -> c_int;
     pub fn aic_read_light_volume(ctx: *mut aic_ctx, layer: c_int, out: *mut u8) -> c_int;
+    pub fn aic_read_light_cubes(ctx: *mut aic_ctx, layer: c_int, n: u32, xyz: *const i32, out: *mut u8) -> c_int;
     pub fn aic_light_chart(weights: *mut f32, children: *mut u32, depth: *mut u32) -> u32;
     pub fn aic_probe_derived(ctx: *mut aic_ctx, layer: c_int, out: *mut f32, out_opaque: *mut u8) -> c_int;
     pub fn aic_probe_log2f(ctx: *mut aic_ctx, x: *const f32, n: u32, out: *mut f32) -> c_int;

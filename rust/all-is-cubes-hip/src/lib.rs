@@ -396,8 +396,8 @@ impl HipRtRenderer {
                     // block indices only; the device relights what changed. (A CubeLight message of the host Space lands
                     // here too and is harmless: the cube's block index is rewritten with the value it already has.)
                     device.update_cubes(layer, &xyz, &idx, None)?;
-                    // (several devices: the updater runs on the first; `aic_multi_light_cubes_changed` marks the volume so that the
-                    //  next draw hands it to the others even if no evaluate_light_budgeted comes in between)
+                    // (several devices: the updater runs on the first; `aic_multi_light_cubes_changed` scatters the texels it
+                    //  wrote there into the others' volumes, so the next draw traces the same light on every device)
                     device.light_cubes_changed(layer, &xyz, idx.len() as u32)?;
                 } else {
                     device.update_cubes(layer, &xyz, &idx, Some(&light))?;

@@ -271,6 +271,48 @@ def test_multi_device_light_evaluation(ctx, golden_dir):
     assert np.abs(many.astype(int) - np.load(golden_dir / "png_light_on_slab-Linear-all.npy").astype(int)).max() <= 1
 
 
+def test_multi_device_cubes_changed_reaches_every_device(ctx):
+    """aic_multi_light_cubes_changed: the OPAQUE texels written on the device that runs the updater are scattered into the other
+    devices' volumes (aic_read_light_cubes + aic_update_cubes), so the strips of the next frame carry the same light -- with
+    no evaluate call in between -- and equal the single-context frame. aic_read_light_cubes itself against the volume."""
+    sp = scenes.light_on_slab_space()
+    opt = oracle.unaltered_colors(lighting=3)
+    w, h = 96, 72
+    eye, look = (0.5, -6.0, 6.0), (0.0, 1.0, -1.0)
+    q = oracle.look_at_y_up(eye, tuple(e + l for e, l in zip(eye, look)))
+    _, _, inv = oracle.camera_matrices(45.0, opt.view_distance, w / h, q, eye)
+    d = oracle.compute_derived(oracle.Space(sp))
+    wall = next(i for i in range(len(d["opaque"])) if d["opaque"][i].all() and not d["emission"][i].any())
+    air = [tuple(int(v) + sp.lo[a] for a, v in enumerate(c)) for c in np.argwhere(sp.block_index == 0)]
+    rng = np.random.default_rng(5)
+    near = [c for c in air if abs(c[0]) <= 5 and abs(c[1]) <= 5 and c[2] <= 2]  # in view
+    xyz = np.array([near[i] for i in rng.choice(len(near), 12, replace=False)], np.int32)
+    bi = np.full(len(xyz), wall, np.uint16)
+
+    def run(c):
+        c.upload_space(abi.LAYER_WORLD, sp)
+        c.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+        c.evaluate_light(abi.LAYER_WORLD, 30)
+        before = c.render(abi.Context.make_frame(w, h, world_inv=inv))["rgba8"]
+        c.update_cubes(abi.LAYER_WORLD, xyz, block_index=bi)
+        c.light_cubes_changed(abi.LAYER_WORLD, xyz)
+        return before, c.render(abi.Context.make_frame(w, h, world_inv=inv))["rgba8"]
+
+    ctx.clear_space(abi.LAYER_UI)
+    one_before, one_after = run(ctx)
+    volume = ctx.read_light_volume(abi.LAYER_WORLD, sp.size)
+    probe = np.concatenate([xyz, np.array(air[:40], np.int32)])
+    rel = probe - np.array(sp.lo, np.int32)
+    assert (ctx.read_light_cubes(abi.LAYER_WORLD, probe) == volume[rel[:, 0], rel[:, 1], rel[:, 2]]).all()
+    assert (ctx.read_light_cubes(abi.LAYER_WORLD, xyz) == np.array([0, 0, 0, 128], np.uint8)).all()  # PackedLight::OPAQUE
+    with pytest.raises(abi.AicError):
+        ctx.read_light_cubes(abi.LAYER_WORLD, [[sp.lo[0] - 1, sp.lo[1], sp.lo[2]]])
+    with abi.MultiContext([0, 0, 0]) as m:
+        many_before, many_after = run(m)
+    assert (one_before == many_before).all() and (one_after == many_after).all()
+    assert (one_after != one_before).any()
+
+
 def _modified_cubes_queue(sp, changes):
     """modified_cube_needs_update (updater.rs:135-173) for [(cube, new block index)] applied to `sp` in order, in Python:
     patches sp.block_index / sp.light and returns the queue entries [(cube, priority)] in insertion order."""
