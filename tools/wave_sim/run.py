@@ -20,13 +20,13 @@ class Params(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("width height n_cus wg_per_cu waves_per_wg t_batch n_few frac_t frac_n step_reps fast_steps fast_min "
                                             "c_sched c_fast c_pass c_leave c_shade c_enter c_finish c_refill c_newray").split()] + \
                [(n, ctypes.c_double) for n in "cyc_per_inst cyc_lone lat_step".split()] + \
-               [(n, ctypes.c_int) for n in "pool reservoir c_xchg_base c_xchg_move min_gain policy deposit_free keep_free cold_order".split()]
+               [(n, ctypes.c_int) for n in "pool reservoir c_xchg_base c_xchg_move min_gain policy deposit_free keep_free cold_order retire".split()]
 
 
 class Out(ctypes.Structure):
     _fields_ = [("makespan", ctypes.c_double), ("busy_inst", ctypes.c_double), ("phases", ctypes.c_double * 4), ("lanes", ctypes.c_double * 4)] + \
                [(n, ctypes.c_double) for n in "fast_iters fast_lanes pass_iters pass_lanes trips trip_lanes xchg_rounds xchg_moved sched_rounds".split()] + \
-               [("inst_kind", ctypes.c_double * 6), ("dry_time_median", ctypes.c_double)]
+               [("inst_kind", ctypes.c_double * 6), ("dry_time_median", ctypes.c_double), ("inst_dry", ctypes.c_double), ("retired", ctypes.c_double)]
 
 
 def build_lib():
@@ -115,7 +115,7 @@ def run(lib, tok, off, p, name, clock_ghz=2.3, scale=1.0):
     tot_inst = (o.phases[1] * p.c_shade + o.phases[2] * p.c_enter + o.phases[3] * (p.c_finish + p.c_refill + p.c_newray) + o.fast_iters * p.c_fast + o.pass_iters * p.c_pass)
     print(f"{name:44s} inst {o.busy_inst / 1e6 * scale:7.1f} M  issue-bound {thr_ms * scale:6.3f} ms  one frame {lat_ms:6.3f} ms | phases k: SHADE {ph[1] / 1e3 * scale:6.1f} @{ln[1]:4.1f}  ENTER {ph[2] / 1e3 * scale:5.1f} @{ln[2]:4.1f}  "
           f"RAY {ph[3] / 1e3 * scale:5.1f} @{ln[3]:4.1f}  trips {o.trips / 1e3 * scale:6.1f} @{o.trip_lanes / max(o.trips, 1):4.1f}  fast {o.fast_iters / 1e3 * scale:7.1f} @{o.fast_lanes / max(o.fast_iters, 1):4.1f}  "
-          f"pass {o.pass_iters / 1e3 * scale:6.1f} @{o.pass_lanes / max(o.pass_iters, 1):4.1f} | lane util {tot_lane_inst / 64 / max(tot_inst, 1):.3f}  xchg rounds {o.xchg_rounds / 1e3 * scale:6.1f} k moved {o.xchg_moved / max(o.xchg_rounds, 1):4.1f}  ({time.time() - t0:.1f} s)",
+          f"pass {o.pass_iters / 1e3 * scale:6.1f} @{o.pass_lanes / max(o.pass_iters, 1):4.1f} | lane util {tot_lane_inst / 64 / max(tot_inst, 1):.3f}  xchg rounds {o.xchg_rounds / 1e3 * scale:6.1f} k moved {o.xchg_moved / max(o.xchg_rounds, 1):4.1f}  inst after dry {o.inst_dry / max(o.busy_inst, 1):.3f}  retired {o.retired * scale:.0f}  ({time.time() - t0:.1f} s)",
           flush=True)
     return o
 

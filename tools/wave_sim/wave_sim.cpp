@@ -149,6 +149,8 @@ struct Params {
     int deposit_free;        // deposit minority lanes into free slots (0 / 1)
     int keep_free;           // free slots the deposits leave alone
     int cold_order;          // 1: tiles in index order (cold frame); 0: costliest first
+    int retire;              // > 0: once the queue is dry, a wave with at most this many rays parks all of them (if the slots are free and another wave of
+                             // the workgroup lives) and ends: the frame's tail is run by fewer, fuller waves
 };
 struct Lane { int ray; int pos; int kind; };  // kind: 0 stepping, 1 SHADE, 2 ENTER, 3 RAY (finish/newray), 4 idle (bubble), 5 done
 enum { K_STEP = 0, K_SHADE = 1, K_ENTER = 2, K_RAY = 3, K_IDLE = 4, K_DONE = 5 };
@@ -157,7 +159,7 @@ struct Wave { Lane l[64]; double clock; int wg; int simd; bool done; int tile; i
 
 struct Out {
     double makespan, busy_inst, phases[4], lanes[4], fast_iters, fast_lanes, pass_iters, pass_lanes, trips, trip_lanes, xchg_rounds, xchg_moved,
-        sched_rounds, inst_kind[6], dry_time_median;
+        sched_rounds, inst_kind[6], dry_time_median, inst_dry, retired;
 };
 
 extern "C" int simulate(const char *tok, const long *off, const Params *Pp, Out *O) {
@@ -202,6 +204,7 @@ extern "C" int simulate(const char *tok, const long *off, const Params *Pp, Out 
     std::vector<std::vector<Slot>> pools(n_wg, std::vector<Slot>(P.pool, Slot{-1, 0, -1}));
     const int simds = P.n_cus * 4;
     std::vector<int> simd_active(simds, 0);
+    std::vector<int> live_in_wg(n_wg, P.waves_per_wg);
     for (int i = 0; i < n_waves; i++) {
         Wave &w = waves[i];
         w.wg = i / P.waves_per_wg; w.clock = 0; w.done = false; w.tile = -1; w.next_idx = 64; w.dry = false; w.queues_tried = 0;
@@ -233,10 +236,22 @@ extern "C" int simulate(const char *tok, const long *off, const Params *Pp, Out 
             // nothing left (idle lanes with an empty pool and a dry queue are done)
             bool any_idle_can_take = false;
             if (!w.dry && cnt[K_IDLE]) any_idle_can_take = true;
-            if (!any_idle_can_take) { w.done = true; simd_active[w.simd]--; O->makespan = std::max(O->makespan, w.clock); continue; }
+            if (!any_idle_can_take) { w.done = true; simd_active[w.simd]--; live_in_wg[w.wg]--; O->makespan = std::max(O->makespan, w.clock); continue; }
         }
         double inst = P.c_sched;
         int n_dep = 0;  // dependent lookups in this round (latency floor)
+        if (P.retire != 0 && P.pool > 0 && w.dry && alive_own > 0 && alive_own <= std::abs(P.retire) && pc[4] >= alive_own && live_in_wg[w.wg] > 1) {
+            for (auto &l : w.l) if (l.kind <= K_RAY) {
+                if (l.ray >= 0 || l.kind != K_RAY) { for (auto &sl : pool) if (sl.kind < 0) { sl = Slot{l.ray, l.pos, l.kind}; break; } }
+                l.ray = -1; l.kind = K_DONE;
+            }
+            inst += P.c_xchg_base + P.c_xchg_move;
+            O->busy_inst += inst; O->inst_dry += inst; O->retired++;
+            const int na_ = std::max(1, simd_active[w.simd]);
+            w.clock += inst * std::max(P.cyc_lone, P.cyc_per_inst * na_);
+            w.done = true; simd_active[w.simd]--; live_in_wg[w.wg]--; O->makespan = std::max(O->makespan, w.clock);
+            continue;
+        }
         O->sched_rounds++;
         // ---- choose the kind to run (the kernel's rule) ----
         auto choose = [&](const int c[4], int n_step_lanes) -> int {
@@ -258,7 +273,7 @@ extern "C" int simulate(const char *tok, const long *off, const Params *Pp, Out 
         for (int k = 0; k < 4; k++) {
             const int mine = cnt[k] + ((k == K_RAY && P.reservoir && !w.dry) ? cnt[K_IDLE] : 0);
             int a = P.pool > 0 ? std::min(pc[k], 64 - cnt[k] - cnt[K_DONE]) : 0;
-            if (a < P.min_gain && mine > 0) a = 0;
+            if (a < ((w.dry && P.retire < 0) ? 1 : P.min_gain) && mine > 0) a = 0;  // (retire < 0: as -retire, and a dry wave tops up by any number)
             add[k] = a; total[k] = mine + a;
         }
         if (P.pool > 0 && P.policy >= 1) {
@@ -386,6 +401,7 @@ extern "C" int simulate(const char *tok, const long *off, const Params *Pp, Out 
         }
         if (run != K_STEP) { O->phases[run]++; O->lanes[run] += served; }
         O->busy_inst += inst;
+        if (w.dry) O->inst_dry += inst;
         const int na = std::max(1, simd_active[w.simd]);
         const double dur = std::max(inst * std::max(P.cyc_lone, P.cyc_per_inst * na), inst * P.cyc_lone + n_dep * P.lat_step);
         w.clock += dur;
