@@ -265,7 +265,7 @@ extern "C" int simulate(const char *tok, const long *off, const Params *Pp, Out 
             if (best > 0 && (best >= t_batch || n_step_lanes <= n_few)) return kind;
             return K_STEP;
         };
-        int run;
+        int run = K_STEP;
         int own[4] = {cnt[K_STEP], cnt[K_SHADE], cnt[K_ENTER], cnt[K_RAY] + ((!w.dry) ? cnt[K_IDLE] * P.reservoir : 0)};
         if (P.pool > 0) inst += P.c_xchg_base;
         // what a kind would run with if chosen: own lanes + what the pool adds (a top-up below min_gain is not made, unless the wave has none of its own)
@@ -276,16 +276,34 @@ extern "C" int simulate(const char *tok, const long *off, const Params *Pp, Out 
             if (a < ((w.dry && P.retire < 0) ? 1 : P.min_gain) && mine > 0) a = 0;  // (retire < 0: as -retire, and a dry wave tops up by any number)
             add[k] = a; total[k] = mine + a;
         }
-        if (P.pool > 0 && P.policy >= 1) {
+        if (P.pool > 0 && P.policy >= 1 && P.policy != 3) {
             // the kind that fills the wave best; events ahead of stepping on ties and once they fill 3/4 of the wave
             run = K_STEP; int best = total[K_STEP];
             for (int k = 1; k < 4; k++) if (total[k] > best || (total[k] == best && best > 0) || (P.policy == 2 && total[k] >= 48)) { best = total[k]; run = k; if (P.policy == 2 && total[k] >= 48) break; }
-        } else {
+        } else if (P.policy != 3) {
             run = choose(own, cnt[K_STEP]);
             if (total[run] == 0) { int best = 0; for (int k = 0; k < 4; k++) if (total[k] > best) { best = total[k]; run = k; } }
         }
+        // (policy 3: the kernel's rule as built -- a wave with 48 lanes of one kind runs it as it is; otherwise the kind with the most own + parked lanes, and an
+        //  exchange only for a top-up of min_gain lanes, for a kind the wave has none of, or to park at least 8 lanes)
+        bool do_exchange = P.pool > 0;
+        if (P.pool > 0 && P.policy == 3) {
+            int cm = own[K_STEP]; run = K_STEP;
+            for (int k = 1; k < 4; k++) if (own[k] >= cm) { cm = own[k]; run = k; }
+            if (cm >= 48) do_exchange = false;
+            else {
+                int best = -1;
+                for (int k = 0; k < 4; k++) { const int t = std::min(64, own[k] + pc[k]); if (t >= best) { best = t; run = k; } }
+                const int mine = own[run];
+                const int alive = own[0] + own[1] + own[2] + own[3];
+                const int n_others = alive - mine;
+                const bool may_park = !w.dry && pc[4] > 0 && n_others > 0;
+                do_exchange = best - mine >= P.min_gain || (mine == 0 && best > 0) || (may_park && n_others >= 8);
+                for (int k = 0; k < 4; k++) add[k] = std::min(pc[k], 64 - cnt[k] - cnt[K_DONE]);
+            }
+        }
         // ---- exchange: top the chosen kind up from the pool; deposit minority lanes ----
-        if (P.pool > 0) {
+        if (do_exchange) {
             int moved = 0;
             // lanes that can give: not of kind `run`, not done. Order: idle first, then the kinds with the fewest lanes in this wave
             std::vector<int> givers;
