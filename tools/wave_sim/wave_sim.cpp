@@ -182,6 +182,17 @@ extern "C" int simulate(const char *tok, const long *off, const Params *Pp, Out 
     std::vector<std::vector<int>> queue(NQ);
     for (int m = 0; m < n_macro; m++) { int mx = m % macros_x, my = m / macros_x; queue[((mx / sb) + 3 * (my / sb)) % NQ].push_back(m); }
     if (!P.cold_order) for (auto &q : queue) std::stable_sort(q.begin(), q.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+    if (P.cold_order == 2) for (auto &q : queue) {  // no cost record, but not index order either: a stride permutation of the queue (golden-ratio stride, made coprime)
+        const size_t n = q.size(); if (n < 3) continue;
+        size_t st = (size_t)(n * 0.6180339887); if (st < 1) st = 1;
+        auto gcd = [](size_t a, size_t b) { while (b) { size_t t = a % b; a = b; b = t; } return a; };
+        while (gcd(st, n) != 1) st++;
+        std::vector<int> r(n); for (size_t i = 0; i < n; i++) r[i] = q[(i * st) % n];
+        q.swap(r);
+    }
+    if (P.cold_order == 3) for (auto &q : queue) {  // bottom-up / reversed index order
+        std::reverse(q.begin(), q.end());
+    }
     std::vector<size_t> qpos(NQ, 0);  // in tiles: 4 per macro
     auto take_tile = [&](Wave &w) -> bool {  // sets w.tile (tile index) ; false when everything is handed out
         int xcd = (w.wg % NQ);
