@@ -1172,7 +1172,10 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
         int c_shade = (int)wave_popc(b_shade), c_enter = (int)wave_popc(b_enter), c_ray = (int)wave_popc(b_ray);
         uint32_t run = 0u;  // kind to run this trip (an EV_* bit), 0 = step
         u32x4 cs_early = u32x4{0u, 0u, 0u, 0u};
-        if constexpr (XCHG) cs_early = *reinterpret_cast<volatile u32x4 *>(&s_census);  // (issued here, waited for where the counts are used: behind the ballots and counts above)
+        // (issued here, waited for where the counts are used: behind the ballots and counts above. A plain LDS load behind a compiler barrier, so that it is made
+        //  again in every round: through a `volatile` pointer it was compiled as a FLAT load -- address-space inference leaves volatile accesses alone -- followed
+        //  by s_waitcnt vmcnt(0), i.e. every scheduler round waited for every store the wave still had in flight)
+        if constexpr (XCHG) { asm volatile("" ::: "memory"); cs_early = s_census; }
         if constexpr (XCHG) {
             // ---- regime-sorted waves: run the kind that fills the wave best, own lanes plus what the workgroup's pool can add ----
             // what this round's exchange (if any) decided: the lanes whose claim succeeded, those of them that took a spare column, the slot's address and
