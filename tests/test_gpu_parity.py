@@ -914,6 +914,63 @@ def test_device_side_handoff_orders_a_foreign_stream_behind_the_trace():
             c.close()
 
 
+def test_opaque_shortcut_counts_on_a_blocks_last_voxel(ctx):
+    """the production variants end a ray on an opaque surface without taking the reference's remaining counted steps -- they work them out from the
+    steps the level has left and from whether the suspended cube grid can still step. The cases where that reasoning is thinnest, per pixel (debug_pixel_cost
+    through the float output): the opaque voxel is the LAST one of its block along the ray (the voxel level ends with it) or of a partly stored volume, in a
+    block at the space's far edge (the cube grid ends with it too) and in one with cubes behind it; seen head-on, diagonally, and from inside the block; for
+    Surface, Volumetric and Threshold transparency; plain and lane-exchanging variants against the aux-recording variant and the oracle."""
+    res = 4
+    pal = np.zeros((3, 8), np.float32)
+    pal[1] = (0.8, 0.3, 0.2, 1.0, 0, 0, 0, 0)   # opaque
+    pal[2] = (0.2, 0.4, 0.9, 0.5, 0, 0, 0, 0)   # translucent
+    blocks = []
+    for axis in range(3):
+        v = np.zeros((res, res, res), np.uint16)
+        idx = [slice(None)] * 3
+        idx[axis] = res - 1
+        v[tuple(idx)] = 1                       # an opaque wall on the block's far face along `axis`
+        idx[axis] = 1
+        v[tuple(idx)] = 2                       # a translucent sheet in front of it
+        blocks.append(flat.voxel_block(res, v, pal))
+        blocks.append(flat.voxel_block(res, np.ascontiguousarray(v[:, :, :res - 1] if axis != 2 else v[:res - 1]), pal))  # part of the volume stored
+    low = np.zeros((res, res, res), np.uint16)
+    low[0, 0, 0] = 1                            # ... and on the near corner: the last voxel going the other way
+    blocks.append(flat.voxel_block(res, low, pal))
+    sp = flat.FlatSpace((-1, 0, -2), (3, 2, 3))
+    sp.set_sky_uniform((0.4, 0.5, 0.9))
+    sp.add_block(flat.air())
+    ids = [sp.add_block(b) for b in blocks]
+    rng = np.random.default_rng(11)
+    for c in np.ndindex(3, 2, 3):               # every cube holds one of the blocks or air: far-edge cubes, interior cubes, neighbours behind and none
+        sp.block_index[c] = 0 if rng.random() < 0.25 else ids[int(rng.integers(0, len(ids)))]
+    sp.light[...] = (200, 180, 160, 255)
+    w, h = 72, 56
+    views = [((-4.0, 1.0, -0.5), (0.5, 1.0, -0.5)), ((0.5, 1.0, 5.0), (0.5, 1.0, -0.5)), ((0.5, 6.0, -0.5), (0.5, 0.0, -0.4)), ((4.5, 3.5, 3.0), (0.5, 1.0, -0.5)),
+             ((0.6, 0.7, -0.4), (2.0, 0.9, -1.9)), ((3.5, 1.0, -0.5), (0.5, 1.0, -0.5))]
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    for transparency in (0, 1, 2):
+        opt = oracle.make_options(transparency=transparency, threshold=0.4, lighting=1, debug_pixel_cost=True)
+        ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+        for eye, target in views:
+            _, _, inv = oracle.camera_matrices(70.0, opt.view_distance, w / h, oracle.look_at_y_up(eye, target), eye)
+            fr = ctx.make_frame(w, h, world_inv=inv)
+            got = ctx.render(fr, want_aux=True)
+            ref = oracle.render(oracle.Space(sp), opt, oracle.make_camera(inv, w, h), want_aux=True)
+            assert_parity(got, ref)
+            assert_production_variants(ctx, fr, got)
+            for tiles in (None, "0"):          # the per-pixel counts of the plain and of the lane-exchanging production variant
+                if tiles is not None:
+                    os.environ["AIC_XCHG_TILES"] = tiles
+                try:
+                    cost = ctx.render(ctx.make_frame(w, h, world_inv=inv, flags=abi.FRAME_OUT_LINEAR))
+                finally:
+                    os.environ.pop("AIC_XCHG_TILES", None)
+                counts = np.rint(cost["rgba8"][..., 1].astype(np.float64) / float(np.float32(0.002))).astype(np.int64)
+                assert (counts == ref["aux"]["cubes_traced"]).all(), (transparency, eye, tiles)
+
+
 def test_block_table_past_14_bits_uses_the_class_table(ctx):
     """More than 16384 blocks: cube-grid entries can no longer carry the class bits (aic_device.h), the
     kernel classifies through the LDS table; growing past the limit by replace_block re-tags the grid."""
