@@ -20,7 +20,7 @@ class Params(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("width height n_cus wg_per_cu waves_per_wg t_batch n_few frac_t frac_n step_reps fast_steps fast_min "
                                             "c_sched c_fast c_pass c_leave c_shade c_enter c_finish c_refill c_newray").split()] + \
                [(n, ctypes.c_double) for n in "cyc_per_inst cyc_lone lat_step".split()] + \
-               [(n, ctypes.c_int) for n in "pool reservoir c_xchg_base c_xchg_move min_gain policy deposit_free keep_free cold_order retire".split()]
+               [(n, ctypes.c_int) for n in "pool reservoir c_xchg_base c_xchg_move min_gain policy deposit_free keep_free cold_order hot retire".split()]
 
 
 class Out(ctypes.Structure):

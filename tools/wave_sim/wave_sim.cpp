@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <queue>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -149,6 +150,7 @@ struct Params {
     int deposit_free;        // deposit minority lanes into free slots (0 / 1)
     int keep_free;           // free slots the deposits leave alone
     int cold_order;          // 1: tiles in index order (cold frame); 0: costliest first
+    int hot;                 // > 0 (with cold_order 1): a ray of more than this many tokens that finishes puts the 8 macro tiles around its own ahead of the queue
     int retire;              // > 0: once the queue is dry, a wave with at most this many rays parks all of them (if the slots are free and another wave of
                              // the workgroup lives) and ends: the frame's tail is run by fewer, fuller waves
 };
@@ -194,7 +196,11 @@ extern "C" int simulate(const char *tok, const long *off, const Params *Pp, Out 
         std::reverse(q.begin(), q.end());
     }
     std::vector<size_t> qpos(NQ, 0);  // in tiles: 4 per macro
+    std::vector<char> mstate(n_macro, 0);  // (hot) 0 untouched, 1 started from the queue, 2 claimed by the hot list
+    std::deque<int> hotq;                  // (hot) tiles handed out ahead of the queue
+    long hot_pushed = 0;
     auto take_tile = [&](Wave &w) -> bool {  // sets w.tile (tile index) ; false when everything is handed out
+        if (P.hot != 0 && !hotq.empty()) { w.tile = hotq.front(); hotq.pop_front(); w.next_idx = 0; return true; }
         int xcd = (w.wg % NQ);
         while (w.queues_tried < NQ) {
             int q = (xcd + w.queues_tried) % NQ;
@@ -203,12 +209,30 @@ extern "C" int simulate(const char *tok, const long *off, const Params *Pp, Out 
                 int m = queue[q][u / 4], inner = (int)(u % 4);
                 int tx = (m % macros_x) * 2 + (inner & 1), ty = (m / macros_x) * 2 + (inner >> 1);
                 if (tx >= tiles_x || ty >= tiles_y) continue;
+                if (P.hot != 0) { if (mstate[m] == 2) continue; mstate[m] = 1; }
                 w.tile = ty * tiles_x + tx; w.next_idx = 0;
                 return true;
             }
             w.queues_tried++;
         }
         return false;
+    };
+    std::vector<char> flagged(n_macro, 0);
+    auto push_hot = [&](int ray) {
+        const int rx = (ray % W) / 16, ry = (ray / W) / 16;
+        if (flagged[ry * macros_x + rx]) return;
+        flagged[ry * macros_x + rx] = 1;
+        for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
+            const int nx = rx + dx, ny = ry + dy;
+            if ((dx == 0 && dy == 0) || nx < 0 || ny < 0 || nx >= macros_x || ny >= macros_y) continue;
+            const int nm = ny * macros_x + nx;
+            if (mstate[nm] != 0) continue;
+            mstate[nm] = 2; hot_pushed++;
+            for (int inner = 0; inner < 4; inner++) {
+                const int tx = nx * 2 + (inner & 1), ty = ny * 2 + (inner >> 1);
+                if (tx < tiles_x && ty < tiles_y) hotq.push_back(ty * tiles_x + tx);
+            }
+        }
     };
     const int n_wg = P.n_cus * P.wg_per_cu, n_waves = n_wg * P.waves_per_wg;
     std::vector<Wave> waves(n_waves);
@@ -239,6 +263,7 @@ extern "C" int simulate(const char *tok, const long *off, const Params *Pp, Out 
         Wave &w = waves[wi];
         int cnt[6] = {0, 0, 0, 0, 0, 0};
         for (auto &l : w.l) cnt[l.kind]++;
+        if (P.hot < 0) for (auto &l : w.l) if (l.kind <= K_RAY && l.ray >= 0 && l.pos > -P.hot) push_hot(l.ray);  // (hot < 0: a ray IN FLIGHT past -hot tokens flags its tile)
         std::vector<Slot> &pool = pools[w.wg];
         int pc[5] = {0, 0, 0, 0, 0};  // pool census by kind; [4] free
         for (auto &s : pool) pc[s.kind < 0 ? 4 : s.kind]++;
@@ -372,6 +397,7 @@ extern "C" int simulate(const char *tok, const long *off, const Params *Pp, Out 
             bool refilled = false;
             for (auto &l : w.l) if (l.kind == K_RAY || (l.kind == K_IDLE && P.reservoir && !w.dry)) {
                 served++;
+                if (P.hot > 0 && l.ray >= 0 && raylen(l.ray) > P.hot) push_hot(l.ray);  // a costly ray ends: its macro tile's neighbours are likely costly too
                 // finish (if it holds a ray), then take a pixel
                 for (;;) {
                     if (w.next_idx >= 64) { if (w.dry || !take_tile(w)) { if (!w.dry) { w.dry = true; dry_times.push_back(w.clock); } break; } }
