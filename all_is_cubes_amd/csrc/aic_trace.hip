@@ -1042,7 +1042,8 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
         if (tid == 0u) s_census = u32x4{0u, 0u, 0u, 0u};
         __syncthreads();
     }
-    bool dry = false;                               // wave-uniform: this wave has seen the tile queue exhausted
+    uint32_t dry = 0u;                              // wave-uniform, 0 / 1: this wave has seen the tile queue exhausted (a word, not a bool: a bool that the compiler
+                                                    // cannot prove uniform is kept as a lane mask, and every read of it costs six instructions)
     // The tile queue this wave takes from (DevFrame::n_queues > 1): its XCD's own to begin with, the next one's when that is empty. How many queues it has
     // seen empty is a word of LDS per wave, read once per tile -- kept in a scalar register for the life of the wave it cost the production variant
     // four spilled VGPRs (12 bytes of scratch per lane, 1.2 GB of scratch written back per C3 frame: profiles/r04_experiments.txt K).
@@ -1081,7 +1082,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
 #ifdef AIC_TAIL_PROF
 // phase clocks after the wave saw the queue dry go to slots 24.. instead (12 step, 13+18 shade, 14 enter, 15-17 ray, 19 scheduler)
 #define AIC_TICK(i) { const uint32_t now_ = (uint32_t)__builtin_readcyclecounter(); const int j_ = (i) == 12 ? 24 : (i) == 13 || (i) == 18 ? 25 : (i) == 14 ? 26 : (i) == 19 ? 28 : 27; \
-                      if (lane == 0u) prof[__builtin_amdgcn_readfirstlane(dry ? 1 : 0) ? j_ : (i)] += now_ - prof_tm; prof_tm = now_; }
+                      if (lane == 0u) prof[__builtin_amdgcn_readfirstlane((int)dry) ? j_ : (i)] += now_ - prof_tm; prof_tm = now_; }
 #else
 #define AIC_TICK(i) { const uint32_t now_ = (uint32_t)__builtin_readcyclecounter(); if (lane == 0u) prof[i] += now_ - prof_tm; prof_tm = now_; }
 #endif
@@ -1171,60 +1172,59 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
         int n_step = (int)wave_popc(m_st);
         int c_shade = (int)wave_popc(b_shade), c_enter = (int)wave_popc(b_enter), c_ray = (int)wave_popc(b_ray);
         uint32_t run = 0u;  // kind to run this trip (an EV_* bit), 0 = step
-        u32x4 cs_early = u32x4{0u, 0u, 0u, 0u};
-        // (issued here, waited for where the counts are used: behind the ballots and counts above. A plain LDS load behind a compiler barrier, so that it is made
-        //  again in every round: through a `volatile` pointer it was compiled as a FLAT load -- address-space inference leaves volatile accesses alone -- followed
-        //  by s_waitcnt vmcnt(0), i.e. every scheduler round waited for every store the wave still had in flight)
-        if constexpr (XCHG) { asm volatile("" ::: "memory"); cs_early = s_census; }
         if constexpr (XCHG) {
             // ---- regime-sorted waves: run the kind that fills the wave best, own lanes plus what the workgroup's pool can add ----
             // what this round's exchange (if any) decided: the lanes whose claim succeeded, those of them that took a spare column, the slot's address and
             // index, the tag the slot is released under, the kind taken (the swap itself sits on the round's common path, below)
             unsigned long long x_got = 0ull, x_fresh = 0ull;
-            uint32_t x_paddr = 0u, x_slot = 0u, x_tag = TAG_FREE, x_want = 0u;
-            // a wave that is full of one kind as it stands (AIC_XCHG_FULL lanes) runs it without looking at the pool
+            // (left undefined in a round without an exchange -- nothing reads them under an empty mask -- rather than zeroed: four vector moves in every round)
+            // (two vector registers and a scalar carried to the swap: each one zeroed in a round without an exchange is an instruction in every round)
+            uint32_t x_paddr = 0u, x_slot_tag = 0u;  // the slot's address; its index | the released tag << 8
+            uint32_t x_want = 0u;                    // (wave-uniform)
+            // a wave that is full of one kind as it stands (AIC_XCHG_FULL lanes: at most one kind can be) runs it without looking at the pool
+            static_assert(AIC_XCHG_FULL > 32, "two kinds could both be full");
+            static_assert(EV_SHADE == (2u << 1) && EV_ENTER == (2u << 2) && EV_FINISH == (2u << 3), "the kinds' event bits");
+            bool settled = true;  // the kind's own lanes are known to be there (no look at the counts after the exchange)
             {
-                int cm = n_step;
-                if (c_shade >= cm) { cm = c_shade; run = EV_SHADE; }
-                if (c_enter >= cm) { cm = c_enter; run = EV_ENTER; }
-                if (c_ray >= cm) { cm = c_ray; run = EV_FINISH; }
-                if (cm < AIC_XCHG_FULL) run = 0xffffffffu;
+                // (the partial maxima through opaque_s: fused, the three become a v_max3 with two copies in front and a v_readfirstlane behind)
+                const int m01 = opaque_s(n_step > c_shade ? n_step : c_shade), m23 = opaque_s(c_enter > c_ray ? c_enter : c_ray);
+                if ((m01 > m23 ? m01 : m23) >= AIC_XCHG_FULL) run = c_ray >= AIC_XCHG_FULL ? EV_FINISH : (c_enter >= AIC_XCHG_FULL ? EV_ENTER : (c_shade >= AIC_XCHG_FULL ? EV_SHADE : 0u));
+                else run = 0xffffffffu;
             }
             if (run == 0xffffffffu) {
-            run = 0u;
-            const u32x4 cs = cs_early;  // parked rays by kind (advisory: a count can run a claim ahead of or behind the tags), read at the top of the round
-            const int pk_step = opaque_s(__builtin_amdgcn_readfirstlane((int)cs.x)), pk_shade = opaque_s(__builtin_amdgcn_readfirstlane((int)cs.y)),
-                      pk_enter = opaque_s(__builtin_amdgcn_readfirstlane((int)cs.z)), pk_ray = opaque_s(__builtin_amdgcn_readfirstlane((int)cs.w));
-            const int parked = (pk_step > 0 ? pk_step : 0) + (pk_shade > 0 ? pk_shade : 0) + (pk_enter > 0 ? pk_enter : 0) + (pk_ray > 0 ? pk_ray : 0);
-            const int alive = n_step + c_shade + c_enter + c_ray;
-            if (alive == 0 && parked == 0) break;  // nothing of its own and nothing parked: whoever parks a ray later is running and serves it
-            // what a kind would run with: its own lanes + the parked rays that fit into the wave's other lanes
-            auto total_of = [](int mine, int pk) -> int {  // (three scalar instructions)
-                const int all = mine + (pk > 0 ? pk : 0);
-                return all < 64 ? all : 64;
+            // parked rays by kind, read at the top of the round. A count is never BEHIND the tags (a parked ray is counted before its slot is released, and taken
+            // off after it is claimed), so it is never negative and "every count zero" means that no claimable ray is parked; it can run AHEAD of them (a ray
+            // claimed by another wave and not yet taken off): then the kind chosen for it may find nothing, which the end of the round handles.
+            // (A plain LDS load behind a compiler barrier, so that it is made again in every round: through a `volatile` pointer it was compiled as a FLAT load --
+            //  address-space inference leaves volatile accesses alone -- followed by s_waitcnt vmcnt(0), i.e. every scheduler round waited for every store the
+            //  wave still had in flight. Made here, not at the top of the round: a wave that is full of one kind does not wait for counts it does not read.)
+            asm volatile("" ::: "memory");
+            const u32x4 cs = s_census;
+            const int pk_step = __builtin_amdgcn_readfirstlane((int)cs.x), pk_shade = __builtin_amdgcn_readfirstlane((int)cs.y),
+                      pk_enter = __builtin_amdgcn_readfirstlane((int)cs.z), pk_ray = __builtin_amdgcn_readfirstlane((int)cs.w);
+            // the kind with the most lanes -- its own + the parked rays that fit into the wave's other lanes; ties go to the events, the later kind first (a
+            // parked event lane blocks its ray, a stepping lane can wait): the four totals as keys  total << 9 | kind << 7 | own lanes  and one maximum
+            // (kind: 0 stepping, 1 SHADE, 2 ENTER, 3 RAY; EV_SHADE / EV_ENTER / EV_FINISH = 2 << kind)
+            auto key_of = [](int own, int pk, int kind) -> int {
+                const int all = own + pk;
+                return ((all < 64 ? all : 64) << 9) | (kind << 7) | own;
             };
-            // the kind with the most lanes; ties go to the events, the later kind first (a parked event lane blocks its ray, a stepping lane can wait): the
-            // four totals as keys  total << 2 | kind  and one maximum (kind: 0 stepping, 1 SHADE, 2 ENTER, 3 RAY; EV_SHADE / EV_ENTER / EV_FINISH = 2 << kind)
-            const int key0 = total_of(n_step, pk_step) << 2, key1 = (total_of(c_shade, pk_shade) << 2) | 1, key2 = (total_of(c_enter, pk_enter) << 2) | 2,
-                      key3 = (total_of(c_ray, pk_ray) << 2) | 3;
-            const int ka = key0 > key1 ? key0 : key1, kb = key2 > key3 ? key2 : key3, kmax = ka > kb ? ka : kb;
-            const int best = kmax >> 2, kind = kmax & 3;
-            const int mine = kind == 0 ? n_step : (kind == 1 ? c_shade : (kind == 2 ? c_enter : c_ray));
+            const int key0 = key_of(n_step, pk_step, 0), key1 = key_of(c_shade, pk_shade, 1), key2 = key_of(c_enter, pk_enter, 2), key3 = key_of(c_ray, pk_ray, 3);
+            const int ka = opaque_s(key0 > key1 ? key0 : key1), kb = opaque_s(key2 > key3 ? key2 : key3), kmax = ka > kb ? ka : kb;
+            if (kmax < 512) break;  // nothing of its own and nothing parked: whoever parks a ray later is running and serves it
+            const int best = kmax >> 9, kind = (kmax >> 7) & 3, mine = kmax & 127;
             run = kind == 0 ? 0u : (2u << kind);
-            static_assert(EV_SHADE == (2u << 1) && EV_ENTER == (2u << 2) && EV_FINISH == (2u << 3), "the kinds' event bits");
-            if (best == 0) {  // only rays in transit between two waves: look again shortly (bounded: a wave never waits for another for good)
-                AIC_PROF(36, 1);
-                if (spun_out()) break;
-                __builtin_amdgcn_s_sleep(8);
-                continue;
-            }
+            settled = mine != 0;
             AIC_TICK(19);
-            const bool dry_u = __builtin_amdgcn_readfirstlane(dry ? 1 : 0) != 0;
+            const bool dry_u = __builtin_amdgcn_readfirstlane((int)dry) != 0;
+            const int alive = n_step + c_shade + c_enter + c_ray, parked = pk_step + pk_shade + pk_enter + pk_ray;
             const int n_others = alive - mine - ((AIC_XCHG_DEPOSIT < 3 && run != 0u) ? n_step : 0);  // lanes holding a ray that will not run now (and may be parked)
-            const bool may_park = AIC_XCHG_DEPOSIT != 0 && !dry_u && parked < (int)NPOOL && n_others > 0;
+            const bool park_ok = AIC_XCHG_DEPOSIT != 0 && !dry_u && parked < (int)NPOOL;
             // (an exchange costs a few hundred instructions: it is made for a top-up of at least AIC_XCHG_MIN_GAIN lanes, for a kind the wave has none of, or to
             //  park at least AIC_XCHG_PARK_MIN lanes)
-            if (best - mine >= AIC_XCHG_MIN_GAIN || (mine == 0 && best > 0) || (may_park && n_others >= AIC_XCHG_PARK_MIN)) {
+            static_assert(AIC_XCHG_PARK_MIN > 0, "parking wants lanes to park");
+            if (best - mine >= AIC_XCHG_MIN_GAIN || mine == 0 || (park_ok && n_others >= AIC_XCHG_PARK_MIN)) {
+                const bool may_park = park_ok && n_others > 0;
                 // ---- the exchange: lanes that would idle ("givers": empty lanes first, then rays of other kinds) are paired with parked rays of the wanted
                 // kind, and -- while the image has pixels left -- what remains of them with free slots. A pairing is a claim (compare-and-swap of the slot's
                 // tag), a plain swap of the 40 hot dwords and the column index, and the release of the slot under the tag of what it now holds. ----
@@ -1288,7 +1288,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 x_got = __builtin_amdgcn_ballot_w64(got);
                 x_fresh = x_got & ~__builtin_amdgcn_ballot_w64(takes);
                 x_paddr = (uint32_t)(uintptr_t)&s_pool[0][0] + slot * 160u;
-                x_slot = slot; x_tag = my_tag; x_want = want;
+                x_slot_tag = slot | (my_tag << 8); x_want = want;
                 AIC_PROF(37, wave_popc(__builtin_amdgcn_ballot_w64(takes | parks)) - wave_popc(x_got));  // claims lost to another wave
                 if (x_got == 0ull) { AIC_PROF(38, 1); }  // an exchange that moved nothing
             }
@@ -1376,11 +1376,13 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
             }
             if (x_got != 0ull) {
                 const bool got = __builtin_amdgcn_inverse_ballot_w64(x_got), fresh = __builtin_amdgcn_inverse_ballot_w64(x_fresh);
-                if (got) __hip_atomic_store(&s_tag[x_slot], x_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // the slot is released under the tag of what it now holds
-                // the counts: every lane that parked a ray adds it to its kind (LDS atomics on one word each: a few cycles per lane, two instructions),
-                // one lane takes off what was taken
+                // the counts: every lane that parked a ray adds it to its kind (LDS atomics on one word each: a few cycles per lane, two instructions) BEFORE
+                // its slot is released under the tag of what it now holds -- LDS operations of a wave are performed in order, so no wave can claim the ray, and
+                // take it off the count, before it is on it: a count is never negative; one lane takes off what was taken
                 const uint32_t n_picked = wave_popc(x_got & ~x_fresh);
+                const uint32_t x_slot = x_slot_tag & 255u, x_tag = x_slot_tag >> 8;
                 if (got && x_tag != TAG_FREE) atomicAdd(reinterpret_cast<uint32_t *>(&s_census) + (x_tag - 1u), 1u);
+                if (got) __hip_atomic_store(&s_tag[x_slot], x_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (lane == 0u && n_picked != 0u) atomicSub(reinterpret_cast<uint32_t *>(&s_census) + (x_want - 1u), n_picked);
                 (void)fresh;
                 AIC_PROF(31, 1);
@@ -1395,7 +1397,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 c_shade = (int)wave_popc(b_shade); c_enter = (int)wave_popc(b_enter); c_ray = (int)wave_popc(b_ray);
                 AIC_TICK(33);
             }
-            if ((run == 0u ? n_step : (run == EV_SHADE ? c_shade : (run == EV_ENTER ? c_enter : c_ray))) == 0) {
+            if (!settled && (run == 0u ? n_step : (run == EV_SHADE ? c_shade : (run == EV_ENTER ? c_enter : c_ray))) == 0) {
                 // (the kind was chosen for what the pool holds, and every claim was lost to another wave -- or only rays in transit were found)
                 AIC_PROF(36, 1);
                 if (spun_out()) break;
@@ -1461,7 +1463,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
             AIC_PROF(0, 1);
             AIC_PROF(1, c_shade + c_enter + c_ray);
 #ifdef AIC_TAIL_PROF
-            if (__builtin_amdgcn_readfirstlane(dry ? 1 : 0)) { tail_events++; AIC_PROF(30, 1); }
+            if (__builtin_amdgcn_readfirstlane((int)dry)) { tail_events++; AIC_PROF(30, 1); }
 #endif
             AIC_PROF(4, run == EV_SHADE ? 1 : 0); AIC_PROF(5, run == EV_SHADE ? c_shade : 0);
             AIC_PROF(6, run == EV_ENTER ? 1 : 0); AIC_PROF(7, run == EV_ENTER ? c_enter : 0);
@@ -1983,14 +1985,14 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                                 if (queues_tried != tried_before && lane == 0u) s_queues_tried[threadIdx.x >> 6] = queues_tried;
                             } else {
                                 if ((int)lane == leader) t = atomicAdd(&F.counters->tile_next, 1u);
-                                t = (uint32_t)__shfl((int)t, leader, 64);
+                                t = (uint32_t)__builtin_amdgcn_readlane((int)t, leader);  // (a scalar: what depends on it -- `dry` -- stays wave-uniform for the compiler)
                             }
                         }
                         if (t >= n_virtual) {  // image exhausted
 #ifdef AIC_PROFILE
                             if (lane == 0u && prof[2] == 0u) prof[2] = (uint32_t)__builtin_readcyclecounter() - prof_t0;  // wave saw the queue run dry
 #endif
-                            dry = true;
+                            dry = 1u;
                             next_idx = tile_px;
                             if (want) ev = EV_DONE;  // these lanes are done
                             break;
@@ -2205,7 +2207,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
         AIC_PROF(22, 1);
         AIC_PROF(23, __popcll(m_act));
 #ifdef AIC_TAIL_PROF
-        if (__builtin_amdgcn_readfirstlane(dry ? 1 : 0)) { tail_trips++; tail_lanes += (uint32_t)__popcll(m_act); AIC_PROF(29, 1); }
+        if (__builtin_amdgcn_readfirstlane((int)dry)) { tail_trips++; tail_lanes += (uint32_t)__popcll(m_act); AIC_PROF(29, 1); }
 #endif
 #define AIC_LANE(m) __builtin_amdgcn_inverse_ballot_w64(m)
 // Waits for a lookup issued into `raw` by an earlier asm statement. The loaded register goes in as a plain INPUT and the code comes
