@@ -1291,9 +1291,6 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 x_slot_tag = slot | (my_tag << 8); x_want = want;
                 AIC_PROF(37, wave_popc(__builtin_amdgcn_ballot_w64(takes | parks)) - wave_popc(x_got));  // claims lost to another wave
                 if (x_got == 0ull) { AIC_PROF(38, 1); }  // an exchange that moved nothing
-            }
-            }
-            else { AIC_TICK(19); }
             // (the two masks through v_readfirstlane: they are wave-uniform by construction, but a build in which the compiler's divergence analysis loses that --
             //  the -DAIC_PROFILE one did -- would hand vector registers to the scalar operands below, and to every mask of the stepping phase after them)
             {
@@ -1303,11 +1300,12 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 x_got = uniform64(x_got);
                 x_fresh = uniform64(x_fresh);
             }
-            // ---- The swap proper, under exec = the lanes whose claim succeeded (none in a round without an exchange: the three blocks are then skipped): one
-            // LDS exchange (`ds_wrxchg_rtn`: write the register, return what was there) per hot variable, IN PLACE and on the round's common path -- like the
-            // stepping code's asm blocks. (Inside the exchange's own branch, or assigned from loaded values in C++, the compiler renames the hot variables
-            // and copies all 38 registers: at the branch in every round, or around each block.) ----
-            {
+            // ---- The swap proper, under exec = the lanes whose claim succeeded: one LDS exchange (`ds_wrxchg_rtn`: write the register, return what was there)
+            // per hot variable, IN PLACE -- like the stepping code's asm blocks. (Assigned from loaded values in C++, the compiler renames the hot variables
+            // and copies all 38 registers around each block. Earlier builds kept these blocks on the round's common path, skipped by an empty mask, because
+            // inside the exchange's branch the same copies appeared at the branch; with the in-place asm they do not, and a round without an exchange -- four
+            // in five -- no longer passes through them: tests/test_kernel_isa.py counts the vector moves of the scheduler.) ----
+            if (x_got != 0ull) {
                 unsigned long long sv;
                 asm volatile(
                     "s_and_saveexec_b64 %[sv], %[m]\n\t"
@@ -1373,8 +1371,6 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                     : [p] "v"(x_paddr), [m] "s"(x_got), [f] "s"(x_fresh)
                     : "memory", "scc");
                 static_assert((EV_NEWRAY | EV_TAKE) == 0xa0u, "the literal in the asm above");
-            }
-            if (x_got != 0ull) {
                 const bool got = __builtin_amdgcn_inverse_ballot_w64(x_got), fresh = __builtin_amdgcn_inverse_ballot_w64(x_fresh);
                 // the counts: every lane that parked a ray adds it to its kind (LDS atomics on one word each: a few cycles per lane, two instructions) BEFORE
                 // its slot is released under the tag of what it now holds -- LDS operations of a wave are performed in order, so no wave can claim the ray, and
@@ -1397,6 +1393,9 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 c_shade = (int)wave_popc(b_shade); c_enter = (int)wave_popc(b_enter); c_ray = (int)wave_popc(b_ray);
                 AIC_TICK(33);
             }
+            }
+            }
+            else { AIC_TICK(19); }
             if (!settled && (run == 0u ? n_step : (run == EV_SHADE ? c_shade : (run == EV_ENTER ? c_enter : c_ray))) == 0) {
                 // (the kind was chosen for what the pool holds, and every claim was lost to another wave -- or only rays in transit were found)
                 AIC_PROF(36, 1);
