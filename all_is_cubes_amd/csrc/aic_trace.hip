@@ -1522,7 +1522,10 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
             //    the surface is discovered: it is the t_max of the step the level takes next. The
             //    contribution is therefore computed here in full and merely *applied* by the stepping code
             //    when that next step is counted (so the order count -> stop-check -> accumulate is kept). --
-            if (run == EV_SHADE && (ev & EV_SHADE)) {
+            // (one kind runs per phase: each kind's section sits behind a UNIFORM branch on `run`, the per-lane test inside it -- written as one combined condition
+            //  the copies that carry a section's conditionally updated variables to the merge behind it are made in every phase, whichever kind runs)
+            if (run == EV_SHADE) {
+            if (ev & EV_SHADE) {
                 const bool inb = (st & ST_IN_BLOCK) != 0;
                 const uint32_t blk_res = 1u << (blk_geo >> 24), blk_vlo = blk_geo & 0xffffffu;
                 const double as = inb ? __hiloint2double((int)((1023u - (blk_geo >> 24)) << 20), 0) : 1.0;  // 1 / resolution
@@ -1778,9 +1781,10 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 }
                 ev &= ~EV_SHADE;
             }
+            } else if (run == EV_ENTER) {
             // -- entering a recursive block: RaycastStep::recursive_raycast (raycast.rs:458-476),
             //    advanced to its first in-bounds voxel (or to its end) --
-            if (run == EV_ENTER && (ev & EV_ENTER)) {
+            if (ev & EV_ENTER) {
                 const uint32_t blk_index = raw & idx_mask;
                 if (DIAG) c32[XCHG ? 0 : (int)K_BLK][col] = blk_index;
                 const DevBlock *tb = &L.blocks[blk_index];
@@ -1821,6 +1825,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 st |= ST_IN_BLOCK;
                 ev = (got ? EV_FRESH : 0u) | (dead ? EV_DEAD : 0u);
             }
+            } else {
             // -- finishing a ray: TracingState::finish + layer tail + (last sample) encode & store --
             uint32_t pxy = 0;
             int sample = 0;
@@ -2171,6 +2176,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 }
             }
             if (run == EV_FINISH && !want) c32[K_PXY][col] = pxy;
+            }
             if (run == EV_SHADE) { AIC_TICK(13) } else if (run == EV_ENTER) { AIC_TICK(14) } else { AIC_TICK(15) }
             continue;
         }
