@@ -1216,15 +1216,22 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
             run = kind == 0 ? 0u : (2u << kind);
             settled = mine != 0;
             AIC_TICK(19);
-            const bool dry_u = __builtin_amdgcn_readfirstlane((int)dry) != 0;
+            const int dry_i = __builtin_amdgcn_readfirstlane((int)dry);
             const int alive = n_step + c_shade + c_enter + c_ray, parked = pk_step + pk_shade + pk_enter + pk_ray;
             const int n_others = alive - mine - ((AIC_XCHG_DEPOSIT < 3 && run != 0u) ? n_step : 0);  // lanes holding a ray that will not run now (and may be parked)
-            const bool park_ok = AIC_XCHG_DEPOSIT != 0 && !dry_u && parked < (int)NPOOL;
-            // (an exchange costs a few hundred instructions: it is made for a top-up of at least AIC_XCHG_MIN_GAIN lanes, for a kind the wave has none of, or to
-            //  park at least AIC_XCHG_PARK_MIN lanes)
-            static_assert(AIC_XCHG_PARK_MIN > 0, "parking wants lanes to park");
-            if (best - mine >= AIC_XCHG_MIN_GAIN || mine == 0 || (park_ok && n_others >= AIC_XCHG_PARK_MIN)) {
-                const bool may_park = park_ok && n_others > 0;
+            // An exchange costs a few hundred instructions: it is made for a top-up of at least AIC_XCHG_MIN_GAIN lanes, for a kind the wave has none of, or -- while
+            // the image has pixels left and the pool a free slot -- to park at least AIC_XCHG_PARK_MIN lanes:
+            //     best - mine >= MIN_GAIN  ||  mine == 0  ||  (!dry && parked < NPOOL && n_others >= PARK_MIN)
+            // as one comparison of integers that are >= 0 where their term holds (a dozen scalar instructions; as booleans every term is a compare, a 64-bit
+            // select and a 64-bit and / or)
+            static_assert(AIC_XCHG_PARK_MIN > 0 && AIC_XCHG_DEPOSIT != 0, "parking wants lanes to park");
+            const int park_room = (int)NPOOL - 1 - parked, not_dry = -dry_i;
+            const int park_ok_i = park_room < not_dry ? park_room : not_dry;                             // >= 0: parking is possible
+            const int t_park = n_others - AIC_XCHG_PARK_MIN, t_gain = best - mine - AIC_XCHG_MIN_GAIN, t_none = -opaque_s(mine);  // (opaque: else the negation is made on the vector unit, for the carry that says mine != 0)
+            const int t_p = park_ok_i < t_park ? park_ok_i : t_park;
+            const int t_a = opaque_s(t_gain > t_none ? t_gain : t_none);  // (kept apart: fused, the two maxima become a v_max3 with copies in front and a vector compare behind)
+            if ((t_a > t_p ? t_a : t_p) >= 0) {
+                const bool may_park = park_ok_i >= 0 && n_others > 0;
                 // ---- the exchange: lanes that would idle ("givers": empty lanes first, then rays of other kinds) are paired with parked rays of the wanted
                 // kind, and -- while the image has pixels left -- what remains of them with free slots. A pairing is a claim (compare-and-swap of the slot's
                 // tag), a plain swap of the 40 hot dwords and the column index, and the release of the slot under the tag of what it now holds. ----
@@ -1304,7 +1311,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
             // per hot variable, IN PLACE -- like the stepping code's asm blocks. (Assigned from loaded values in C++, the compiler renames the hot variables
             // and copies all 38 registers around each block. Earlier builds kept these blocks on the round's common path, skipped by an empty mask, because
             // inside the exchange's branch the same copies appeared at the branch; with the in-place asm they do not, and a round without an exchange -- four
-            // in five -- no longer passes through them: tests/test_kernel_isa.py counts the vector moves of the scheduler.) ----
+            // in five -- no longer passes through them; profiles/r05_experiments.txt L has the listings' instruction counts.) ----
             if (x_got != 0ull) {
                 unsigned long long sv;
                 asm volatile(
@@ -2208,7 +2215,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
         // Fast steps need AIC_FAST_MIN takers while the frame is in full swing (other waves want the issue slots); once this wave has
         // seen the pixel queue dry it is draining its last rays and what counts is how soon the longest of them ends: a lone ray
         // then takes its fast steps too (38 instructions a step instead of a full pass's ~180).
-        const uint32_t fast_min = (uint32_t)__builtin_amdgcn_readfirstlane(dry ? 1 : AIC_FAST_MIN);  // (`dry` is wave-uniform; the compiler cannot tell)
+        const uint32_t fast_min = (uint32_t)AIC_FAST_MIN - (uint32_t)__builtin_amdgcn_readfirstlane((int)dry) * (uint32_t)(AIC_FAST_MIN - 1);  // (`dry` is wave-uniform; the compiler cannot tell)
         AIC_PROF(22, 1);
         AIC_PROF(23, __popcll(m_act));
 #ifdef AIC_TAIL_PROF
