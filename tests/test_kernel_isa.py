@@ -29,6 +29,10 @@ def test_no_register_of_a_lookup_in_flight_is_touched_before_its_wait():
         return tuple(int(x) for x in m.groups())
     production = {k: v for k, v in res.items() if targs(k)[2] == 0 and targs(k)[1] != 3}  # DIAG = false, not Bounce; with and without the exchange
     assert len(production) == 24, sorted(production)
+    # No FLAT memory instruction in any trace kernel: every access names its address space (LDS, global, scalar). Round 5 read the pool's counts through a `volatile`
+    # pointer, which address-space inference leaves alone: a flat load and an s_waitcnt vmcnt(0) at the top of every scheduler round (profiles/r05_experiments.txt J).
+    flat = [line.strip() for line in asm.split("\n") if re.match(r"\s*flat_(load|store|atomic)", line)]
+    assert not flat, flat[:5]
     for name, r in production.items():
         assert r["scratch_bytes"] == 0, (name, r)
         assert r["vgprs"] <= 128, (name, r)
