@@ -1056,10 +1056,11 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
             // the exchange (a pool of parked rays per workgroup: more rays in flight than lanes, lanes traded between waves) pays when a wave refills its lanes
             // several times over: from AIC_XCHG_TILES tiles per resident wave (default 5: the whole 1080p frame has 7.9 and gains 6.5 %, a rank's share at
             // N = 2 has 4 and gains nothing, at N = 4 / 8 two / one and loses 3-6 % -- profiles/r05_rank_share.txt); the UI pre-pass follows the world pass
-            // -- and from 3 for frames that are streamed (aic_render_submit), where a share of C3 at N = 8 (4 tiles per wave) gains 9 % by it)
+            // -- and from 1.9 for frames that are streamed (aic_render_submit), where a share of C3 at N = 8 (4 tiles per wave) gains 9 % by it and, since the
+            // scheduler round was trimmed, a share of C2 at N = 4 (2 tiles per wave) 1.8 %; at one tile per wave (N = 8) the plain variant stays 2.5 % ahead)
             const double x_tiles = [] { const char *e = std::getenv("AIC_XCHG_TILES"); return e ? std::atof(e) : -1.0; }();  // (per frame: tests switch it inside one process)
             const double resident_waves = (double)c->n_cus * 16.0;
-            const double need = x_tiles >= 0.0 ? x_tiles : (c->streaming_submit ? 3.0 : 5.0);
+            const double need = x_tiles >= 0.0 ? x_tiles : (c->streaming_submit ? 1.9 : 5.0);
             F.exchange = ((double)F.tiles_x * (double)F.tiles_y >= need * resident_waves) ? 1u : 0u;
         }
     }
