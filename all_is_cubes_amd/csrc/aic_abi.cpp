@@ -170,7 +170,9 @@ struct aic_ctx {
         DevBuf<float4> acc;  // UI pre-pass accumulators
         // cost feedback: the longest ray of every tile of the slot's last frame, and the tile order made from it
         DevBuf<uint32_t> tile_cost, tile_order, queue_start;
-        DevBuf<uint4> ray_cold;  // the production trace kernels' per-ray state in global memory (DevFrame::ray_cold)
+        DevBuf<uint4> ray_cold;  // the exchanging trace kernels' antialiasing sums in global memory (DevFrame::ray_cold; antialiased frames only)
+        DevBuf<double> edges;    // DevFrame::edge_x / edge_y of the slot's frame shape: width + 1, then height + 1 doubles
+        uint32_t edges_w = 0, edges_h = 0;
         uint32_t cost_sig[4] = {0, 0, 0, 0};  // width, local rows, partition of the frame tile_cost describes
         double cost_cam[16] = {0};            // ... and its world camera
         bool busy = false;
@@ -465,7 +467,7 @@ void aic_destroy(aic_ctx *c) {
     for (uint32_t i = 0; i < AIC_MAX_IN_FLIGHT; i++) {
         aic_ctx::FrameSlot &fs = c->slots[i];
         if (fs.stream) (void)hipStreamSynchronize(fs.stream);
-        fs.counters.release(); fs.acc.release(); fs.tile_cost.release(); fs.tile_order.release(); fs.queue_start.release(); fs.ray_cold.release();
+        fs.counters.release(); fs.acc.release(); fs.tile_cost.release(); fs.tile_order.release(); fs.queue_start.release(); fs.ray_cold.release(); fs.edges.release();
         if (fs.ev0) (void)hipEventDestroy(fs.ev0);
         if (fs.ev1) (void)hipEventDestroy(fs.ev1);
         if (fs.ev2) (void)hipEventDestroy(fs.ev2);
@@ -1044,15 +1046,30 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         if ((e = fs.acc.ensure(samples * npix)) != hipSuccess) return hip_fail(c, "alloc accumulators", e);
         F.acc_buf = fs.acc.p;
     }
+    if (!patches && !ortho_n) {
+        // Viewport's pixel edges (viewport.rs:104-113), once per frame shape: x / width * 2 - 1 and -(y / height * 2 - 1) in the reference's own f64
+        // operations (this file is built with -ffp-contract=off, like the kernels), so that the kernel reads them instead of dividing per ray
+        if (fs.edges_w != f->width || fs.edges_h != f->height || !fs.edges.p) {
+            std::vector<double> host((size_t)f->width + 1 + (size_t)f->height + 1);
+            for (uint32_t x = 0; x <= f->width; x++) host[x] = ((double)x) / (double)f->width * 2.0 - 1.0;
+            for (uint32_t y = 0; y <= f->height; y++) host[(size_t)f->width + 1 + y] = -(((double)y) / (double)f->height * 2.0 - 1.0);
+            fs.edges_w = fs.edges_h = 0;
+            if ((e = fs.edges.ensure(host.size())) != hipSuccess) return hip_fail(c, "alloc pixel edges", e);
+            // (the slot's stream may still be reading the table of the previous shape: the copy is ordered behind it, and staged before the call returns)
+            HIP_TRY(c, hipMemcpyAsync(fs.edges.p, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, fs.stream));
+            HIP_TRY(c, hipStreamSynchronize(fs.stream));
+            fs.edges_w = f->width; fs.edges_h = f->height;
+        }
+        F.edge_x = fs.edges.p;
+        F.edge_y = fs.edges.p + (size_t)f->width + 1;
+    }
     if (!diag) {
-        // the production variants keep a ray's origin / direction / antialiasing sums in global memory (aic_trace.hip, lane exchange): one
-        // region per persistent workgroup, the same for the UI pre-pass and the world pass of a frame (they follow one another on the stream)
+        // The production variants exist with and without the lane exchange (aic_trace.hip). The exchanging ones keep a pixel's antialiasing sums in global
+        // memory -- one region per persistent workgroup, the same for the UI pre-pass and the world pass of a frame (they follow one another on the
+        // stream) -- which only a frame traced with antialiasing needs.
         uint32_t groups = 0;
         const size_t bytes = trace_ray_cold_bytes(c->n_cus, &groups);
         if (bytes) {
-            if ((e = fs.ray_cold.ensure(bytes / sizeof(uint4))) != hipSuccess) return hip_fail(c, "alloc ray state", e);
-            F.ray_cold = fs.ray_cold.p;
-            F.ray_cold_groups = groups;
             // the exchange (a pool of parked rays per workgroup: more rays in flight than lanes, lanes traded between waves) pays when a wave refills its lanes
             // several times over: from AIC_XCHG_TILES tiles per resident wave (default 5: the whole 1080p frame has 7.9 and gains 6.5 %, a rank's share at
             // N = 2 has 4 and gains nothing, at N = 4 / 8 two / one and loses 3-6 % -- profiles/r05_rank_share.txt); the UI pre-pass follows the world pass
@@ -1062,6 +1079,11 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
             const double resident_waves = (double)c->n_cus * 16.0;
             const double need = x_tiles >= 0.0 ? x_tiles : (c->streaming_submit ? 1.9 : 5.0);
             F.exchange = ((double)F.tiles_x * (double)F.tiles_y >= need * resident_waves) ? 1u : 0u;
+            if (F.exchange && F.antialias) {
+                if ((e = fs.ray_cold.ensure(bytes / sizeof(uint4))) != hipSuccess) return hip_fail(c, "alloc ray state", e);
+                F.ray_cold = fs.ray_cold.p;
+                F.ray_cold_groups = groups;
+            }
         }
     }
     HIP_TRY(c, hipEventRecord(fs.ev0, fs.stream));

@@ -169,9 +169,14 @@ struct DevFrame {
     unsigned long long *host_counters;
     const float *light_lut;  // 256 floats
     const float *srgb_thr;   // 256 floats: srgb_thr[k] = smallest linear value whose sRGB8 encoding is >= k
-    // Per-ray state the trace kernel keeps in global memory (production variants: aic_trace.hip "lane exchange"): 64 bytes per
-    // (workgroup, LDS column) -- the ray's origin and sanitised direction (6 f64: read by the ENTER and SHADE events) and the four
-    // antialiasing sums of its pixel. Sized by the host from trace_ray_cold_bytes(); `ray_cold_groups` workgroups fit.
+    // Pixel-edge tables (host-made, per frame shape): edge_x[x] = x / width * 2 - 1 for x = 0..width, edge_y[y] = -(y / height * 2 - 1) for
+    // y = 0..height -- Viewport's pixel edges (viewport.rs:104-113) evaluated once in the reference's own f64 operations, so that starting a
+    // ray (and re-deriving its origin, below) costs two 16-byte loads instead of four f64 divisions. Null for patch batches and orthographic views.
+    const double *edge_x, *edge_y;
+    // Per-ray state the exchanging trace variants keep in global memory (aic_trace.hip "lane exchange"): the four ColorBuf::mean sums of the
+    // ray's pixel, 16 bytes per (workgroup, LDS column), ONLY in frames traced with antialiasing (null otherwise). A ray's origin is not kept
+    // at all by those variants: ENTER re-derives it from the pixel and the camera matrix (round 6; rounds 5 kept origin and direction here,
+    // 64 bytes per column, which tripled C3's HBM-side traffic). Sized by the host from trace_ray_cold_bytes(); `ray_cold_groups` workgroups fit.
     uint4 *ray_cold;
     uint32_t ray_cold_groups;
     uint32_t exchange;       // host-side: launch the exchanging variant (aic_trace.hip "lane exchange") -- a frame with several tiles per persistent wave; a frame of

@@ -900,7 +900,8 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u
                              // whose eight waves lose more claims to one another and fill the frame's tail worse -- profiles/r05_experiments.txt B)
 #endif
 #ifndef AIC_POOL
-#define AIC_POOL (AIC_XWG_THREADS >= 512 ? 160 : 72)  // parked rays per workgroup (<= 192: three tags per lane are scanned); what the CU's 160 KB leave room for
+#define AIC_POOL (AIC_XWG_THREADS >= 512 ? 160 : 64)  // parked rays per workgroup (<= 192: up to three tags per lane are scanned); what the CU's 160 KB leave room for beside 80-byte
+                                                       // columns (round 5: 72 slots beside 72-byte columns, the ray's origin and direction in global memory)
 #endif
 #ifndef AIC_XCHG_MIN_GAIN
 #define AIC_XCHG_MIN_GAIN 8  // a wave that has lanes of the chosen kind tops up only if the pool adds at least this many
@@ -1012,10 +1013,13 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
     // ---- per-lane state, cold: only events touch it, so it lives in LDS (one column per thread: conflict-free
     //      ds_read/ds_write), not in registers -- that is what lets the kernel run at 3-4 waves per SIMD ----
     //      A column belongs to a RAY, not to a lane: it travels with the ray when lanes are exchanged (`col`), and every pool slot holds a spare one.
-    //      The exchanging variants keep the rows after C_HOLEN / K_PXY in global memory instead (DevFrame::ray_cold: 64 bytes per column).
-    enum { C_STX, C_STY, C_STZ, C_SLAST,            // the suspended outer level while inside a block: t_max, last t
-           C_TABS, C_HOLEN,                         // |direction| (sr.rs:146); 0.5 / |direction| (raycast.rs:669)
-           C_OX, C_OY, C_OZ, C_DX, C_DY, C_DZ, N_C64_ALL };  // ray origin, direction (sanitised: Parameters::new, raycast.rs:749-771)
+    //      The exchanging variants hold the rows up to C_DZ / K_PXY only (80 bytes per column): they re-derive a ray's origin from its pixel where ENTER
+    //      needs it (`ray_of_pixel`, the code NEWRAY runs: the same bits) and keep the antialiasing sums in global memory (DevFrame::ray_cold; antialiased frames only).
+    //      (The suspended level's last t is not kept: a level that is resumed steps -- and sets it -- before anything reads it, or the ray is over.)
+    enum { C_STX, C_STY, C_STZ,                     // the suspended outer level while inside a block: t_max
+           C_TABS,                                  // |direction| (sr.rs:146)
+           C_DX, C_DY, C_DZ,                        // ray direction (sanitised: Parameters::new, raycast.rs:749-771)
+           C_OX, C_OY, C_OZ, N_C64_ALL };           // ray origin
     enum { K_SRX, K_SRY, K_SRZ, K_SBOFF,            // the suspended outer level: steps left, byte offset
            K_TVIEW, K_PXY,                          // |direction| / view distance; pixel x | row << 16
            K_BLK, K_S0, K_S1, K_S2, K_ST, N_C32_ALL };  // block index (aux records); ColorBuf::mean accumulators (antialiasing)
@@ -1025,7 +1029,8 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
     __shared__ uint32_t s_steps[WGT];               // per thread: steps of the rays it finished (RaytraceInfo)
     // the pool of parked rays (XCHG): per slot the ray's 40 hot dwords (or, free, just the spare column in word 38), and its tag
     __shared__ u32x4 s_pool[NPOOL ? NPOOL : 1u][10];
-    __shared__ uint32_t s_tag[192];                 // (padded: three tags per lane are read; the entries past the pool stay BUSY)
+    constexpr uint32_t NTAG = NPOOL > 128u ? 192u : (NPOOL > 64u ? 128u : 64u);
+    __shared__ uint32_t s_tag[NTAG];                // (padded to a multiple of 64: one to three tags per lane are read; the entries past the pool stay BUSY)
     __shared__ u32x4 s_census;                      // parked rays by kind: STEP, SHADE, ENTER, RAY (advisory: read without a claim)
     __shared__ uint8_t s_pick[WGT / 64u][2][64];    // per wave: the slots a round's givers are paired with (wanted kind; free)
     const uint32_t tid = threadIdx.x;
@@ -1034,7 +1039,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
     if (!XCHG) c32[XCHG ? 0 : (int)K_BLK][tid] = 0u;
     c32[K_PXY][tid] = 0u;
     if (XCHG) {
-        for (uint32_t i = tid; i < 192u; i += WGT) s_tag[i] = i < NPOOL ? TAG_FREE : TAG_BUSY;
+        for (uint32_t i = tid; i < NTAG; i += WGT) s_tag[i] = i < NPOOL ? TAG_FREE : TAG_BUSY;
         for (uint32_t i = tid; i < NPOOL; i += WGT) {
             s_pool[i][9] = u32x4{0u, 0u, WGT + i, 0u};  // the slot's spare column
             c32[K_PXY][WGT + i] = 0u;
@@ -1290,8 +1295,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                     uint32_t seen = expect;
                     got = __hip_atomic_compare_exchange_strong(&s_tag[slot], &seen, TAG_BUSY, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                // (this ray's stores to its global cold state -- NEWRAY, FINISH -- are in L2 before another wave can be handed the ray)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // (nothing of a ray lives in global memory except the antialiasing sums, and whoever stores those waits for the store at once: cold_sums_store)
                 x_got = __builtin_amdgcn_ballot_w64(got);
                 x_fresh = x_got & ~__builtin_amdgcn_ballot_w64(takes);
                 x_paddr = (uint32_t)(uintptr_t)&s_pool[0][0] + slot * 160u;
@@ -1474,37 +1478,103 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
             AIC_PROF(4, run == EV_SHADE ? 1 : 0); AIC_PROF(5, run == EV_SHADE ? c_shade : 0);
             AIC_PROF(6, run == EV_ENTER ? 1 : 0); AIC_PROF(7, run == EV_ENTER ? c_enter : 0);
             AIC_PROF(8, run == EV_FINISH ? 1 : 0); AIC_PROF(9, run == EV_FINISH ? c_ray : 0);
-            // The exchanging variants' global part of the cold state: 64 bytes per column of this workgroup -- origin and direction (6 f64), then the
-            // four antialiasing sums. Loads are workgroup-scope atomics (`sc0`: past the CU's vector L1, which a store made by another wave of the
-            // workgroup does not update -- the ray may have been started, or its sums last written, by a lane of another wave -- and served by the L2; agent
-            // scope, `sc1`, goes past the XCD's L2 as well: 6 k cycles per SHADE phase, measured).
-            // Layout: per workgroup six arrays of NCOL doubles (origin x y z, direction x y z), then four of NCOL floats: a wave's lanes read neighbouring words
-            // (columns stay mostly in lane order), 8 cache lines per load instead of the 64 of a 64-byte record per column.
-            char *const cold_wg = XCHG ? reinterpret_cast<char *>(F.ray_cold) + (size_t)blockIdx.x * (size_t)(NCOL * 64u) : nullptr;
-#ifndef AIC_COLD_SOA
-#define AIC_COLD_SOA 1
-#endif
-            // byte offset of the ray's k-th double (k = 0..5) / k-th float sum (k = 0..3) inside the workgroup's region
-            auto off64 = [&](uint32_t k) -> uint32_t { return AIC_COLD_SOA ? (k * NCOL + col) * 8u : col * 64u + k * 8u; };
-            auto off32 = [&](uint32_t k) -> uint32_t { return AIC_COLD_SOA ? NCOL * 48u + (k * NCOL + col) * 4u : col * 64u + 48u + k * 4u; };
+            // -- The ray of a pixel: RtScene::trace_patch's sample point (renderer.rs:424-451) through Camera::project_ndc_into_world
+            //    (camera_struct.rs:238-257), or MultiOrthoCamera::project_pixel_into_world for orthographic views. `o` = the ray's origin and, if asked
+            //    for, `dir` = its direction as given (not yet sanitised). NEWRAY runs this when the ray starts; the exchanging variants run it AGAIN
+            //    (origin only) wherever a later event needs the origin, instead of keeping 24 bytes per ray for the whole of its life: same code, same
+            //    inputs (the pixel in K_PXY, the sample in st, the kernel arguments), hence the same bits. Returns false when there is no ray. --
+            auto ray_of_pixel = [&](const uint32_t x, const uint32_t lrow, const int sample, const bool want_dir, double o[3], double dir[3]) -> bool {
+                const size_t pix = (size_t)lrow * F.width + x;
+                // global row of this local row under the strip partition
+                uint32_t y = lrow;
+                if (F.n_parts > 1u) {
+                    const uint32_t srows = opaque_s(F.strip_rows);
+                    const uint32_t strip = lrow / srows;
+                    y = (F.part + strip * F.n_parts) * srows + (lrow - strip * srows);
+                }
+                double px, py;  // renderer.rs:428-433 sample points, else the patch centre
+                if (F.pixel_centers) {  // Viewport::normalize_fb_x / _y (viewport.rs:89-99): the text renderer's rays
+                    const uint32_t fw = opaque_s(F.width), fh = opaque_s(F.height);
+                    px = ((double)x + 0.5) / (double)fw * 2.0 - 1.0;
+                    py = -(((double)y + 0.5) / (double)fh * 2.0 - 1.0);
+                } else {
+                    double x0, x1, y0, y1;  // the pixel's NdcRect {min: (x0, y0), max: (x1, y1)} (renderer.rs:537-550)
+                    if (F.patches) {
+                        const double *r = F.patches + 4u * pix;
+                        x0 = r[0]; y0 = r[1]; x1 = r[2]; y1 = r[3];
+                    } else if (F.edge_x) {
+                        // fb_x_edge / fb_y_edge of the pixel's two edges each, from the frame's tables (DevFrame::edge_x: made by the same operations)
+                        x0 = F.edge_x[x]; x1 = F.edge_x[x + 1u]; y0 = F.edge_y[y]; y1 = F.edge_y[y + 1u];
+                    } else {
+                        const uint32_t fw = opaque_s(F.width), fh = opaque_s(F.height);
+                        x0 = fb_x_edge(fw, x); x1 = fb_x_edge(fw, x + 1);
+                        y0 = fb_y_edge(fh, y); y1 = fb_y_edge(fh, y + 1);
+                    }
+                    if (n_samples == 4) {
+                        const double ux = (sample == 0) ? 1. / 8. : (sample == 1) ? 3. / 8. : (sample == 2) ? 5. / 8. : 7. / 8.;
+                        const double uy = (sample == 0) ? 5. / 8. : (sample == 1) ? 1. / 8. : (sample == 2) ? 7. / 8. : 3. / 8.;
+                        px = x0 + (x1 - x0) * ux;
+                        py = y0 + (y1 - y0) * uy;
+                    } else {
+                        px = (x0 + x1) / 2.0;
+                        py = (y0 + y1) / 2.0;
+                    }
+                }
+                bool have_ray = L.present != 0;
+                o[0] = o[1] = o[2] = 0.0;
+                if (want_dir) dir[0] = dir[1] = dir[2] = 0.0;
+                if (have_ray && F.ortho_n) {
+                    // MultiOrthoCamera::project_pixel_into_world (ortho.rs:186-199, 284-294): the view whose rectangle holds
+                    // the pixel, its transform applied to the pixel, then TryFrom<Ray> for AaRay / From<AaRay> for Ray
+                    // (ray.rs:305-358: the origin becomes cube + f32 offset, the direction the unit axis vector).
+                    // trace_axis_aligned_ray produces what trace_ray produces on that Ray (axis_aligned.rs:8-9).
+                    int vsel = -1;
+                    for (int v = 0; v < F.ortho_n; v++) {
+                        const uint32_t vx = F.ortho[v].x0, vy = F.ortho[v].y0, vw = F.ortho[v].w, vh = F.ortho[v].h;
+                        if (vsel < 0 && x >= vx && y >= vy && x - vx < vw && y - vy < vh) vsel = v;
+                    }
+                    have_ray = false;
+                    if (vsel >= 0) {
+                        const DevOrthoView *V = &F.ortho[vsel];
+                        double p[3];
+                        unproject(V->m, (double)(x - V->x0), (double)(y - V->y0), 0.0, p);
+                        int cube[3];
+                        if (cube_containing(p, cube)) {
+                            have_ray = true;
+                            for (int a = 0; a < 3; a++) {
+                                o[a] = (double)cube[a] + (double)(float)(p[a] - (double)cube[a]);
+                                if (want_dir) dir[a] = V->dir[a];
+                            }
+                        }
+                    }
+                } else if (have_ray) {
+                    unproject(L.inv, px, py, 0.0, o);
+                    if (want_dir) {
+                        double f[3];
+                        unproject(L.inv, px, py, 1.0, f);
+                        dir[0] = f[0] - o[0]; dir[1] = f[1] - o[1]; dir[2] = f[2] - o[2];
+                    }
+                }
+                return have_ray;
+            };
+            // The exchanging variants' global part of the cold state: the four antialiasing sums, 16 bytes per column of this workgroup, in frames traced with
+            // antialiasing only. Loads are workgroup-scope atomics (`sc0`: past the CU's vector L1, which a store made by another wave of the workgroup does
+            // not update -- the sums may last have been written by a lane of another wave -- and served by the L2; agent scope, `sc1`, goes past the XCD's L2
+            // as well). A store is waited for at once: the ray may be parked and claimed by another wave in the very next round.
+            // Layout: per workgroup four arrays of NCOL floats: a wave's lanes read neighbouring words (columns stay mostly in lane order).
+            char *const cold_wg = XCHG ? reinterpret_cast<char *>(F.ray_cold) + (size_t)blockIdx.x * (size_t)(NCOL * 16u) : nullptr;
+            auto off32 = [&](uint32_t k) -> uint32_t { return (k * NCOL + col) * 4u; };
             auto cold_origin = [&](double &ox, double &oy, double &oz) {
                 if constexpr (XCHG) {
-                    ox = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(cold_wg + off64(0u)), __ATOMIC_RELAXED, AIC_COLD_SCOPE));
-                    oy = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(cold_wg + off64(1u)), __ATOMIC_RELAXED, AIC_COLD_SCOPE));
-                    oz = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(cold_wg + off64(2u)), __ATOMIC_RELAXED, AIC_COLD_SCOPE));
+                    const uint32_t pxy_ = c32[K_PXY][col];
+                    double o_[3];
+                    (void)ray_of_pixel(pxy_ & 0xffffu, pxy_ >> 16, (int)((st >> 14) & 3u), false, o_, nullptr);
+                    ox = o_[0]; oy = o_[1]; oz = o_[2];
                 } else {
                     ox = c64[XCHG ? 0 : (int)C_OX][col]; oy = c64[XCHG ? 0 : (int)C_OY][col]; oz = c64[XCHG ? 0 : (int)C_OZ][col];
                 }
             };
-            auto cold_direction = [&](double &dx, double &dy, double &dz) {
-                if constexpr (XCHG) {
-                    dx = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(cold_wg + off64(3u)), __ATOMIC_RELAXED, AIC_COLD_SCOPE));
-                    dy = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(cold_wg + off64(4u)), __ATOMIC_RELAXED, AIC_COLD_SCOPE));
-                    dz = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(cold_wg + off64(5u)), __ATOMIC_RELAXED, AIC_COLD_SCOPE));
-                } else {
-                    dx = c64[XCHG ? 0 : (int)C_DX][col]; dy = c64[XCHG ? 0 : (int)C_DY][col]; dz = c64[XCHG ? 0 : (int)C_DZ][col];
-                }
-            };
+            auto cold_direction = [&](double &dx, double &dy, double &dz) { dx = c64[C_DX][col]; dy = c64[C_DY][col]; dz = c64[C_DZ][col]; };
             auto cold_sums_load = [&](float v[4]) {
                 if constexpr (XCHG) {
                     for (uint32_t k = 0; k < 4u; k++) v[k] = __uint_as_float(__hip_atomic_load(reinterpret_cast<uint32_t *>(cold_wg + off32(k)), __ATOMIC_RELAXED, AIC_COLD_SCOPE));
@@ -1517,6 +1587,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 if constexpr (XCHG) {
                     *reinterpret_cast<float *>(cold_wg + off32(0u)) = v0; *reinterpret_cast<float *>(cold_wg + off32(1u)) = v1;
                     *reinterpret_cast<float *>(cold_wg + off32(2u)) = v2; *reinterpret_cast<float *>(cold_wg + off32(3u)) = v3;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (in L2 before another wave can be handed the ray)
                 } else {
                     c32[XCHG ? 0 : (int)K_S0][col] = __float_as_uint(v0); c32[XCHG ? 0 : (int)K_S1][col] = __float_as_uint(v1);
                     c32[XCHG ? 0 : (int)K_S2][col] = __float_as_uint(v2); c32[XCHG ? 0 : (int)K_ST][col] = __float_as_uint(v3);
@@ -1809,13 +1880,13 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 const int acx = coord(posx, osx_i, rx) + olx, acy = coord(posy, osy_i, ry) + oly, acz = coord(posz, osz_i, rz) + olz;
                 const double sx_ = (ox - (double)acx) * kd, sy_ = (oy - (double)acy) * kd, sz_ = (oz - (double)acz) * kd;
                 // suspend the outer level; its Face goes to st[16..18]
-                c64[C_STX][col] = tx; c64[C_STY][col] = ty; c64[C_STZ][col] = tz; c64[C_SLAST][col] = last_t;
+                c64[C_STX][col] = tx; c64[C_STY][col] = ty; c64[C_STZ][col] = tz;
                 c32[K_SRX][col] = rx; c32[K_SRY][col] = ry; c32[K_SRZ][col] = rz; c32[K_SBOFF][col] = boff;
                 st = (st & ~((7u << 16) | ST_OUTER_ALIVE)) | (face_now() << 16) | ((ev & EV_DEAD) ? 0u : ST_OUTER_ALIVE);
                 const int ilx = (int)(blk_vlo & 255u), ily = (int)((blk_vlo >> 8) & 255u), ilz = (int)((blk_vlo >> 16) & 255u);
                 const int isx = (int)(blk_vsz & 255u), isy = (int)((blk_vsz >> 8) & 255u), isz = (int)((blk_vsz >> 16) & 255u);
                 const RayDir rd = make_rd(edx, edy, edz);
-                const LvlLim ll = lvl_init(sx_, sy_, sz_, rd, true, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz, true, c64[C_HOLEN][col]);
+                const LvlLim ll = lvl_init(sx_, sy_, sz_, rd, true, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz, true, 0.5 / c64[C_TABS][col]);  // (0.5 / direction.length(), raycast.rs:669: the quotient NEWRAY's fast-forward used)
                 bool got;
                 const Lvl f = lvl_first(ll.s, ll.lim, rd, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz, &got);
                 tx = f.tx; ty = f.ty; tz = f.tz; last_t = f.last_t;
@@ -2062,31 +2133,6 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                         }
                     }
                 }
-                // global row of this local row under the strip partition
-                const uint32_t srows = opaque_s(F.strip_rows), fw = opaque_s(F.width), fh = opaque_s(F.height);
-                const uint32_t strip = lrow / srows;
-                const uint32_t y = (F.part + strip * F.n_parts) * srows + (lrow - strip * srows);
-                double x0, x1, y0, y1;  // the pixel's NdcRect {min: (x0, y0), max: (x1, y1)} (renderer.rs:537-550)
-                if (F.patches) {
-                    const double *r = F.patches + 4u * pix;
-                    x0 = r[0]; y0 = r[1]; x1 = r[2]; y1 = r[3];
-                } else {
-                    x0 = fb_x_edge(fw, x); x1 = fb_x_edge(fw, x + 1);
-                    y0 = fb_y_edge(fh, y); y1 = fb_y_edge(fh, y + 1);
-                }
-                double px, py;  // renderer.rs:428-433 sample points, else the patch centre
-                if (n_samples == 4) {
-                    const double ux = (sample == 0) ? 1. / 8. : (sample == 1) ? 3. / 8. : (sample == 2) ? 5. / 8. : 7. / 8.;
-                    const double uy = (sample == 0) ? 5. / 8. : (sample == 1) ? 1. / 8. : (sample == 2) ? 7. / 8. : 3. / 8.;
-                    px = x0 + (x1 - x0) * ux;
-                    py = y0 + (y1 - y0) * uy;
-                } else if (F.pixel_centers) {  // Viewport::normalize_fb_x / _y (viewport.rs:89-99): the text renderer's rays
-                    px = ((double)x + 0.5) / (double)fw * 2.0 - 1.0;
-                    py = -(((double)y + 0.5) / (double)fh * 2.0 - 1.0);
-                } else {
-                    px = (x0 + x1) / 2.0;
-                    py = (y0 + y1) / 2.0;
-                }
                 if (F.use_init) {
                     const float4 v = F.acc_buf[(size_t)sample * npix + pix];
                     acc.l0 = v.x; acc.l1 = v.y; acc.l2 = v.z; acc.t = v.w;
@@ -2101,38 +2147,8 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 }
                 count = 0;
                 st = (uint32_t)sample << 14;
-                bool have_ray = L.present != 0;
-                double o[3] = {0.0, 0.0, 0.0}, dir[3] = {0.0, 0.0, 0.0};
-                if (have_ray && F.ortho_n) {
-                    // MultiOrthoCamera::project_pixel_into_world (ortho.rs:186-199, 284-294): the view whose rectangle holds
-                    // the pixel, its transform applied to the pixel, then TryFrom<Ray> for AaRay / From<AaRay> for Ray
-                    // (ray.rs:305-358: the origin becomes cube + f32 offset, the direction the unit axis vector).
-                    // trace_axis_aligned_ray produces what trace_ray produces on that Ray (axis_aligned.rs:8-9).
-                    int vsel = -1;
-                    for (int v = 0; v < F.ortho_n; v++) {
-                        const uint32_t vx = F.ortho[v].x0, vy = F.ortho[v].y0, vw = F.ortho[v].w, vh = F.ortho[v].h;
-                        if (vsel < 0 && x >= vx && y >= vy && x - vx < vw && y - vy < vh) vsel = v;
-                    }
-                    have_ray = false;
-                    if (vsel >= 0) {
-                        const DevOrthoView *V = &F.ortho[vsel];
-                        double p[3];
-                        unproject(V->m, (double)(x - V->x0), (double)(y - V->y0), 0.0, p);
-                        int cube[3];
-                        if (cube_containing(p, cube)) {
-                            have_ray = true;
-                            for (int a = 0; a < 3; a++) {
-                                o[a] = (double)cube[a] + (double)(float)(p[a] - (double)cube[a]);
-                                dir[a] = V->dir[a];
-                            }
-                        }
-                    }
-                } else if (have_ray) {
-                    double f[3];
-                    unproject(L.inv, px, py, 0.0, o);
-                    unproject(L.inv, px, py, 1.0, f);
-                    dir[0] = f[0] - o[0]; dir[1] = f[1] - o[1]; dir[2] = f[2] - o[2];
-                }
+                double o[3], dir[3];
+                const bool have_ray = ray_of_pixel(x, lrow, sample, true, o, dir);
                 if (have_ray) {
                     const double ox = o[0], oy = o[1], oz = o[2];
                     const double dirx = dir[0], diry = dir[1], dirz = dir[2];
@@ -2145,20 +2161,14 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                     c64[C_TABS][col] = t_abs;
                     c32[K_TVIEW][col] = __float_as_uint((float)(t_abs / opt.view_distance));  // sr.rs:149-151
                     const RayDir rd = raydir_init(dirx, diry, dirz);
-                    if constexpr (XCHG) {
-                        *reinterpret_cast<double *>(cold_wg + off64(0u)) = ox; *reinterpret_cast<double *>(cold_wg + off64(1u)) = oy; *reinterpret_cast<double *>(cold_wg + off64(2u)) = oz;
-                        *reinterpret_cast<double *>(cold_wg + off64(3u)) = rd.dx; *reinterpret_cast<double *>(cold_wg + off64(4u)) = rd.dy; *reinterpret_cast<double *>(cold_wg + off64(5u)) = rd.dz;
-                    } else {
-                        c64[XCHG ? 0 : (int)C_OX][col] = ox; c64[XCHG ? 0 : (int)C_OY][col] = oy; c64[XCHG ? 0 : (int)C_OZ][col] = oz;
-                        c64[XCHG ? 0 : (int)C_DX][col] = rd.dx; c64[XCHG ? 0 : (int)C_DY][col] = rd.dy; c64[XCHG ? 0 : (int)C_DZ][col] = rd.dz;
-                    }
+                    c64[C_DX][col] = rd.dx; c64[C_DY][col] = rd.dy; c64[C_DZ][col] = rd.dz;
+                    if constexpr (!XCHG) { c64[XCHG ? 0 : (int)C_OX][col] = ox; c64[XCHG ? 0 : (int)C_OY][col] = oy; c64[XCHG ? 0 : (int)C_OZ][col] = oz; }
                     tdx = rd.tdx; tdy = rd.tdy; tdz = rd.tdz;
                     const uint32_t qx = dirx >= 0.0 ? 1u : 0u, qy = diry >= 0.0 ? 1u : 0u, qz = dirz >= 0.0 ? 1u : 0u;
                     const uint32_t octant = (qx << 2) + (qy << 1) + qz;
                     const int ohx = olx + osx_i, ohy = oly + osy_i, ohz = olz + osz_i;
                     // the sanitised direction equals the original unless it was zeroed, in which case no fast-forward happens
                     const double half_over_len = 0.5 / t_abs;
-                    c64[C_HOLEN][col] = half_over_len;
                     const LvlLim ll = lvl_init(ox, oy, oz, rd, true, olx, oly, olz, ohx, ohy, ohz, true, half_over_len);
                     bool got;
                     const Lvl fs = lvl_first(ll.s, ll.lim, rd, olx, oly, olz, ohx, ohy, ohz, &got);
@@ -2403,7 +2413,6 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                     "ds_read_b64 %[tx], %[a64] offset:%[o0]\n\t"
                     "ds_read_b64 %[ty], %[a64] offset:%[o1]\n\t"
                     "ds_read_b64 %[tz], %[a64] offset:%[o2]\n\t"
-                    "ds_read_b64 %[lt], %[a64] offset:%[o3]\n\t"
                     "ds_read_b32 %[rx], %[a32] offset:%[p0]\n\t"
                     "ds_read_b32 %[ry], %[a32] offset:%[p1]\n\t"
                     "ds_read_b32 %[rz], %[a32] offset:%[p2]\n\t"
@@ -2425,13 +2434,13 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                     "v_and_b32 %[st], %[notinb], %[st]\n\t"
                     "s_waitcnt lgkmcnt(0)\n\t"
                     "s_mov_b64 exec, %[sv]\n\t"
-                    : [tx] "+v"(tx), [ty] "+v"(ty), [tz] "+v"(tz), [lt] "+v"(last_t), [rx] "+v"(rx), [ry] "+v"(ry), [rz] "+v"(rz),
+                    : [tx] "+v"(tx), [ty] "+v"(ty), [tz] "+v"(tz), [rx] "+v"(rx), [ry] "+v"(ry), [rz] "+v"(rz),
                       [bo] "+v"(boff), [ssx] "+v"(ssx), [ssy] "+v"(ssy), [ssz] "+v"(ssz), [thr] "+v"(thr), [lax] "+v"(lax), [st] "+v"(st),
                       [t] "=&v"(t_), [sv] "=&s"(sv), [nd] "=&s"(m_newdead)
                     : [a64] "v"(lds64), [a32] "v"(lds32), [m] "s"(m_leave), [osx] "s"(ostx), [osy] "s"(osty), [othr] "n"(BIG ? 0x10000u : (1u << kCubeClassShift)),
                       [alive] "n"(ST_OUTER_ALIVE), [notinb] "n"(~ST_IN_BLOCK),
                       [o0] "n"(C_STX * NCOL * 8), [o1] "n"(C_STY * NCOL * 8), [o2] "n"(C_STZ * NCOL * 8),
-                      [o3] "n"(C_SLAST * NCOL * 8), [p0] "n"(K_SRX * NCOL * 4), [p1] "n"(K_SRY * NCOL * 4),
+                      [p0] "n"(K_SRX * NCOL * 4), [p1] "n"(K_SRY * NCOL * 4),
                       [p2] "n"(K_SRZ * NCOL * 4), [p3] "n"(K_SBOFF * NCOL * 4)
                     : "memory");
                 m_inb &= ~m_leave;
@@ -2773,7 +2782,7 @@ static void launch_trace_x(const DevFrame &F, hipStream_t stream) {
     const uint32_t floor_groups = by_tiles < 128u ? by_tiles : 128u;
     if (grid < floor_groups) grid = floor_groups;
     if (grid > resident_groups) grid = resident_groups;
-    if (XCHG && grid > F.ray_cold_groups) grid = F.ray_cold_groups;  // (the host sizes the buffer for the resident grid: trace_ray_cold_bytes)
+    if (XCHG && F.antialias && grid > F.ray_cold_groups) grid = F.ray_cold_groups;  // (the host sizes the antialiasing sums' buffer for the resident grid: trace_ray_cold_bytes)
     if (grid == 0) return;
     hipLaunchKernelGGL((trace_image_kernel<VOL, LMODE, DIAG, BIG, XC>), dim3(grid), dim3(WGT), 0, stream, F);
 }
@@ -2783,7 +2792,7 @@ static void launch_trace_x(const DevFrame &F, hipStream_t stream) {
 template <bool VOL, int LMODE, bool DIAG, bool BIG>
 static void launch_trace(const DevFrame &F, hipStream_t stream) {
     if constexpr (AIC_EXCHANGE && !DIAG && LMODE != 3) {
-        if (F.exchange && F.ray_cold) { launch_trace_x<VOL, LMODE, DIAG, BIG, true>(F, stream); return; }
+        if (F.exchange && (F.ray_cold || !F.antialias)) { launch_trace_x<VOL, LMODE, DIAG, BIG, true>(F, stream); return; }
     }
     launch_trace_x<VOL, LMODE, DIAG, BIG, false>(F, stream);
 }
@@ -2803,12 +2812,12 @@ static void launch_trace_diag(const DevFrame &F, bool vol, int lmode, hipStream_
     }
 }
 
-// DevFrame::ray_cold of the production variants: 64 bytes per LDS column (a lane's or a pool slot's) of every workgroup of the resident grid
+// DevFrame::ray_cold of the exchanging variants (antialiased frames): 16 bytes per LDS column (a lane's or a pool slot's) of every workgroup of the resident grid
 size_t trace_ray_cold_bytes(uint32_t n_cus, uint32_t *groups) {
     if (!AIC_EXCHANGE) { *groups = 0; return 0; }
     const uint32_t g = n_cus * 4u * (uint32_t)AIC_MIN_WAVES / ((uint32_t)AIC_XWG_THREADS / 64u);
     *groups = g;
-    return (size_t)g * ((size_t)AIC_XWG_THREADS + (size_t)AIC_POOL) * 64u;
+    return (size_t)g * ((size_t)AIC_XWG_THREADS + (size_t)AIC_POOL) * 16u;
 }
 
 void launch_trace_image(const DevFrame &F, bool diag, hipStream_t stream) {

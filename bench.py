@@ -248,26 +248,11 @@ def main() -> int:
         renderer.set_world_camera_override(REPLAY["inv"], REPLAY["exposure"])
     renderer.update()
     light_update = None
+    loop = None   # orbit / relight: what changes in the scene before every frame (SceneLoop)
     relight = None
-    if args.workload == "relight":
-        renderer.device_light = True
-        renderer.device_light_queue_order = 0
-        li = renderer.evaluate_light(30, True, 1, 8192, 0)  # the starting light: large batches to convergence
-        light_update = {"mode": "initial light: fast_evaluate_light + evaluate_light(1), batch 8192", "updates": int(li["updates"]),
-                        "launches": int(li["batches"]), "device_ms": round(li["device_ms"], 3), "total_ms": round(li["total_ms"], 3)}
-        lo_s, sz_s = np.array(flat_space.lo), np.array(flat_space.size)
-        air_i = next(i for i, b in enumerate(flat_space.blocks) if b.is_air)
-        lamp_i = len(flat_space.blocks) - 1
-        # lamp sites: air cubes of the scene's middle column region, spread over the orbit
-        bi = np.asarray(flat_space.block_index)
-        rng = np.random.default_rng(7)
-        sites = []
-        while len(sites) < 30:
-            c = rng.integers(0, sz_s)
-            if int(bi[tuple(c)]) == air_i and tuple(c) not in sites:
-                sites.append(tuple(int(v) for v in c))
-        relight = {"sites": [tuple(int(l + c) for l, c in zip(lo_s, s_)) for s_ in sites], "air": air_i, "lamp": lamp_i, "updates": 0, "calls": 0,
-                   "light_ms": 0.0, "queue_left": 0}
+    if args.workload in ("orbit", "relight"):
+        loop = SceneLoop(args.workload, H, flat_space, cams, renderer, eye, target, args.relight_period, args.light_budget)
+        light_update, relight = loop.light_update, loop.relight
     if args.workload == "light-bench":
         # light.rs "both": fast_evaluate_light then evaluate_light(1), LightPhysics::Rays { maximum_distance: 30 },
         # batches of 32 in the reference's queue order -- the configuration that reproduces the reference's texels
@@ -325,23 +310,6 @@ def main() -> int:
     uncollected = {}  # render slot -> True: its frame was handed to the gather on the device, its report is still to be read
 
     kernel_ms = []
-    orbit = None
-    if args.workload == "relight":
-        views = [H.look_at_y_up((0.5 + 7.0 * np.sin(2.0 * np.pi * k / 60.0), eye[1], 7.0 * np.cos(2.0 * np.pi * k / 60.0)), target) for k in range(60)]
-        orbit = {"k": 0, "lights": None, "views": views}
-    if args.workload == "orbit":
-        # 60 key frames: the eye circles the atrium's axis, the light field breathes (status bytes kept)
-        base = flat_space.light.copy()
-        lights, views = [], []
-        for k in range(60):
-            a = 2.0 * np.pi * k / 60.0
-            gain = 0.85 + 0.15 * np.sin(a)
-            lk = base.copy()
-            lk[..., 0:3] = np.clip(np.round(base[..., 0:3].astype(np.float32) + 10.0 * np.log2(gain)), 0, 255).astype(np.uint8) * (base[..., 0:3] > 0)
-            lights.append(np.ascontiguousarray(lk.reshape(-1, 4)))
-            views.append(H.look_at_y_up((0.5 + 7.0 * np.sin(a), eye[1], 7.0 * np.cos(a)), target))
-        orbit = {"k": 0, "lights": lights, "views": views}
-
     frame_no = [0]
     traced = []  # frames whose trace is in flight: (frame number, render slot)
 
@@ -391,25 +359,8 @@ def main() -> int:
     def step() -> None:
         i = frame_no[0]
         frame_no[0] += 1
-        if relight is not None:
-            k = i % 60
-            if i % args.relight_period == 0:   # a lamp placed (first pass over the 30 sites) or removed (second pass)
-                j = i // args.relight_period
-                x, y, z = relight["sites"][j % 30]
-                cams.world_space.set(x, y, z, relight["lamp"] if (j // 30) % 2 == 0 else relight["air"])
-            cams.world_view_transform = orbit["views"][k]
-            renderer.update()                                  # block delta -> aic_update_cubes + aic_light_cubes_changed
-            t_l = time.perf_counter()
-            li = renderer.evaluate_light(30, False, 1, args.light_budget, 0, 0, True, args.light_budget)  # one launch of that many cube updates
-            relight["light_ms"] += (time.perf_counter() - t_l) * 1e3
-            relight["updates"] += int(li["updates"]); relight["calls"] += 1; relight["queue_left"] = int(li["queue_left"])
-            relight["queue_max"] = max(relight.get("queue_max", 0), int(li["queue_left"]))
-            relight["drained"] = relight.get("drained", 0) + (1 if int(li["queue_left"]) == 0 else 0)
-        elif orbit is not None:
-            k = i % 60
-            cams.world_space.load_light(orbit["lights"][k])   # SpaceChange burst -> aic_update_light_volume
-            cams.world_view_transform = orbit["views"][k]
-            renderer.update()                                  # (waits for the frames in flight: they read the light volume)
+        if loop is not None:
+            loop.before_frame(i)
         if not streamed:
             info = renderer.draw_rows_to_device(render_target(i).data_ptr(), strip, world, rank)
             kernel_ms.append(info.kernel_ms)
@@ -502,7 +453,7 @@ def main() -> int:
     # longer than its share of the device's time, and the kernel's rate is bytes of the launches completed in the timed region /
     # the region's duration = bytes per launch / frame period. One frame at a time (--no-pipeline) the two coincide.
     launch_period_ms = (elapsed / args.steps * 1e3) if streamed else mean_kernel_ms
-    achieved_gbs = (my_bytes / (launch_period_ms * 1e-3)) / 1e9 if launch_period_ms > 0 else 0.0
+    period_gbs = (my_bytes / (launch_period_ms * 1e-3)) / 1e9 if launch_period_ms > 0 else 0.0
 
     # BASELINE.json quotes a *single-frame* raytrace: next to the streamed frame period, the time of one frame alone
     # (submit, wait, repeat) -- "warm": tile order learnt from the identical previous frame; "cold": no feedback used or
@@ -651,6 +602,11 @@ def main() -> int:
             secondary = {"s256": secondary_workload_leg("s256", H, D, torch, dev, local_rank, space_from_flat)}
         except Exception as exc:  # the headline line must not be lost to the extra leg
             secondary = {"s256": {"error": repr(exc)}}
+        for leg in ("orbit", "relight"):  # configs[4]: the sim + render loops, a second or two each
+            try:
+                secondary[leg] = secondary_loop_leg(leg, H, D, torch, dev, local_rank, space_from_flat)
+            except Exception as exc:
+                secondary[leg] = {"error": repr(exc)}
 
     result = None
     if rank == 0:
@@ -685,30 +641,8 @@ def main() -> int:
                 "handoff": ("device (aic_stream_wait_frame: the gather's stream waits for the trace's event)" if device_handoff else "host (aic_render_wait before each gather)") if exchange else None,
                 "assembled_frame_equals_single_rank_frame": verified,
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved_gbs, 3),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved_gbs / HBM_PEAK_GBS, 6),
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "kernel": "trace_image_kernel",
-                "kernel_ms": round(mean_kernel_ms, 4),
-                "launches_in_flight": depth if streamed else 1,
-                "launch_period_ms": round(launch_period_ms, 4),
-                "rate_basis": ("launches overlap: achieved = algorithmic bytes per launch / launch period (the frame period of this rank); kernel_ms is "
-                               "the mean duration of one launch (HIP events on its stream; what rocprofv3's per-kernel average shows)") if streamed
-                              else "one launch at a time: achieved = algorithmic bytes per launch / kernel_ms",
-                "algorithmic_bytes_per_launch": int(my_bytes),
-                # the KERNEL's own fraction: one launch alone on the device (warm tile order; HIP events), whatever the timed
-                # region above streams -- the figure to compare with rocprofv3's per-kernel duration of a --no-pipeline run
-                "kernel_ms_one_at_a_time": single["kernel_ms_warm"] if single is not None else (round(mean_kernel_ms, 4) if not streamed else None),
-                "frac_one_at_a_time": (round(my_bytes / (single["kernel_ms_warm"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if single is not None and single["kernel_ms_warm"] > 0
-                                       else (round(achieved_gbs / HBM_PEAK_GBS, 6) if not streamed else None)),
-                "gsteps_per_s": round((info.cubes_traced / (launch_period_ms * 1e-3)) / 1e9, 3) if launch_period_ms > 0 else 0.0,
-                "note": "rank-0 launch; cache-resident scene: the path is latency/ALU-bound, not HBM-bound (DESIGN.md)",
-            },
+            "roofline": roofline_object(my_bytes, mean_kernel_ms, launch_period_ms, period_gbs, streamed, depth,
+                                        single["kernel_ms_warm"] if single is not None else None, traffic, traffic_src, info.cubes_traced),
             "device": renderer.device_name(),
         }
         if valu is not None:
@@ -756,6 +690,156 @@ def main() -> int:
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+class SceneLoop:
+    """What the sim + render loops change before every frame (BASELINE.json configs[4]):
+    `orbit`   -- the camera moves 6 degrees about the atrium's axis and the whole light volume is re-uploaded (aic_update_light_volume);
+    `relight` -- the light is computed ON THE DEVICE (SURVEY.md 8f N1 + N2): every `period` frames a lamp block is placed or removed, the
+                 changed cube and its neighbours are queued (aic_light_cubes_changed), every frame the light updater gets `budget` cube
+                 updates in one launch (aic_evaluate_light, continuing the layer's queue) and the camera moves. No light volume crosses PCIe."""
+
+    def __init__(self, name, H, flat_space, cams, renderer, eye, target, period=30, budget=2048):
+        self.name, self.cams, self.renderer, self.period, self.budget = name, cams, renderer, period, budget
+        self.light_update, self.relight, self.lights = None, None, None
+        self.views = [H.look_at_y_up((0.5 + 7.0 * np.sin(2.0 * np.pi * k / 60.0), eye[1], 7.0 * np.cos(2.0 * np.pi * k / 60.0)), target) for k in range(60)]
+        if name == "relight":
+            renderer.device_light = True
+            renderer.device_light_queue_order = 0
+            li = renderer.evaluate_light(30, True, 1, 8192, 0)  # the starting light: large batches to convergence
+            self.light_update = {"mode": "initial light: fast_evaluate_light + evaluate_light(1), batch 8192", "updates": int(li["updates"]),
+                                 "launches": int(li["batches"]), "device_ms": round(li["device_ms"], 3), "total_ms": round(li["total_ms"], 3)}
+            lo_s, sz_s = np.array(flat_space.lo), np.array(flat_space.size)
+            air_i = next(i for i, b in enumerate(flat_space.blocks) if b.is_air)
+            lamp_i = len(flat_space.blocks) - 1
+            # lamp sites: air cubes of the scene's middle column region, spread over the orbit
+            bi = np.asarray(flat_space.block_index)
+            rng = np.random.default_rng(7)
+            sites = []
+            while len(sites) < 30:
+                c = rng.integers(0, sz_s)
+                if int(bi[tuple(c)]) == air_i and tuple(c) not in sites:
+                    sites.append(tuple(int(v) for v in c))
+            self.relight = {"sites": [tuple(int(l + c) for l, c in zip(lo_s, s_)) for s_ in sites], "air": air_i, "lamp": lamp_i, "updates": 0, "calls": 0,
+                            "light_ms": 0.0, "queue_left": 0}
+        else:
+            # 60 key frames: the eye circles the atrium's axis, the light field breathes (status bytes kept)
+            base = flat_space.light.copy()
+            self.lights = []
+            for k in range(60):
+                gain = 0.85 + 0.15 * np.sin(2.0 * np.pi * k / 60.0)
+                lk = base.copy()
+                lk[..., 0:3] = np.clip(np.round(base[..., 0:3].astype(np.float32) + 10.0 * np.log2(gain)), 0, 255).astype(np.uint8) * (base[..., 0:3] > 0)
+                self.lights.append(np.ascontiguousarray(lk.reshape(-1, 4)))
+
+    def before_frame(self, i):
+        k = i % 60
+        cams, renderer, relight = self.cams, self.renderer, self.relight
+        if relight is not None:
+            if i % self.period == 0:   # a lamp placed (first pass over the 30 sites) or removed (second pass)
+                j = i // self.period
+                x, y, z = relight["sites"][j % 30]
+                cams.world_space.set(x, y, z, relight["lamp"] if (j // 30) % 2 == 0 else relight["air"])
+            cams.world_view_transform = self.views[k]
+            renderer.update()                                  # block delta -> aic_update_cubes + aic_light_cubes_changed
+            t_l = time.perf_counter()
+            li = renderer.evaluate_light(30, False, 1, self.budget, 0, 0, True, self.budget)  # one launch of that many cube updates
+            relight["light_ms"] += (time.perf_counter() - t_l) * 1e3
+            relight["updates"] += int(li["updates"]); relight["calls"] += 1; relight["queue_left"] = int(li["queue_left"])
+            relight["queue_max"] = max(relight.get("queue_max", 0), int(li["queue_left"]))
+            relight["drained"] = relight.get("drained", 0) + (1 if int(li["queue_left"]) == 0 else 0)
+        else:
+            cams.world_space.load_light(self.lights[k])        # SpaceChange burst -> aic_update_light_volume
+            cams.world_view_transform = self.views[k]
+            renderer.update()                                  # (waits for the frames in flight: they read the light volume)
+
+
+def secondary_loop_leg(name, H, D, torch, dev, local_rank, space_from_flat, frames=120, warm=12):
+    """configs[4] inside the default run (C5 was a builder-run number the driver never timed): the `orbit` or `relight`
+    loop on its own renderer, `frames` streamed frames (4 in flight) after `warm`, a second or two in all."""
+    flat_space, (w, h), eye, target, view_distance, label = build_workload(name)
+    cams = H.StandardCameras()
+    opts = H.GraphicsOptions()
+    opts.bloom_intensity = 0.0
+    opts.view_distance = view_distance
+    opts.debug_info_text = False
+    cams.graphics_options = opts
+    cams.viewport = H.Viewport.with_scale(1.0, w, h)
+    cams.world_space = space_from_flat(flat_space)
+    cams.world_view_transform = H.look_at_y_up(eye, target)
+    r = H.HipRtRenderer(cams, None, local_rank)
+    r.update()
+    loop = SceneLoop(name, H, flat_space, cams, r, eye, target)
+    strip, depth = D.STRIP_ROWS, 4
+    bufs = [torch.empty((h, w, 4), dtype=torch.uint8, device=dev) for _ in range(depth)]
+    n = [0]
+
+    def run(count):
+        first = n[0]
+        for _ in range(count):
+            i = n[0]
+            n[0] += 1
+            loop.before_frame(i)
+            if i - first >= depth:
+                r.wait_rows(i % depth)
+            r.submit_rows_to_device(bufs[i % depth].data_ptr(), strip, 1, 0, i % depth)
+        for i in range(max(first, n[0] - depth), n[0]):
+            r.wait_rows(i % depth)
+        r.synchronize()
+
+    run(warm)
+    if loop.relight is not None:
+        loop.relight.update(updates=0, calls=0, light_ms=0.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(frames)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / frames * 1e3
+    out = {"workload": label, "rays_per_frame": w * h, "frames": frames, "frames_in_flight": depth, "ms_per_step": round(ms, 4),
+           "value": round(w * h / (ms * 1e-3) / 1e6, 3), "unit": "Mrays/s", "frames_per_s": round(1e3 / ms, 2)}
+    if loop.relight is not None and loop.relight["calls"]:
+        out["light_ms_per_frame"] = round(loop.relight["light_ms"] / loop.relight["calls"], 4)
+        out["light_updates_per_frame"] = round(loop.relight["updates"] / loop.relight["calls"], 1)
+    del r
+    return out
+
+
+def roofline_object(nbytes, mean_kernel_ms, launch_period_ms, period_gbs, streamed, depth, kernel_alone_ms, traffic, traffic_src, cubes_traced):
+    """The bench line's `roofline` object. `achieved` / `frac` are the KERNEL's own: algorithmic bytes per launch / the duration of one launch
+    alone on the device (HIP events on its stream; rocprofv3's per-kernel average of a --no-pipeline run agrees: profiles/rNN_kernel_stats_*_nopipe.csv).
+    Until round 5 `frac` was bytes / the frame period of overlapping launches -- device throughput, which no per-kernel duration reproduces
+    (VERDICT r05 weak 6); that figure is `frac_streamed_period` now."""
+    if kernel_alone_ms is None and not streamed:
+        kernel_alone_ms = mean_kernel_ms
+    if kernel_alone_ms and kernel_alone_ms > 0:
+        basis_ms, basis = kernel_alone_ms, ("achieved = algorithmic bytes per launch / kernel_ms_one_at_a_time: one launch alone on the device (HIP events on its "
+                                            "stream, warm tile order), whatever the timed region streams")
+    else:  # (--no-extras on a streamed run: no launch was timed alone)
+        basis_ms, basis = mean_kernel_ms, ("achieved = algorithmic bytes per launch / kernel_ms, the mean duration of the timed region's OVERLAPPING launches "
+                                           "(no launch was timed alone in this run): a lower bound of the kernel's own rate")
+    achieved = (nbytes / (basis_ms * 1e-3)) / 1e9 if basis_ms and basis_ms > 0 else 0.0
+    return {
+        "bound": "hbm",
+        "achieved": round(achieved, 3),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 6),
+        "traffic": traffic,
+        "traffic_source": traffic_src,
+        "kernel": "trace_image_kernel",
+        "kernel_ms": round(mean_kernel_ms, 4),
+        "kernel_ms_one_at_a_time": round(kernel_alone_ms, 4) if kernel_alone_ms else None,
+        "frac_one_at_a_time": round(achieved / HBM_PEAK_GBS, 6) if kernel_alone_ms else None,  # (= frac; the key rounds 3-5 carried)
+        "launches_in_flight": depth if streamed else 1,
+        "launch_period_ms": round(launch_period_ms, 4),
+        "achieved_streamed_period": round(period_gbs, 3),
+        "frac_streamed_period": round(period_gbs / HBM_PEAK_GBS, 6),
+        "rate_basis": basis + ("; frac_streamed_period = bytes per launch / launch period: the device's throughput with launches_in_flight launches "
+                               "overlapping, not a property of one kernel" if streamed else ""),
+        "algorithmic_bytes_per_launch": int(nbytes),
+        "gsteps_per_s": round((cubes_traced / (launch_period_ms * 1e-3)) / 1e9, 3) if launch_period_ms > 0 else 0.0,
+        "note": "rank-0 launch; cache-resident scene: the path is latency/ALU-bound, not HBM-bound (DESIGN.md)",
+    }
 
 
 def secondary_workload_leg(name, H, D, torch, dev, local_rank, space_from_flat, frames=16, one_by_one_frames=6):
@@ -811,8 +895,9 @@ def secondary_workload_leg(name, H, D, torch, dev, local_rank, space_from_flat, 
            "single_frame_warm_ms": round(float(np.median(ts)), 4), "single_frame_cold_ms": round(float(np.median(cold)), 4),
            "value_single_frame": round(w * h / (float(np.median(cold)) * 1e-3) / 1e6, 3),
            "algorithmic_bytes_per_launch": int(nbytes), "kernel_ms_one_at_a_time": round(k_ms, 4),
+           "frac": round(nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if k_ms > 0 else None,  # the kernel's own (one launch alone), as in `roofline`
            "frac_one_at_a_time": round(nbytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if k_ms > 0 else None,
-           "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if ms > 0 else None}
+           "frac_streamed_period": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if ms > 0 else None}
     del r
     return out
 
@@ -881,11 +966,26 @@ def cpu_baseline(flat_space, opts, w, h, eye, target, view_distance, target_seco
             break
     dt = time.perf_counter() - t0
     rays = frames * w * h
+    # the same port as rounds 1-5 built it (-O2), a quarter of the sample: so that the two sets of GPU / CPU ratios can be told apart
+    try:
+        lib2 = oracle.lib_o2()
+        oracle.render(sp, oo, cam, threads=threads, use_lib=lib2)
+        f2, t2 = 0, time.perf_counter()
+        while True:
+            oracle.render(sp, oo, cam, threads=threads, use_lib=lib2)
+            f2 += 1
+            if time.perf_counter() - t2 >= target_seconds / 4.0 or f2 >= 100:
+                break
+        d2 = time.perf_counter() - t2
+        extra["o2"] = {"value": round(f2 * w * h / d2 / 1e6, 4), "unit": "Mrays/s", "frames": f2, "flags": "-O2 -ffp-contract=off -fno-fast-math (rounds 1-5)"}
+    except Exception as exc:  # (the baseline's main figure must not be lost to the comparison)
+        extra["o2"] = {"error": repr(exc)}
     return {
         "value": round(rays / dt / 1e6, 4),
         "unit": "Mrays/s",
         "cores": threads,
         "kind": "port",
+        "flags": "-O3 -ffp-contract=off -fno-fast-math (SURVEY.md 8d)",
         "sample": f"{frames} whole {w}x{h} frames of the same workload in {dt:.1f} s wall (median {1e3 * float(np.median(per_frame)):.1f} ms/frame), "
                   f"oracle/aic_oracle.cpp row-parallel on {threads} threads ({cpu_note})",
         "frames_per_s": round(frames / dt, 4),

@@ -19,7 +19,8 @@ _LIB_PATH = _HERE / "libaic_oracle.so"
 
 def build(force: bool = False) -> Path:
     srcs = (_HERE / "aic_oracle.cpp", _HERE / "aic_light.inc", _HERE / "aic_ortho.inc", _HERE / "aic_oracle.h")
-    stale = (not _LIB_PATH.exists()) or any(p.stat().st_mtime > _LIB_PATH.stat().st_mtime for p in srcs)
+    srcs = srcs + (_HERE / "Makefile",)
+    stale = (not _LIB_PATH.exists()) or (not (_HERE / "libaic_oracle_o2.so").exists()) or any(p.stat().st_mtime > _LIB_PATH.stat().st_mtime for p in srcs)
     if force or stale:
         subprocess.run(["make", "-C", str(_HERE), "-B" if force else "-s"], check=True)
     return _LIB_PATH
@@ -267,9 +268,15 @@ def trace_ray(space: Space, options: OrcOptions, origin, direction, include_sky=
     return int(n), lt, depth.value
 
 
+def lib_o2() -> C.CDLL:
+    """The same oracle built at -O2 (rounds 1-5's flags): only bench.py's cpu_baseline leg loads it, to report both."""
+    lib()  # (builds both)
+    return C.CDLL(str(_HERE / "libaic_oracle_o2.so"))
+
+
 def render(world: Optional[Space], world_opt: OrcOptions, world_cam: OrcCamera, ui: Optional[Space] = None,
            ui_opt: Optional[OrcOptions] = None, ui_cam: Optional[OrcCamera] = None, backdrop=(0, 0, 0, 0),
-           rows=None, threads: int = 0, want_linear=False, want_aux=False):
+           rows=None, threads: int = 0, want_linear=False, want_aux=False, use_lib=None):
     """RtRenderer::draw_rgba equivalent. Returns dict(rgba8, linear, aux, info)."""
     w, h = world_cam.width, world_cam.height
     r0, r1 = (0, h) if rows is None else rows
@@ -280,7 +287,7 @@ def render(world: Optional[Space], world_opt: OrcOptions, world_cam: OrcCamera, 
     bd = np.ascontiguousarray(backdrop, dtype=np.float32)
     if threads <= 0:
         threads = os.cpu_count() or 1
-    rc = lib().orc_render(
+    rc = (use_lib if use_lib is not None else lib()).orc_render(
         C.byref(world.c) if world is not None else None, C.byref(world_opt), C.byref(world_cam),
         C.byref(ui.c) if ui is not None else None,
         C.byref(ui_opt) if ui_opt is not None else None,
