@@ -21,6 +21,22 @@ LAYER_WORLD, LAYER_UI = 0, 1
 MAX_IN_FLIGHT = 32  # AIC_MAX_IN_FLIGHT
 FLAW_UNSUPPORTED, FLAW_NO_BLOOM = 1, 2
 FRAME_COUNTERS, FRAME_AUX, FRAME_PIXEL_CENTERS, FRAME_OUT_LINEAR, FRAME_OUT_COLORBUF, FRAME_NO_FEEDBACK = 1, 2, 4, 8, 16, 32
+# aic_frame_desc.tuning / aic_frame_info.variant (include/aic_hip.h)
+TUNE_QUEUES_SHIFT, TUNE_SUPER_SHIFT, TUNE_VARIANT_SHIFT = 0, 4, 9
+VARIANT_AUTO, VARIANT_PLAIN, VARIANT_EXCHANGING, VARIANT_RECORDING = 0, 1, 2, 3
+
+
+def tuning(queues=None, super_shift=None, variant=None) -> int:
+    """aic_frame_desc.tuning: the number of tile queues (1..8), the super-block edge in macro tiles (log2) and the production variant of the
+    trace kernel (VARIANT_*); None leaves the library's choice. Any value gives the same image."""
+    t = 0
+    if queues is not None:
+        t |= (int(queues) & 15) << TUNE_QUEUES_SHIFT
+    if super_shift is not None:
+        t |= ((int(super_shift) + 1) & 31) << TUNE_SUPER_SHIFT
+    if variant is not None:
+        t |= (int(variant) & 3) << TUNE_VARIANT_SHIFT
+    return t
 
 # every symbol include/aic_hip.h declares
 ABI_SYMBOLS = [
@@ -98,13 +114,13 @@ class Partition(C.Structure):
 
 class FrameDesc(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("world", Camera), ("ui", Camera), ("backdrop", C.c_float * 4),
-                ("partition", Partition), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+                ("partition", Partition), ("flags", C.c_uint32), ("tuning", C.c_uint32)]
 
 
 class FrameInfo(C.Structure):
     _fields_ = [("cubes_traced", C.c_uint64), ("n_outer", C.c_uint64), ("n_inner", C.c_uint64), ("n_hits", C.c_uint64),
                 ("n_light", C.c_uint64), ("kernel_ms", C.c_float), ("total_ms", C.c_float), ("rows_rendered", C.c_uint32),
-                ("flaws", C.c_uint32)]
+                ("flaws", C.c_uint32), ("variant", C.c_uint32), ("tile_queues", C.c_uint32)]
 
 
 PIXEL_AUX_DTYPE = np.dtype(
@@ -382,7 +398,7 @@ class Context:
     # -- drawing ---------------------------------------------------------------------------
     @staticmethod
     def make_frame(width, height, world_inv=None, ui_inv=None, exposure=1.0, ui_exposure=1.0, backdrop=(0, 0, 0, 0),
-                   partition=None, flags=0) -> FrameDesc:
+                   partition=None, flags=0, tuning=0) -> FrameDesc:
         f = FrameDesc()
         f.width, f.height = int(width), int(height)
         ident = np.eye(4).reshape(16)
@@ -395,6 +411,7 @@ class Context:
         if partition is not None:
             f.partition.strip_rows, f.partition.n_parts, f.partition.part = (int(v) for v in partition)
         f.flags = flags
+        f.tuning = int(tuning)
         return f
 
     def partition_rows(self, height: int, partition) -> int:

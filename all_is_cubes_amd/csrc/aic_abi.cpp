@@ -177,6 +177,7 @@ struct aic_ctx {
         double cost_cam[16] = {0};            // ... and its world camera
         bool busy = false;
         bool diag = false;  // the slot's frame ran the aux-recording kernel variant
+        uint32_t variant = 0, tile_queues = 0;  // what aic_frame_info reports of the slot's frame
         const void *light_used[2] = {nullptr, nullptr};  // per layer: the light buffer the slot's frame reads
         uint32_t flaws = 0, local_rows = 0;
         size_t npix = 0;
@@ -962,6 +963,7 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
     fs.light_used[1] = hl[1].light;
     fs.local_rows = local_rows;
     fs.npix = npix;
+    fs.variant = fs.tile_queues = 0;
     if (allow_aux) c->aux_records = 0;
     if (!npix) return AIC_OK;
     hipError_t e;
@@ -983,9 +985,9 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         const uint32_t n_tiles = F.macros_x * F.macros_y;  // the feedback works on macro tiles
         // XCD-local tile queues (aic_trace.hip order_tiles_kernel): one per XCD (32 CUs each on this part), a macro tile in the queue of the
         // 2^sb_shift-macro-tile super-block it lies in. AIC_TILE_QUEUES=1 is the single dispenser of rounds 1-3; AIC_SUPER_SHIFT the block edge.
-        // (both read per frame: tests switch them inside one process)
-        const int queues_env = [] { const char *e = std::getenv("AIC_TILE_QUEUES"); return e ? std::atoi(e) : 0; }();
-        const int super_env = [] { const char *e = std::getenv("AIC_SUPER_SHIFT"); return e ? std::atoi(e) : -1; }();
+        // (aic_frame_desc.tuning; environment variables read per frame until round 5)
+        const int queues_env = (int)((f->tuning >> AIC_TUNE_QUEUES_SHIFT) & 15u);
+        const int super_env = (int)((f->tuning >> AIC_TUNE_SUPER_SHIFT) & 31u) - 1;
         uint32_t n_queues = queues_env > 0 ? (uint32_t)queues_env : (uint32_t)c->n_cus / 32u;
         if (n_queues > kMaxTileQueues) n_queues = kMaxTileQueues;
         if (n_queues < 2u || patches || ortho_n || !n_tiles) n_queues = 0u;
@@ -1075,10 +1077,10 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
             // N = 2 has 4 and gains nothing, at N = 4 / 8 two / one and loses 3-6 % -- profiles/r05_rank_share.txt); the UI pre-pass follows the world pass
             // -- and from 1.9 for frames that are streamed (aic_render_submit), where a share of C3 at N = 8 (4 tiles per wave) gains 9 % by it and, since the
             // scheduler round was trimmed, a share of C2 at N = 4 (2 tiles per wave) 1.8 %; at one tile per wave (N = 8) the plain variant stays 2.5 % ahead)
-            const double x_tiles = [] { const char *e = std::getenv("AIC_XCHG_TILES"); return e ? std::atof(e) : -1.0; }();  // (per frame: tests switch it inside one process)
+            const uint32_t asked = (f->tuning >> AIC_TUNE_VARIANT_SHIFT) & 3u;  // (AIC_XCHG_TILES, an environment variable read per frame, until round 5)
             const double resident_waves = (double)c->n_cus * 16.0;
-            const double need = x_tiles >= 0.0 ? x_tiles : (c->streaming_submit ? 1.9 : 5.0);
-            F.exchange = ((double)F.tiles_x * (double)F.tiles_y >= need * resident_waves) ? 1u : 0u;
+            const double need = c->streaming_submit ? 1.9 : 5.0;
+            F.exchange = asked == AIC_VARIANT_EXCHANGING ? 1u : (asked == AIC_VARIANT_PLAIN ? 0u : (((double)F.tiles_x * (double)F.tiles_y >= need * resident_waves) ? 1u : 0u));
             if (F.exchange && F.antialias) {
                 if ((e = fs.ray_cold.ensure(bytes / sizeof(uint4))) != hipSuccess) return hip_fail(c, "alloc ray state", e);
                 F.ray_cold = fs.ray_cold.p;
@@ -1114,6 +1116,9 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
     F.layer = hl[0];
     F.layer_transparency = hl[0].opt.transparency;
     F.layer_lighting = hl[0].opt.lighting;
+    // (Bounce lighting has no exchanging variant: aic_trace.hip launch_trace)
+    fs.variant = diag ? AIC_VARIANT_RECORDING : ((F.exchange && hl[0].opt.lighting != 5 && (F.ray_cold || !F.antialias)) ? AIC_VARIANT_EXCHANGING : AIC_VARIANT_PLAIN);
+    fs.tile_queues = F.n_queues;
     launch_trace_image(F, diag, fs.stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(fs.ev1, fs.stream));
@@ -1186,6 +1191,8 @@ int wait_frame(aic_ctx *c, uint32_t slot, aic_frame_info *info, bool whole_strea
         info->kernel_ms = kernel_ms;
         info->rows_rendered = fs.local_rows;
         info->flaws = fs.flaws;
+        info->variant = fs.npix ? fs.variant : 0u;
+        info->tile_queues = fs.npix ? fs.tile_queues : 0u;
         info->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - fs.t_begin).count();
     }
     return AIC_OK;

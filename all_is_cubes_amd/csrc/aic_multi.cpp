@@ -239,6 +239,7 @@ int aic_multi_render(aic_multi *m, const aic_frame_desc *f, void *out_rgba8, int
             info->cubes_traced += fi.cubes_traced; info->n_outer += fi.n_outer; info->n_inner += fi.n_inner;
             info->n_hits += fi.n_hits; info->n_light += fi.n_light; info->flaws |= fi.flaws;
             if (fi.kernel_ms > info->kernel_ms) info->kernel_ms = fi.kernel_ms;
+            if (i == 0) { info->variant = fi.variant; info->tile_queues = fi.tile_queues; }  // (every device runs the same variant on a share of the same shape, bar the last strip)
         }
         if (!rows[i]) continue;
         char *dst = (char *)m->gathered + i * (size_t)max_rows * row_bytes;

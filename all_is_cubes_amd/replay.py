@@ -30,7 +30,7 @@ _OPTIONS = np.dtype([("fog", "<i4"), ("transparency", "<i4"), ("threshold", "<f4
                      ("bloom_intensity", "<f4"), ("view_distance", "<f8")], align=True)
 _CAMERA = np.dtype([("inverse_projection_view", "<f8", 16), ("exposure", "<f4"), ("reserved", "<i4")], align=True)
 _FRAME = np.dtype([("width", "<u4"), ("height", "<u4"), ("world", _CAMERA), ("ui", _CAMERA), ("backdrop", "<f4", 4),
-                   ("partition", "<u4", 4), ("flags", "<u4"), ("reserved", "<u4")], align=True)
+                   ("partition", "<u4", 4), ("flags", "<u4"), ("tuning", "<u4")], align=True)
 
 
 @dataclass

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AIC_ABI_VERSION 2
+#define AIC_ABI_VERSION 3
 
 /* status codes */
 #define AIC_OK 0
@@ -124,8 +124,23 @@ typedef struct aic_frame_desc {
     float backdrop[4];           /* UiViewState.backdrop; all-zero = none (renderer.rs:235-253) */
     aic_partition partition;
     uint32_t flags;              /* AIC_FRAME_* */
-    uint32_t reserved;
+    uint32_t tuning;             /* 0 = the library's choices. Otherwise (measurement and tests; ABI 3 -- until then these were environment
+                                  * variables the library read per frame: AIC_TILE_QUEUES, AIC_SUPER_SHIFT, AIC_XCHG_TILES):
+                                  *   bits 0-3   number of tile queues the frame's work tiles are dealt to, 1..8 (0: one per XCD)
+                                  *   bits 4-8   super-block edge in macro tiles, log2, PLUS ONE (0: the largest power of two within an eighth of
+                                  *              the image height)
+                                  *   bits 9-10  AIC_VARIANT_*: which production variant of the trace kernel runs (0: by the frame's size)
+                                  * aic_frame_info.variant / .tile_queues report what ran. Any value gives the same image. */
 } aic_frame_desc;
+
+#define AIC_TUNE_QUEUES_SHIFT 0
+#define AIC_TUNE_SUPER_SHIFT 4
+#define AIC_TUNE_VARIANT_SHIFT 9
+/* production variants of the trace kernel (aic_frame_desc.tuning to ask for one, aic_frame_info.variant to learn which ran) */
+#define AIC_VARIANT_AUTO 0       /* request only: the exchanging variant for a frame of several tiles per resident wave */
+#define AIC_VARIANT_PLAIN 1      /* persistent waves, per-lane refill */
+#define AIC_VARIANT_EXCHANGING 2 /* ... and lanes exchanged between the waves of a workgroup through a pool of parked rays */
+#define AIC_VARIANT_RECORDING 3  /* report only: the variant that writes aic_pixel_aux records / the four byte counters (AIC_FRAME_AUX, AIC_FRAME_COUNTERS) */
 
 #define AIC_FRAME_COUNTERS 1u /* also accumulate n_outer/n_inner/n_hits/n_light */
 #define AIC_FRAME_AUX 2u      /* also write the per-pixel aic_pixel_aux records */
@@ -152,6 +167,8 @@ typedef struct aic_frame_info {
     float total_ms;        /* launch + read-back wall time of the call */
     uint32_t rows_rendered;
     uint32_t flaws;        /* AIC_FLAW_* */
+    uint32_t variant;      /* AIC_VARIANT_*: the trace kernel variant that traced the frame's world pass (ABI 3) */
+    uint32_t tile_queues;  /* tile queues the frame's work tiles were dealt to (0: the single counter -- patch batches, orthographic views) */
 } aic_frame_info;
 
 /* Optional per-pixel record (N4 "other accumulators": first-hit id and depth): the first

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     lib = abi.load()
     for sym in sorted(declared):
         assert hasattr(lib, sym), sym
-    assert lib.aic_abi_version() == 2
+    assert lib.aic_abi_version() == 3
 
 
 def test_every_entry_point_taking_a_context_has_its_ctypes_signature():
@@ -40,7 +40,7 @@ def test_struct_layouts_match_header():
     assert abi.PIXEL_AUX_DTYPE.itemsize == 56
     assert ctypes.sizeof(abi.Options) == 48
     assert ctypes.sizeof(abi.Camera) == 136
-    assert ctypes.sizeof(abi.FrameInfo) == 56
+    assert ctypes.sizeof(abi.FrameInfo) == 64
 
 
 def test_partition_rows_helper():

@@ -81,21 +81,19 @@ def test_random_scene_camera_options(seed):
         ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
         got = ctx.render(ctx.make_frame(w, h, world_inv=inv, backdrop=backdrop), want_aux=True)
         # the production kernel variants (no per-pixel records; built for 4 waves per SIMD): the plain one an image this small gets, and the one that
-        # exchanges lanes between the waves of a workgroup (round 5; AIC_XCHG_TILES=0: for every frame, read per frame) -- parked rays, spare columns,
+        # exchanges lanes between the waves of a workgroup (round 5; asked for through aic_frame_desc.tuning) -- parked rays, spare columns,
         # claims lost to other waves and the drain at the frame's end all happen at this size too
         fast = ctx.render(ctx.make_frame(w, h, world_inv=inv, backdrop=backdrop))
-        os.environ["AIC_XCHG_TILES"] = "0"
         cost = None
-        try:
-            exchanged = ctx.render(ctx.make_frame(w, h, world_inv=inv, backdrop=backdrop))
-            if opt.antialiasing == 0 and opt.lighting != 5:  # (a mean of four samples / secondary rays' steps do not come back from one channel)
-                was = opt.debug_pixel_cost
-                opt.debug_pixel_cost = 1
-                ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
-                cost = ctx.render(ctx.make_frame(w, h, world_inv=inv, backdrop=backdrop, flags=abi.FRAME_OUT_LINEAR))
-                opt.debug_pixel_cost = was
-        finally:
-            del os.environ["AIC_XCHG_TILES"]
+        xt = abi.tuning(variant=abi.VARIANT_EXCHANGING)
+        exchanged = ctx.render(ctx.make_frame(w, h, world_inv=inv, backdrop=backdrop, tuning=xt))
+        assert fast["info"].variant == abi.VARIANT_PLAIN and exchanged["info"].variant == (abi.VARIANT_PLAIN if opt.lighting == 5 else abi.VARIANT_EXCHANGING)
+        if opt.antialiasing == 0 and opt.lighting != 5:  # (a mean of four samples / secondary rays' steps do not come back from one channel)
+            was = opt.debug_pixel_cost
+            opt.debug_pixel_cost = 1
+            ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+            cost = ctx.render(ctx.make_frame(w, h, world_inv=inv, backdrop=backdrop, flags=abi.FRAME_OUT_LINEAR, tuning=xt))
+            opt.debug_pixel_cost = was
     assert (fast["rgba8"] == got["rgba8"]).all() and fast["info"].cubes_traced == got["info"].cubes_traced
     assert (exchanged["rgba8"] == got["rgba8"]).all() and exchanged["info"].cubes_traced == got["info"].cubes_traced
     if cost is not None:

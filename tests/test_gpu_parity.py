@@ -35,19 +35,25 @@ def to_abi_options(o: oracle.OrcOptions) -> abi.Options:
 
 
 def assert_production_variants(ctx, frame, got):
-    """The production kernel variants of `frame` -- the plain one an image this small gets and the lane-exchanging one (forced: AIC_XCHG_TILES is read per
-    frame) -- must give the aux-recording variant's bytes and step total."""
-    fast = ctx.render(frame)
-    os.environ["AIC_XCHG_TILES"] = "0"
+    """The production kernel variants of `frame` -- the plain one an image this small gets and the lane-exchanging one (asked for through
+    aic_frame_desc.tuning) -- must give the aux-recording variant's bytes and step total; aic_frame_info.variant says which ran."""
+    keep_flags, keep_tuning = frame.flags, frame.tuning
+    frame.flags &= ~(abi.FRAME_AUX | abi.FRAME_COUNTERS)  # (ctx.render(.., want_aux=True) left them set)
     try:
+        fast = ctx.render(frame)
+        frame.tuning = keep_tuning | abi.tuning(variant=abi.VARIANT_EXCHANGING)
         exchanged = ctx.render(frame)
     finally:
-        del os.environ["AIC_XCHG_TILES"]
+        frame.flags, frame.tuning = keep_flags, keep_tuning
+    if got["info"].rows_rendered and frame.width:
+        assert got["info"].variant == abi.VARIANT_RECORDING or not (keep_flags & (abi.FRAME_AUX | abi.FRAME_COUNTERS))
+        assert exchanged["info"].variant in (abi.VARIANT_EXCHANGING, abi.VARIANT_PLAIN)  # (Bounce lighting has no exchanging variant)
+        assert fast["info"].variant in (abi.VARIANT_PLAIN, abi.VARIANT_EXCHANGING)
     for name, other in (("plain", fast), ("exchanging", exchanged)):
         assert (other["rgba8"] == got["rgba8"]).all() and other["info"].cubes_traced == got["info"].cubes_traced, f"production variant ({name}) differs from the aux-recording one"
 
 
-def render_both(ctx, space, opt: oracle.OrcOptions, size, eye, quat=(0, 0, 0, 1), fov=90.0, ui=None, ui_eye=(0, 0, 0), backdrop=(0, 0, 0, 0)):
+def render_both(ctx, space, opt: oracle.OrcOptions, size, eye, quat=(0, 0, 0, 1), fov=90.0, ui=None, ui_eye=(0, 0, 0), backdrop=(0, 0, 0, 0), tuning=0):
     w, h = size
     _, _, inv = oracle.camera_matrices(fov, opt.view_distance, w / h, quat, eye)
     ui_inv = None
@@ -63,7 +69,7 @@ def render_both(ctx, space, opt: oracle.OrcOptions, size, eye, quat=(0, 0, 0, 1)
     else:
         ctx.clear_space(abi.LAYER_UI)
     opt.exposure = 1.0
-    frame = ctx.make_frame(w, h, world_inv=inv, ui_inv=ui_inv, backdrop=backdrop)
+    frame = ctx.make_frame(w, h, world_inv=inv, ui_inv=ui_inv, backdrop=backdrop, tuning=tuning)
     got = ctx.render(frame, want_aux=True)
     # every scene that goes through this helper (goldens, options matrix, layers, antialiasing, UI pre-pass + world pass) covers the production variants too
     assert_production_variants(ctx, frame, got)
@@ -240,32 +246,31 @@ def test_bounce_with_octant_sky_ui_layer_and_antialiasing(ctx):
     assert_parity(got, ref)
 
 
-def test_xcd_local_tile_queues_trace_every_pixel_once(ctx, synth_space, monkeypatch):
+def test_xcd_local_tile_queues_trace_every_pixel_once(ctx, synth_space):
     """The persistent kernel's waves take their tiles from one queue per XCD (macro tiles dealt to queues by super-block, a workgroup
     starting on its XCD's queue and moving on when it is empty: csrc/aic_trace.hip order_tiles_kernel). Whatever the number of queues
     and the block size, and with or without the previous frame's cost record, the frame is the one the single dispenser gives --
     pixels, per-pixel step counts and totals -- and the oracle's."""
     opt = oracle.make_options(fog=1, transparency=1, lighting=2)
     size = (416, 232)  # not a multiple of the tile, the macro tile or any super-block
-    monkeypatch.setenv("AIC_TILE_QUEUES", "1")
-    base, ref = render_both(ctx, synth_space, opt, size, SYNTH_EYE, synth_quat())
+    base, ref = render_both(ctx, synth_space, opt, size, SYNTH_EYE, synth_quat(), tuning=abi.tuning(queues=1))
     assert_parity(base, ref)
+    assert base["info"].tile_queues == 0  # (one queue = the single counter)
     w, h = size
     _, _, inv = oracle.camera_matrices(90.0, opt.view_distance, w / h, synth_quat(), SYNTH_EYE)
-    for queues, shift in [("8", None), ("8", "0"), ("8", "2"), ("8", "7"), ("3", "1"), ("5", None), ("2", "12")]:
-        monkeypatch.setenv("AIC_TILE_QUEUES", queues)
-        if shift is None:
-            monkeypatch.delenv("AIC_SUPER_SHIFT", raising=False)
-        else:
-            monkeypatch.setenv("AIC_SUPER_SHIFT", shift)
-        frame = ctx.make_frame(w, h, world_inv=inv)
+    for queues, shift in [(8, None), (8, 0), (8, 2), (8, 7), (3, 1), (5, None), (2, 12)]:
+        tune = abi.tuning(queues=queues, super_shift=shift)
+        frame = ctx.make_frame(w, h, world_inv=inv, tuning=tune)
         for attempt in range(2):  # the second frame of the same view is ordered by the first one's cost record
             got = ctx.render(frame, want_aux=True)
             assert (got["rgba8"] == base["rgba8"]).all(), (queues, shift, attempt)
             assert (got["aux"]["cubes_traced"] == base["aux"]["cubes_traced"]).all()
             assert got["info"].cubes_traced == base["info"].cubes_traced
-        plain = ctx.render(ctx.make_frame(w, h, world_inv=inv))  # the production variant
-        assert (plain["rgba8"] == base["rgba8"]).all() and plain["info"].cubes_traced == base["info"].cubes_traced
+            assert got["info"].tile_queues == queues and got["info"].variant == abi.VARIANT_RECORDING
+        for variant in (abi.VARIANT_PLAIN, abi.VARIANT_EXCHANGING):  # the production variants
+            plain = ctx.render(ctx.make_frame(w, h, world_inv=inv, tuning=tune | abi.tuning(variant=variant)))
+            assert (plain["rgba8"] == base["rgba8"]).all() and plain["info"].cubes_traced == base["info"].cubes_traced
+            assert plain["info"].variant == variant and plain["info"].tile_queues == queues
 
 
 def test_frames_of_changing_shape_on_one_slot(ctx, synth_space):
@@ -960,15 +965,11 @@ def test_opaque_shortcut_counts_on_a_blocks_last_voxel(ctx):
             ref = oracle.render(oracle.Space(sp), opt, oracle.make_camera(inv, w, h), want_aux=True)
             assert_parity(got, ref)
             assert_production_variants(ctx, fr, got)
-            for tiles in (None, "0"):          # the per-pixel counts of the plain and of the lane-exchanging production variant
-                if tiles is not None:
-                    os.environ["AIC_XCHG_TILES"] = tiles
-                try:
-                    cost = ctx.render(ctx.make_frame(w, h, world_inv=inv, flags=abi.FRAME_OUT_LINEAR))
-                finally:
-                    os.environ.pop("AIC_XCHG_TILES", None)
+            for variant in (abi.VARIANT_PLAIN, abi.VARIANT_EXCHANGING):  # the per-pixel counts of the plain and of the lane-exchanging production variant
+                cost = ctx.render(ctx.make_frame(w, h, world_inv=inv, flags=abi.FRAME_OUT_LINEAR, tuning=abi.tuning(variant=variant)))
+                assert cost["info"].variant == variant
                 counts = np.rint(cost["rgba8"][..., 1].astype(np.float64) / float(np.float32(0.002))).astype(np.int64)
-                assert (counts == ref["aux"]["cubes_traced"]).all(), (transparency, eye, tiles)
+                assert (counts == ref["aux"]["cubes_traced"]).all(), (transparency, eye, variant)
 
 
 def test_block_table_past_14_bits_uses_the_class_table(ctx):
