@@ -24,6 +24,7 @@ FRAME_COUNTERS, FRAME_AUX, FRAME_PIXEL_CENTERS, FRAME_OUT_LINEAR, FRAME_OUT_COLO
 # aic_frame_desc.tuning / aic_frame_info.variant (include/aic_hip.h)
 TUNE_QUEUES_SHIFT, TUNE_SUPER_SHIFT, TUNE_VARIANT_SHIFT = 0, 4, 9
 VARIANT_AUTO, VARIANT_PLAIN, VARIANT_EXCHANGING, VARIANT_RECORDING = 0, 1, 2, 3
+LIGHT_HOOK_SESSION, LIGHT_HOOK_POOL_SHIFT = 1, 8
 
 
 def tuning(queues=None, super_shift=None, variant=None) -> int:
@@ -67,7 +68,7 @@ class BlockDesc(C.Structure):
 
 class LightParams(C.Structure):
     _fields_ = [("maximum_distance", C.c_int32), ("fast", C.c_int32), ("epsilon", C.c_int32), ("batch", C.c_int32),
-                ("queue_order", C.c_int32), ("n_queue", C.c_int32), ("lanes_per_cube", C.c_int32), ("reserved", C.c_int32), ("queue_cubes", C.c_void_p), ("queue_priorities", C.c_void_p),
+                ("queue_order", C.c_int32), ("n_queue", C.c_int32), ("lanes_per_cube", C.c_int32), ("hooks", C.c_int32), ("queue_cubes", C.c_void_p), ("queue_priorities", C.c_void_p),
                 ("max_updates", C.c_uint64)]
 
 
@@ -496,11 +497,13 @@ class Context:
         return out
 
     def evaluate_light(self, layer: int, maximum_distance: int, fast: bool = True, epsilon: int = 1, batch: int = 32,
-                       queue_order: int = 16, queue=None, max_updates: int = 0, lanes_per_cube: int = 0) -> LightInfo:
+                       queue_order: int = 16, queue=None, max_updates: int = 0, lanes_per_cube: int = 0, session: bool = False,
+                       dep_pool_chunks: int = 0) -> LightInfo:
         """`Mutation::fast_evaluate_light` (if `fast`) then `Mutation::evaluate_light(epsilon)` (space.rs:1496-1540) on
         the uploaded space, compute_light on the device. `queue`: None = every Uninitialized texel (when not `fast`), or a
         list of ((x, y, z), priority). The layer's light volume is updated in place."""
-        p = LightParams(maximum_distance, int(fast), epsilon, batch, queue_order, -1, lanes_per_cube, 0, None, None, max_updates)
+        hooks = (LIGHT_HOOK_SESSION if session else 0) | ((int(dep_pool_chunks) & 0xffff) << LIGHT_HOOK_POOL_SHIFT)  # (test hooks: aic_light_params.hooks)
+        p = LightParams(maximum_distance, int(fast), epsilon, batch, queue_order, -1, lanes_per_cube, hooks, None, None, max_updates)
         keep = []
         if queue is not None:
             qc = np.ascontiguousarray([q[0] for q in queue], np.int32).reshape(-1, 3)

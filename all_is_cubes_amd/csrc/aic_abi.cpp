@@ -187,6 +187,14 @@ struct aic_ctx {
     std::FILE *dump = nullptr;  // AIC_DUMP=path: every scene / options / frame argument is appended here
     char devname[256] = {0};
     uint32_t n_cus = 256;
+    // measurement switches, read from the environment ONCE, when the context is made -- nothing on the frame path reads the environment
+    struct Switches {
+        int tile = 0, macro = 0;         // AIC_TILE, AIC_MACRO: work-tile edge in pixels (8 | 16), tiles per macro tile edge
+        bool feedback = true;            // AIC_TILE_FEEDBACK=0: no cost-feedback tile order
+        bool wait_whole_stream = false;  // AIC_WAIT_WHOLE_STREAM=1: aic_render_wait drains the slot's stream (rounds 1-3)
+        uint32_t tiles_per_wave = 0;     // AIC_TILES_PER_WAVE: grid sizing of streamed frames smaller than the chip
+        std::string wave_prof;           // AIC_WAVE_PROF (-DAIC_PROFILE builds): file for the per-wave clocks
+    } sw;
 };
 
 namespace {
@@ -385,6 +393,15 @@ aic_ctx *aic_create(int device_id, int *status) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) std::snprintf(c->devname, sizeof(c->devname), "%s (%s)", prop.name, prop.gcnArchName);
+    {
+        auto env_int = [](const char *name, int dflt) { const char *e = std::getenv(name); return e ? std::atoi(e) : dflt; };
+        c->sw.tile = env_int("AIC_TILE", 0);
+        c->sw.macro = env_int("AIC_MACRO", 0);
+        c->sw.feedback = env_int("AIC_TILE_FEEDBACK", 1) != 0;
+        c->sw.wait_whole_stream = env_int("AIC_WAIT_WHOLE_STREAM", 0) != 0;
+        c->sw.tiles_per_wave = (uint32_t)std::max(0, env_int("AIC_TILES_PER_WAVE", 0));
+        if (const char *p = std::getenv("AIC_WAVE_PROF")) c->sw.wave_prof = p;
+    }
     if (const char *path = std::getenv("AIC_DUMP")) {
         static int n_dumps = 0;  // one file per context: <path>, <path>.1, <path>.2 ...
         std::string pth = path;
@@ -940,18 +957,18 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         // 8x8-pixel tiles: one wave-full of pixels per fetch from the tile counter. Measured against
         // 16x16 (AIC_TILE=16): -24 % frame time at 1080p, -11 % at 4K -- the coarser tiles left the
         // 2048 persistent waves with ~4 work items each and a long unbalanced tail.
-        static const int forced = [] { const char *e = std::getenv("AIC_TILE"); return e ? std::atoi(e) : 0; }();
+        const int forced = c->sw.tile;
         F.tile = (forced == 8 || forced == 16) ? (uint32_t)forced : 8u;
         F.tiles_x = (f->width + F.tile - 1) / F.tile;
         F.tiles_y = (local_rows + F.tile - 1) / F.tile;
-        static const int macro_env = [] { const char *e = std::getenv("AIC_MACRO"); return e ? std::atoi(e) : 0; }();
+        const int macro_env = c->sw.macro;
         F.macro = (macro_env == 1 || macro_env == 2 || macro_env == 4 || macro_env == 8 || macro_env == 16) ? (uint32_t)macro_env : 2u;
         F.macros_x = (F.tiles_x + F.macro - 1) / F.macro;
         F.macros_y = (F.tiles_y + F.macro - 1) / F.macro;
     }
     F.light_lut = c->lut.p;
     F.n_cus = c->n_cus;
-    F.tiles_per_wave = c->streaming_submit ? 4u : 1u;
+    F.tiles_per_wave = c->sw.tiles_per_wave ? c->sw.tiles_per_wave : (c->streaming_submit ? 4u : 1u);
     F.srgb_thr = c->srgb_thr.p;
     F.counters = fs.counters.p;
 
@@ -972,8 +989,10 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         if ((e = c->aux.ensure(npix)) != hipSuccess) return hip_fail(c, "alloc aux", e);
         F.aux = c->aux.p;
     }
-    if (!fs.host_counters)  // (on a slot's first frame: most contexts only ever use slot 0, and a context is cheap to make and drop)
+    if (!fs.host_counters) {  // (on a slot's first frame: most contexts only ever use slot 0, and a context is cheap to make and drop)
         HIP_TRY(c, hipHostMalloc((void **)&fs.host_counters, sizeof(DevCounters), hipHostMallocDefault));
+        std::memset(fs.host_counters, 0, sizeof(DevCounters));
+    }
     if (!fs.counters_clean) HIP_TRY(c, hipMemsetAsync(fs.counters.p, 0, sizeof(DevCounters), fs.stream));
     fs.counters_clean = false;
     uint32_t order_key[6] = {0, 0, 0, 0, 0, 0};
@@ -981,7 +1000,7 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
     {
         // tile order for this frame from the cost the slot's previous frame recorded, if that frame
         // had the same shape (else index order); the record was turned into an order, and cleared, behind that frame
-        static const bool feedback = [] { const char *e = std::getenv("AIC_TILE_FEEDBACK"); return !e || std::atoi(e) != 0; }();
+        const bool feedback = c->sw.feedback;
         const uint32_t n_tiles = F.macros_x * F.macros_y;  // the feedback works on macro tiles
         // XCD-local tile queues (aic_trace.hip order_tiles_kernel): one per XCD (32 CUs each on this part), a macro tile in the queue of the
         // 2^sb_shift-macro-tile super-block it lies in. AIC_TILE_QUEUES=1 is the single dispenser of rounds 1-3; AIC_SUPER_SHIFT the block edge.
@@ -1163,11 +1182,11 @@ int wait_frame(aic_ctx *c, uint32_t slot, aic_frame_info *info, bool whole_strea
         DevCounters hc;
         fs.busy = false;  // released whatever happens below: a frame that failed must not block its slot for good
         // the frame and its counters (ev2), not the slot's housekeeping behind them -- unless the caller has enqueued a copy of its own behind the frame
-        static const bool always_whole = [] { const char *e = std::getenv("AIC_WAIT_WHOLE_STREAM"); return e && std::atoi(e) != 0; }();  // (a measurement switch: DESIGN.md 4.6)
-        if (whole_stream || always_whole) HIP_TRY(c, hipStreamSynchronize(fs.stream));
+        if (whole_stream || c->sw.wait_whole_stream) HIP_TRY(c, hipStreamSynchronize(fs.stream));  // (the switch: a measurement)
         else HIP_TRY(c, hipEventSynchronize(fs.ev2));
         std::memcpy(&hc, fs.host_counters, sizeof(hc));
         HIP_TRY(c, hipEventElapsedTime(&kernel_ms, fs.ev0, fs.ev1));
+        if (hc.bailed) return fail(c, AIC_ERR_DEVICE, "trace kernel: a wave gave up waiting for rays in transit between waves; the frame has unwritten pixels");
         if (info) {
             info->cubes_traced = hc.cubes_traced;
             info->n_outer = hc.n_outer;
@@ -1179,7 +1198,7 @@ int wait_frame(aic_ctx *c, uint32_t slot, aic_frame_info *info, bool whole_strea
         { static const char *names[40] = {"max_lifetime","max_until_dry","cyc_until_dry","cyc_lifetime","shade_ph","shade_ln","enter_ph","enter_ln","ray_ph","ray_ln","step_iters","step_lanes","cyc_step","cyc_shade_rest","cyc_enter","cyc_newray","cyc_finish","cyc_refill","cyc_shade_light","cyc_sched","fast_iters","fast_lanes","trips","trip_lanes","pass_hl_lanes","pass_fast_eligible","leave_blocks","leave_lanes","apply_blocks","apply_lanes","pass_needed_lanes","xchg_rounds","xchg_lanes","cyc_xchg","xchg_picked","xchg_parked","idle_spins","xchg_claims_lost","xchg_empty","-"};
           // (only the production variant's frames: the aux-recording variant is another kernel, at half the occupancy)
           if (!fs.diag) for (int i = 0; i < 39; i++) std::fprintf(stderr, "PROF %s %llu\n", names[i], hc.prof[i]);
-          if (const char *path = fs.diag ? nullptr : std::getenv("AIC_WAVE_PROF")) {
+          if (const char *path = (fs.diag || c->sw.wave_prof.empty()) ? nullptr : c->sw.wave_prof.c_str()) {
               if (FILE *fp = std::fopen(path, "w")) {
                   for (int w = 0; w < 2048; w++) std::fprintf(fp, "%u %u %u %u\n", hc.wave_prof[w][0], hc.wave_prof[w][1], hc.wave_prof[w][2], hc.wave_prof[w][3]);
                   std::fclose(fp);
@@ -1377,7 +1396,18 @@ int aic_trace_patches(aic_ctx *c, const aic_frame_desc *f, uint32_t n, const dou
 static int ensure_slot(aic_ctx *c, uint32_t slot) {
     aic_ctx::FrameSlot &fs = c->slots[slot];
     if (fs.stream && fs.ev0 && fs.ev1 && fs.ev2 && fs.counters.p) return AIC_OK;
-    if (!fs.stream) HIP_TRY(c, hipStreamCreateWithFlags(&fs.stream, hipStreamNonBlocking));
+    if (!fs.stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&fs.stream, hipStreamNonBlocking));
+        // "Everything the context queues afterwards waits for the event" (aic_wait_event) must hold for a stream made later too: the context's first
+        // stream received every such wait, so the new stream is ordered behind where that one stands now (a first frame on slot >= 8
+        // after an aic_wait_event raced the gather still reading its strip buffer)
+        hipEvent_t ev = nullptr;
+        HIP_TRY(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e1 = hipEventRecord(ev, c->stream);
+        if (e1 == hipSuccess) e1 = hipStreamWaitEvent(fs.stream, ev, 0);
+        (void)hipEventDestroy(ev);  // (released once the recorded work is done)
+        if (e1 != hipSuccess) return hip_fail(c, "order a new slot's stream behind the context's waits", e1);
+    }
     if (!fs.ev0) HIP_TRY(c, hipEventCreate(&fs.ev0));
     if (!fs.ev1) HIP_TRY(c, hipEventCreate(&fs.ev1));
     if (!fs.ev2) HIP_TRY(c, hipEventCreate(&fs.ev2));

@@ -93,6 +93,8 @@ struct DevCounters {
     unsigned long long n_inner;
     unsigned long long n_hits;
     unsigned long long n_light;
+    unsigned long long bailed;    // waves of the exchanging variants that gave up waiting for rays in transit (spun_out): never, short of a bug -- the host
+                                  // turns a non-zero count into AIC_ERR_DEVICE, because such a wave abandons its rays and pixels stay unwritten
     unsigned long long prof[48];  // AIC_PROFILE builds only
     uint32_t tile_next;           // dynamic tile dispenser of the persistent trace kernel
     uint32_t waves_done;          // waves of the world pass that have added their sums: the last one hands the sums to the host (DevFrame::host_counters)
@@ -164,7 +166,7 @@ struct DevFrame {
     uint32_t n_queues;
     uint32_t pad_q;
     const uint32_t *queue_start;
-    // pinned host memory for the frame's five sums (cubes_traced, n_outer, n_inner, n_hits, n_light), written by the last wave of the world pass
+    // pinned host memory for the frame's five sums (cubes_traced, n_outer, n_inner, n_hits, n_light) and the `bailed` count, written by the last wave of the world pass
     // to finish: no copy launch behind the trace (a blit kernel that, with frames streamed, waits ~0.2 ms for a CU to have room). Null: the host copies.
     unsigned long long *host_counters;
     const float *light_lut;  // 256 floats

@@ -178,6 +178,7 @@ int aic_multi_light_cubes_changed(aic_multi *m, int layer, uint32_t n, const int
     rc = forward(m, 0, aic_read_light_cubes(m->ctx[0], layer, n, xyz, texels.data()));
     for (size_t i = 1; rc == AIC_OK && i < m->ctx.size(); i++) rc = forward(m, i, aic_update_cubes(m->ctx[i], layer, n, xyz, nullptr, texels.data()));
     if (rc == AIC_OK) m->light_stale[layer] = false;
+    else m->err.clear();  // (the call succeeds: the failed hand-over must not be left behind as the multi context's last error -- ADVICE r05)
     return AIC_OK;  // device 0 has taken the change; what the others lack is owed (light_stale) and paid by aic_multi_render
 }
 

@@ -1095,6 +1095,13 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
 #define AIC_PROF(i, v)
 #define AIC_TICK(i)
 #endif
+// -DAIC_SECTION_MARKS: comments in the listing that tools/listing_lines.py --sections splits the instruction stream by (static counts per section; the
+// markers are volatile asm statements and pin a little of the schedule, so this is a reading aid, not the production build)
+#ifdef AIC_SECTION_MARKS
+#define AIC_SECTION(name) asm volatile("; AIC_SECTION " #name ::: "memory")
+#else
+#define AIC_SECTION(name)
+#endif
     uint32_t next_idx = F.tile * F.tile;  // wave-uniform: next unassigned pixel of tile_cur (tile_px = tile exhausted)
     if (XCHG && lane == 0u) { s_tile_state[tid >> 6][0] = 0u; s_tile_state[tid >> 6][1] = 0u; s_tile_state[tid >> 6][2] = next_idx; }
 
@@ -1160,12 +1167,25 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
             : "vcc", "scc");  // (the scalar mask operations write SCC)
         return bz;  // lanes whose level ran out of steps: it left its bounds
     };
-    auto spun_out = [&]() -> bool {  // (XCHG) counts a round that could do nothing; true once the wave has had 2^22 of them (a bug's hang would cost the GPU box)
+    // (XCHG) counts a round that could do nothing; true once the wave has had 2^22 of them (a bug's hang would cost the GPU box). The count is cumulative over the
+    // wave's life, not reset by progress (a reset would be a masked LDS store in every round): an idle round sleeps >= 256 cycles, so the bound is >= 10^9 cycles --
+    // half a second -- of ONE wave's life spent waiting for rays in transit, against frames of milliseconds with a few such rounds per wave
+    // (profiles/r05_phase_cycles.txt: 649 / 4415 in a whole C2 / C3 frame). A wave that does give up says so: DevCounters::bailed makes the frame fail on the host.
+    auto spun_out = [&]() -> bool {
         const uint32_t n_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_idle_spins[threadIdx.x >> 6]) + 1u;
         if (lane == 0u) s_idle_spins[threadIdx.x >> 6] = n_;
-        return n_ > (1u << 22);
+        if (n_ > (1u << 22)) {
+            // (the argument through the opaque kernel-argument pointer, like the event phase's: a plain use of `F` here would hold the pointer in registers for the life of the wave)
+            typedef const __attribute__((address_space(4))) DevFrame KFrameB;
+            KFrameB *Fb = (KFrameB *)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(Fb));
+            if (lane == 0u) atomicAdd(&Fb->counters->bailed, 1ull);
+            return true;
+        }
+        return false;
     };
     for (;;) {
+        AIC_SECTION(scheduler);
         // ---- wave scheduler: step, or run ONE kind of parked work for all lanes waiting on it ----
         // Kinds: SHADE (light + composite a surface), ENTER (a block), RAY (finish / start a ray). A
         // kind is run when enough lanes wait on it to fill the wave reasonably (AIC_T_BATCH), or when
@@ -1236,6 +1256,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
             const int t_p = park_ok_i < t_park ? park_ok_i : t_park;
             const int t_a = opaque_s(t_gain > t_none ? t_gain : t_none);  // (kept apart: fused, the two maxima become a v_max3 with copies in front and a vector compare behind)
             if ((t_a > t_p ? t_a : t_p) >= 0) {
+                AIC_SECTION(exchange);
                 const bool may_park = park_ok_i >= 0 && n_others > 0;
                 // ---- the exchange: lanes that would idle ("givers": empty lanes first, then rays of other kinds) are paired with parked rays of the wanted
                 // kind, and -- while the image has pixels left -- what remains of them with free slots. A pairing is a claim (compare-and-swap of the slot's
@@ -1282,6 +1303,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                     if (NPOOL > 64u) { const uint32_t u_ = nf0 + below(f1), i_ = down ? n_f - 1u - u_ : u_; if ((t1 == TAG_FREE) & (i_ < 64u)) pick_f[i_] = (uint8_t)(ln + 64u); }
                     if (NPOOL > 128u) { const uint32_t u_ = nf0 + nf1 + below(f2), i_ = down ? n_f - 1u - u_ : u_; if ((t2 == TAG_FREE) & (i_ < 64u)) pick_f[i_] = (uint8_t)(ln + 128u); }
                 }
+                __builtin_amdgcn_wave_barrier();  // (the lists are written by some lanes and read by others of this wave: LDS operations of a wave are performed in order; this keeps the compiler from reordering them)
                 const uint32_t n_take = n_w < n_giv ? n_w : n_giv;  // (at most 64)
                 const uint32_t n_free = n_f < 64u ? n_f : 64u;
                 // a giver of rank < n_take takes a parked ray; the rays of the ranks after that are parked while slots are free
@@ -1407,6 +1429,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
             }
             }
             else { AIC_TICK(19); }
+            AIC_SECTION(scheduler_tail);
             if (!settled && (run == 0u ? n_step : (run == EV_SHADE ? c_shade : (run == EV_ENTER ? c_enter : c_ray))) == 0) {
                 // (the kind was chosen for what the pool holds, and every claim was lost to another wave -- or only rays in transit were found)
                 AIC_PROF(36, 1);
@@ -1439,6 +1462,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
         AIC_TICK(19);
         }
         if (run != 0u) {
+            AIC_SECTION(event_prologue);
             // ============================ event phase ======================================
             // the kernel arguments, through an opaque pointer (see the top of the kernel): `F`, `L`, `opt` below shadow the
             // by-value parameter for the whole phase
@@ -1603,6 +1627,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
             // (one kind runs per phase: each kind's section sits behind a UNIFORM branch on `run`, the per-lane test inside it -- written as one combined condition
             //  the copies that carry a section's conditionally updated variables to the merge behind it are made in every phase, whichever kind runs)
             if (run == EV_SHADE) {
+            AIC_SECTION(shade_geometry);
             if (ev & EV_SHADE) {
                 const bool inb = (st & ST_IN_BLOCK) != 0;
                 const uint32_t blk_res = 1u << (blk_geo >> 24), blk_vlo = blk_geo & 0xffffffu;
@@ -1627,6 +1652,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 float i0 = 1.0f, i1 = 1.0f, i2 = 1.0f;
                 uint32_t nl = 0;
                 double ip[3] = {0.0, 0.0, 0.0};  // the surface point in space coordinates (LMODE 2: light interpolation; 3: the bounce rays' origin)
+                AIC_SECTION(shade_light);
                 if (LMODE != 0) {
                     const int face = lvl_face(ca);
                     if (LMODE == 1 || LMODE == 3) {  // Flat; Bounce falls back to it for surfaces that are not fully opaque (surface.rs:171-176)
@@ -1669,6 +1695,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                     }
                 }
                 AIC_TICK(18);
+                AIC_SECTION(shade_colour_span);
                 // colour record
                 float r, g, b, a, e0, e1, e2;
                 if (shade_ref & 0x80000000u) {
@@ -1720,6 +1747,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                     const float c = ps_clamped(coeff);
                     e0 = ps_mul(e0, c); e1 = ps_mul(e1, c); e2 = ps_mul(e2, c);
                 }
+                AIC_SECTION(shade_to_light_fog);
                 // Surface::to_light (surface.rs:73-106)
                 if (opt.transparency == 2) {  // limit_alpha (graphics_options.rs:496-507)
                     if (a > opt.threshold) a = 1.0f;
@@ -1780,6 +1808,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                         tr *= comp;
                     }
                 }
+                AIC_SECTION(shade_apply);
                 SurfDiag sd;
                 if (DIAG) {
                     sd.nlight = nl;
@@ -1859,7 +1888,9 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 }
                 ev &= ~EV_SHADE;
             }
+            AIC_SECTION(shade_end);
             } else if (run == EV_ENTER) {
+            AIC_SECTION(enter);
             // -- entering a recursive block: RaycastStep::recursive_raycast (raycast.rs:458-476),
             //    advanced to its first in-bounds voxel (or to its end) --
             if (ev & EV_ENTER) {
@@ -1903,7 +1934,9 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 st |= ST_IN_BLOCK;
                 ev = (got ? EV_FRESH : 0u) | (dead ? EV_DEAD : 0u);
             }
+            AIC_SECTION(enter_end);
             } else {
+            AIC_SECTION(finish);
             // -- finishing a ray: TracingState::finish + layer tail + (last sample) encode & store --
             uint32_t pxy = 0;
             int sample = 0;
@@ -2017,6 +2050,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                     ev = EV_NEWRAY | EV_TAKE;
                 }
             }
+            AIC_SECTION(refill);
             if (run == EV_FINISH) { AIC_TICK(16) }
             // -- starting a ray: lane refill + Camera::project_ndc_into_world + Raycaster::within --
             if (run == EV_FINISH) {
@@ -2113,6 +2147,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                     if (lane == 0u) { s_tile_state[wv_][0] = tile_x0; s_tile_state[wv_][1] = tile_y0; s_tile_state[wv_][2] = next_idx; }
                 }
             }
+            AIC_SECTION(newray);
             if (run == EV_FINISH) { AIC_TICK(17) }
             if (run == EV_FINISH && (ev & EV_NEWRAY) && ev != EV_DONE && !want) {
                 const uint32_t x = pxy & 0xffffu, lrow = pxy >> 16;
@@ -2193,11 +2228,13 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 }
             }
             if (run == EV_FINISH && !want) c32[K_PXY][col] = pxy;
+            AIC_SECTION(newray_end);
             }
             if (run == EV_SHADE) { AIC_TICK(13) } else if (run == EV_ENTER) { AIC_TICK(14) } else { AIC_TICK(15) }
             continue;
         }
 
+        AIC_SECTION(stepping);
         // ============================ stepping phase ======================================
         // One Amanatides-Woo step of the lane's current level -- the cube grid or a block's voxel
         // volume: same registers, same code, one 2-byte lookup in the shared pool
@@ -2511,6 +2548,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
         AIC_TICK(12);
     }
 
+    AIC_SECTION(epilogue);
 #ifdef AIC_PROFILE
     if (lane == 0) {
         prof[3] = (uint32_t)__builtin_readcyclecounter() - prof_t0;  // wave lifetime
@@ -2570,9 +2608,9 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
     if (lane == 0 && F.host_counters) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (atomicAdd(&F.counters->waves_done, 1u) == gridDim.x * (blockDim.x >> 6) - 1u) {
-            unsigned long long *const src = &F.counters->cubes_traced;  // five consecutive sums (DevCounters)
+            unsigned long long *const src = &F.counters->cubes_traced;  // five consecutive sums and `bailed` (DevCounters)
 #pragma unroll
-            for (int i = 0; i < 5; i++) F.host_counters[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < 6; i++) F.host_counters[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -2775,8 +2813,7 @@ static void launch_trace_x(const DevFrame &F, hipStream_t stream) {
     // after one tile, and the kernels of the frames in flight are resident side by side (an eighth of a 1080p frame, 8 in
     // flight: 0.105 ms per frame against 0.138 with one tile per wave). A synchronous frame (aic_render) is a matter of
     // latency: one tile per wave, as many waves as there are tiles.
-    static const uint32_t tpw_override = [] { const char *e = std::getenv("AIC_TILES_PER_WAVE"); const int v = e ? std::atoi(e) : 0; return (uint32_t)(v > 0 ? v : 0); }();
-    const uint32_t tiles_per_wave = tpw_override ? tpw_override : (F.tiles_per_wave ? F.tiles_per_wave : 1u);
+    const uint32_t tiles_per_wave = F.tiles_per_wave ? F.tiles_per_wave : 1u;  // (the host's choice; AIC_TILES_PER_WAVE, read when the context is made, overrides it)
     const uint32_t by_tiles = (n_tiles + wg_waves - 1u) / wg_waves;
     uint32_t grid = (n_tiles + wg_waves * tiles_per_wave - 1u) / (wg_waves * tiles_per_wave);
     const uint32_t floor_groups = by_tiles < 128u ? by_tiles : 128u;

@@ -363,11 +363,16 @@ typedef struct aic_light_params {
     int32_t lanes_per_cube;   /* how compute_light is mapped to the device: 256 (or 0 = default) / 64: a block of four waves / one
                                  wave per cube walks the ray-bundle tree level by level and the contributions are added in the
                                  reference's order; 1 = one lane per cube (the plain restatement). Same results, bit for bit */
-    int32_t reserved;
+    int32_t hooks;            /* 0 in normal use. Test / experiment hooks (ABI 3; environment variables read per call until then): bit 0 = serve a call's
+                                 small batches from one session kernel fed through pinned host memory (AIC_LIGHT_HOOK_SESSION; measured neutral,
+                                 profiles/r04_experiments.txt J); bits 8-23 = chunks the layer's dependency pool STARTS with (0: eight per cube),
+                                 to force the grow-and-recompute path */
     const int32_t *queue_cubes;      /* [n_queue][3] */
     const int32_t *queue_priorities; /* [n_queue], 0..255 */
     uint64_t max_updates;     /* stop once this many cubes were updated (checked between batches); 0 = run until done */
 } aic_light_params;
+#define AIC_LIGHT_HOOK_SESSION 1
+#define AIC_LIGHT_HOOK_POOL_SHIFT 8
 typedef struct aic_light_info {
     uint64_t updates;     /* cubes computed and applied (LightUpdatesInfo::update_count) */
     uint64_t batches;     /* device launches */

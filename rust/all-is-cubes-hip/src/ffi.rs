@@ -1,10 +1,10 @@
-//! Raw bindings to libaic_hip.so: one item per declaration of `include/aic_hip.h` (AIC_ABI_VERSION 2), same
+//! Raw bindings to libaic_hip.so: one item per declaration of `include/aic_hip.h` (AIC_ABI_VERSION 3), same
 //! names, same field order. Kept in step with the header by `tests/test_rust_shim.py` of the MI355X repository.
 #![allow(non_camel_case_types, missing_docs, clippy::missing_safety_doc)]
 
 use core::ffi::{c_char, c_int, c_void};
 
-pub const AIC_ABI_VERSION: c_int = 2;
+pub const AIC_ABI_VERSION: c_int = 3;
 pub const AIC_OK: c_int = 0;
 pub const AIC_ERR_INVALID: c_int = 1;
 pub const AIC_ERR_NO_DEVICE: c_int = 2;
@@ -24,6 +24,15 @@ pub const AIC_FRAME_OUT_LINEAR: u32 = 8;
 pub const AIC_FRAME_OUT_COLORBUF: u32 = 16;
 pub const AIC_FRAME_NO_FEEDBACK: u32 = 32;
 pub const AIC_MAX_IN_FLIGHT: u32 = 32;
+pub const AIC_TUNE_QUEUES_SHIFT: u32 = 0;
+pub const AIC_TUNE_SUPER_SHIFT: u32 = 4;
+pub const AIC_TUNE_VARIANT_SHIFT: u32 = 9;
+pub const AIC_VARIANT_AUTO: u32 = 0;
+pub const AIC_VARIANT_PLAIN: u32 = 1;
+pub const AIC_VARIANT_EXCHANGING: u32 = 2;
+pub const AIC_VARIANT_RECORDING: u32 = 3;
+pub const AIC_LIGHT_HOOK_SESSION: i32 = 1;
+pub const AIC_LIGHT_HOOK_POOL_SHIFT: i32 = 8;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -99,7 +108,7 @@ pub struct aic_frame_desc {
     pub backdrop: [f32; 4],
     pub partition: aic_partition,
     pub flags: u32,
-    pub reserved: u32,
+    pub tuning: u32,
 }
 
 #[repr(C)]
@@ -114,6 +123,8 @@ pub struct aic_frame_info {
     pub total_ms: f32,
     pub rows_rendered: u32,
     pub flaws: u32,
+    pub variant: u32,
+    pub tile_queues: u32,
 }
 
 #[repr(C)]
@@ -158,7 +169,7 @@ pub struct aic_light_params {
     pub queue_order: i32,
     pub n_queue: i32,
     pub lanes_per_cube: i32,
-    pub reserved: i32,
+    pub hooks: i32,
     pub queue_cubes: *const i32,
     pub queue_priorities: *const i32,
     pub max_updates: u64,

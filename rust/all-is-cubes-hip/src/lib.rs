@@ -439,7 +439,7 @@ impl HipRtRenderer {
             },
             partition: ffi::aic_partition::default(),
             flags: 0,
-            reserved: 0,
+            tuning: 0, // the library's choices (tile queues, kernel variant); `HipInfo` reports what ran
         };
         let mut info = ffi::aic_frame_info::default();
         if !data.is_empty() {
@@ -483,7 +483,7 @@ impl HipRtRenderer {
             queue_order: QUEUE_ORDER,
             n_queue,
             lanes_per_cube: 0,
-            reserved: 0,
+            hooks: 0,
             queue_cubes: core::ptr::null(),
             queue_priorities: core::ptr::null(),
             max_updates,

@@ -123,18 +123,17 @@ def test_uninitialized_queue_and_update_limit(ctx):
 
 
 @pytest.mark.parametrize("batch", [32, 100])
-def test_dependency_pool_grows_when_a_batch_overflows_it(batch, monkeypatch):
+def test_dependency_pool_grows_when_a_batch_overflows_it(batch):
     """The dependency lists go through a chunk pool on the device; a batch that runs out of chunks is computed again with a
     larger pool (aic_evaluate_light). A fresh context started with a four-chunk pool (test hook) must still give the
     oracle's bytes -- with the small-batch path (cubes and texels in the launch arguments) and the copying path."""
-    monkeypatch.setenv("AIC_LIGHT_DEP_POOL_CHUNKS", "4")
     sp = scenes.light_spread_space()
     ref = copy.deepcopy(sp)
     n_ref = oracle.evaluate_light(ref, maximum_distance=30, fast=True, epsilon=1, batch=batch, hb_width=16)
     c = abi.Context(0)
     try:
         c.upload_space(abi.LAYER_WORLD, sp)
-        info = c.evaluate_light(abi.LAYER_WORLD, 30, fast=True, epsilon=1, batch=batch, queue_order=16)
+        info = c.evaluate_light(abi.LAYER_WORLD, 30, fast=True, epsilon=1, batch=batch, queue_order=16, dep_pool_chunks=4)
         got = c.read_light_volume(abi.LAYER_WORLD, sp.size)
     finally:
         c.close()
@@ -142,26 +141,23 @@ def test_dependency_pool_grows_when_a_batch_overflows_it(batch, monkeypatch):
     assert (got == np.asarray(ref.light).reshape(got.shape)).all()
 
 
-@pytest.mark.parametrize("name,batch,lanes,pool", [("light_spread", 32, 256, None), ("light_on_slab", 7, 64, None), ("fog", 32, 256, None), ("light_spread", 32, 256, "4")])
-def test_session_kernel_gives_the_same_bytes(name, batch, lanes, pool, monkeypatch):
-    """AIC_LIGHT_SESSION=1: one launch serves every small batch of a call, fed through pinned host memory (an experiment kept
+@pytest.mark.parametrize("name,batch,lanes,pool", [("light_spread", 32, 256, 0), ("light_on_slab", 7, 64, 0), ("fog", 32, 256, 0), ("light_spread", 32, 256, 4)])
+def test_session_kernel_gives_the_same_bytes(name, batch, lanes, pool):
+    """aic_light_params.hooks bit 0 (AIC_LIGHT_SESSION=1 until round 5): one launch serves every small batch of a call, fed through pinned host memory (an experiment kept
     reproducible, csrc/aic_light.h LightMailbox). Same texels, same update count -- also when the dependency pool overflows
     and the session has to end, grow the pool and start again, and in a relight that continues the queue."""
-    monkeypatch.setenv("AIC_LIGHT_SESSION", "1")
-    if pool:
-        monkeypatch.setenv("AIC_LIGHT_DEP_POOL_CHUNKS", pool)
     sp = SCENES[name]()
     ref = copy.deepcopy(sp)
     n_ref = oracle.evaluate_light(ref, maximum_distance=30, fast=True, epsilon=1, batch=batch, hb_width=16)
     c = abi.Context(0)
     try:
         c.upload_space(abi.LAYER_WORLD, sp)
-        info = c.evaluate_light(abi.LAYER_WORLD, 30, fast=True, epsilon=1, batch=batch, queue_order=16, lanes_per_cube=lanes)
+        info = c.evaluate_light(abi.LAYER_WORLD, 30, fast=True, epsilon=1, batch=batch, queue_order=16, lanes_per_cube=lanes, session=True, dep_pool_chunks=pool)
         got = c.read_light_volume(abi.LAYER_WORLD, sp.size)
         assert info.updates == n_ref and info.device_ms > 0
         assert (got == np.asarray(ref.light).reshape(got.shape)).all()
         # a second call on the same context: another session, the queue continued (nothing left: no updates, no hang)
-        again = c.evaluate_light(abi.LAYER_WORLD, 30, fast=False, epsilon=1, batch=batch, queue_order=16, queue=[], lanes_per_cube=lanes)
+        again = c.evaluate_light(abi.LAYER_WORLD, 30, fast=False, epsilon=1, batch=batch, queue_order=16, queue=[], lanes_per_cube=lanes, session=True)
         assert again.updates == 0
         assert (c.read_light_volume(abi.LAYER_WORLD, sp.size) == got).all()
     finally:
