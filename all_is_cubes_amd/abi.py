@@ -420,7 +420,9 @@ class Context:
         return int(self._lib.aic_partition_rows(height, C.byref(p)))
 
     def render(self, frame: FrameDesc, want_aux: bool = False, counters: bool = False):
-        """Returns dict(rgba8 [rows,w,4], info FrameInfo, aux or None)."""
+        """Returns dict(rgba8 [rows,w,4], info FrameInfo, aux or None). `frame` is left as it was given (until round 6 want_aux / counters
+        stayed set in it, and a later plain render of the same object quietly ran the recording variant again)."""
+        keep_flags = frame.flags
         if want_aux:
             frame.flags |= FRAME_AUX
         if counters:
@@ -429,7 +431,10 @@ class Context:
         floats = bool(frame.flags & (FRAME_OUT_LINEAR | FRAME_OUT_COLORBUF))  # 16-byte float pixels instead of RGBA8
         out = np.zeros((rows, frame.width, 4), np.float32 if floats else np.uint8)
         info = FrameInfo()
-        self._check(self._lib.aic_render(self._h, C.byref(frame), _ptr(out), 0, C.byref(info)))
+        try:
+            self._check(self._lib.aic_render(self._h, C.byref(frame), _ptr(out), 0, C.byref(info)))
+        finally:
+            frame.flags = keep_flags
         aux = None
         if want_aux:
             aux = np.zeros((rows, frame.width), PIXEL_AUX_DTYPE)

@@ -38,7 +38,7 @@ def assert_production_variants(ctx, frame, got):
     """The production kernel variants of `frame` -- the plain one an image this small gets and the lane-exchanging one (asked for through
     aic_frame_desc.tuning) -- must give the aux-recording variant's bytes and step total; aic_frame_info.variant says which ran."""
     keep_flags, keep_tuning = frame.flags, frame.tuning
-    frame.flags &= ~(abi.FRAME_AUX | abi.FRAME_COUNTERS)  # (ctx.render(.., want_aux=True) left them set)
+    frame.flags &= ~(abi.FRAME_AUX | abi.FRAME_COUNTERS)
     try:
         fast = ctx.render(frame)
         frame.tuning = keep_tuning | abi.tuning(variant=abi.VARIANT_EXCHANGING)
