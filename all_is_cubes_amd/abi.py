@@ -43,13 +43,13 @@ def tuning(queues=None, super_shift=None, variant=None) -> int:
 ABI_SYMBOLS = [
     "aic_abi_version", "aic_create", "aic_destroy", "aic_last_error", "aic_device_name", "aic_upload_space",
     "aic_clear_space", "aic_update_cubes", "aic_update_light_volume", "aic_replace_block", "aic_replace_blocks", "aic_compact", "aic_set_options",
-    "aic_render", "aic_render_submit", "aic_render_wait", "aic_trace_patches", "aic_partition_rows", "aic_assemble_strips", "aic_assemble_strips_async", "aic_read_aux", "aic_synchronize", "aic_stream", "aic_wait_event", "aic_stream_wait_frame",
+    "aic_render", "aic_render_submit", "aic_render_wait", "aic_render_submit_batch", "aic_render_wait_batch", "aic_trace_patches", "aic_partition_rows", "aic_assemble_strips", "aic_assemble_strips_async", "aic_assemble_strips_on", "aic_read_aux", "aic_synchronize", "aic_stream", "aic_wait_event", "aic_stream_wait_frame",
     "aic_probe_raycast", "aic_probe_light_lut", "aic_probe_powf",
     "aic_ortho_image_size", "aic_render_orthographic",
     "aic_evaluate_light", "aic_light_cubes_changed", "aic_read_light_volume", "aic_read_light_cubes", "aic_light_chart", "aic_probe_derived", "aic_probe_log2f",
     "aic_create_multi", "aic_destroy_multi", "aic_multi_device_count", "aic_multi_context", "aic_multi_last_error", "aic_multi_upload_space",
     "aic_multi_clear_space", "aic_multi_update_cubes", "aic_multi_update_light_volume", "aic_multi_evaluate_light", "aic_multi_light_cubes_changed", "aic_multi_replace_blocks", "aic_multi_set_options",
-    "aic_multi_render",
+    "aic_multi_render", "aic_multi_render_submit", "aic_multi_render_wait",
 ]
 
 
@@ -170,6 +170,8 @@ def load() -> C.CDLL:
         lib.aic_render.argtypes = [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.c_int, C.POINTER(FrameInfo)]
         lib.aic_render_submit.argtypes = [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.c_uint32]
         lib.aic_render_wait.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(FrameInfo)]
+        lib.aic_render_submit_batch.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(FrameDesc), C.POINTER(C.c_void_p), C.c_uint32]
+        lib.aic_render_wait_batch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(FrameInfo)]
         lib.aic_trace_patches.argtypes = [C.c_void_p, C.POINTER(FrameDesc), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FrameInfo)]
         lib.aic_assemble_strips.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.aic_assemble_strips_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
@@ -461,6 +463,17 @@ class Context:
         """Queues a frame on `slot` (0..MAX_IN_FLIGHT-1); returns without waiting (aic_render_submit)."""
         self._check(self._lib.aic_render_submit(self._h, C.byref(frame), C.c_void_p(device_ptr), int(slot)))
 
+    def render_submit_batch(self, frames, device_ptrs, slot: int) -> None:
+        """aic_render_submit_batch: 1, 2, 4 or 8 frames (same size, partition, flags) traced by one launch, frame i into device_ptrs[i]."""
+        arr = (FrameDesc * len(frames))(*frames)
+        ptrs = (C.c_void_p * len(frames))(*[int(p) for p in device_ptrs])
+        self._check(self._lib.aic_render_submit_batch(self._h, len(frames), arr, ptrs, slot))
+
+    def render_wait_batch(self, slot: int, n_frames: int):
+        infos = (FrameInfo * n_frames)()
+        self._check(self._lib.aic_render_wait_batch(self._h, slot, n_frames, infos))
+        return list(infos)
+
     def render_wait(self, slot: int) -> FrameInfo:
         info = FrameInfo()
         self._check(self._lib.aic_render_wait(self._h, int(slot), C.byref(info)))
@@ -579,6 +592,8 @@ class MultiContext:
         lib.aic_multi_light_cubes_changed.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_int]
         lib.aic_multi_update_cubes.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.aic_multi_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        lib.aic_multi_render_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint32]
+        lib.aic_multi_render_wait.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         ids = np.ascontiguousarray(device_ids, np.int32)
         st = C.c_int(0)
         self._h = lib.aic_create_multi(len(ids), _ptr(ids), C.byref(st))
@@ -640,3 +655,14 @@ class MultiContext:
         info = FrameInfo()
         self._check(self._lib.aic_multi_render(self._h, C.byref(frame), _ptr(out), 0, C.byref(info)))
         return {"rgba8": out, "info": info}
+
+    def render_submit(self, frame: FrameDesc, slot: int, device_ptr: int = 0):
+        """aic_multi_render_submit: the frame is queued on `slot` of every device; returns the host array the wait fills (or None: device_ptr)."""
+        out = None if device_ptr else np.zeros((frame.height, frame.width, 4), np.uint8)
+        self._check(self._lib.aic_multi_render_submit(self._h, C.byref(frame), C.c_void_p(device_ptr) if device_ptr else _ptr(out), 1 if device_ptr else 0, slot))
+        return out
+
+    def render_wait(self, slot: int) -> FrameInfo:
+        info = FrameInfo()
+        self._check(self._lib.aic_multi_render_wait(self._h, slot, C.byref(info)))
+        return info

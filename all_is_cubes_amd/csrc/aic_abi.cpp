@@ -28,6 +28,9 @@ void launch_scatter_cubes(uint16_t *grid, uint32_t *light, const int32_t *xyz, c
 void launch_probe_powf(const float *x, const float *y, float *out, uint32_t n, hipStream_t stream);
 void launch_order_tiles(const uint32_t *cost, uint32_t *order, uint32_t n_tiles, uint32_t macros_x, uint32_t sb_shift, uint32_t n_queues, uint32_t *queue_start,
                         hipStream_t stream, bool clear_cost = false, uint32_t *clear_words = nullptr, uint32_t n_clear_words = 0);
+// the same for the frames of a batch, one workgroup each, in ONE launch (OrderJobs: aic_device.h)
+void launch_order_tiles_jobs(const OrderJobs &jobs, uint32_t n_jobs, uint32_t n_tiles, uint32_t macros_x, uint32_t sb_shift, uint32_t n_queues, hipStream_t stream,
+                             bool clear_cost, uint32_t n_clear_words);
 void launch_tag_cubes(uint16_t *grid, size_t n, const uint32_t *cls, int from_tagged, int to_tagged, hipStream_t stream);
 void launch_assemble_strips(const uint32_t *gathered, uint32_t *out, uint32_t w, uint32_t h, uint32_t strip_rows,
                             uint32_t n_parts, uint32_t max_rows, hipStream_t stream);
@@ -89,7 +92,11 @@ struct Layer {
     DevBuf<uint32_t> cls;    // 2-bit block classes
     std::vector<uint32_t> host_cls;
     DevBuf<uint32_t> light;
-    DevBuf<uint32_t> light_alt;  // the other half of the light double buffer (aic_update_light_volume)
+    // Spare light volumes: a new volume (aic_update_light_volume, aic_evaluate_light beside frames in flight) is made in one NO frame in flight reads and
+    // becomes current for the frames submitted from then on. Two halves (rounds 2-5) made every update wait for the frame submitted two updates before --
+    // a sim + render loop with four frames in flight was held to two --, so there are as many spares as it takes (up to kLightSpares), made on demand.
+    static constexpr int kLightSpares = 7;
+    DevBuf<uint32_t> light_spare[kLightSpares];
     DevBuf<DevBlock> blocks;
     DevBuf<DevPaletteEntry> palette;
     std::vector<DevBlock> host_blocks;  // mirror of the block table (for replace/append)
@@ -111,7 +118,8 @@ struct Layer {
     LightState *lstate = nullptr;
     size_t n_cubes() const { return (size_t)size[0] * (size_t)size[1] * (size_t)size[2]; }
     void release() {
-        pool.release(); cls.release(); light.release(); light_alt.release(); blocks.release(); palette.release();
+        pool.release(); cls.release(); light.release(); blocks.release(); palette.release();
+        for (auto &sp : light_spare) sp.release();
         host_blocks.clear(); host_cls.clear(); vox_cap.clear(); pal_cap.clear(); vox_base.clear(); pal_base.clear();
         garbage_vox = garbage_pal = 0;
         present = false;
@@ -152,10 +160,9 @@ struct aic_ctx {
     bool streaming_submit = false;  // set around aic_render_submit: frames meant to overlap are sized for throughput, synchronous ones for latency
     // frames in flight: slot 0 runs on `stream` (and serves the synchronous aic_render), slot 1 on a
     // second stream so that a submitted frame's trace can start while the previous one drains
-    struct FrameSlot {
-        hipStream_t stream = nullptr;
-        hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the trace launch(es): the frame's kernel time
-        hipEvent_t ev2 = nullptr;                  // behind the copy of the counters to `host_counters`: what aic_render_wait waits for
+    // What each frame of a slot owns. A plain frame is sub-frame 0; aic_render_submit_batch traces up to kMaxSub frames in one launch (DevSub) and each has
+    // its own counters, tile queues and cost record.
+    struct SubSlot {
         DevBuf<DevCounters> counters;
         DevCounters *host_counters = nullptr;      // pinned
         // What a frame needs cleared or ordered is enqueued BEHIND the previous frame of the slot, not ahead of this one (round 4): the counters
@@ -164,17 +171,31 @@ struct aic_ctx {
         bool counters_clean = false;       // the device counters are zero (cleared behind the slot's last frame)
         size_t cost_clean_n = 0;           // this many entries of tile_cost are zero
         bool record_ready = false;         // tile_order / queue_start hold the cost order of the frame described by cost_sig / cost_cam / order_key
-        bool static_ready = false;         // tile_static / queue_static hold the index order for static_key
-        uint32_t order_key[6] = {0, 0, 0, 0, 0, 0}, static_key[6] = {0, 0, 0, 0, 0, 0};  // cost_sig + number of queues + super-block shift
-        DevBuf<uint32_t> tile_static, queue_static;
+        uint32_t order_key[6] = {0, 0, 0, 0, 0, 0};  // cost_sig + number of queues + super-block shift
         DevBuf<float4> acc;  // UI pre-pass accumulators
-        // cost feedback: the longest ray of every tile of the slot's last frame, and the tile order made from it
+        // cost feedback: the longest ray of every tile of the sub-frame's last frame, and the tile order made from it
         DevBuf<uint32_t> tile_cost, tile_order, queue_start;
+        uint32_t cost_sig[4] = {0, 0, 0, 0};  // width, local rows, partition of the frame tile_cost describes
+        double cost_cam[16] = {0};            // ... and its world camera
+        void release() {
+            counters.release(); acc.release(); tile_cost.release(); tile_order.release(); queue_start.release();
+            if (host_counters) (void)hipHostFree(host_counters);
+            host_counters = nullptr;
+            counters_clean = record_ready = false; cost_clean_n = 0;
+        }
+    };
+    struct FrameSlot {
+        hipStream_t stream = nullptr;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the trace launch(es): the frame's kernel time
+        hipEvent_t ev2 = nullptr;                  // behind the copy of the counters to `host_counters`: what aic_render_wait waits for
+        SubSlot sub[kMaxSub];
+        uint32_t n_sub = 1;                // frames of the batch in flight
+        bool static_ready = false;         // tile_static / queue_static hold the index order for static_key (a matter of the frame's shape: shared by a batch's frames)
+        uint32_t static_key[6] = {0, 0, 0, 0, 0, 0};
+        DevBuf<uint32_t> tile_static, queue_static;
         DevBuf<uint4> ray_cold;  // the exchanging trace kernels' antialiasing sums in global memory (DevFrame::ray_cold; antialiased frames only)
         DevBuf<double> edges;    // DevFrame::edge_x / edge_y of the slot's frame shape: width + 1, then height + 1 doubles
         uint32_t edges_w = 0, edges_h = 0;
-        uint32_t cost_sig[4] = {0, 0, 0, 0};  // width, local rows, partition of the frame tile_cost describes
-        double cost_cam[16] = {0};            // ... and its world camera
         bool busy = false;
         bool diag = false;  // the slot's frame ran the aux-recording kernel variant
         uint32_t variant = 0, tile_queues = 0;  // what aic_frame_info reports of the slot's frame
@@ -235,6 +256,33 @@ int hip_fail(aic_ctx *c, const char *what, hipError_t e) {
         hipError_t e_ = (expr);                               \
         if (e_ != hipSuccess) return hip_fail(ctx, #expr, e_); \
     } while (0)
+
+// A light volume of `n` cubes that no frame in flight reads: an existing spare, else a new one, else -- every spare in use by a frame -- the first one, once
+// the frame reading it is done. *index says which (the caller swaps it with Layer::light when its contents are complete).
+int take_light_spare(aic_ctx *c, Layer &l, int layer, size_t n, int *index) {
+    auto in_use = [&](const DevBuf<uint32_t> &b) {
+        for (uint32_t i = 0; i < AIC_MAX_IN_FLIGHT; i++)
+            if (c->slots[i].busy && b.p && c->slots[i].light_used[layer] == (const void *)b.p) return true;
+        return false;
+    };
+    int pick = -1;
+    for (int k = 0; k < Layer::kLightSpares && pick < 0; k++)
+        if (l.light_spare[k].p && l.light_spare[k].cap >= n && !in_use(l.light_spare[k])) pick = k;
+    for (int k = 0; k < Layer::kLightSpares && pick < 0; k++)
+        if (!l.light_spare[k].p || (l.light_spare[k].cap < n && !in_use(l.light_spare[k]))) pick = k;  // (a buffer of an earlier, smaller space is re-made)
+    if (pick < 0) {
+        pick = 0;
+        for (uint32_t i = 0; i < AIC_MAX_IN_FLIGHT; i++)
+            if (c->slots[i].busy && c->slots[i].light_used[layer] == (const void *)l.light_spare[0].p) {
+                const hipError_t e = hipStreamSynchronize(c->slots[i].stream);
+                if (e != hipSuccess) return fail(c, AIC_ERR_DEVICE, "waiting for a frame that reads a spare light volume", e);
+            }
+    }
+    const hipError_t e = l.light_spare[pick].ensure(n);
+    if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? AIC_ERR_OOM : AIC_ERR_DEVICE, "alloc light (spare volume)", e);
+    *index = pick;
+    return AIC_OK;
+}
 
 // Every scene mutation waits for the frames in flight: they read the buffers it is about to change.
 int quiesce(aic_ctx *c) {
@@ -417,7 +465,7 @@ aic_ctx *aic_create(int device_id, int *status) {
         aic_ctx::FrameSlot &fs = c->slots[i];
         if (i == 0) fs.stream = c->stream;
         else ok = hipStreamCreateWithFlags(&fs.stream, hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipEventCreate(&fs.ev0) == hipSuccess && hipEventCreate(&fs.ev1) == hipSuccess && hipEventCreate(&fs.ev2) == hipSuccess && fs.counters.ensure(1) == hipSuccess;
+        ok = ok && hipEventCreate(&fs.ev0) == hipSuccess && hipEventCreate(&fs.ev1) == hipSuccess && hipEventCreate(&fs.ev2) == hipSuccess && fs.sub[0].counters.ensure(1) == hipSuccess;
     }
     // created after the frame streams: HIP deals streams onto a few hardware queues in creation order
     // (4 by default), and two frame slots sharing a queue would serialise their kernels
@@ -485,12 +533,11 @@ void aic_destroy(aic_ctx *c) {
     for (uint32_t i = 0; i < AIC_MAX_IN_FLIGHT; i++) {
         aic_ctx::FrameSlot &fs = c->slots[i];
         if (fs.stream) (void)hipStreamSynchronize(fs.stream);
-        fs.counters.release(); fs.acc.release(); fs.tile_cost.release(); fs.tile_order.release(); fs.queue_start.release(); fs.ray_cold.release(); fs.edges.release();
+        for (auto &sb : fs.sub) sb.release();
+        fs.ray_cold.release(); fs.edges.release();
         if (fs.ev0) (void)hipEventDestroy(fs.ev0);
         if (fs.ev1) (void)hipEventDestroy(fs.ev1);
         if (fs.ev2) (void)hipEventDestroy(fs.ev2);
-        if (fs.host_counters) (void)hipHostFree(fs.host_counters);
-        fs.host_counters = nullptr;
         fs.tile_static.release(); fs.queue_static.release();
         if (i > 0 && fs.stream) (void)hipStreamDestroy(fs.stream);
     }
@@ -655,13 +702,11 @@ int aic_update_light_volume(aic_ctx *c, int layer, const uint8_t *light) {
     // stream, and becomes current for the frames submitted from now on -- a streaming loop that
     // re-lights every frame (BASELINE config 5) keeps its frames overlapped.
     const size_t n = l.n_cubes();
-    hipError_t e;
-    if ((e = l.light_alt.ensure(n)) != hipSuccess) return hip_fail(c, "alloc light (double buffer)", e);
-    for (uint32_t i = 0; i < AIC_MAX_IN_FLIGHT; i++)
-        if (c->slots[i].busy && c->slots[i].light_used[layer] == (const void *)l.light_alt.p) HIP_TRY(c, hipStreamSynchronize(c->slots[i].stream));
-    if (n) HIP_TRY(c, hipMemcpyAsync(l.light_alt.p, light, n * 4, hipMemcpyHostToDevice, c->upload_stream));
+    int spare = 0;
+    { const int rc = take_light_spare(c, l, layer, n, &spare); if (rc != AIC_OK) return rc; }
+    if (n) HIP_TRY(c, hipMemcpyAsync(l.light_spare[spare].p, light, n * 4, hipMemcpyHostToDevice, c->upload_stream));
     HIP_TRY(c, hipStreamSynchronize(c->upload_stream));
-    std::swap(l.light, l.light_alt);
+    std::swap(l.light, l.light_spare[spare]);
     l.version++;
     {
         const uint64_t h = n;
@@ -897,11 +942,15 @@ bool cameras_close(const double a[16], const double b[16]) {
     return true;
 }
 
-// Queues one frame on a slot's stream: counters reset, optional UI pre-pass, the trace. No waiting.
-int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint32_t slot, bool allow_aux, const double *patches = nullptr,
-                 uint32_t n_patches = 0, const DevOrthoView *ortho = nullptr, int32_t ortho_n = 0) {
+// Queues the frames of one launch on a slot's stream: counters reset, optional UI pre-pass, the trace. No waiting. k = 1: a plain frame. k = 2, 4, 8
+// (aic_render_submit_batch): frames of the same shape, partition and flags under the scene and options as they stand, each with its own cameras, backdrop,
+// output buffer, counters and cost record -- traced side by side by ONE launch per pass (DevSub), every persistent workgroup bound to one of them.
+int submit_frames(aic_ctx *c, uint32_t k, const aic_frame_desc *frames, uint32_t *const *out_devices, uint32_t slot, bool allow_aux, const double *patches = nullptr,
+                  uint32_t n_patches = 0, const DevOrthoView *ortho = nullptr, int32_t ortho_n = 0) {
     aic_ctx::FrameSlot &fs = c->slots[slot];
+    const aic_frame_desc *f = &frames[0];
     fs.t_begin = std::chrono::steady_clock::now();
+    fs.n_sub = k;
     aic_partition part = f->partition;
     if (part.n_parts <= 1 || part.strip_rows == 0) {
         part.n_parts = 1;
@@ -911,8 +960,10 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
     if (part.part >= part.n_parts) return fail(c, AIC_ERR_INVALID, "aic_render: partition.part >= n_parts");
     const uint32_t local_rows = aic_partition_rows(f->height, &part);
     const size_t npix = (size_t)f->width * local_rows;
-    if (npix && !out_device) return fail(c, AIC_ERR_INVALID, "aic_render: output buffer is null");
-    if (!patches) dump_record(c, DUMP_FRAME, slot, {{f, sizeof(*f)}});
+    for (uint32_t j = 0; j < k; j++)
+        if (npix && !out_devices[j]) return fail(c, AIC_ERR_INVALID, "aic_render: output buffer is null");
+    if (!patches)
+        for (uint32_t j = 0; j < k; j++) dump_record(c, DUMP_FRAME, slot, {{&frames[j], sizeof(frames[j])}});
     if (f->width > 65535u || local_rows > 65535u) return fail(c, AIC_ERR_INVALID, "aic_render: frame dimensions above 65535 are not supported");
 
     uint32_t flaws = 0;
@@ -927,8 +978,7 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
     }
     F.width = f->width;
     F.height = f->height;
-    std::memcpy(F.backdrop, f->backdrop, sizeof(F.backdrop));
-    F.has_backdrop = !(f->backdrop[0] == 0.f && f->backdrop[1] == 0.f && f->backdrop[2] == 0.f && f->backdrop[3] == 0.f);
+    F.n_sub = k;
     // the encoder and the sampling pattern follow the WORLD camera's options (renderer.rs:283-291, 426)
     F.pixel_centers = (f->flags & AIC_FRAME_PIXEL_CENTERS) && !patches ? 1 : 0;
     F.out_mode = (f->flags & AIC_FRAME_OUT_LINEAR) ? 1 : ((f->flags & AIC_FRAME_OUT_COLORBUF) ? 2 : 0);
@@ -946,7 +996,6 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         flaws = 0;
     }
     F.antialias = (hl[0].opt.antialiasing == 2 && !F.pixel_centers) ? 1 : 0;
-    F.exposure = hl[0].exposure;
     F.maximum_intensity = hl[0].opt.maximum_intensity;
     F.tone_mapping = hl[0].opt.tone_mapping;
     F.strip_rows = part.strip_rows;
@@ -970,7 +1019,6 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
     F.n_cus = c->n_cus;
     F.tiles_per_wave = c->sw.tiles_per_wave ? c->sw.tiles_per_wave : (c->streaming_submit ? 4u : 1u);
     F.srgb_thr = c->srgb_thr.p;
-    F.counters = fs.counters.p;
 
     const bool want_aux = allow_aux && (f->flags & AIC_FRAME_AUX) != 0;
     const bool diag = want_aux || (f->flags & AIC_FRAME_COUNTERS) != 0;
@@ -984,88 +1032,98 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
     if (allow_aux) c->aux_records = 0;
     if (!npix) return AIC_OK;
     hipError_t e;
-    F.out = out_device;
     if (want_aux) {
         if ((e = c->aux.ensure(npix)) != hipSuccess) return hip_fail(c, "alloc aux", e);
         F.aux = c->aux.p;
     }
-    if (!fs.host_counters) {  // (on a slot's first frame: most contexts only ever use slot 0, and a context is cheap to make and drop)
-        HIP_TRY(c, hipHostMalloc((void **)&fs.host_counters, sizeof(DevCounters), hipHostMallocDefault));
-        std::memset(fs.host_counters, 0, sizeof(DevCounters));
+    const bool ui = hl[1].present != 0;
+    const uint32_t n_tiles = F.macros_x * F.macros_y;  // the feedback works on macro tiles
+    // XCD-local tile queues (aic_trace.hip order_tiles_kernel): one per XCD (32 CUs each on this part), a macro tile in the queue of the
+    // 2^sb_shift-macro-tile super-block it lies in. One queue (aic_frame_desc.tuning) is the single dispenser of rounds 1-3.
+    // (aic_frame_desc.tuning; environment variables read per frame until round 5)
+    const int queues_env = (int)((f->tuning >> AIC_TUNE_QUEUES_SHIFT) & 15u);
+    const int super_env = (int)((f->tuning >> AIC_TUNE_SUPER_SHIFT) & 31u) - 1;
+    uint32_t n_queues = queues_env > 0 ? (uint32_t)queues_env : (uint32_t)c->n_cus / 32u;
+    if (n_queues > kMaxTileQueues) n_queues = kMaxTileQueues;
+    if (n_queues < 2u || patches || ortho_n || !n_tiles) n_queues = 0u;
+    const uint32_t macro_log2 = F.macro >= 16 ? 4u : (F.macro >= 8 ? 3u : (F.macro >= 4 ? 2u : (F.macro >= 2 ? 1u : 0u)));
+    const uint32_t tile_log2 = F.tile >= 16 ? 4u : 3u;
+    // default super-block edge: the largest power of two within an eighth of the (local) image height -- 128 pixels at 1080p, 256 at 4K, ~135 blocks
+    // either way: larger blocks fetch less (s256: 9.0 GB per frame with one dispenser, 5.2 at 128 pixels, 3.6 at 512) but leave a queue with too few
+    // blocks to even out a scene that is part sky (profiles/r04_experiments.txt K)
+    uint32_t sb_px_log2 = 0;
+    while ((2u << sb_px_log2) <= std::max(1u, local_rows / 8u)) sb_px_log2++;
+    const uint32_t sb_shift = super_env >= 0 ? (uint32_t)std::min(super_env, 12) : (sb_px_log2 > macro_log2 + tile_log2 ? sb_px_log2 - macro_log2 - tile_log2 : 0u);
+    // tile order for a frame from the cost the sub-frame's previous frame recorded, if that frame
+    // had the same shape (else index order); the record was turned into an order, and cleared, behind that frame
+    const bool use_feedback = c->sw.feedback && n_tiles && !patches && !ortho_n && !(f->flags & AIC_FRAME_NO_FEEDBACK);
+    const uint32_t sig[4] = {f->width, local_rows, (part.n_parts << 16) | part.part, (part.strip_rows << 8) | (F.macro << 4) | (F.tile >> 3)};
+    uint32_t order_key[6] = {sig[0], sig[1], sig[2], sig[3], n_queues, sb_shift};
+    const bool ordered = use_feedback || n_queues;  // the frames take their tiles through an order (else: the plain counter, index order)
+    F.n_queues = ordered ? n_queues : 0u;
+    if (ordered && n_queues) {
+        // no record to go by: index order inside each queue, made once per frame shape
+        bool any_static = false;
+        for (uint32_t j = 0; j < k; j++) {
+            aic_ctx::SubSlot &sb = fs.sub[j];
+            const bool same = use_feedback && sb.record_ready && std::memcmp(order_key, sb.order_key, sizeof(order_key)) == 0 && sb.tile_order.n >= n_tiles &&
+                              cameras_close(frames[j].world.inverse_projection_view, sb.cost_cam);
+            any_static = any_static || !same;
+        }
+        if (any_static && (!fs.static_ready || std::memcmp(order_key, fs.static_key, sizeof(order_key)) != 0 || fs.tile_static.n < n_tiles)) {
+            fs.static_ready = false;
+            if ((e = fs.tile_static.ensure(n_tiles)) != hipSuccess || (e = fs.queue_static.ensure(kMaxTileQueues + 1)) != hipSuccess) return hip_fail(c, "alloc tile queues", e);
+            launch_order_tiles(nullptr, fs.tile_static.p, n_tiles, F.macros_x, sb_shift, n_queues, fs.queue_static.p, fs.stream);
+            HIP_TRY(c, hipGetLastError());
+            std::memcpy(fs.static_key, order_key, sizeof(order_key));
+            fs.static_ready = true;
+        }
     }
-    if (!fs.counters_clean) HIP_TRY(c, hipMemsetAsync(fs.counters.p, 0, sizeof(DevCounters), fs.stream));
-    fs.counters_clean = false;
-    uint32_t order_key[6] = {0, 0, 0, 0, 0, 0};
-    uint32_t order_tiles_n = 0, order_sb_shift = 0, order_queues = 0;
-    {
-        // tile order for this frame from the cost the slot's previous frame recorded, if that frame
-        // had the same shape (else index order); the record was turned into an order, and cleared, behind that frame
-        const bool feedback = c->sw.feedback;
-        const uint32_t n_tiles = F.macros_x * F.macros_y;  // the feedback works on macro tiles
-        // XCD-local tile queues (aic_trace.hip order_tiles_kernel): one per XCD (32 CUs each on this part), a macro tile in the queue of the
-        // 2^sb_shift-macro-tile super-block it lies in. AIC_TILE_QUEUES=1 is the single dispenser of rounds 1-3; AIC_SUPER_SHIFT the block edge.
-        // (aic_frame_desc.tuning; environment variables read per frame until round 5)
-        const int queues_env = (int)((f->tuning >> AIC_TUNE_QUEUES_SHIFT) & 15u);
-        const int super_env = (int)((f->tuning >> AIC_TUNE_SUPER_SHIFT) & 31u) - 1;
-        uint32_t n_queues = queues_env > 0 ? (uint32_t)queues_env : (uint32_t)c->n_cus / 32u;
-        if (n_queues > kMaxTileQueues) n_queues = kMaxTileQueues;
-        if (n_queues < 2u || patches || ortho_n || !n_tiles) n_queues = 0u;
-        const uint32_t macro_log2 = F.macro >= 16 ? 4u : (F.macro >= 8 ? 3u : (F.macro >= 4 ? 2u : (F.macro >= 2 ? 1u : 0u)));
-        const uint32_t tile_log2 = F.tile >= 16 ? 4u : 3u;
-        // default super-block edge: the largest power of two within an eighth of the (local) image height -- 128 pixels at 1080p, 256 at 4K, ~135 blocks
-        // either way: larger blocks fetch less (s256: 9.0 GB per frame with one dispenser, 5.2 at 128 pixels, 3.6 at 512) but leave a queue with too few
-        // blocks to even out a scene that is part sky (profiles/r04_experiments.txt K)
-        uint32_t sb_px_log2 = 0;
-        while ((2u << sb_px_log2) <= std::max(1u, local_rows / 8u)) sb_px_log2++;
-        const uint32_t sb_shift = super_env >= 0 ? (uint32_t)std::min(super_env, 12) : (sb_px_log2 > macro_log2 + tile_log2 ? sb_px_log2 - macro_log2 - tile_log2 : 0u);
-        const bool use_feedback = feedback && n_tiles && !patches && !ortho_n && !(f->flags & AIC_FRAME_NO_FEEDBACK);
-        if (use_feedback || n_queues) {
-            const uint32_t sig[4] = {f->width, local_rows, (part.n_parts << 16) | part.part, (part.strip_rows << 8) | (F.macro << 4) | (F.tile >> 3)};
-            std::memcpy(order_key, sig, sizeof(sig));
-            order_key[4] = n_queues;
-            order_key[5] = sb_shift;
-            order_tiles_n = n_tiles; order_sb_shift = sb_shift; order_queues = n_queues;
-            bool same = use_feedback && fs.record_ready && std::memcmp(order_key, fs.order_key, sizeof(order_key)) == 0 && fs.tile_order.n >= n_tiles;
+    for (uint32_t j = 0; j < k; j++) {
+        aic_ctx::SubSlot &sb = fs.sub[j];
+        DevSub &S = F.sub[j];
+        std::memcpy(S.backdrop, frames[j].backdrop, sizeof(S.backdrop));
+        S.has_backdrop = !(frames[j].backdrop[0] == 0.f && frames[j].backdrop[1] == 0.f && frames[j].backdrop[2] == 0.f && frames[j].backdrop[3] == 0.f);
+        S.exposure = ortho_n ? 1.0f : frames[j].world.exposure;
+        S.out = out_devices[j];
+        if ((e = sb.counters.ensure(1)) != hipSuccess) return hip_fail(c, "alloc frame counters", e);
+        S.counters = sb.counters.p;
+        if (!sb.host_counters) {  // (on a sub-frame's first frame: most contexts only ever use slot 0, and a context is cheap to make and drop)
+            HIP_TRY(c, hipHostMalloc((void **)&sb.host_counters, sizeof(DevCounters), hipHostMallocDefault));
+            std::memset(sb.host_counters, 0, sizeof(DevCounters));
+        }
+        if (!sb.counters_clean) HIP_TRY(c, hipMemsetAsync(sb.counters.p, 0, sizeof(DevCounters), fs.stream));
+        sb.counters_clean = false;
+        if (ordered) {
+            bool same = use_feedback && sb.record_ready && std::memcmp(order_key, sb.order_key, sizeof(order_key)) == 0 && sb.tile_order.n >= n_tiles;
             if (same) {
                 // the record only predicts this frame if the camera has barely moved since: the view rays
                 // through the centre and two corners within a degree, the eye within a quarter cube.
                 // (A stale order is worse than none.)
-                same = cameras_close(f->world.inverse_projection_view, fs.cost_cam);
+                same = cameras_close(frames[j].world.inverse_projection_view, sb.cost_cam);
             }
             if (same) {
-                F.tile_order = fs.tile_order.p;
-                F.n_queues = n_queues;
-                F.queue_start = n_queues ? fs.queue_start.p : nullptr;
+                S.tile_order = sb.tile_order.p;
+                S.queue_start = n_queues ? sb.queue_start.p : nullptr;
             } else if (n_queues) {
-                // no record to go by: index order inside each queue, made once per frame shape
-                if (!fs.static_ready || std::memcmp(order_key, fs.static_key, sizeof(order_key)) != 0 || fs.tile_static.n < n_tiles) {
-                    fs.static_ready = false;
-                    if ((e = fs.tile_static.ensure(n_tiles)) != hipSuccess || (e = fs.queue_static.ensure(kMaxTileQueues + 1)) != hipSuccess) return hip_fail(c, "alloc tile queues", e);
-                    launch_order_tiles(nullptr, fs.tile_static.p, n_tiles, F.macros_x, sb_shift, n_queues, fs.queue_static.p, fs.stream);
-                    HIP_TRY(c, hipGetLastError());
-                    std::memcpy(fs.static_key, order_key, sizeof(order_key));
-                    fs.static_ready = true;
-                }
-                F.tile_order = fs.tile_static.p;
-                F.n_queues = n_queues;
-                F.queue_start = fs.queue_static.p;
+                S.tile_order = fs.tile_static.p;
+                S.queue_start = fs.queue_static.p;
             }
             if (use_feedback) {
-                const uint32_t *const before = fs.tile_cost.p;
-                if ((e = fs.tile_cost.ensure(n_tiles)) != hipSuccess) return hip_fail(c, "alloc tile feedback", e);
-                if (fs.tile_cost.p != before) fs.cost_clean_n = 0;
-                if (fs.cost_clean_n < n_tiles) HIP_TRY(c, hipMemsetAsync(fs.tile_cost.p, 0, (size_t)n_tiles * sizeof(uint32_t), fs.stream));
-                fs.cost_clean_n = 0;  // (this frame writes it)
-                F.tile_cost = fs.tile_cost.p;
-                std::memcpy(fs.cost_sig, sig, sizeof(sig));
+                const uint32_t *const before = sb.tile_cost.p;
+                if ((e = sb.tile_cost.ensure(n_tiles)) != hipSuccess) return hip_fail(c, "alloc tile feedback", e);
+                if (sb.tile_cost.p != before) sb.cost_clean_n = 0;
+                if (sb.cost_clean_n < n_tiles) HIP_TRY(c, hipMemsetAsync(sb.tile_cost.p, 0, (size_t)n_tiles * sizeof(uint32_t), fs.stream));
+                sb.cost_clean_n = 0;  // (this frame writes it)
+                S.tile_cost = sb.tile_cost.p;
+                std::memcpy(sb.cost_sig, sig, sizeof(sig));
             }
         }
-    }
-    const bool ui = hl[1].present != 0;
-    if (ui) {
-        const size_t samples = F.antialias ? 4 : 1;
-        if ((e = fs.acc.ensure(samples * npix)) != hipSuccess) return hip_fail(c, "alloc accumulators", e);
-        F.acc_buf = fs.acc.p;
+        if (ui) {
+            const size_t samples = F.antialias ? 4 : 1;
+            if ((e = sb.acc.ensure(samples * npix)) != hipSuccess) return hip_fail(c, "alloc accumulators", e);
+            S.acc_buf = sb.acc.p;
+        }
     }
     if (!patches && !ortho_n) {
         // Viewport's pixel edges (viewport.rs:104-113), once per frame shape: x / width * 2 - 1 and -(y / height * 2 - 1) in the reference's own f64
@@ -1092,12 +1150,13 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         const size_t bytes = trace_ray_cold_bytes(c->n_cus, &groups);
         if (bytes) {
             // the exchange (a pool of parked rays per workgroup: more rays in flight than lanes, lanes traded between waves) pays when a wave refills its lanes
-            // several times over: from AIC_XCHG_TILES tiles per resident wave (default 5: the whole 1080p frame has 7.9 and gains 6.5 %, a rank's share at
+            // several times over: from 5 tiles per resident wave for a frame alone (the whole 1080p frame has 7.9 and gains 6.5 %, a rank's share at
             // N = 2 has 4 and gains nothing, at N = 4 / 8 two / one and loses 3-6 % -- profiles/r05_rank_share.txt); the UI pre-pass follows the world pass
             // -- and from 1.9 for frames that are streamed (aic_render_submit), where a share of C3 at N = 8 (4 tiles per wave) gains 9 % by it and, since the
-            // scheduler round was trimmed, a share of C2 at N = 4 (2 tiles per wave) 1.8 %; at one tile per wave (N = 8) the plain variant stays 2.5 % ahead)
+            // scheduler round was trimmed, a share of C2 at N = 4 (2 tiles per wave) 1.8 %; at one tile per wave (N = 8) the plain variant stays 2.5 % ahead).
+            // A batch's frames share the resident grid: each has 1 / k of the waves.
             const uint32_t asked = (f->tuning >> AIC_TUNE_VARIANT_SHIFT) & 3u;  // (AIC_XCHG_TILES, an environment variable read per frame, until round 5)
-            const double resident_waves = (double)c->n_cus * 16.0;
+            const double resident_waves = (double)c->n_cus * 16.0 / (double)k;
             const double need = c->streaming_submit ? 1.9 : 5.0;
             F.exchange = asked == AIC_VARIANT_EXCHANGING ? 1u : (asked == AIC_VARIANT_PLAIN ? 0u : (((double)F.tiles_x * (double)F.tiles_y >= need * resident_waves) ? 1u : 0u));
             if (F.exchange && F.antialias) {
@@ -1114,24 +1173,30 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
         F.layer = hl[1];
         F.layer_transparency = hl[1].opt.transparency;
         F.layer_lighting = hl[1].opt.lighting;
-        const uint32_t *order_keep = F.tile_order;
-        uint32_t *cost_keep = F.tile_cost;
+        DevSub keep[kMaxSub];
+        std::memcpy(keep, F.sub, sizeof(keep));
         const uint32_t queues_keep = F.n_queues;
-        F.tile_order = nullptr;  // the feedback describes the world pass
-        F.tile_cost = nullptr;
+        for (uint32_t j = 0; j < k; j++) {
+            std::memcpy(F.sub[j].inv, frames[j].ui.inverse_projection_view, sizeof(F.sub[j].inv));
+            F.sub[j].tile_order = nullptr;  // the feedback describes the world pass
+            F.sub[j].tile_cost = nullptr;
+            F.sub[j].queue_start = nullptr;
+            F.sub[j].host_counters = nullptr;  // (the world pass hands over the sums of both)
+        }
         F.n_queues = 0u;
-        F.host_counters = nullptr;  // (the world pass hands over the sums of both)
         launch_trace_image(F, diag, fs.stream);
-        F.tile_order = order_keep;
-        F.tile_cost = cost_keep;
+        std::memcpy(F.sub, keep, sizeof(keep));
         F.n_queues = queues_keep;
-        HIP_TRY(c, hipMemsetAsync(&fs.counters.p->tile_next, 0, sizeof(uint32_t), fs.stream));
+        for (uint32_t j = 0; j < k; j++) HIP_TRY(c, hipMemsetAsync(&fs.sub[j].counters.p->tile_next, 0, sizeof(uint32_t), fs.stream));
         F.use_init = 1;
     }
     F.pass = 0;
+    for (uint32_t j = 0; j < k; j++) {
+        std::memcpy(F.sub[j].inv, ortho_n ? hl[0].inv : frames[j].world.inverse_projection_view, sizeof(F.sub[j].inv));
 #ifndef AIC_PROFILE
-    F.host_counters = reinterpret_cast<unsigned long long *>(fs.host_counters);  // (DevCounters begins with the five sums)
+        F.sub[j].host_counters = reinterpret_cast<unsigned long long *>(fs.sub[j].host_counters);  // (DevCounters begins with the five sums)
 #endif
+    }
     F.layer = hl[0];
     F.layer_transparency = hl[0].opt.transparency;
     F.layer_lighting = hl[0].opt.lighting;
@@ -1144,76 +1209,106 @@ int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint
     // behind the trace: the frame's sums are in pinned host memory -- written by the last wave of the trace itself, or (profile builds: the whole
     // counter block) copied there; ev2 is what a wait waits for ...
 #ifdef AIC_PROFILE
-    HIP_TRY(c, hipMemcpyAsync(fs.host_counters, fs.counters.p, sizeof(DevCounters), hipMemcpyDeviceToHost, fs.stream));
+    for (uint32_t j = 0; j < k; j++) HIP_TRY(c, hipMemcpyAsync(fs.sub[j].host_counters, fs.sub[j].counters.p, sizeof(DevCounters), hipMemcpyDeviceToHost, fs.stream));
 #endif
     HIP_TRY(c, hipEventRecord(fs.ev2, fs.stream));
     fs.busy = true;  // the frame is in flight and a wait can collect it; nothing below can fail the call any more
     // ... and the slot is made ready for its next frame: this frame's cost record becomes the tile order of the next frame of the same view, the
     // record and the counters are cleared. A failure here costs the next frame its head start (it clears and orders for itself), not this frame its result.
     bool cleared = false;
-    if (F.tile_cost && order_tiles_n) {
-        fs.record_ready = false;
-        fs.cost_clean_n = 0;
-        if (fs.tile_order.ensure(order_tiles_n) == hipSuccess && fs.queue_start.ensure(kMaxTileQueues + 1) == hipSuccess) {
-            // (one launch: orders, then clears the record it has read and the counters)
-            launch_order_tiles(fs.tile_cost.p, fs.tile_order.p, order_tiles_n, F.macros_x, order_sb_shift, order_queues ? order_queues : 1u, fs.queue_start.p, fs.stream,
-                               true, reinterpret_cast<uint32_t *>(fs.counters.p), (uint32_t)(sizeof(DevCounters) / 4));
+    if (use_feedback && n_tiles) {
+        OrderJobs jobs;
+        std::memset(&jobs, 0, sizeof(jobs));
+        bool ok = true;
+        for (uint32_t j = 0; j < k; j++) {
+            aic_ctx::SubSlot &sb = fs.sub[j];
+            sb.record_ready = false;
+            sb.cost_clean_n = 0;
+            ok = ok && sb.tile_order.ensure(n_tiles) == hipSuccess && sb.queue_start.ensure(kMaxTileQueues + 1) == hipSuccess;
+            jobs.cost[j] = sb.tile_cost.p; jobs.order[j] = sb.tile_order.p; jobs.queue_start[j] = sb.queue_start.p;
+            jobs.clear_words[j] = reinterpret_cast<uint32_t *>(sb.counters.p);
+        }
+        if (ok) {
+            // (one launch, a workgroup per frame: orders, then clears the record it has read and the counters)
+            launch_order_tiles_jobs(jobs, k, n_tiles, F.macros_x, sb_shift, n_queues ? n_queues : 1u, fs.stream, true, (uint32_t)(sizeof(DevCounters) / 4));
             if (hipGetLastError() == hipSuccess) {
                 cleared = true;
-                fs.cost_clean_n = order_tiles_n;
-                std::memcpy(fs.order_key, order_key, sizeof(order_key));
-                std::memcpy(fs.cost_cam, f->world.inverse_projection_view, sizeof(fs.cost_cam));
-                fs.record_ready = true;
+                for (uint32_t j = 0; j < k; j++) {
+                    aic_ctx::SubSlot &sb = fs.sub[j];
+                    sb.cost_clean_n = n_tiles;
+                    std::memcpy(sb.order_key, order_key, sizeof(order_key));
+                    std::memcpy(sb.cost_cam, frames[j].world.inverse_projection_view, sizeof(sb.cost_cam));
+                    sb.record_ready = true;
+                }
             }
         }
     }
-    if (!cleared) cleared = hipMemsetAsync(fs.counters.p, 0, sizeof(DevCounters), fs.stream) == hipSuccess;
-    fs.counters_clean = cleared;
+    if (!cleared) {
+        cleared = true;
+        for (uint32_t j = 0; j < k; j++) cleared = (hipMemsetAsync(fs.sub[j].counters.p, 0, sizeof(DevCounters), fs.stream) == hipSuccess) && cleared;
+    }
+    for (uint32_t j = 0; j < k; j++) fs.sub[j].counters_clean = cleared;
     if (want_aux) c->aux_records = npix;
     return AIC_OK;
 }
+int submit_frame(aic_ctx *c, const aic_frame_desc *f, uint32_t *out_device, uint32_t slot, bool allow_aux, const double *patches = nullptr,
+                 uint32_t n_patches = 0, const DevOrthoView *ortho = nullptr, int32_t ortho_n = 0) {
+    uint32_t *const outs[1] = {out_device};
+    return submit_frames(c, 1, f, outs, slot, allow_aux, patches, n_patches, ortho, ortho_n);
+}
 
-// Waits for a slot's frame and reports it.
-int wait_frame(aic_ctx *c, uint32_t slot, aic_frame_info *info, bool whole_stream = false) {
+// Waits for a slot's frame (or batch of frames) and reports it: `info` = the frame's, or the batch's sums; `infos` (may be null) = each frame's.
+int wait_frame(aic_ctx *c, uint32_t slot, aic_frame_info *info, bool whole_stream = false, aic_frame_info *infos = nullptr, uint32_t n_infos = 0) {
     aic_ctx::FrameSlot &fs = c->slots[slot];
     if (info) std::memset(info, 0, sizeof(*info));
+    for (uint32_t j = 0; infos && j < n_infos; j++) std::memset(&infos[j], 0, sizeof(infos[j]));
     float kernel_ms = 0.f;
+    const uint32_t k = fs.n_sub ? fs.n_sub : 1u;
     if (fs.busy) {
-        DevCounters hc;
         fs.busy = false;  // released whatever happens below: a frame that failed must not block its slot for good
         // the frame and its counters (ev2), not the slot's housekeeping behind them -- unless the caller has enqueued a copy of its own behind the frame
         if (whole_stream || c->sw.wait_whole_stream) HIP_TRY(c, hipStreamSynchronize(fs.stream));  // (the switch: a measurement)
         else HIP_TRY(c, hipEventSynchronize(fs.ev2));
-        std::memcpy(&hc, fs.host_counters, sizeof(hc));
         HIP_TRY(c, hipEventElapsedTime(&kernel_ms, fs.ev0, fs.ev1));
-        if (hc.bailed) return fail(c, AIC_ERR_DEVICE, "trace kernel: a wave gave up waiting for rays in transit between waves; the frame has unwritten pixels");
-        if (info) {
-            info->cubes_traced = hc.cubes_traced;
-            info->n_outer = hc.n_outer;
-            info->n_inner = hc.n_inner;
-            info->n_hits = hc.n_hits;
-            info->n_light = hc.n_light;
-        }
+        for (uint32_t j = 0; j < k; j++) {
+            DevCounters hc;
+            std::memcpy(&hc, fs.sub[j].host_counters, sizeof(hc));
+            if (hc.bailed) return fail(c, AIC_ERR_DEVICE, "trace kernel: a wave gave up waiting for rays in transit between waves; the frame has unwritten pixels");
+            if (info) {
+                info->cubes_traced += hc.cubes_traced;
+                info->n_outer += hc.n_outer;
+                info->n_inner += hc.n_inner;
+                info->n_hits += hc.n_hits;
+                info->n_light += hc.n_light;
+            }
+            if (infos && j < n_infos) {
+                infos[j].cubes_traced = hc.cubes_traced; infos[j].n_outer = hc.n_outer; infos[j].n_inner = hc.n_inner;
+                infos[j].n_hits = hc.n_hits; infos[j].n_light = hc.n_light;
+            }
 #ifdef AIC_PROFILE
-        { static const char *names[40] = {"max_lifetime","max_until_dry","cyc_until_dry","cyc_lifetime","shade_ph","shade_ln","enter_ph","enter_ln","ray_ph","ray_ln","step_iters","step_lanes","cyc_step","cyc_shade_rest","cyc_enter","cyc_newray","cyc_finish","cyc_refill","cyc_shade_light","cyc_sched","fast_iters","fast_lanes","trips","trip_lanes","pass_hl_lanes","pass_fast_eligible","leave_blocks","leave_lanes","apply_blocks","apply_lanes","pass_needed_lanes","xchg_rounds","xchg_lanes","cyc_xchg","xchg_picked","xchg_parked","idle_spins","xchg_claims_lost","xchg_empty","-"};
-          // (only the production variant's frames: the aux-recording variant is another kernel, at half the occupancy)
-          if (!fs.diag) for (int i = 0; i < 39; i++) std::fprintf(stderr, "PROF %s %llu\n", names[i], hc.prof[i]);
-          if (const char *path = (fs.diag || c->sw.wave_prof.empty()) ? nullptr : c->sw.wave_prof.c_str()) {
-              if (FILE *fp = std::fopen(path, "w")) {
-                  for (int w = 0; w < 2048; w++) std::fprintf(fp, "%u %u %u %u\n", hc.wave_prof[w][0], hc.wave_prof[w][1], hc.wave_prof[w][2], hc.wave_prof[w][3]);
-                  std::fclose(fp);
-              }
-          } }
+            { static const char *names[40] = {"max_lifetime","max_until_dry","cyc_until_dry","cyc_lifetime","shade_ph","shade_ln","enter_ph","enter_ln","ray_ph","ray_ln","step_iters","step_lanes","cyc_step","cyc_shade_rest","cyc_enter","cyc_newray","cyc_finish","cyc_refill","cyc_shade_light","cyc_sched","fast_iters","fast_lanes","trips","trip_lanes","pass_hl_lanes","pass_fast_eligible","leave_blocks","leave_lanes","apply_blocks","apply_lanes","pass_needed_lanes","xchg_rounds","xchg_lanes","cyc_xchg","xchg_picked","xchg_parked","idle_spins","xchg_claims_lost","xchg_empty","-"};
+              // (only the production variant's frames: the aux-recording variant is another kernel, at half the occupancy)
+              if (!fs.diag) for (int i = 0; i < 39; i++) std::fprintf(stderr, "PROF %s %llu\n", names[i], hc.prof[i]);
+              if (const char *path = (fs.diag || c->sw.wave_prof.empty()) ? nullptr : c->sw.wave_prof.c_str()) {
+                  if (FILE *fp = std::fopen(path, "w")) {
+                      for (int w = 0; w < 2048; w++) std::fprintf(fp, "%u %u %u %u\n", hc.wave_prof[w][0], hc.wave_prof[w][1], hc.wave_prof[w][2], hc.wave_prof[w][3]);
+                      std::fclose(fp);
+                  }
+              } }
 #endif
+        }
     }
-    if (info) {
-        info->kernel_ms = kernel_ms;
-        info->rows_rendered = fs.local_rows;
-        info->flaws = fs.flaws;
-        info->variant = fs.npix ? fs.variant : 0u;
-        info->tile_queues = fs.npix ? fs.tile_queues : 0u;
-        info->total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - fs.t_begin).count();
-    }
+    const float total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - fs.t_begin).count();
+    auto fill = [&](aic_frame_info *o) {
+        o->kernel_ms = kernel_ms;
+        o->rows_rendered = fs.local_rows;
+        o->flaws = fs.flaws;
+        o->variant = fs.npix ? fs.variant : 0u;
+        o->tile_queues = fs.npix ? fs.tile_queues : 0u;
+        o->total_ms = total_ms;
+    };
+    if (info) fill(info);
+    for (uint32_t j = 0; infos && j < n_infos && j < k; j++) fill(&infos[j]);
     return AIC_OK;
 }
 
@@ -1395,7 +1490,7 @@ int aic_trace_patches(aic_ctx *c, const aic_frame_desc *f, uint32_t n, const dou
 // a frame slot's stream, events and counter block (slots past the eighth: on first use)
 static int ensure_slot(aic_ctx *c, uint32_t slot) {
     aic_ctx::FrameSlot &fs = c->slots[slot];
-    if (fs.stream && fs.ev0 && fs.ev1 && fs.ev2 && fs.counters.p) return AIC_OK;
+    if (fs.stream && fs.ev0 && fs.ev1 && fs.ev2 && fs.sub[0].counters.p) return AIC_OK;
     if (!fs.stream) {
         HIP_TRY(c, hipStreamCreateWithFlags(&fs.stream, hipStreamNonBlocking));
         // "Everything the context queues afterwards waits for the event" (aic_wait_event) must hold for a stream made later too: the context's first
@@ -1411,7 +1506,7 @@ static int ensure_slot(aic_ctx *c, uint32_t slot) {
     if (!fs.ev0) HIP_TRY(c, hipEventCreate(&fs.ev0));
     if (!fs.ev1) HIP_TRY(c, hipEventCreate(&fs.ev1));
     if (!fs.ev2) HIP_TRY(c, hipEventCreate(&fs.ev2));
-    hipError_t e = fs.counters.ensure(1);
+    hipError_t e = fs.sub[0].counters.ensure(1);
     if (e != hipSuccess) return hip_fail(c, "alloc frame counters", e);
     return AIC_OK;
 }
@@ -1427,14 +1522,39 @@ int aic_render_submit(aic_ctx *c, const aic_frame_desc *f, void *out_device, uin
     return rc;
 }
 
+int aic_render_submit_batch(aic_ctx *c, uint32_t n_frames, const aic_frame_desc *frames, void *const *out_devices, uint32_t slot) {
+    if (!c || !frames || !out_devices || slot >= AIC_MAX_IN_FLIGHT) return fail(c, AIC_ERR_INVALID, "aic_render_submit_batch: bad argument");
+    if (n_frames != 1u && n_frames != 2u && n_frames != 4u && n_frames != 8u) return fail(c, AIC_ERR_INVALID, "aic_render_submit_batch: 1, 2, 4 or 8 frames per launch");
+    for (uint32_t j = 1; j < n_frames; j++) {
+        const aic_frame_desc &a = frames[0], &b = frames[j];
+        if (a.width != b.width || a.height != b.height || a.flags != b.flags || a.tuning != b.tuning || std::memcmp(&a.partition, &b.partition, sizeof(a.partition)) != 0)
+            return fail(c, AIC_ERR_INVALID, "aic_render_submit_batch: the frames of a batch share size, partition, flags and tuning");
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->slots[slot].busy) return fail(c, AIC_ERR_INVALID, "aic_render_submit_batch: slot busy (aic_render_wait it first)");
+    { const int rs = ensure_slot(c, slot); if (rs != AIC_OK) return rs; }
+    uint32_t *outs[kMaxSub];
+    for (uint32_t j = 0; j < n_frames; j++) outs[j] = (uint32_t *)out_devices[j];
+    c->streaming_submit = true;
+    const int rc = submit_frames(c, n_frames, frames, outs, slot, false);
+    c->streaming_submit = false;
+    return rc;
+}
+
 int aic_render_wait(aic_ctx *c, uint32_t slot, aic_frame_info *info) {
     if (!c || slot >= AIC_MAX_IN_FLIGHT) return fail(c, AIC_ERR_INVALID, "aic_render_wait: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     return wait_frame(c, slot, info);
 }
 
-int aic_assemble_strips_async(aic_ctx *c, const void *gathered_device, void *out_device, uint32_t width, uint32_t height,
-                              uint32_t strip_rows, uint32_t n_parts) {
+int aic_render_wait_batch(aic_ctx *c, uint32_t slot, uint32_t n_frames, aic_frame_info *infos) {
+    if (!c || slot >= AIC_MAX_IN_FLIGHT || (n_frames && !infos)) return fail(c, AIC_ERR_INVALID, "aic_render_wait_batch: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    return wait_frame(c, slot, nullptr, false, infos, n_frames);
+}
+
+int aic_assemble_strips_on(aic_ctx *c, const void *gathered_device, void *out_device, uint32_t width, uint32_t height,
+                           uint32_t strip_rows, uint32_t n_parts, void *hip_stream) {
     if (!c || !gathered_device || !out_device || !strip_rows || !n_parts) return fail(c, AIC_ERR_INVALID, "aic_assemble_strips: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     uint32_t max_rows = 0;
@@ -1443,9 +1563,14 @@ int aic_assemble_strips_async(aic_ctx *c, const void *gathered_device, void *out
         uint32_t r = aic_partition_rows(height, &pp);
         if (r > max_rows) max_rows = r;
     }
-    launch_assemble_strips((const uint32_t *)gathered_device, (uint32_t *)out_device, width, height, strip_rows, n_parts, max_rows, c->stream);
+    launch_assemble_strips((const uint32_t *)gathered_device, (uint32_t *)out_device, width, height, strip_rows, n_parts, max_rows, hip_stream ? (hipStream_t)hip_stream : c->stream);
     HIP_TRY(c, hipGetLastError());
     return AIC_OK;
+}
+
+int aic_assemble_strips_async(aic_ctx *c, const void *gathered_device, void *out_device, uint32_t width, uint32_t height,
+                              uint32_t strip_rows, uint32_t n_parts) {
+    return aic_assemble_strips_on(c, gathered_device, out_device, width, height, strip_rows, n_parts, nullptr);
 }
 
 int aic_assemble_strips(aic_ctx *c, const void *gathered_device, void *out_device, uint32_t width, uint32_t height,

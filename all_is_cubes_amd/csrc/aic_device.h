@@ -124,16 +124,37 @@ struct DevOrthoView {
     double dir[3];
 };
 
+// What differs between the frames ONE launch of the trace kernel traces (aic_render_submit_batch: up to kMaxSub frames that share the scene, the options,
+// the image shape and the partition -- a rank's shares of consecutive frames of a multi-GPU stream, a camera path over a still scene). Every persistent workgroup
+// belongs to one of them for its whole life (sub-frame = workgroup index mod n_sub, n_sub a power of two), so everything here is wave-uniform: scalar loads from the
+// kernel-argument segment at a uniform offset. Each sub-frame has its own counters, tile queues and cost record: the launch is n_sub independent frames that
+// are resident together by construction, not n_sub kernels that HIP may or may not run side by side. A plain frame is n_sub = 1.
+struct DevSub {
+    double inv[16];          // the camera of the pass this launch runs (world pass: the world camera's inverse_projection_view; UI pre-pass: the UI camera's)
+    float backdrop[4];
+    float exposure;          // world Camera::exposure()
+    int32_t has_backdrop;
+    uint32_t *out;           // [local_rows][width] RGBA8 (or float4: out_mode)
+    float4 *acc_buf;         // [samples][local_rows][width] ColorBuf {light rgb, transmittance}: written by the UI pre-pass, read by the world pass
+    DevCounters *counters;
+    // pinned host memory for the frame's five sums (cubes_traced, n_outer, n_inner, n_hits, n_light) and the `bailed` count, written by the last wave of the world pass
+    // to finish: no copy launch behind the trace (a blit kernel that, with frames streamed, waits ~0.2 ms for a CU to have room). Null: the host copies.
+    unsigned long long *host_counters;
+    // cost feedback (aic_trace.hip order_tiles_kernel): tile_order[k] = k-th macro tile to hand out, longest
+    // rays of the previous frame first (null: index order); tile_cost[macro tile] receives this frame's longest ray
+    const uint32_t *tile_order;
+    uint32_t *tile_cost;
+    const uint32_t *queue_start;  // XCD-local tile queues: see DevFrame::n_queues
+};
+constexpr uint32_t kMaxSub = 8;
+
 struct DevFrame {
     DevLayer layer;          // the layer this launch traces, BY VALUE: kernarg fields are fetched with
                              // scalar loads into SGPRs (a pointer to a device-memory struct costs a
                              // dependent vector load in front of every lookup)
     int32_t layer_transparency, layer_lighting;  // host-side copy, selects the kernel variant
     uint32_t width, height;
-    float backdrop[4];
-    int32_t has_backdrop;
     int32_t antialias;       // world camera options: AntialiasingOption::Always
-    float exposure;          // world Camera::exposure()
     float maximum_intensity; // world options (encoder)
     int32_t tone_mapping;
     uint32_t strip_rows, n_parts, part;
@@ -152,23 +173,13 @@ struct DevFrame {
     int32_t ortho_n;
     const double *patches;   // aic_trace_patches: [n_patches][4] NDC rectangles replacing the pixel grid (pixel i = row-major index)
     uint32_t n_patches;
-    float4 *acc_buf;         // [samples][local_rows][width] ColorBuf {light rgb, transmittance}
-    uint32_t *out;           // [local_rows][width] RGBA8
-    DevAux *aux;             // [local_rows][width] or null
-    DevCounters *counters;
-    // cost feedback (aic_trace.hip order_tiles_kernel): tile_order[k] = k-th macro tile to hand out, longest
-    // rays of the previous frame first (null: index order); tile_cost[macro tile] receives this frame's longest ray
-    const uint32_t *tile_order;
-    uint32_t *tile_cost;
+    DevAux *aux;             // [local_rows][width] or null (the recording variants; single frames only)
     // XCD-local tile queues (0: one queue for the whole chip, counters->tile_next). tile_order is then n_queues segments, segment q =
     // positions queue_start[q] .. queue_start[q+1] of it (queue_start: device array of n_queues + 1), each costliest first. A macro
     // tile belongs to the queue of the super-block it lies in (order_tiles_kernel), a workgroup starts on the queue of the XCD it runs on.
     uint32_t n_queues;
-    uint32_t pad_q;
-    const uint32_t *queue_start;
-    // pinned host memory for the frame's five sums (cubes_traced, n_outer, n_inner, n_hits, n_light) and the `bailed` count, written by the last wave of the world pass
-    // to finish: no copy launch behind the trace (a blit kernel that, with frames streamed, waits ~0.2 ms for a CU to have room). Null: the host copies.
-    unsigned long long *host_counters;
+    uint32_t n_sub;          // frames this launch traces: 1, 2, 4 or 8 (DevSub)
+    DevSub sub[kMaxSub];
     const float *light_lut;  // 256 floats
     const float *srgb_thr;   // 256 floats: srgb_thr[k] = smallest linear value whose sRGB8 encoding is >= k
     // Pixel-edge tables (host-made, per frame shape): edge_x[x] = x / width * 2 - 1 for x = 0..width, edge_y[y] = -(y / height * 2 - 1) for
@@ -183,6 +194,15 @@ struct DevFrame {
     uint32_t ray_cold_groups;
     uint32_t exchange;       // host-side: launch the exchanging variant (aic_trace.hip "lane exchange") -- a frame with several tiles per persistent wave; a frame of
                              // about one tile per wave (a rank's share at N >= 4, small images) runs the variant without the pool, which it would only pay for
+};
+
+// order_tiles_kernel's jobs: one workgroup each -- the cost record to read (null: index order), the order and the queues' starts to write, and words to clear
+// (the frame's counters) once the record has been read
+struct OrderJobs {
+    const uint32_t *cost[kMaxSub];
+    uint32_t *order[kMaxSub];
+    uint32_t *queue_start[kMaxSub];
+    uint32_t *clear_words[kMaxSub];
 };
 
 // Largest work tile edge in pixels (DevFrame.tile is 8 by default, 16 with AIC_TILE=16); row strips of

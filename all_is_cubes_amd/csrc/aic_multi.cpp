@@ -21,15 +21,26 @@ namespace {
 constexpr uint32_t kStripRows = 16;
 }
 
-struct aic_multi {
-    std::vector<aic_ctx *> ctx;
-    std::vector<int> dev;
+// A frame in flight (aic_multi_render_submit): its buffers and what aic_multi_render_wait needs to finish it
+struct MultiSlot {
     std::vector<void *> local;       // per device: compact strips [local_rows][width] RGBA8
     std::vector<size_t> local_bytes;
     void *gathered = nullptr;        // on device 0: [n][max_rows][width]
     size_t gathered_bytes = 0;
     void *frame = nullptr;           // on device 0: the assembled frame when the caller wants a host copy
     size_t frame_bytes = 0;
+    hipEvent_t done = nullptr;       // on device 0's transfer stream, behind the frame's assemble
+    bool busy = false;
+    size_t submitted = 0;            // devices whose share was submitted (they are waited for whatever happens)
+    void *host_out = nullptr;        // where the finished frame goes when the caller asked for a host copy
+    size_t frame_size = 0;           // bytes of the assembled frame
+};
+
+struct aic_multi {
+    std::vector<aic_ctx *> ctx;
+    std::vector<int> dev;
+    MultiSlot slots[AIC_MULTI_MAX_IN_FLIGHT];
+    hipStream_t xfer = nullptr;      // device 0: the peer copies and the de-interleave of every frame, in submission order, beside the traces
     size_t n_cubes[2] = {0, 0};      // per layer: cubes of the uploaded space (sizes the light volume hand-over)
     bool light_stale[2] = {false, false};  // device 0's light volume was changed (aic_multi_light_cubes_changed) and not yet handed to the others
     std::string err;
@@ -76,8 +87,15 @@ aic_multi *aic_create_multi(int n_devices, const int *device_ids, int *status) {
         m->ctx.push_back(c);
         m->dev.push_back(device_ids[i]);
     }
-    m->local.assign((size_t)n_devices, nullptr);
-    m->local_bytes.assign((size_t)n_devices, 0);
+    for (MultiSlot &sl : m->slots) {
+        sl.local.assign((size_t)n_devices, nullptr);
+        sl.local_bytes.assign((size_t)n_devices, 0);
+    }
+    if (hipSetDevice(device_ids[0]) != hipSuccess || hipStreamCreateWithFlags(&m->xfer, hipStreamNonBlocking) != hipSuccess) {
+        *status = AIC_ERR_DEVICE;
+        aic_destroy_multi(m);
+        return nullptr;
+    }
     // let device 0 be written by its peers directly (a failure only means the copies are staged by the runtime)
     for (int i = 1; i < n_devices; i++) {
         if (device_ids[i] == device_ids[0]) continue;
@@ -92,15 +110,21 @@ aic_multi *aic_create_multi(int n_devices, const int *device_ids, int *status) {
 
 void aic_destroy_multi(aic_multi *m) {
     if (!m) return;
-    for (size_t i = 0; i < m->ctx.size(); i++) {
-        if (m->local[i]) { (void)hipSetDevice(m->dev[i]); (void)hipFree(m->local[i]); }
-        aic_destroy(m->ctx[i]);
+    for (uint32_t s = 0; s < AIC_MULTI_MAX_IN_FLIGHT; s++)
+        if (m->slots[s].busy) (void)aic_multi_render_wait(m, s, nullptr);
+    if (!m->dev.empty() && m->xfer) { (void)hipSetDevice(m->dev[0]); (void)hipStreamSynchronize(m->xfer); }
+    for (MultiSlot &sl : m->slots) {
+        for (size_t i = 0; i < m->ctx.size() && i < sl.local.size(); i++)
+            if (sl.local[i]) { (void)hipSetDevice(m->dev[i]); (void)hipFree(sl.local[i]); }
+        if (!m->dev.empty()) {
+            (void)hipSetDevice(m->dev[0]);
+            if (sl.gathered) (void)hipFree(sl.gathered);
+            if (sl.frame) (void)hipFree(sl.frame);
+            if (sl.done) (void)hipEventDestroy(sl.done);
+        }
     }
-    if (!m->dev.empty()) {
-        (void)hipSetDevice(m->dev[0]);
-        if (m->gathered) (void)hipFree(m->gathered);
-        if (m->frame) (void)hipFree(m->frame);
-    }
+    for (size_t i = 0; i < m->ctx.size(); i++) aic_destroy(m->ctx[i]);
+    if (!m->dev.empty() && m->xfer) { (void)hipSetDevice(m->dev[0]); (void)hipStreamDestroy(m->xfer); }
     delete m;
 }
 
@@ -182,23 +206,24 @@ int aic_multi_light_cubes_changed(aic_multi *m, int layer, uint32_t n, const int
     return AIC_OK;  // device 0 has taken the change; what the others lack is owed (light_stale) and paid by aic_multi_render
 }
 
-int aic_multi_render(aic_multi *m, const aic_frame_desc *f, void *out_rgba8, int out_is_device, aic_frame_info *info) {
-    if (!m || !f || !out_rgba8) return mfail(m, AIC_ERR_INVALID, "aic_multi_render: bad argument");
+// A frame in flight: every device traces its strips on ITS slot `slot` (aic_render_submit: the submits return at once, the traces overlap); device 0's
+// transfer stream waits for each share ON THE DEVICE (aic_stream_wait_frame), copies it over the peer's direct link and de-interleaves -- the host only enqueues.
+// With several slots the next frames' traces run under this frame's copies, which is what a caller that renders frame after frame
+// (record.rs:97-113) gets from a single context's aic_render_submit / aic_render_wait.
+int aic_multi_render_submit(aic_multi *m, const aic_frame_desc *f, void *out_rgba8, int out_is_device, uint32_t slot) {
+    if (!m || !f || !out_rgba8 || slot >= AIC_MULTI_MAX_IN_FLIGHT) return mfail(m, AIC_ERR_INVALID, "aic_multi_render_submit: bad argument");
     if (f->flags & (AIC_FRAME_AUX | AIC_FRAME_OUT_LINEAR | AIC_FRAME_OUT_COLORBUF))
         return mfail(m, AIC_ERR_INVALID, "aic_multi_render: RGBA8 frames only (use a single context for aux records / float output)");
     if (f->partition.n_parts > 1) return mfail(m, AIC_ERR_INVALID, "aic_multi_render partitions the frame itself");
+    MultiSlot &sl = m->slots[slot];
+    if (sl.busy) return mfail(m, AIC_ERR_INVALID, "aic_multi_render_submit: slot busy (aic_multi_render_wait it first)");
     const size_t n = m->ctx.size();
     const uint32_t w = f->width, h = f->height;
-    if (info) std::memset(info, 0, sizeof(*info));
     for (int layer = 0; layer < 2; layer++)
         if (m->light_stale[layer]) {
             const int rc = broadcast_light(m, layer);
             if (rc != AIC_OK) return rc;
         }
-    if (n == 1) {
-        const int rc = forward(m, 0, aic_render(m->ctx[0], f, out_rgba8, out_is_device, info));
-        return rc;
-    }
     std::vector<uint32_t> rows(n);
     uint32_t max_rows = 0;
     for (size_t i = 0; i < n; i++) {
@@ -207,62 +232,100 @@ int aic_multi_render(aic_multi *m, const aic_frame_desc *f, void *out_rgba8, int
         if (rows[i] > max_rows) max_rows = rows[i];
     }
     const size_t row_bytes = (size_t)w * 4;
-    if (!w || !h) return AIC_OK;
+    sl.submitted = 0;
+    sl.host_out = nullptr;
+    sl.frame_size = (size_t)h * row_bytes;
+    if (!w || !h) { sl.busy = true; return AIC_OK; }  // (an empty frame: nothing to trace, the wait reports zeros)
     for (size_t i = 0; i < n; i++) {
-        const int rc = ensure(m, m->dev[i], &m->local[i], &m->local_bytes[i], (size_t)(rows[i] ? rows[i] : 1) * row_bytes);
+        const int rc = ensure(m, m->dev[i], &sl.local[i], &sl.local_bytes[i], (size_t)(rows[i] ? rows[i] : 1) * row_bytes);
         if (rc != AIC_OK) return rc;
     }
-    { const int rc = ensure(m, m->dev[0], &m->gathered, &m->gathered_bytes, n * (size_t)max_rows * row_bytes); if (rc != AIC_OK) return rc; }
-    // 1. every device traces its strips (the submits return at once: the traces overlap)
-    // A failure from here on must not leave slot 0 of the other contexts busy (every later frame would fail with "slot
-    // busy"): whatever was submitted is waited for before the error is returned.
-    size_t submitted = 0, waited = 0;
+    { const int rc = ensure(m, m->dev[0], &sl.gathered, &sl.gathered_bytes, n * (size_t)max_rows * row_bytes); if (rc != AIC_OK) return rc; }
+    void *target = out_rgba8;
+    if (!out_is_device) {
+        const int rc = ensure(m, m->dev[0], &sl.frame, &sl.frame_bytes, sl.frame_size);
+        if (rc != AIC_OK) return rc;
+        target = sl.frame;
+    }
+    if (hipSetDevice(m->dev[0]) != hipSuccess) return mfail(m, AIC_ERR_DEVICE, "hipSetDevice failed");
+    if (!sl.done && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) return mfail(m, AIC_ERR_DEVICE, "hipEventCreate failed");
+    // A failure from here on must not leave the devices' slots busy (every later frame would fail with "slot busy"): whatever was
+    // submitted is waited for before the error is returned.
     auto drain = [&](int rc, const std::string &msg) {
-        for (size_t k = waited; k < submitted; k++) (void)aic_render_wait(m->ctx[k], 0, nullptr);
+        for (size_t k = 0; k < sl.submitted; k++) (void)aic_render_wait(m->ctx[k], slot, nullptr);
+        sl.submitted = 0;
         if (!msg.empty()) m->err = msg;
         return rc;
     };
+    // 1. every device traces its strips
     for (size_t i = 0; i < n; i++) {
         aic_frame_desc fi = *f;
-        fi.partition = aic_partition{kStripRows, (uint32_t)n, (uint32_t)i, 0};
-        const int rc = forward(m, i, aic_render_submit(m->ctx[i], &fi, m->local[i], 0));
+        fi.partition = n > 1 ? aic_partition{kStripRows, (uint32_t)n, (uint32_t)i, 0} : aic_partition{0, 1, 0, 0};
+        const int rc = forward(m, i, aic_render_submit(m->ctx[i], &fi, n > 1 ? sl.local[i] : target, slot));
         if (rc != AIC_OK) return drain(rc, m->err);
-        submitted = i + 1;
+        sl.submitted = i + 1;
     }
-    // 2. as each finishes, its compact strips go to device 0 (peer copy over the direct link)
-    hipStream_t s0 = (hipStream_t)aic_stream(m->ctx[0]);
+    // 2. behind each share, on device 0's transfer stream: its compact strips go to device 0 (peer copy over the direct link) ...
     for (size_t i = 0; i < n; i++) {
-        aic_frame_info fi;
-        const int rc = forward(m, i, aic_render_wait(m->ctx[i], 0, &fi));
-        waited = i + 1;  // the slot is released by aic_render_wait whatever it returns
+        const int rc = forward(m, i, aic_stream_wait_frame(m->ctx[i], slot, m->xfer));
         if (rc != AIC_OK) return drain(rc, m->err);
+        if (n == 1 || !rows[i]) continue;
+        char *dst = (char *)sl.gathered + i * (size_t)max_rows * row_bytes;
+        if (hipSetDevice(m->dev[0]) != hipSuccess) return drain(AIC_ERR_DEVICE, "hipSetDevice failed");
+        const hipError_t e = m->dev[i] == m->dev[0]
+                                 ? hipMemcpyAsync(dst, sl.local[i], (size_t)rows[i] * row_bytes, hipMemcpyDeviceToDevice, m->xfer)
+                                 : hipMemcpyPeerAsync(dst, m->dev[0], sl.local[i], m->dev[i], (size_t)rows[i] * row_bytes, m->xfer);
+        if (e != hipSuccess) return drain(AIC_ERR_DEVICE, std::string("peer copy: ") + hipGetErrorString(e));
+    }
+    // 3. ... and are de-interleaved there
+    if (n > 1) {
+        const int rc = forward(m, 0, aic_assemble_strips_on(m->ctx[0], sl.gathered, target, w, h, kStripRows, (uint32_t)n, m->xfer));
+        if (rc != AIC_OK) return drain(rc, m->err);
+    }
+    if (hipSetDevice(m->dev[0]) != hipSuccess || hipEventRecord(sl.done, m->xfer) != hipSuccess) return drain(AIC_ERR_DEVICE, "hipEventRecord failed");
+    if (!out_is_device) sl.host_out = out_rgba8;
+    sl.busy = true;
+    return AIC_OK;
+}
+
+int aic_multi_render_wait(aic_multi *m, uint32_t slot, aic_frame_info *info) {
+    if (!m || slot >= AIC_MULTI_MAX_IN_FLIGHT) return mfail(m, AIC_ERR_INVALID, "aic_multi_render_wait: bad argument");
+    if (info) std::memset(info, 0, sizeof(*info));
+    MultiSlot &sl = m->slots[slot];
+    if (!sl.busy) return AIC_OK;
+    sl.busy = false;
+    int result = AIC_OK;
+    for (size_t i = 0; i < sl.submitted; i++) {
+        aic_frame_info fi;
+        const int rc = forward(m, i, aic_render_wait(m->ctx[i], slot, &fi));  // (every share is waited for, whatever another returned)
+        if (rc != AIC_OK) { if (result == AIC_OK) result = rc; continue; }
         if (info) {
             info->cubes_traced += fi.cubes_traced; info->n_outer += fi.n_outer; info->n_inner += fi.n_inner;
             info->n_hits += fi.n_hits; info->n_light += fi.n_light; info->flaws |= fi.flaws;
+            info->rows_rendered += fi.rows_rendered;
             if (fi.kernel_ms > info->kernel_ms) info->kernel_ms = fi.kernel_ms;
+            if (fi.total_ms > info->total_ms) info->total_ms = fi.total_ms;
             if (i == 0) { info->variant = fi.variant; info->tile_queues = fi.tile_queues; }  // (every device runs the same variant on a share of the same shape, bar the last strip)
         }
-        if (!rows[i]) continue;
-        char *dst = (char *)m->gathered + i * (size_t)max_rows * row_bytes;
-        if (hipSetDevice(m->dev[0]) != hipSuccess) return drain(AIC_ERR_DEVICE, "hipSetDevice failed");
-        const hipError_t e = m->dev[i] == m->dev[0]
-                                 ? hipMemcpyAsync(dst, m->local[i], (size_t)rows[i] * row_bytes, hipMemcpyDeviceToDevice, s0)
-                                 : hipMemcpyPeerAsync(dst, m->dev[0], m->local[i], m->dev[i], (size_t)rows[i] * row_bytes, s0);
-        if (e != hipSuccess) return drain(AIC_ERR_DEVICE, std::string("peer copy: ") + hipGetErrorString(e));
     }
-    // 3. de-interleave on device 0
-    void *target = out_rgba8;
-    if (!out_is_device) {
-        const int rc = ensure(m, m->dev[0], &m->frame, &m->frame_bytes, (size_t)h * row_bytes);
-        if (rc != AIC_OK) return rc;
-        target = m->frame;
+    const size_t submitted = sl.submitted;
+    sl.submitted = 0;
+    if (!submitted) return result;  // an empty frame
+    if (hipSetDevice(m->dev[0]) != hipSuccess || hipEventSynchronize(sl.done) != hipSuccess) return result != AIC_OK ? result : mfail(m, AIC_ERR_DEVICE, "waiting for the assembled frame failed");
+    if (result == AIC_OK && sl.host_out) {
+        const void *src = m->ctx.size() > 1 || sl.frame ? sl.frame : nullptr;
+        if (!src || hipMemcpy(sl.host_out, src, sl.frame_size, hipMemcpyDeviceToHost) != hipSuccess) return mfail(m, AIC_ERR_DEVICE, "read-back failed");
     }
-    { const int rc = forward(m, 0, aic_assemble_strips(m->ctx[0], m->gathered, target, w, h, kStripRows, (uint32_t)n)); if (rc != AIC_OK) return rc; }
-    if (!out_is_device) {
-        if (hipMemcpyAsync(out_rgba8, target, (size_t)h * row_bytes, hipMemcpyDeviceToHost, s0) != hipSuccess) return mfail(m, AIC_ERR_DEVICE, "read-back failed");
-    }
-    if (hipStreamSynchronize(s0) != hipSuccess) return mfail(m, AIC_ERR_DEVICE, "synchronize failed");
-    return AIC_OK;
+    sl.host_out = nullptr;
+    return result;
+}
+
+// One frame, start to finish (= submit + wait on slot 0).
+int aic_multi_render(aic_multi *m, const aic_frame_desc *f, void *out_rgba8, int out_is_device, aic_frame_info *info) {
+    if (info) std::memset(info, 0, sizeof(*info));
+    const int rc = aic_multi_render_submit(m, f, out_rgba8, out_is_device, 0);
+    if (rc != AIC_OK) return rc;
+    return aic_multi_render_wait(m, 0, info);
 }
 
 }  // extern "C"

@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
             typedef const __attribute__((address_space(4))) DevFrame KFrameB;
             KFrameB *Fb = (KFrameB *)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(Fb));
-            if (lane == 0u) atomicAdd(&Fb->counters->bailed, 1ull);
+            if (lane == 0u) atomicAdd(&Fb->sub[Fb->n_sub > 1u ? (blockIdx.x & (Fb->n_sub - 1u)) : 0u].counters->bailed, 1ull);
             return true;
         }
         return false;
@@ -1472,6 +1472,12 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
             KFrame &F = *Fq;
             const auto &L = F.layer;
             const auto &opt = L.opt;
+            // the frame this workgroup belongs to (DevSub: a launch may trace several; everything per frame is a scalar load at a uniform offset)
+            typedef const __attribute__((address_space(4))) DevSub KSub;
+            KSub *Sq = reinterpret_cast<KSub *>(reinterpret_cast<const __attribute__((address_space(4))) char *>(Fq) + offsetof(DevFrame, sub)) +
+                       (F.n_sub > 1u ? (blockIdx.x & (F.n_sub - 1u)) : 0u);
+            asm volatile("" : "+s"(Sq));
+            KSub &S = *Sq;
             const bool ui_pass = F.pass == 1;
             const bool include_sky = !ui_pass;
             const bool fog_on = (opt.fog != 0) && include_sky;
@@ -1572,10 +1578,10 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                         }
                     }
                 } else if (have_ray) {
-                    unproject(L.inv, px, py, 0.0, o);
+                    unproject(S.inv, px, py, 0.0, o);
                     if (want_dir) {
                         double f[3];
-                        unproject(L.inv, px, py, 1.0, f);
+                        unproject(S.inv, px, py, 1.0, f);
                         dir[0] = f[0] - o[0]; dir[1] = f[1] - o[1]; dir[2] = f[2] - o[2];
                     }
                 }
@@ -1974,16 +1980,16 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 }
                 const uint32_t x = pxy & 0xffffu, lrow = pxy >> 16;
                 float aa_sum[4] = {0.f, 0.f, 0.f, 0.f};
-                if (F.tile_cost && count > 48u) {
+                if (S.tile_cost && count > 48u) {
                     // longest ray of the macro tile so far. Only rays long enough to matter for the frame's
                     // tail are recorded (the rest leave their tile at cost 0: handed out last, in index
                     // order), and the plain read filters out almost every atomic.
-                    uint32_t *tc = &F.tile_cost[(lrow >> macro_px_shift) * F.macros_x + (x >> macro_px_shift)];  // tile edge and macro are powers of two
+                    uint32_t *tc = &S.tile_cost[(lrow >> macro_px_shift) * F.macros_x + (x >> macro_px_shift)];  // tile edge and macro are powers of two
                     if (count > *tc) atomicMax(tc, count);
                 }
                 const size_t pix = (size_t)lrow * F.width + x;
                 if (ui_pass) {
-                    F.acc_buf[(size_t)sample * npix + pix] = make_float4(acc.l0, acc.l1, acc.l2, acc.t);
+                    S.acc_buf[(size_t)sample * npix + pix] = make_float4(acc.l0, acc.l1, acc.l2, acc.t);
                 } else {
                     if (!F.ortho_n && !cb_opaque(acc)) {  // renderer.rs:474-477: P::paint(NO_WORLD_TO_SHOW) replaces the accumulator
                         // (render_orthographic has no such layer tail: ortho.rs:103-131)
@@ -2013,10 +2019,10 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                         float c[4];
                         cb_to_rgba(pixel, c);
                         if (F.out_mode != 0) {  // float outputs: the linear Rgba, or the ColorBuf as it is
-                            reinterpret_cast<float4 *>(F.out)[pix] =
+                            reinterpret_cast<float4 *>(S.out)[pix] =
                                 F.out_mode == 1 ? make_float4(c[0], c[1], c[2], c[3]) : make_float4(pixel.l0, pixel.l1, pixel.l2, pixel.t);
                         } else {
-                        const float ex = F.exposure;
+                        const float ex = S.exposure;
                         float r = ps_mul(c[0], ex), g = ps_mul(c[1], ex), bl = ps_mul(c[2], ex);
                         const float m = F.maximum_intensity;
                         if (isfinite(m)) {  // ToneMappingOperator::apply (graphics_options.rs:352-368)
@@ -2033,7 +2039,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                         const uint32_t G = srgb8_channel(g, s_thr);
                         const uint32_t B = srgb8_channel(bl, s_thr);
                         const uint32_t A = round_sat_u8(c[3] * 255.0f);
-                        F.out[pix] = R | (G << 8) | (B << 16) | (A << 24);
+                        S.out[pix] = R | (G << 8) | (B << 16) | (A << 24);
                         }
                     }
                     if (DIAG) {
@@ -2087,9 +2093,9 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                                 const uint32_t tried_before = queues_tried;
                                 while (queues_tried < nq) {
                                     uint32_t u = 0u;
-                                    if ((int)lane == leader) u = atomicAdd(&F.counters->tile_next_q[my_queue][0], 1u);
+                                    if ((int)lane == leader) u = atomicAdd(&S.counters->tile_next_q[my_queue][0], 1u);
                                     u = (uint32_t)__builtin_amdgcn_readlane((int)u, leader);
-                                    const uint32_t q0 = F.queue_start[my_queue], q1 = F.queue_start[my_queue + 1u];
+                                    const uint32_t q0 = S.queue_start[my_queue], q1 = S.queue_start[my_queue + 1u];
                                     const uint32_t j = u >> (macro_shift * 2u);
                                     if (j < q1 - q0) {
                                         t = ((q0 + j) << (macro_shift * 2u)) | (u & ((1u << (macro_shift * 2u)) - 1u));
@@ -2100,7 +2106,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                                 }
                                 if (queues_tried != tried_before && lane == 0u) s_queues_tried[threadIdx.x >> 6] = queues_tried;
                             } else {
-                                if ((int)lane == leader) t = atomicAdd(&F.counters->tile_next, 1u);
+                                if ((int)lane == leader) t = atomicAdd(&S.counters->tile_next, 1u);
                                 t = (uint32_t)__builtin_amdgcn_readlane((int)t, leader);  // (a scalar: what depends on it -- `dry` -- stays wave-uniform for the compiler)
                             }
                         }
@@ -2116,7 +2122,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                         const uint32_t m_shift = macro_shift * 2u;
                         uint32_t mt = t >> m_shift;
                         const uint32_t inner = t & ((1u << m_shift) - 1u);
-                        if (F.tile_order) mt = F.tile_order[mt];
+                        if (S.tile_order) mt = S.tile_order[mt];
                         // (divisors taken through opaque_s: a division by a loop-invariant value is otherwise expanded into a
                         //  reciprocal that is computed before the persistent loop and then lives in -- or is spilled from -- a VGPR)
                         const uint32_t mx_ = opaque_s(F.macros_x);
@@ -2169,16 +2175,16 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                     }
                 }
                 if (F.use_init) {
-                    const float4 v = F.acc_buf[(size_t)sample * npix + pix];
+                    const float4 v = S.acc_buf[(size_t)sample * npix + pix];
                     acc.l0 = v.x; acc.l1 = v.y; acc.l2 = v.z; acc.t = v.w;
                 } else {
                     acc.l0 = acc.l1 = acc.l2 = 0.f;
                     acc.t = KF(1.0f);  // made here: as a literal it is hoisted into a register that lives across the whole loop
                 }
                 if (DIAG && sample > 0) dg.hit = dg.hit | 2;  // only the first sample's position is reported
-                if (!ui_pass && F.has_backdrop) {  // Exception::Backdrop hit: ColorBuf::from(Rgba)
-                    const float a = opaque_s(F.backdrop[3]);
-                    cb_add(acc, F.backdrop[0] * a, F.backdrop[1] * a, F.backdrop[2] * a, 1.0f - a);
+                if (!ui_pass && S.has_backdrop) {  // Exception::Backdrop hit: ColorBuf::from(Rgba)
+                    const float a = opaque_s(S.backdrop[3]);
+                    cb_add(acc, S.backdrop[0] * a, S.backdrop[1] * a, S.backdrop[2] * a, 1.0f - a);
                 }
                 count = 0;
                 st = (uint32_t)sample << 14;
@@ -2549,24 +2555,32 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
     }
 
     AIC_SECTION(epilogue);
+    // the frame this workgroup belongs to (as in the event phase: through the opaque kernel-argument pointer)
+    typedef const __attribute__((address_space(4))) DevFrame KFrameE;
+    typedef const __attribute__((address_space(4))) DevSub KSubE;
+    KFrameE *Fe = (KFrameE *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(Fe));
+    const uint32_t n_sub_e = Fe->n_sub > 1u ? Fe->n_sub : 1u;
+    KSubE &SE = Fe->sub[blockIdx.x & (n_sub_e - 1u)];
+    DevCounters *const counters_e = SE.counters;
 #ifdef AIC_PROFILE
     if (lane == 0) {
         prof[3] = (uint32_t)__builtin_readcyclecounter() - prof_t0;  // wave lifetime
         const uint32_t wid = blockIdx.x * (WGT / 64u) + (threadIdx.x >> 6);
         if (wid < 2048u) {
-            F.counters->wave_prof[wid][0] = prof_t0;
-            F.counters->wave_prof[wid][1] = prof_t0 + prof[2];
-            F.counters->wave_prof[wid][2] = prof_t0 + prof[3];
-            F.counters->wave_prof[wid][3] = prof[9];
+            counters_e->wave_prof[wid][0] = prof_t0;
+            counters_e->wave_prof[wid][1] = prof_t0 + prof[2];
+            counters_e->wave_prof[wid][2] = prof_t0 + prof[3];
+            counters_e->wave_prof[wid][3] = prof[9];
         }
-        atomicMax(&F.counters->prof[0], (unsigned long long)prof[3]);
-        atomicMax(&F.counters->prof[1], (unsigned long long)prof[2]);
+        atomicMax(&counters_e->prof[0], (unsigned long long)prof[3]);
+        atomicMax(&counters_e->prof[1], (unsigned long long)prof[2]);
     }
 #ifdef AIC_TAIL_PROF
     {   // trips (12 bits), event phases (10 bits) and mean lanes stepping per trip (x16, 10 bits) after the wave saw the queue dry
         const uint32_t wid = blockIdx.x * (WGT / 64u) + (threadIdx.x >> 6);
         const uint32_t ml = tail_trips ? (tail_lanes * 16u) / tail_trips : 0u;
-        if (lane == 0 && wid < 2048u) F.counters->wave_prof[wid][3] = (tail_trips > 4095u ? 4095u : tail_trips) | ((tail_events > 1023u ? 1023u : tail_events) << 12) | ((ml > 1023u ? 1023u : ml) << 22);
+        if (lane == 0 && wid < 2048u) counters_e->wave_prof[wid][3] = (tail_trips > 4095u ? 4095u : tail_trips) | ((tail_events > 1023u ? 1023u : tail_events) << 12) | ((ml > 1023u ? 1023u : ml) << 22);
     }
 #endif
 #ifdef AIC_RAY_PROF
@@ -2575,10 +2589,10 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { const uint32_t o_ = (uint32_t)__shfl_down((int)best_, off, 64); best_ = o_ > best_ ? o_ : best_; }
         const uint32_t wid = blockIdx.x * (WGT / 64u) + (threadIdx.x >> 6);
-        if (lane == 0 && wid < 2048u) F.counters->wave_prof[wid][3] = best_;
+        if (lane == 0 && wid < 2048u) counters_e->wave_prof[wid][3] = best_;
     }
 #endif
-    if (lane == 0) for (int i = 2; i < 40; i++) atomicAdd(&F.counters->prof[i], (unsigned long long)prof[i]);
+    if (lane == 0) for (int i = 2; i < 40; i++) atomicAdd(&counters_e->prof[i], (unsigned long long)prof[i]);
 #endif
     // ---- RaytraceInfo sum (renderer.rs:555): wave reduction then one atomic per wave ----
     uint32_t t_end = threadIdx.x;
@@ -2586,7 +2600,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
     unsigned long long s = s_steps[t_end];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0 && s) atomicAdd(&F.counters->cubes_traced, s);
+    if (lane == 0 && s) atomicAdd(&counters_e->cubes_traced, s);
     if (DIAG) {
         unsigned long long v[4] = {tot_outer, tot_inner, tot_hits, tot_light};
 #pragma unroll
@@ -2595,22 +2609,24 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
             for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
         }
         if (lane == 0) {
-            if (v[0]) atomicAdd(&F.counters->n_outer, v[0]);
-            if (v[1]) atomicAdd(&F.counters->n_inner, v[1]);
-            if (v[2]) atomicAdd(&F.counters->n_hits, v[2]);
-            if (v[3]) atomicAdd(&F.counters->n_light, v[3]);
+            if (v[0]) atomicAdd(&counters_e->n_outer, v[0]);
+            if (v[1]) atomicAdd(&counters_e->n_inner, v[1]);
+            if (v[2]) atomicAdd(&counters_e->n_hits, v[2]);
+            if (v[3]) atomicAdd(&counters_e->n_light, v[3]);
         }
     }
     // the last wave out hands the frame's sums to the host (pinned memory; the end of the kernel makes the stores visible)
     // (No fences: an agent-scope release fence writes the XCD's whole L2 back -- the frame's pixels -- and 4096 waves doing that cost 10 % of a C2
     //  frame. The sums are agent-scope atomics, performed at the memory side; the wave waits for its own to be acknowledged before it is counted, and
     //  the last wave reads them with agent-scope loads.)
-    if (lane == 0 && F.host_counters) {
+    unsigned long long *const host_counters_e = SE.host_counters;
+    if (lane == 0 && host_counters_e) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (atomicAdd(&F.counters->waves_done, 1u) == gridDim.x * (blockDim.x >> 6) - 1u) {
-            unsigned long long *const src = &F.counters->cubes_traced;  // five consecutive sums and `bailed` (DevCounters)
+        // (the waves of THIS frame: the grid is a multiple of n_sub workgroups, dealt to the frames round-robin)
+        if (atomicAdd(&counters_e->waves_done, 1u) == (gridDim.x / n_sub_e) * (blockDim.x >> 6) - 1u) {
+            unsigned long long *const src = &counters_e->cubes_traced;  // five consecutive sums and `bailed` (DevCounters)
 #pragma unroll
-            for (int i = 0; i < 6; i++) F.host_counters[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < 6; i++) host_counters_e[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -2672,14 +2688,19 @@ __device__ __forceinline__ uint32_t tile_queue_of(uint32_t mt, uint32_t macros_x
 // threads it needed a whole CU to drain, and while frames are streamed every CU is full of persistent trace workgroups: rocprofv3 showed it
 // waiting 0.14 ms (C2) / 1.6 ms (C3) for a place to run (profiles/r04_experiments.txt L).
 constexpr uint32_t kOrderThreads = 256;
-__global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const uint32_t *__restrict__ cost, uint32_t *__restrict__ order, uint32_t n_tiles, uint32_t macros_x,
-                                                                    uint32_t sb_shift, uint32_t n_queues, uint32_t *__restrict__ queue_start, uint32_t *clear_cost,
-                                                                    uint32_t *clear_words, uint32_t n_clear_words) {
+// (a workgroup per job -- OrderJobs, aic_device.h: the frames of a batch, aic_render_submit_batch, are ordered by one launch)
+__global__ __launch_bounds__(kOrderThreads) void order_tiles_kernel(const OrderJobs jobs, uint32_t n_tiles, uint32_t macros_x, uint32_t sb_shift, uint32_t n_queues,
+                                                                    uint32_t clear_the_cost, uint32_t n_clear_words) {
+    const uint32_t *__restrict__ const cost = jobs.cost[blockIdx.x];
+    uint32_t *__restrict__ const order = jobs.order[blockIdx.x];
+    uint32_t *__restrict__ const queue_start = jobs.queue_start[blockIdx.x];
+    uint32_t *const clear_cost = (clear_the_cost && cost) ? const_cast<uint32_t *>(cost) : nullptr;
+    uint32_t *const clear_words = jobs.clear_words[blockIdx.x];
     __shared__ uint32_t hist[kMaxTileQueues * 1024];
     __shared__ uint32_t scan[kOrderThreads];
     // (behind a frame this launch also does the slot's clearing -- the frame's counters, and below the cost record once it has been read -- instead of two
     //  fill launches that would each wait for room on a CU)
-    for (uint32_t i = threadIdx.x; i < n_clear_words; i += kOrderThreads) clear_words[i] = 0u;
+    if (clear_words) for (uint32_t i = threadIdx.x; i < n_clear_words; i += kOrderThreads) clear_words[i] = 0u;
     const uint32_t tid = threadIdx.x;
     const uint32_t n_bins = n_queues * 1024u;
     const uint32_t per_thread = n_bins / kOrderThreads;  // 4 * n_queues consecutive buckets each
@@ -2807,7 +2828,8 @@ static void launch_trace_x(const DevFrame &F, hipStream_t stream) {
     constexpr bool XCHG = AIC_EXCHANGE && XC && !DIAG && LMODE != 3;
     constexpr uint32_t WGT = XCHG ? (uint32_t)AIC_XWG_THREADS : (uint32_t)AIC_WG_THREADS;
     const uint32_t wg_waves = WGT / 64u;
-    const uint32_t resident_groups = F.n_cus * 4u * (uint32_t)((DIAG || LMODE == 3) ? 2 : AIC_MIN_WAVES) / wg_waves;  // 4 SIMDs per CU, that many waves on each
+    const uint32_t n_sub = F.n_sub > 1u ? F.n_sub : 1u;  // frames of this launch (DevSub): each gets an equal share of the resident grid
+    const uint32_t resident_groups = F.n_cus * 4u * (uint32_t)((DIAG || LMODE == 3) ? 2 : AIC_MIN_WAVES) / wg_waves / n_sub;  // 4 SIMDs per CU, that many waves on each
     // A frame smaller than the chip that is STREAMED (aic_render_submit: a rank's strips of a multi-GPU frame, several in
     // flight) gets a grid in proportion to its tiles -- four tiles per wave, so that lanes are refilled instead of waves ending
     // after one tile, and the kernels of the frames in flight are resident side by side (an eighth of a 1080p frame, 8 in
@@ -2819,7 +2841,8 @@ static void launch_trace_x(const DevFrame &F, hipStream_t stream) {
     const uint32_t floor_groups = by_tiles < 128u ? by_tiles : 128u;
     if (grid < floor_groups) grid = floor_groups;
     if (grid > resident_groups) grid = resident_groups;
-    if (XCHG && F.antialias && grid > F.ray_cold_groups) grid = F.ray_cold_groups;  // (the host sizes the antialiasing sums' buffer for the resident grid: trace_ray_cold_bytes)
+    if (XCHG && F.antialias && grid > F.ray_cold_groups / n_sub) grid = F.ray_cold_groups / n_sub;  // (the host sizes the antialiasing sums' buffer for the resident grid: trace_ray_cold_bytes)
+    grid *= n_sub;
     if (grid == 0) return;
     hipLaunchKernelGGL((trace_image_kernel<VOL, LMODE, DIAG, BIG, XC>), dim3(grid), dim3(WGT), 0, stream, F);
 }
@@ -2888,13 +2911,19 @@ void launch_probe_powf(const float *x, const float *y, float *out, uint32_t n, h
     hipLaunchKernelGGL(probe_powf_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, x, y, out, n);
 }
 
-void launch_order_tiles(const uint32_t *cost, uint32_t *order, uint32_t n_tiles, uint32_t macros_x, uint32_t sb_shift, uint32_t n_queues, uint32_t *queue_start,
-                        hipStream_t stream, bool clear_cost, uint32_t *clear_words, uint32_t n_clear_words) {
-    if (!n_tiles) return;
+void launch_order_tiles_jobs(const OrderJobs &jobs, uint32_t n_jobs, uint32_t n_tiles, uint32_t macros_x, uint32_t sb_shift, uint32_t n_queues, hipStream_t stream,
+                             bool clear_cost, uint32_t n_clear_words) {
+    if (!n_tiles || !n_jobs) return;
     if (n_queues < 1u) n_queues = 1u;
     if (n_queues > kMaxTileQueues) n_queues = kMaxTileQueues;
-    hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(kOrderThreads), 0, stream, cost, order, n_tiles, macros_x ? macros_x : 1u, sb_shift, n_queues, queue_start,
-                       clear_cost ? const_cast<uint32_t *>(cost) : nullptr, clear_words, n_clear_words);
+    hipLaunchKernelGGL(order_tiles_kernel, dim3(n_jobs), dim3(kOrderThreads), 0, stream, jobs, n_tiles, macros_x ? macros_x : 1u, sb_shift, n_queues, clear_cost ? 1u : 0u,
+                       n_clear_words);
+}
+void launch_order_tiles(const uint32_t *cost, uint32_t *order, uint32_t n_tiles, uint32_t macros_x, uint32_t sb_shift, uint32_t n_queues, uint32_t *queue_start,
+                        hipStream_t stream, bool clear_cost, uint32_t *clear_words, uint32_t n_clear_words) {
+    OrderJobs jobs{};
+    jobs.cost[0] = cost; jobs.order[0] = order; jobs.queue_start[0] = queue_start; jobs.clear_words[0] = clear_words;
+    launch_order_tiles_jobs(jobs, 1u, n_tiles, macros_x, sb_shift, n_queues, stream, clear_cost, n_clear_words);
 }
 
 void launch_assemble_strips(const uint32_t *gathered, uint32_t *out, uint32_t w, uint32_t h, uint32_t strip_rows,

@@ -251,6 +251,16 @@ int aic_render(aic_ctx *ctx, const aic_frame_desc *frame, void *out_rgba8, int o
 #define AIC_MAX_IN_FLIGHT 32u
 int aic_render_submit(aic_ctx *ctx, const aic_frame_desc *frame, void *out_device, uint32_t slot);
 int aic_render_wait(aic_ctx *ctx, uint32_t slot, aic_frame_info *info);
+/* Several frames in ONE launch (ABI 3): n_frames = 1, 2, 4 or 8 frames of the same size, partition, flags and tuning, each with its own cameras, backdrop
+ * and output buffer (out_devices[i], device memory), under the scene and options as they stand -- the frames a recording loop knows ahead of time
+ * (record.rs:97-113 steps a camera path over a scene that does not change), or a rank's shares of consecutive frames of a multi-GPU stream. The
+ * persistent grid is split between the frames (every workgroup traces one of them, each frame has its own tile queues and cost record), so they are
+ * resident side by side by construction: n small frames fill the chip like one large one -- one ramp, one tail, and the lane-exchanging variant where
+ * a frame alone would be too small for it -- instead of n launches that share the hardware queues as the runtime sees fit. The batch occupies `slot`
+ * like one frame: aic_render_wait reports the sums of its frames' counts, aic_render_wait_batch each frame's; aic_stream_wait_frame orders a foreign
+ * stream behind all of them. Every frame's pixels and counts are those of the same frame submitted alone. */
+int aic_render_submit_batch(aic_ctx *ctx, uint32_t n_frames, const aic_frame_desc *frames, void *const *out_devices, uint32_t slot);
+int aic_render_wait_batch(aic_ctx *ctx, uint32_t slot, uint32_t n_frames, aic_frame_info *infos);
 /* replaces: RtScene::trace_patch (renderer.rs:418-451) for a batch of pixel rectangles -- the call
  * all-is-cubes-gpu's raytrace_to_texture makes for its incremental pixel batches
  * (raytrace_to_texture.rs:603-633). rects = [n][4] {min.x, min.y, max.x, max.y} in normalized device
@@ -270,6 +280,10 @@ int aic_assemble_strips(aic_ctx *ctx, const void *gathered_device, void *out_dev
  * event of the caller's recorded behind it through aic_stream). */
 int aic_assemble_strips_async(aic_ctx *ctx, const void *gathered_device, void *out_device, uint32_t width, uint32_t height,
                               uint32_t strip_rows, uint32_t n_parts);
+/* ... or on a stream of the caller's on the context's device (hip_stream: a hipStream_t; NULL = the context's own): the exchange step of a pipeline that
+ * keeps its copies and de-interleaves off the streams the frames are traced on (aic_multi_render_submit does). */
+int aic_assemble_strips_on(aic_ctx *ctx, const void *gathered_device, void *out_device, uint32_t width, uint32_t height,
+                           uint32_t strip_rows, uint32_t n_parts, void *hip_stream);
 /* read back the aux records of the last aic_render issued with AIC_FRAME_AUX
  * ([rows_rendered][width]). */
 int aic_read_aux(aic_ctx *ctx, aic_pixel_aux *out, uint64_t n_records);
@@ -323,6 +337,15 @@ int aic_multi_replace_blocks(aic_multi *m, int layer, uint32_t n, const uint32_t
 int aic_multi_set_options(aic_multi *m, int layer, const aic_options *options);
 /* out_rgba8: [height][width] RGBA8; out_is_device != 0: a device pointer on device_ids[0] */
 int aic_multi_render(aic_multi *m, const aic_frame_desc *frame, void *out_rgba8, int out_is_device, aic_frame_info *info);
+/* The streaming pair of the multi-device context (ABI 3), as aic_render_submit / aic_render_wait are of one context's: submit queues the frame on
+ * slot 0..AIC_MULTI_MAX_IN_FLIGHT-1 of every device and returns at once -- each device traces its strips, device 0's transfer stream waits for the
+ * shares on the device, copies them over the peers' links and de-interleaves --; wait blocks until that slot's frame is in out_rgba8 (a device pointer on
+ * device_ids[0], or host memory: then the read-back happens in the wait) and reports it. With two or more slots in use the next frame's traces run
+ * under this frame's copies: the only way a caller that renders frame after frame (all-is-cubes-desktop/src/record.rs:97-113) keeps N devices busy.
+ * Scene calls (aic_multi_upload_space ...) wait for the frames in flight as the single-context ones do. aic_multi_render is submit + wait on slot 0. */
+#define AIC_MULTI_MAX_IN_FLIGHT 8u
+int aic_multi_render_submit(aic_multi *m, const aic_frame_desc *frame, void *out_rgba8, int out_is_device, uint32_t slot);
+int aic_multi_render_wait(aic_multi *m, uint32_t slot, aic_frame_info *info);
 
 /* --- device-side probes used by the parity tests (not part of the render path) --------- */
 /* runs Raycaster::new(origin,dir)[.within(lo,hi,include_exit)] on the device, one ray,

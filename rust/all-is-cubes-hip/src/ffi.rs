@@ -24,6 +24,7 @@ pub const AIC_FRAME_OUT_LINEAR: u32 = 8;
 pub const AIC_FRAME_OUT_COLORBUF: u32 = 16;
 pub const AIC_FRAME_NO_FEEDBACK: u32 = 32;
 pub const AIC_MAX_IN_FLIGHT: u32 = 32;
+pub const AIC_MULTI_MAX_IN_FLIGHT: u32 = 8;
 pub const AIC_TUNE_QUEUES_SHIFT: u32 = 0;
 pub const AIC_TUNE_SUPER_SHIFT: u32 = 4;
 pub const AIC_TUNE_VARIANT_SHIFT: u32 = 9;
@@ -205,10 +206,13 @@ unsafe extern "C" {
     pub fn aic_render(ctx: *mut aic_ctx, frame: *const aic_frame_desc, out_rgba8: *mut c_void, out_is_device: c_int, info: *mut aic_frame_info) -> c_int;
     pub fn aic_render_submit(ctx: *mut aic_ctx, frame: *const aic_frame_desc, out_device: *mut c_void, slot: u32) -> c_int;
     pub fn aic_render_wait(ctx: *mut aic_ctx, slot: u32, info: *mut aic_frame_info) -> c_int;
+    pub fn aic_render_submit_batch(ctx: *mut aic_ctx, n_frames: u32, frames: *const aic_frame_desc, out_devices: *const *mut c_void, slot: u32) -> c_int;
+    pub fn aic_render_wait_batch(ctx: *mut aic_ctx, slot: u32, n_frames: u32, infos: *mut aic_frame_info) -> c_int;
     pub fn aic_trace_patches(ctx: *mut aic_ctx, frame: *const aic_frame_desc, n: u32, rects: *const f64, out_rgba8: *mut c_void, aux: *mut aic_pixel_aux, info: *mut aic_frame_info) -> c_int;
     pub fn aic_partition_rows(height: u32, partition: *const aic_partition) -> u32;
     pub fn aic_assemble_strips(ctx: *mut aic_ctx, gathered_device: *const c_void, out_device: *mut c_void, width: u32, height: u32, strip_rows: u32, n_parts: u32) -> c_int;
     pub fn aic_assemble_strips_async(ctx: *mut aic_ctx, gathered_device: *const c_void, out_device: *mut c_void, width: u32, height: u32, strip_rows: u32, n_parts: u32) -> c_int;
+    pub fn aic_assemble_strips_on(ctx: *mut aic_ctx, gathered_device: *const c_void, out_device: *mut c_void, width: u32, height: u32, strip_rows: u32, n_parts: u32, hip_stream: *mut c_void) -> c_int;
     pub fn aic_read_aux(ctx: *mut aic_ctx, out: *mut aic_pixel_aux, n_records: u64) -> c_int;
     pub fn aic_synchronize(ctx: *mut aic_ctx) -> c_int;
     pub fn aic_stream(ctx: *mut aic_ctx) -> *mut c_void;
@@ -228,6 +232,8 @@ unsafe extern "C" {
     pub fn aic_multi_replace_blocks(m: *mut aic_multi, layer: c_int, n: u32, indices: *const u32, descs: *const aic_block_desc, voxels: *const *const u16, palettes: *const *const f32) -> c_int;
     pub fn aic_multi_set_options(m: *mut aic_multi, layer: c_int, options: *const aic_options) -> c_int;
     pub fn aic_multi_render(m: *mut aic_multi, frame: *const aic_frame_desc, out_rgba8: *mut c_void, out_is_device: c_int, info: *mut aic_frame_info) -> c_int;
+    pub fn aic_multi_render_submit(m: *mut aic_multi, frame: *const aic_frame_desc, out_rgba8: *mut c_void, out_is_device: c_int, slot: u32) -> c_int;
+    pub fn aic_multi_render_wait(m: *mut aic_multi, slot: u32, info: *mut aic_frame_info) -> c_int;
     pub fn aic_probe_raycast(ctx: *mut aic_ctx, origin: *const f64, direction: *const f64, use_bounds: c_int, lo: *const i32, hi: *const i32, include_exit: c_int, max_steps: u32, out: *mut aic_rc_step, n_out: *mut u32, ended: *mut c_int) -> c_int;
     pub fn aic_probe_powf(ctx: *mut aic_ctx, x: *const f32, y: *const f32, n: u32, out: *mut f32) -> c_int;
     pub fn aic_probe_light_lut(ctx: *mut aic_ctx, out: *mut f32) -> c_int;

@@ -1277,6 +1277,104 @@ def test_multi_device_context_equals_single(ctx, n):
         assert (ctx.render(ctx.make_frame(w, h, world_inv=inv))["rgba8"] == m.render(abi.Context.make_frame(w, h, world_inv=inv))["rgba8"]).all()
 
 
+def test_multi_device_streamed_submit_and_wait_equal_single(ctx):
+    """aic_multi_render_submit / aic_multi_render_wait (ABI 3): frames queued on several slots of a three-device context (device ids repeated: one GPU)
+    -- different cameras and backdrops, host and device targets, slots reused, waits out of order -- come out as the single-context frames, byte for
+    byte and count for count; a busy slot is refused; aic_multi_render still works between them."""
+    import torch
+
+    sp = scenes.synthetic_space(n=24, resolution=8, n_blocks=8, seed=11)
+    opt = to_abi_options(oracle.make_options())
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.set_options(abi.LAYER_WORLD, opt)
+    w, h = 200, 117
+    frames = []
+    for k in range(7):
+        eye = (12.5 + 0.7 * k, 20.5 - 0.5 * k, 40.0 - k)
+        _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, (12.0, 8.0, 12.0)), eye)
+        frames.append(abi.Context.make_frame(w, h, world_inv=inv, backdrop=(0.1 * k, 0.2, 0.3, 0.5) if k % 2 else (0, 0, 0, 0)))
+    want = [ctx.render(f) for f in frames]
+    with abi.MultiContext([0, 0, 0]) as m:
+        m.upload_space(abi.LAYER_WORLD, sp)
+        m.set_options(abi.LAYER_WORLD, opt)
+        dev = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(3)]
+        # three frames in flight on slots 0..2: host target, device target, host target
+        o0 = m.render_submit(frames[0], 0)
+        m.render_submit(frames[1], 1, dev[1].data_ptr())
+        o2 = m.render_submit(frames[2], 2)
+        with pytest.raises(abi.AicError):
+            m.render_submit(frames[3], 1)  # busy
+        i2, i0, i1 = m.render_wait(2), m.render_wait(0), m.render_wait(1)
+        torch.cuda.synchronize()
+        for got, info, k in ((o0, i0, 0), (dev[1].cpu().numpy(), i1, 1), (o2, i2, 2)):
+            assert (got == want[k]["rgba8"]).all(), k
+            assert info.cubes_traced == want[k]["info"].cubes_traced and info.rows_rendered == h
+        # the synchronous call between streamed ones, then the slots again
+        assert (m.render(frames[3])["rgba8"] == want[3]["rgba8"]).all()
+        outs = {}
+        for k in (4, 5, 6):
+            slot = k % 2
+            if slot in outs:
+                kk, arr = outs.pop(slot)
+                m.render_wait(slot)
+                assert (arr == want[kk]["rgba8"]).all(), kk
+            outs[slot] = (k, m.render_submit(frames[k], slot))
+        for slot, (kk, arr) in outs.items():
+            info = m.render_wait(slot)
+            assert (arr == want[kk]["rgba8"]).all() and info.cubes_traced == want[kk]["info"].cubes_traced
+        assert m.render_wait(5).cubes_traced == 0  # a slot with nothing in flight
+
+
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_frames_of_one_launch_equal_the_frames_alone(ctx, synth_space, k):
+    """aic_render_submit_batch (ABI 3): k frames traced by ONE launch -- every persistent workgroup bound to one of them (DevSub), each with its own
+    cameras, backdrop, output, tile queues, cost record and counters -- are the frames submitted alone: bytes and per-frame step totals, for both
+    production variants, with a UI layer (the pre-pass is a launch of its own over the same k frames), with antialiasing (the exchanging variant's
+    sums in global memory, a region per workgroup), under a strip partition, and again when the batch is repeated (tile orders from the k cost records)."""
+    import torch
+
+    ui = scenes.synthetic_space(n=8, resolution=4, n_blocks=4, seed=5)
+    w, h = 416, 232
+    cams = []
+    for j in range(k):
+        eye = (SYNTH_EYE[0] + 1.3 * j, SYNTH_EYE[1] - 0.9 * j, SYNTH_EYE[2] - 1.1 * j)
+        _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, (14.0, 8.0, 14.0)), eye)
+        _, _, ui_inv = oracle.camera_matrices(90.0, 200.0, w / h, (0, 0, 0, 1), (4.0 + 0.2 * j, 4.0, 12.0))
+        cams.append((inv, ui_inv, (0.2, 0.1 * j, 0.4, 0.6) if j % 3 == 1 else (0, 0, 0, 0)))
+    for antialiasing, with_ui, partition in ((0, False, None), (0, True, None), (2, False, None), (0, False, (16, 4, 1)), (2, True, (16, 2, 1))):
+        opt = oracle.make_options(fog=1, transparency=1, lighting=3, antialiasing=antialiasing)
+        ctx.upload_space(abi.LAYER_WORLD, synth_space)
+        ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+        if with_ui:
+            ctx.upload_space(abi.LAYER_UI, ui)
+            ctx.set_options(abi.LAYER_UI, to_abi_options(opt))
+        else:
+            ctx.clear_space(abi.LAYER_UI)
+        rows = ctx.partition_rows(h, partition) if partition else h
+        for variant in (abi.VARIANT_PLAIN, abi.VARIANT_EXCHANGING):
+            frames = [ctx.make_frame(w, h, world_inv=c[0], ui_inv=c[1], backdrop=c[2], partition=partition, tuning=abi.tuning(variant=variant)) for c in cams]
+            want = [ctx.render(f) for f in frames]
+            bufs = [torch.zeros((rows, w, 4), dtype=torch.uint8, device="cuda") for _ in range(k)]
+            for attempt in range(2):  # the second batch takes its tiles in the order of the first one's k cost records
+                for b in bufs:
+                    b.zero_()
+                torch.cuda.synchronize()
+                ctx.render_submit_batch(frames, [b.data_ptr() for b in bufs], 1)
+                infos = ctx.render_wait_batch(1, k)
+                torch.cuda.synchronize()
+                for j in range(k):
+                    assert (bufs[j].cpu().numpy() == want[j]["rgba8"]).all(), (antialiasing, with_ui, partition, variant, attempt, j)
+                    assert infos[j].cubes_traced == want[j]["info"].cubes_traced and infos[j].variant == variant
+            # aic_render_wait on a batch reports the sums
+            ctx.render_submit_batch(frames, [b.data_ptr() for b in bufs], 2)
+            assert ctx.render_wait(2).cubes_traced == sum(wj["info"].cubes_traced for wj in want)
+    with pytest.raises(abi.AicError):
+        ctx.render_submit_batch(frames[:1] + [ctx.make_frame(w + 8, h, world_inv=cams[0][0])], [bufs[0].data_ptr(), bufs[1].data_ptr()], 1)  # shapes differ
+    with pytest.raises(abi.AicError):
+        ctx.render_submit_batch(frames[:1] * 3, [b.data_ptr() for b in bufs[:3]], 1)  # three frames
+
+
 @pytest.mark.parametrize("resolution", [8, 32])
 def test_render_orthographic(ctx, resolution):
     """aic_render_orthographic = raytracer::ortho::render_orthographic (ortho.rs:30-88): five axis-aligned views, traced
