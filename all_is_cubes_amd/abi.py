@@ -46,7 +46,7 @@ ABI_SYMBOLS = [
     "aic_render", "aic_render_submit", "aic_render_wait", "aic_render_submit_batch", "aic_render_wait_batch", "aic_trace_patches", "aic_partition_rows", "aic_assemble_strips", "aic_assemble_strips_async", "aic_assemble_strips_on", "aic_read_aux", "aic_synchronize", "aic_stream", "aic_wait_event", "aic_stream_wait_frame",
     "aic_probe_raycast", "aic_probe_light_lut", "aic_probe_powf",
     "aic_ortho_image_size", "aic_render_orthographic",
-    "aic_evaluate_light", "aic_light_cubes_changed", "aic_read_light_volume", "aic_read_light_cubes", "aic_light_chart", "aic_probe_derived", "aic_probe_log2f",
+    "aic_evaluate_light", "aic_evaluate_light_submit", "aic_evaluate_light_wait", "aic_evaluate_light_poll", "aic_light_cubes_changed", "aic_read_light_volume", "aic_read_light_cubes", "aic_light_chart", "aic_probe_derived", "aic_probe_log2f",
     "aic_create_multi", "aic_destroy_multi", "aic_multi_device_count", "aic_multi_context", "aic_multi_last_error", "aic_multi_upload_space",
     "aic_multi_clear_space", "aic_multi_update_cubes", "aic_multi_update_light_volume", "aic_multi_evaluate_light", "aic_multi_light_cubes_changed", "aic_multi_replace_blocks", "aic_multi_set_options",
     "aic_multi_render", "aic_multi_render_submit", "aic_multi_render_wait",
@@ -185,6 +185,9 @@ def load() -> C.CDLL:
         lib.aic_probe_light_lut.argtypes = [C.c_void_p, C.c_void_p]
         lib.aic_probe_powf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.aic_evaluate_light.argtypes = [C.c_void_p, C.c_int, C.POINTER(LightParams), C.POINTER(LightInfo)]
+        lib.aic_evaluate_light_submit.argtypes = [C.c_void_p, C.c_int, C.POINTER(LightParams)]
+        lib.aic_evaluate_light_wait.argtypes = [C.c_void_p, C.c_int, C.POINTER(LightInfo)]
+        lib.aic_evaluate_light_poll.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         lib.aic_read_light_volume.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         lib.aic_read_light_cubes.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
         lib.aic_light_cubes_changed.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_int]
@@ -533,6 +536,32 @@ class Context:
         info = LightInfo()
         self._check(self._lib.aic_evaluate_light(self._h, layer, C.byref(p), C.byref(info)))
         del keep
+        return info
+
+    def evaluate_light_submit(self, layer: int, maximum_distance: int, fast: bool = True, epsilon: int = 1, batch: int = 32, queue_order: int = 16,
+                              queue=None, max_updates: int = 0, lanes_per_cube: int = 0) -> None:
+        """aic_evaluate_light_submit: the same update on the context's worker thread; `evaluate_light_wait` publishes and reports it."""
+        p = LightParams(maximum_distance, int(fast), epsilon, batch, queue_order, -1, lanes_per_cube, 0, None, None, max_updates)
+        keep = []
+        if queue is not None:
+            qc = np.ascontiguousarray([q[0] for q in queue], np.int32).reshape(-1, 3)
+            qp = np.ascontiguousarray([q[1] for q in queue], np.int32)
+            keep = [qc, qp]
+            p.n_queue = len(qp)
+            p.queue_cubes = qc.ctypes.data
+            p.queue_priorities = qp.ctypes.data
+        self._check(self._lib.aic_evaluate_light_submit(self._h, layer, C.byref(p)))
+        del keep  # (the library copied the arrays)
+
+    def evaluate_light_done(self, layer: int) -> bool:
+        """aic_evaluate_light_poll: False while a submitted update is still running."""
+        d = C.c_int(1)
+        self._check(self._lib.aic_evaluate_light_poll(self._h, layer, C.byref(d)))
+        return bool(d.value)
+
+    def evaluate_light_wait(self, layer: int) -> LightInfo:
+        info = LightInfo()
+        self._check(self._lib.aic_evaluate_light_wait(self._h, layer, C.byref(info)))
         return info
 
     def light_cubes_changed(self, layer: int, xyz, queue_order: int = 16) -> None:

@@ -10,6 +10,9 @@
 
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <initializer_list>
@@ -208,6 +211,24 @@ struct aic_ctx {
     std::FILE *dump = nullptr;  // AIC_DUMP=path: every scene / options / frame argument is appended here
     char devname[256] = {0};
     uint32_t n_cus = 256;
+    // aic_evaluate_light_submit / _wait: ONE light update at a time runs on a worker thread the context owns, against a spare light volume (Layer::light_spare);
+    // the frames submitted meanwhile read the volume as it stood. The update is PUBLISHED -- the spare becomes the layer's volume -- by aic_evaluate_light_wait,
+    // or by whatever call next needs the scene still (every scene or light call finishes a pending update first: light_job_finish).
+    struct LightJob {
+        std::thread worker;
+        std::mutex mu;
+        std::condition_variable cv;
+        bool has_work = false, quit = false;   // (under mu)
+        bool running = false;                   // (under mu) the worker is inside the update
+        bool pending = false;                   // an update was submitted and has not been published yet (caller's thread only)
+        bool result_ready = false;              // rc / info / err describe an update aic_evaluate_light_wait has not reported yet
+        int layer = 0, spare = -1;
+        aic_light_params params;
+        std::vector<int32_t> queue_cubes, queue_priorities;
+        int rc = AIC_OK;
+        aic_light_info info;
+        std::string err;
+    } ljob;
     // measurement switches, read from the environment ONCE, when the context is made -- nothing on the frame path reads the environment
     struct Switches {
         int tile = 0, macro = 0;         // AIC_TILE, AIC_MACRO: work-tile edge in pixels (8 | 16), tiles per macro tile edge
@@ -220,16 +241,20 @@ struct aic_ctx {
 
 namespace {
 
+// (the light worker's failures go to its job's own string, not to the context's last error, which the caller's thread may be writing: see LightJob)
+thread_local std::string *tl_err_sink = nullptr;
 int fail(aic_ctx *c, int code, const char *what, hipError_t e = hipSuccess) {
     if (c) {
-        c->err = what;
+        std::string &dst = tl_err_sink ? *tl_err_sink : c->err;
+        dst = what;
         if (e != hipSuccess) {
-            c->err += ": ";
-            c->err += hipGetErrorString(e);
+            dst += ": ";
+            dst += hipGetErrorString(e);
         }
     }
     return code;
 }
+int light_job_finish(aic_ctx *c);  // aic_light_host.inc
 // ---- call recorder: AIC_DUMP=<path> makes a context append every argument it is given --
 // scene snapshots, deltas, options, frame descriptors -- to <path>, verbatim, so that a scene produced by
 // the reference (which cannot be generated here) can be captured where the Rust shim runs and replayed
@@ -286,6 +311,7 @@ int take_light_spare(aic_ctx *c, Layer &l, int layer, size_t n, int *index) {
 
 // Every scene mutation waits for the frames in flight: they read the buffers it is about to change.
 int quiesce(aic_ctx *c) {
+    { const int rc = light_job_finish(c); if (rc != AIC_OK) return rc; }  // (a light update in flight reads the scene too, and its result is published first)
     for (uint32_t i = 0; i < AIC_MAX_IN_FLIGHT; i++)
         if (c->slots[i].busy) HIP_TRY(c, hipStreamSynchronize(c->slots[i].stream));
     return AIC_OK;
@@ -529,6 +555,12 @@ aic_ctx *aic_create(int device_id, int *status) {
 void aic_destroy(aic_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)light_job_finish(c);  // a light update in flight ends (and is published) before anything it uses is freed ...
+    if (c->ljob.worker.joinable()) {  // ... and the worker leaves
+        { std::lock_guard<std::mutex> lk(c->ljob.mu); c->ljob.quit = true; }
+        c->ljob.cv.notify_all();
+        c->ljob.worker.join();
+    }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (uint32_t i = 0; i < AIC_MAX_IN_FLIGHT; i++) {
         aic_ctx::FrameSlot &fs = c->slots[i];
@@ -698,6 +730,7 @@ int aic_update_light_volume(aic_ctx *c, int layer, const uint8_t *light) {
     Layer &l = c->layers[layer];
     if (!l.present) return fail(c, AIC_ERR_INVALID, "aic_update_light_volume: no space uploaded for this layer");
     HIP_TRY(c, hipSetDevice(c->device));
+    { const int rc = light_job_finish(c); if (rc != AIC_OK) return rc; }
     // Double-buffered: the new volume goes into the buffer no frame in flight is reading, on its own
     // stream, and becomes current for the frames submitted from now on -- a streaming loop that
     // re-lights every frame (BASELINE config 5) keeps its frames overlapped.

@@ -766,6 +766,17 @@ void HipRtRenderer::submit_rows_to_device(void *device_out, uint32_t strip_rows,
     f.partition = aic_partition{strip_rows, n_parts, part, 0};
     check(aic_render_submit(ctx_, &f, device_out, slot), "aic_render_submit");
 }
+void HipRtRenderer::submit_rows_batch_to_device(const std::vector<void *> &device_outs, uint32_t strip_rows, uint32_t n_parts, uint32_t part, uint32_t slot,
+                                                const std::vector<std::array<double, 16>> &inverse_projection_views) {
+    if (!inverse_projection_views.empty() && inverse_projection_views.size() != device_outs.size())
+        throw std::invalid_argument("submit_rows_batch_to_device: one camera per frame, or none");
+    std::vector<aic_frame_desc> frames(device_outs.size(), make_frame());
+    for (size_t j = 0; j < frames.size(); j++) {
+        frames[j].partition = aic_partition{strip_rows, n_parts, part, 0};
+        if (!inverse_projection_views.empty()) std::memcpy(frames[j].world.inverse_projection_view, inverse_projection_views[j].data(), sizeof(double) * 16);
+    }
+    check(aic_render_submit_batch(ctx_, (uint32_t)frames.size(), frames.data(), device_outs.data(), slot), "aic_render_submit_batch");
+}
 ImageInfo HipRtRenderer::wait_rows(uint32_t slot) {
     aic_frame_info fi;
     check(aic_render_wait(ctx_, slot, &fi), "aic_render_wait");
@@ -787,6 +798,31 @@ HipRtRenderer::LightUpdateInfo HipRtRenderer::evaluate_light(int maximum_distanc
     p.lanes_per_cube = lanes_per_cube;
     aic_light_info info;
     check(aic_evaluate_light(ctx_, AIC_LAYER_WORLD, &p, &info), "aic_evaluate_light");
+    return LightUpdateInfo{info.updates, info.batches, info.cost, info.device_ms, info.total_ms, info.queue_left, info.bundles_visited};
+}
+
+void HipRtRenderer::evaluate_light_submit(int maximum_distance, bool fast, int epsilon, int batch, int queue_order, int lanes_per_cube, bool continue_queue,
+                                          uint64_t max_updates) {
+    aic_light_params p;
+    std::memset(&p, 0, sizeof(p));
+    p.maximum_distance = maximum_distance;
+    p.fast = fast ? 1 : 0;
+    p.epsilon = epsilon;
+    p.batch = batch;
+    p.queue_order = queue_order;
+    p.n_queue = continue_queue ? 0 : -1;
+    p.max_updates = max_updates;
+    p.lanes_per_cube = lanes_per_cube;
+    check(aic_evaluate_light_submit(ctx_, AIC_LAYER_WORLD, &p), "aic_evaluate_light_submit");
+}
+bool HipRtRenderer::evaluate_light_done() {
+    int done = 1;
+    check(aic_evaluate_light_poll(ctx_, AIC_LAYER_WORLD, &done), "aic_evaluate_light_poll");
+    return done != 0;
+}
+HipRtRenderer::LightUpdateInfo HipRtRenderer::evaluate_light_wait() {
+    aic_light_info info;
+    check(aic_evaluate_light_wait(ctx_, AIC_LAYER_WORLD, &info), "aic_evaluate_light_wait");
     return LightUpdateInfo{info.updates, info.batches, info.cost, info.device_ms, info.total_ms, info.queue_left, info.bundles_visited};
 }
 

@@ -321,6 +321,10 @@ class HipRtRenderer : public HeadlessRenderer {
     void assemble_strips(const void *gathered_device, void *out_device, uint32_t strip_rows, uint32_t n_parts, bool wait = true);
     // streaming pair (aic_render_submit / aic_render_wait): up to AIC_MAX_IN_FLIGHT frames in flight
     void submit_rows_to_device(void *device_out, uint32_t strip_rows, uint32_t n_parts, uint32_t part, uint32_t slot);
+    // aic_render_submit_batch: 1, 2, 4 or 8 frames traced by ONE launch, frame j into device_outs[j]. `inverse_projection_views` (16 doubles per frame, may be
+    // empty) gives each frame its own world camera -- a camera path known ahead of time --; empty: every frame is the current view.
+    void submit_rows_batch_to_device(const std::vector<void *> &device_outs, uint32_t strip_rows, uint32_t n_parts, uint32_t part, uint32_t slot,
+                                     const std::vector<std::array<double, 16>> &inverse_projection_views = {});
     ImageInfo wait_rows(uint32_t slot);
     void synchronize();  // blocks until everything queued on the context's stream is done (aic_synchronize)
     Viewport modified_viewport() const;
@@ -333,6 +337,12 @@ class HipRtRenderer : public HeadlessRenderer {
     // Mutation::evaluate_light(epsilon) (space.rs:1496-1540) on the WORLD space as uploaded, with
     // LightPhysics::Rays { maximum_distance }; the device's light volume is updated in place (the host Space's is not).
     struct LightUpdateInfo { uint64_t updates, batches, cost; double device_ms, total_ms; uint32_t queue_left; uint64_t bundles_visited; };
+    // aic_evaluate_light_submit / _wait: the same update on the library's worker thread, beside the frames submitted meanwhile (which read the light as it
+    // stood); the wait -- or the next update() that changes the scene -- publishes it
+    void evaluate_light_submit(int maximum_distance, bool fast, int epsilon, int batch, int queue_order, int lanes_per_cube = 0, bool continue_queue = false,
+                               uint64_t max_updates = 0);
+    LightUpdateInfo evaluate_light_wait();
+    bool evaluate_light_done();  // aic_evaluate_light_poll: false while a submitted update is still running
     // `continue_queue`: add nothing to the layer's update queue (what update() queued through aic_light_cubes_changed is
     // drained); `max_updates`: stop after that many cube updates (a per-frame light budget), 0 = run to the end.
     LightUpdateInfo evaluate_light(int maximum_distance, bool fast = true, int epsilon = 1, int batch = 32, int queue_order = 16, int lanes_per_cube = 0,

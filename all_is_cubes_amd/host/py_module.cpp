@@ -234,6 +234,12 @@ PYBIND11_MODULE(_host, m) {
         .def("submit_rows_to_device", [](HipRtRenderer &r, uintptr_t ptr, uint32_t strip_rows, uint32_t n_parts, uint32_t part, uint32_t slot) {
             r.submit_rows_to_device(reinterpret_cast<void *>(ptr), strip_rows, n_parts, part, slot);
         }, py::arg("device_ptr"), py::arg("strip_rows"), py::arg("n_parts"), py::arg("part"), py::arg("slot"))
+        .def("submit_rows_batch_to_device", [](HipRtRenderer &r, const std::vector<uintptr_t> &ptrs, uint32_t strip_rows, uint32_t n_parts, uint32_t part, uint32_t slot,
+                                               const std::vector<std::array<double, 16>> &views) {
+            std::vector<void *> outs;
+            for (uintptr_t p : ptrs) outs.push_back(reinterpret_cast<void *>(p));
+            r.submit_rows_batch_to_device(outs, strip_rows, n_parts, part, slot, views);
+        }, py::arg("device_ptrs"), py::arg("strip_rows"), py::arg("n_parts"), py::arg("part"), py::arg("slot"), py::arg("inverse_projection_views") = std::vector<std::array<double, 16>>())
         .def("wait_rows", [](HipRtRenderer &r, uint32_t slot) { py::gil_scoped_release rel; return r.wait_rows(slot); }, py::arg("slot"))
         .def("synchronize", [](HipRtRenderer &r) { py::gil_scoped_release rel; r.synchronize(); })
         .def("assemble_strips", [](HipRtRenderer &r, uintptr_t gathered, uintptr_t out, uint32_t strip_rows, uint32_t n_parts, bool wait) {
@@ -254,6 +260,20 @@ PYBIND11_MODULE(_host, m) {
             return d;
         }, py::arg("maximum_distance"), py::arg("fast") = true, py::arg("epsilon") = 1, py::arg("batch") = 32, py::arg("queue_order") = 16, py::arg("lanes_per_cube") = 0, py::arg("continue_queue") = false,
            py::arg("max_updates") = 0)
+        .def("evaluate_light_submit", [](HipRtRenderer &r, int maximum_distance, bool fast, int epsilon, int batch, int queue_order, int lanes_per_cube, bool continue_queue,
+                                         uint64_t max_updates) { r.evaluate_light_submit(maximum_distance, fast, epsilon, batch, queue_order, lanes_per_cube, continue_queue, max_updates); },
+             py::arg("maximum_distance"), py::arg("fast") = true, py::arg("epsilon") = 1, py::arg("batch") = 32, py::arg("queue_order") = 16, py::arg("lanes_per_cube") = 0,
+             py::arg("continue_queue") = false, py::arg("max_updates") = 0)
+        .def("evaluate_light_done", &HipRtRenderer::evaluate_light_done)
+        .def("evaluate_light_wait", [](HipRtRenderer &r) {
+            py::gil_scoped_release rel;
+            const HipRtRenderer::LightUpdateInfo i = r.evaluate_light_wait();
+            py::gil_scoped_acquire acq;
+            py::dict d;
+            d["updates"] = i.updates; d["batches"] = i.batches; d["cost"] = i.cost; d["device_ms"] = i.device_ms;
+            d["total_ms"] = i.total_ms; d["queue_left"] = i.queue_left; d["bundles_visited"] = i.bundles_visited;
+            return d;
+        })
         .def_readwrite("device_light", &HipRtRenderer::device_light)
         .def_readwrite("device_light_queue_order", &HipRtRenderer::device_light_queue_order)
         .def_readwrite("enable_counters", &HipRtRenderer::enable_counters);

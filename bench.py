@@ -158,6 +158,10 @@ def main() -> int:
                     help="N > 1: consecutive frames moved to rank 0 by one collective; default 1 (a frame is gathered as soon as it is traced). More "
                          "frames per collective trade latency for fewer host calls: to be measured on a real 8-GPU node before it becomes a default "
                          "(README: the SCALE commands)")
+    ap.add_argument("--frames-per-launch", type=int, default=0,
+                    help="1, 2, 4 or 8: that many consecutive frames (of a rank: its shares of them) are traced by ONE launch (aic_render_submit_batch); --in-flight "
+                         "then counts frames too (at least two launches are kept in flight). Default: 1 at N < 4, 8 from N = 4 -- a rank's share is then too small "
+                         "to fill the chip alone, and eight of them in one launch are a whole frame's worth of tiles (profiles/r06_rank_share.txt)")
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: gather each frame before tracing the next")
     ap.add_argument("--gather-at-one", action="store_true",
                     help="N = 1: run the exchange step all the same (a one-rank process group over the nccl backend, the strip ring, the gather and the "
@@ -171,6 +175,7 @@ def main() -> int:
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed single-frame / moving-camera / read-back measurements (counter passes)")
     ap.add_argument("--relight-period", type=int, default=30, help="relight: frames between two lamp toggles")
     ap.add_argument("--light-budget", type=int, default=2048, help="relight: cube updates of the light updater per frame (one launch)")
+    ap.add_argument("--blocking-light", action="store_true", help="relight: the blocking aic_evaluate_light per frame (rounds 2-5) instead of aic_evaluate_light_submit / _wait")
     ap.add_argument("--no-secondary", action="store_true", help="atrium (the default line): skip the short s256 leg reported as `secondary`")
     ap.add_argument("--min-seconds", type=float, default=3.0, help="repeat the K-step timed region until the regions add up to this much time")
     args = ap.parse_args()
@@ -251,7 +256,7 @@ def main() -> int:
     loop = None   # orbit / relight: what changes in the scene before every frame (SceneLoop)
     relight = None
     if args.workload in ("orbit", "relight"):
-        loop = SceneLoop(args.workload, H, flat_space, cams, renderer, eye, target, args.relight_period, args.light_budget)
+        loop = SceneLoop(args.workload, H, flat_space, cams, renderer, eye, target, args.relight_period, args.light_budget, args.blocking_light)
         light_update, relight = loop.light_update, loop.relight
     if args.workload == "light-bench":
         # light.rs "both": fast_evaluate_light then evaluate_light(1), LightPhysics::Rays { maximum_distance: 30 },
@@ -291,8 +296,14 @@ def main() -> int:
     streamed = not args.no_pipeline
     # traces in flight (AIC_MAX_IN_FLIGHT = 32): a rank's share of a frame shrinks with N while a ray's latency does not -- the default keeps about four
     # frames' worth of rays on each device (profiles/r05_rank_share.txt)
-    depth = max(1, min(32, args.in_flight if args.in_flight > 0 else (4 if world < 4 else (8 if world < 8 else 16))))
-    per_gather = max(1, min(depth, args.frames_per_gather if args.frames_per_gather > 0 else 1)) if streamed else 1
+    per_launch = (args.frames_per_launch if args.frames_per_launch in (1, 2, 4, 8) else (1 if world < 4 else 8)) if streamed else 1  # frames traced by one launch (aic_render_submit_batch)
+    # (with eight shares per launch: two launches in flight at N = 4, four from N = 8 -- what the share's time stops falling at on one GPU, profiles/r06_rank_share.txt)
+    depth = max(1, min(32, args.in_flight if args.in_flight > 0 else (4 if world < 4 else ((8 if world < 8 else 16) if per_launch == 1 else (16 if world < 8 else 32)))))
+    launches = max(2, depth // per_launch) if per_launch > 1 else depth  # render slots in use (a launch occupies one)
+    if per_launch > 1:
+        depth = launches * per_launch
+    # (the frames of one launch are done together: they travel in one collective -- no frame waits for another that is not done anyway)
+    per_gather = max(1, min(depth, args.frames_per_gather if args.frames_per_gather > 0 else per_launch)) if streamed else 1
     ring = ((depth + per_gather - 1) // per_gather + (1 if per_gather == 1 else 2)) if streamed else 1  # group slots: the groups being traced, one being gathered
     pipe = D.StripGatherPipeline(h, w, strip, "cpu" if one_gpu_test else dev, depth=ring,
                                  wait_event=None if one_gpu_test else renderer.wait_event, frames=per_gather) if exchange else None
@@ -311,7 +322,8 @@ def main() -> int:
 
     kernel_ms = []
     frame_no = [0]
-    traced = []  # frames whose trace is in flight: (frame number, render slot)
+    traced = []   # launches whose trace is in flight: (first frame number, render slot, frames)
+    pending = []  # frames-per-launch > 1: frames waiting for their launch to fill up
 
     filled = {}  # group slot -> frames of it traced since its last gather
 
@@ -341,20 +353,41 @@ def main() -> int:
         if uncollected.pop(rslot, None):
             kernel_ms.append(renderer.wait_rows(rslot).kernel_ms)
 
-    def complete_oldest() -> None:  # the oldest traced frame: hand its strips to the gather
-        i, rslot = traced.pop(0)
+    def complete_oldest() -> None:  # the oldest launch in flight: hand its frames' strips to the gather
+        i0, rslot, count = traced.pop(0)
         if device_handoff:
             renderer.stream_wait_rows(rslot, torch.cuda.current_stream(dev).cuda_stream)
             uncollected[rslot] = True
         else:
             info = renderer.wait_rows(rslot)
             kernel_ms.append(info.kernel_ms)
-        if pipe is not None:
-            if one_gpu_test:
-                pipe.frame_buffer(slot_of(i), i % per_gather)[:local_rows].copy_(local_bufs[i % n_local][:local_rows])
-            filled[slot_of(i)] = i % per_gather + 1
-            if i % per_gather == per_gather - 1:
-                pipe.submit(slot_of(i))
+        for i in range(i0, i0 + count):
+            if pipe is not None:
+                if one_gpu_test:
+                    pipe.frame_buffer(slot_of(i), i % per_gather)[:local_rows].copy_(local_bufs[i % n_local][:local_rows])
+                filled[slot_of(i)] = i % per_gather + 1
+                if i % per_gather == per_gather - 1:
+                    pipe.submit(slot_of(i))
+
+    def launch(frames) -> None:  # one launch for these consecutive frames (1, 2, 4 or 8 of them)
+        if len(traced) == launches:
+            complete_oldest()
+        rslot = (frames[0] // per_launch) % launches
+        for i in frames:
+            if pipe is not None and i % per_gather == 0:
+                finish(slot_of(i))  # the gather that last used this ring slot
+        collect(rslot)
+        if len(frames) == 1:
+            renderer.submit_rows_to_device(render_target(frames[0]).data_ptr(), strip, world, rank, rslot)
+        else:
+            renderer.submit_rows_batch_to_device([render_target(i).data_ptr() for i in frames], strip, world, rank, rslot)
+        traced.append((frames[0], rslot, len(frames)))
+
+    def flush_pending() -> None:  # a partial batch (the timed region's last frames): launches of the largest power of two that fits
+        while pending:
+            n = 1 << (len(pending).bit_length() - 1)
+            launch(pending[:n])
+            del pending[:n]
 
     def step() -> None:
         i = frame_no[0]
@@ -370,15 +403,13 @@ def main() -> int:
                     pipe.local[0][:local_rows].copy_(local_bufs[0][:local_rows])
                 pipe.submit(0)
             return
-        if len(traced) == depth:
-            complete_oldest()
-        if pipe is not None and i % per_gather == 0:
-            finish(slot_of(i))  # the gather that last used this ring slot
-        collect(i % depth)
-        renderer.submit_rows_to_device(render_target(i).data_ptr(), strip, world, rank, i % depth)
-        traced.append((i, i % depth))
+        pending.append(i)
+        if len(pending) == per_launch:
+            launch(list(pending))
+            pending.clear()
 
     def drain() -> None:  # every frame issued so far is traced, gathered and assembled
+        flush_pending()
         while traced:
             complete_oldest()
         for rslot in list(uncollected):
@@ -520,6 +551,32 @@ def main() -> int:
             "note": "medians of one frame at a time (host submit to completion); moving camera: 6 degrees per frame about the view target",
         }
 
+    # Several frames per launch (aic_render_submit_batch, round 6): the same static view streamed as launches of 4 frames, two launches in flight -- what a
+    # caller that knows its next cameras (a camera path over a still scene) gets; reported beside `value`, which stays the one-frame-per-launch rate
+    batched = None
+    if world == 1 and single is not None and per_launch == 1 and not is_replay:
+        kb, lb, nb = 4, 2, 16  # frames per launch, launches in flight, launches timed
+        bb = [[torch.empty((h, w, 4), dtype=torch.uint8, device=dev) for _ in range(kb)] for _ in range(lb)]
+
+        def run_batched(n):
+            for i in range(n):
+                if i >= lb:
+                    renderer.wait_rows(i % lb)
+                renderer.submit_rows_batch_to_device([b.data_ptr() for b in bb[i % lb]], strip, 1, 0, i % lb)
+            for i in range(max(0, n - lb), n):
+                renderer.wait_rows(i % lb)
+            renderer.synchronize()
+
+        run_batched(4)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_batched(nb)
+        torch.cuda.synchronize()
+        ms_b = (time.perf_counter() - t1) / (nb * kb) * 1e3
+        batched = {"frames_per_launch": kb, "launches_in_flight": lb, "frames": nb * kb, "ms_per_step": round(ms_b, 4),
+                   "value": round(rays_per_frame / (ms_b * 1e-3) / 1e6, 3), "unit": "Mrays/s",
+                   "frames_equal_single_frame": bool((bb[0][0] == bb[lb - 1][kb - 1]).all().item())}
+
     fps_with_readback = None
     if world == 1 and not args.no_extras:
         n_rb = max(3, min(10, args.steps))
@@ -637,6 +694,7 @@ def main() -> int:
                 "partition": f"interleaved {strip}-row strips over {world} GPU(s), scene replicated, RCCL gather to rank 0",
                 "steps_per_ray": round(cubes_traced / rays_per_frame, 2),
                 "frames_in_flight": depth if streamed else 1,
+                "frames_per_launch": per_launch,
                 "frames_per_gather": per_gather if exchange else None,
                 "handoff": ("device (aic_stream_wait_frame: the gather's stream waits for the trace's event)" if device_handoff else "host (aic_render_wait before each gather)") if exchange else None,
                 "assembled_frame_equals_single_rank_frame": verified,
@@ -658,6 +716,8 @@ def main() -> int:
                 result["config"]["value_is"] = ("`value` = streamed frames (frames_in_flight traces overlapping, static camera: the recording loop's rate); "
                                                 "BASELINE.json config 2 names a single-frame raytrace, which is `value_single_frame` (one frame alone, cold; "
                                                 "`value_single_frame_warm` with the tile order learnt from the identical previous frame)")
+        if batched is not None:
+            result["streamed_batched"] = batched
         if secondary is not None:
             result["secondary"] = secondary
         if criterion is not None:
@@ -699,8 +759,12 @@ class SceneLoop:
                  changed cube and its neighbours are queued (aic_light_cubes_changed), every frame the light updater gets `budget` cube
                  updates in one launch (aic_evaluate_light, continuing the layer's queue) and the camera moves. No light volume crosses PCIe."""
 
-    def __init__(self, name, H, flat_space, cams, renderer, eye, target, period=30, budget=2048):
+    def __init__(self, name, H, flat_space, cams, renderer, eye, target, period=30, budget=2048, blocking_light=False):
         self.name, self.cams, self.renderer, self.period, self.budget = name, cams, renderer, period, budget
+        self.blocking_light = blocking_light  # relight: aic_evaluate_light per frame (rounds 2-5) instead of aic_evaluate_light_submit / _wait
+        self.light_pending = False
+        self.light_lag = 0       # steps the pending update has been left running
+        self.light_carry = 0     # budget of the steps that started no update of their own (added to the next one)
         self.light_update, self.relight, self.lights = None, None, None
         self.views = [H.look_at_y_up((0.5 + 7.0 * np.sin(2.0 * np.pi * k / 60.0), eye[1], 7.0 * np.cos(2.0 * np.pi * k / 60.0)), target) for k in range(60)]
         if name == "relight":
@@ -741,9 +805,34 @@ class SceneLoop:
                 x, y, z = relight["sites"][j % 30]
                 cams.world_space.set(x, y, z, relight["lamp"] if (j // 30) % 2 == 0 else relight["air"])
             cams.world_view_transform = self.views[k]
-            renderer.update()                                  # block delta -> aic_update_cubes + aic_light_cubes_changed
             t_l = time.perf_counter()
-            li = renderer.evaluate_light(30, False, 1, self.budget, 0, 0, True, self.budget)  # one launch of that many cube updates
+            if self.blocking_light:
+                renderer.update()                              # block delta -> aic_update_cubes + aic_light_cubes_changed
+                t_l = time.perf_counter()
+                li = renderer.evaluate_light(30, False, 1, self.budget, 0, 0, True, self.budget)  # one launch of that many cube updates
+            else:
+                # the step's light update runs on the library's worker thread BESIDE the frame the caller submits next (which reads the light as the
+                # previous step left it): collect the previous step's update here, apply this step's block change, start this step's update
+                # (an update that is still running is left running for up to two steps -- its budget joins the next one's --: the frames keep their pace, the
+                #  light is at most two steps behind them; a block change publishes it in any case)
+                li = {"updates": 0, "queue_left": relight["queue_left"]}
+                start = True
+                if self.light_pending:
+                    if self.light_lag < 2 and i % self.period != 0 and not renderer.evaluate_light_done():
+                        self.light_lag += 1
+                        self.light_carry += self.budget
+                        start = False
+                    else:
+                        li = renderer.evaluate_light_wait()
+                        self.light_pending = False
+                t_w = time.perf_counter() - t_l
+                renderer.update()                              # block delta -> aic_update_cubes + aic_light_cubes_changed
+                t_l = time.perf_counter()
+                if start:
+                    n_b = self.budget + self.light_carry
+                    renderer.evaluate_light_submit(30, False, 1, n_b, 0, 0, True, n_b)
+                    self.light_pending, self.light_lag, self.light_carry = True, 0, 0
+                t_l -= t_w                                     # (the host's time in the light calls)
             relight["light_ms"] += (time.perf_counter() - t_l) * 1e3
             relight["updates"] += int(li["updates"]); relight["calls"] += 1; relight["queue_left"] = int(li["queue_left"])
             relight["queue_max"] = max(relight.get("queue_max", 0), int(li["queue_left"]))

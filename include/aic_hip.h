@@ -408,6 +408,19 @@ typedef struct aic_light_info {
                                 * distance checks, updater.rs:427-530): the unit of work of the light updater's roofline (ABI 2) */
 } aic_light_info;
 int aic_evaluate_light(aic_ctx *ctx, int layer, const aic_light_params *params, aic_light_info *info);
+/* The same update WITHOUT blocking the caller (ABI 3): aic_evaluate_light_submit copies `params` (and its queue arrays), hands the update to a worker thread
+ * the context owns and returns; the update works on a spare light volume, a copy of the current one, so every frame submitted while it runs reads the
+ * light as it stood. aic_evaluate_light_wait blocks until the update is done, PUBLISHES it -- the frames submitted from then on read the updated volume --
+ * and reports it. A sim + render loop (Space::step's light budget, space.rs:1496-1540, then a frame) calls submit, submits its frame, and waits at the top
+ * of the next step: the update's host half (queue, apply) and its launches run beside the frame instead of in front of it. One update at a time per
+ * context; every other scene or light call (aic_update_cubes, aic_light_cubes_changed, aic_read_light_volume, aic_evaluate_light ...) first finishes and
+ * publishes a pending update, whose report stays available to aic_evaluate_light_wait. The volume after the wait is byte for byte what the blocking call
+ * produces. Nothing submitted for `layer`: the wait returns zeros. */
+int aic_evaluate_light_submit(aic_ctx *ctx, int layer, const aic_light_params *params);
+int aic_evaluate_light_wait(aic_ctx *ctx, int layer, aic_light_info *info);
+/* *done = 0 while a submitted update of `layer` is still running, 1 otherwise (finished and waiting to be collected, or none): a loop that must not stall
+ * on the light (frames at their own pace, the light a step or two behind) asks before it waits. Publishes nothing. */
+int aic_evaluate_light_poll(aic_ctx *ctx, int layer, int *done);
 /* After aic_update_cubes changed the blocks of these cubes: what LightStorage::modified_cube_needs_update (updater.rs:135-173) does
  * for each -- a cube that is now opaque for light gets PackedLight::OPAQUE at once, any other is queued at Priority::NEWLY_VISIBLE,
  * and so are the neighbours that are not opaque towards it. The queue is the layer's own and lives until the next

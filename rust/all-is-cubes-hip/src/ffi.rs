@@ -239,6 +239,9 @@ unsafe extern "C" {
     pub fn aic_probe_light_lut(ctx: *mut aic_ctx, out: *mut f32) -> c_int;
     // light propagation on the device (Space::evaluate_light / fast_evaluate_light)
     pub fn aic_evaluate_light(ctx: *mut aic_ctx, layer: c_int, params: *const aic_light_params, info: *mut aic_light_info) -> c_int;
+    pub fn aic_evaluate_light_submit(ctx: *mut aic_ctx, layer: c_int, params: *const aic_light_params) -> c_int;
+    pub fn aic_evaluate_light_wait(ctx: *mut aic_ctx, layer: c_int, info: *mut aic_light_info) -> c_int;
+    pub fn aic_evaluate_light_poll(ctx: *mut aic_ctx, layer: c_int, done: *mut c_int) -> c_int;
     pub fn aic_light_cubes_changed(ctx: *mut aic_ctx, layer: c_int, n: u32, xyz: *const i32, queue_order: c_int) -> c_int;
     pub fn aic_read_light_volume(ctx: *mut aic_ctx, layer: c_int, out: *mut u8) -> c_int;
     pub fn aic_read_light_cubes(ctx: *mut aic_ctx, layer: c_int, n: u32, xyz: *const i32, out: *mut u8) -> c_int;

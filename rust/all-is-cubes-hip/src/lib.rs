@@ -210,6 +210,22 @@ impl Device {
             }
         })
     }
+    /// `aic_evaluate_light_submit` / `_wait`: the update on the context's worker thread, published by the wait (single device only:
+    /// the multi-device context runs the updater on device 0 and hands the volume over, which is a blocking step).
+    fn evaluate_light_submit(self, layer: core::ffi::c_int, params: &ffi::aic_light_params) -> Result<bool, RenderError> {
+        match self {
+            // SAFETY: live handle; the library copies `params` before it returns
+            Device::One(c) => self.check(unsafe { ffi::aic_evaluate_light_submit(c.as_ptr(), layer, params) }).map(|()| true),
+            Device::Many(_) => Ok(false),
+        }
+    }
+    fn evaluate_light_wait(self, layer: core::ffi::c_int, info: &mut ffi::aic_light_info) -> Result<(), RenderError> {
+        match self {
+            // SAFETY: live handle, `info` is a valid out-pointer
+            Device::One(c) => self.check(unsafe { ffi::aic_evaluate_light_wait(c.as_ptr(), layer, info) }),
+            Device::Many(_) => Ok(()),
+        }
+    }
     /// `aic_light_cubes_changed` for cubes whose block `update_cubes` just changed (updater.rs:135-173).
     fn light_cubes_changed(self, layer: core::ffi::c_int, xyz: &[i32], n: u32) -> Result<(), RenderError> {
         // SAFETY: live handle, `xyz` holds 3 * n coordinates and outlives the call
@@ -519,6 +535,34 @@ impl HipRtRenderer {
         let params = Self::light_params(maximum_distance, false, 1, 0, max_updates);
         let mut info = ffi::aic_light_info::default();
         self.device.evaluate_light(ffi::AIC_LAYER_WORLD, &params, &mut info)?;
+        Ok((info.updates, info.queue_left))
+    }
+}
+
+impl HipRtRenderer {
+    /// [`Self::evaluate_light_budgeted`] without blocking: the update runs on the library's worker thread beside the frames drawn
+    /// meanwhile (which see the light as it stood); [`Self::finish_light_update`] -- or the next `update` -- publishes it. On a
+    /// multi-device renderer the blocking call is made instead.
+    ///
+    /// # Errors
+    /// As [`HeadlessRenderer::draw`] for device failures.
+    pub fn start_light_update(&mut self, max_updates: u64) -> Result<(), RenderError> {
+        let maximum_distance = self.device_light.expect("start_light_update needs set_device_light(Some(..))");
+        let params = Self::light_params(maximum_distance, false, 1, 0, max_updates);
+        if !self.device.evaluate_light_submit(ffi::AIC_LAYER_WORLD, &params)? {
+            let mut info = ffi::aic_light_info::default();
+            self.device.evaluate_light(ffi::AIC_LAYER_WORLD, &params, &mut info)?;
+        }
+        Ok(())
+    }
+
+    /// Waits for the update [`Self::start_light_update`] began and makes its light current. Returns (updates done, queue entries left).
+    ///
+    /// # Errors
+    /// As [`HeadlessRenderer::draw`] for device failures.
+    pub fn finish_light_update(&mut self) -> Result<(u64, u32), RenderError> {
+        let mut info = ffi::aic_light_info::default();
+        self.device.evaluate_light_wait(ffi::AIC_LAYER_WORLD, &mut info)?;
         Ok((info.updates, info.queue_left))
     }
 }

@@ -473,6 +473,88 @@ def test_light_updater_fuzz(ctx, seed):
     assert (got == np.asarray(ref.light).reshape(got.shape)).all(), f"seed {seed}: {(got != np.asarray(ref.light).reshape(got.shape)).any(axis=-1).sum()} texels differ"
 
 
+def test_light_update_on_the_worker_thread_equals_the_blocking_call():
+    """aic_evaluate_light_submit / aic_evaluate_light_wait (ABI 3): a sim + render loop of 120 steps -- a lamp block placed or removed every ten steps, a budget of
+    cube updates per step, frames streamed on four slots -- run twice: with the blocking aic_evaluate_light in front of each frame, and with the update on the
+    library's worker thread BESIDE the frame. At every step the two light volumes are byte for byte equal once the update is collected (same update
+    counts, same queue left), a frame submitted while the update runs shows the light as it stood (the blocking run's frame of the step before the
+    update), and scene calls made while an update is pending (aic_update_cubes, aic_light_cubes_changed, aic_read_light_volume) publish it first."""
+    import torch
+
+    sp = copy.deepcopy(lit(scenes.light_spread_space))
+    lo, size = np.array(sp.lo), np.array(sp.size)
+    rng = np.random.default_rng(3)
+    air = next(i for i, b in enumerate(sp.blocks) if b.is_air)
+    lamp = next(i for i, b in enumerate(sp.blocks) if not b.is_air)
+    sites = []
+    bi = np.asarray(sp.block_index)
+    while len(sites) < 6:
+        c = rng.integers(1, size - 1)
+        if int(bi[tuple(c)]) == air and tuple(c) not in sites:
+            sites.append(tuple(int(v) for v in c))
+    w, h = 320, 200
+    eye = tuple(float(v) for v in lo + size * np.array([0.5, 0.5, 1.6]))
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, tuple(float(v) for v in lo + size / 2)), eye)
+    budget = 64
+    steps = 120
+
+    def run(blocking):
+        volumes, infos, frames = [], [], []
+        with abi.Context(0) as c:
+            c.upload_space(abi.LAYER_WORLD, sp)
+            c.set_options(abi.LAYER_WORLD, abi.make_options())
+            fr = c.make_frame(w, h, world_inv=inv)
+            bufs = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(4)]
+            in_flight = {}
+            pending = False
+            for i in range(steps):
+                if not blocking and pending:
+                    infos.append(c.evaluate_light_wait(abi.LAYER_WORLD))      # the previous step's update: collected, published
+                    volumes.append(c.read_light_volume(abi.LAYER_WORLD, sp.size))
+                if i % 10 == 0:
+                    x, y, z = sites[(i // 10) % 6]
+                    cube = [(int(lo[0] + x), int(lo[1] + y), int(lo[2] + z))]
+                    c.update_cubes(abi.LAYER_WORLD, cube, [lamp if (i // 60) % 2 == 0 else air])
+                    c.light_cubes_changed(abi.LAYER_WORLD, cube, queue_order=0)
+                if blocking:
+                    slot = i % 4
+                    if slot in in_flight:
+                        c.render_wait(slot)
+                        frames.append(in_flight.pop(slot).cpu().numpy().copy())
+                    # (the frame of the step BEFORE this step's update: what the other run's frame, submitted beside the update, must show)
+                    c.render_submit(fr, bufs[slot].data_ptr(), slot)
+                    in_flight[slot] = bufs[slot]
+                    infos.append(c.evaluate_light(abi.LAYER_WORLD, 30, fast=False, epsilon=1, batch=budget, queue_order=0, queue=[], max_updates=budget))
+                    volumes.append(c.read_light_volume(abi.LAYER_WORLD, sp.size))
+                else:
+                    c.evaluate_light_submit(abi.LAYER_WORLD, 30, fast=False, epsilon=1, batch=budget, queue_order=0, queue=[], max_updates=budget)
+                    pending = True
+                    slot = i % 4
+                    if slot in in_flight:
+                        c.render_wait(slot)
+                        frames.append(in_flight.pop(slot).cpu().numpy().copy())
+                    c.render_submit(fr, bufs[slot].data_ptr(), slot)           # beside the update: the light as it stood
+                    in_flight[slot] = bufs[slot]
+            if not blocking:
+                infos.append(c.evaluate_light_wait(abi.LAYER_WORLD))
+                volumes.append(c.read_light_volume(abi.LAYER_WORLD, sp.size))
+                assert c.evaluate_light_wait(abi.LAYER_WORLD).updates == 0   # nothing submitted: zeros
+            for slot in sorted(in_flight):
+                c.render_wait(slot)
+        return volumes, infos, frames
+
+    v0, i0, f0 = run(True)
+    v1, i1, f1 = run(False)
+    assert len(v0) == len(v1) == steps and sum(i.updates for i in i0) > 100
+    for k in range(steps):
+        assert i0[k].updates == i1[k].updates and i0[k].queue_left == i1[k].queue_left, k
+        assert (v0[k] == v1[k]).all(), f"light volume after step {k}"
+    assert len(f0) == len(f1) == steps - 4
+    for k, (a, b) in enumerate(zip(f0, f1)):
+        assert (a == b).all(), f"frame {k}: a frame submitted beside the update did not see the light as it stood"
+    assert any((v0[k] != v0[k - 1]).any() for k in range(1, steps)), "the loop never changed the light"
+
+
 def test_light_update_beside_frames_in_flight(ctx):
     """aic_evaluate_light no longer waits for the frames in flight (round 4): it works on the other half of the light double buffer.
     A frame submitted BEFORE the update shows the old light whatever the update does meanwhile; a frame rendered after it shows the

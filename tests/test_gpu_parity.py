@@ -1400,8 +1400,10 @@ def test_render_orthographic(ctx, resolution):
     ctx.clear_space(abi.LAYER_UI)
 
 
-def test_exchange_step_over_the_nccl_backend_on_one_gpu():
-    """bench.py --gather-at-one: the N > 1 exchange step -- strip ring, collective, retire event, de-interleave -- over torch.distributed's
+@pytest.mark.parametrize("per_launch", [1, 4])
+def test_exchange_step_over_the_nccl_backend_on_one_gpu(per_launch):
+    """(per_launch = 4: the rank's shares of four consecutive frames traced by one launch, aic_render_submit_batch; seven steps so that the region ends on a partial batch.)
+    bench.py --gather-at-one: the N > 1 exchange step -- strip ring, collective, retire event, de-interleave -- over torch.distributed's
     nccl backend (RCCL) with a one-rank group, device-side hand-off; the assembled frame must equal the single-rank frame (the bench
     exits non-zero otherwise) and the line must say which hand-off ran. The only execution of the RCCL leg a one-GPU box allows."""
     import json
@@ -1410,16 +1412,17 @@ def test_exchange_step_over_the_nccl_backend_on_one_gpu():
 
     root = Path(__file__).resolve().parents[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, str(root / "bench.py"), "--gather-at-one", "--workload", "small", "--steps", "6", "--warmup", "2",
-                          "--min-seconds", "0", "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--gather-at-one", "--workload", "small", "--steps", "7" if per_launch > 1 else "6", "--warmup", "2",
+                          "--min-seconds", "0", "--no-extras", "--no-cpu-baseline", "--frames-per-launch", str(per_launch)], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["config"]["assembled_frame_equals_single_rank_frame"] is True
+    assert line["config"]["assembled_frame_equals_single_rank_frame"] is True and line["config"]["frames_per_launch"] == per_launch
     assert line["config"]["handoff"].startswith("device")
     assert out.stdout.strip().splitlines()[-1].startswith("{"), "the bench line must be the last line of the output"
 
 
-def test_two_ranks_launched_as_the_driver_launches_them():
+@pytest.mark.parametrize("per_launch", [1, 2])
+def test_two_ranks_launched_as_the_driver_launches_them(per_launch):
     """`python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...`, the driver's own command for N > 1, with the two ranks sharing the one
     MI355X (AIC_BENCH_ONE_GPU=1: RCCL refuses two ranks on one device, so the strips are gathered through host memory over gloo). Interleaved strips,
     the exchange pipeline, verification against a single-rank frame and the one JSON line from rank 0 are exactly what runs on a node."""
@@ -1430,7 +1433,8 @@ def test_two_ranks_launched_as_the_driver_launches_them():
     root = Path(__file__).resolve().parents[1]
     env = dict(os.environ, AIC_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29549",
-           str(root / "bench.py"), "--gpus", "2", "--workload", "small", "--steps", "6", "--warmup", "2", "--min-seconds", "0", "--no-extras", "--no-cpu-baseline"]
+           str(root / "bench.py"), "--gpus", "2", "--workload", "small", "--steps", "6", "--warmup", "2", "--min-seconds", "0", "--no-extras", "--no-cpu-baseline",
+           "--frames-per-launch", str(per_launch)]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(root))
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -1443,8 +1447,8 @@ def test_two_ranks_launched_as_the_driver_launches_them():
 
 def test_eight_ranks_launched_as_the_driver_launches_them():
     """The driver's N = 8 command line -- `python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 ...` -- run once before it meets a node (VERDICT
-    r04 next 5): eight processes share the one MI355X (AIC_BENCH_ONE_GPU=1, strips gathered through host memory over gloo), 16 frames in flight per rank (the
-    N >= 8 default: slots past the eighth are made on first use), the assembled frame equal to the single-rank frame."""
+    r04 next 5): eight processes share the one MI355X (AIC_BENCH_ONE_GPU=1, strips gathered through host memory over gloo), the N >= 8 defaults -- a rank's shares
+    of eight consecutive frames per launch, four launches (32 frames) in flight --, the assembled frame equal to the single-rank frame."""
     import json
     import subprocess
     import sys
@@ -1460,5 +1464,5 @@ def test_eight_ranks_launched_as_the_driver_launches_them():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 8 and line["scaling"] == "strong"
     assert line["config"]["assembled_frame_equals_single_rank_frame"] is True
-    assert line["config"]["frames_in_flight"] == 16
+    assert line["config"]["frames_in_flight"] == 32 and line["config"]["frames_per_launch"] == 8
 
