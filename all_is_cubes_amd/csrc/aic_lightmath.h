@@ -21,6 +21,13 @@
 #else
 #define AIC_HD static inline
 #endif
+// "does any lane of the wave ...": a wave-uniform condition on the device (work that NO lane needs is skipped without per-lane exec-mask scaffolding),
+// the condition itself on the host
+#if defined(__HIP_DEVICE_COMPILE__)
+#define AIC_LM_ANY(x) (__ballot(x) != 0ull)
+#else
+#define AIC_LM_ANY(x) (x)
+#endif
 
 namespace aic {
 
@@ -175,10 +182,15 @@ AIC_HD void lm_interpolated_light(const LightGridView &G, const float *lut, int 
     uint32_t tf01 = texels[all_inside ? bnf + q01 : 0u];
     uint32_t tf10 = texels[all_inside ? bnf + q10 : 0u];
     uint32_t tf11 = texels[all_inside ? bnf + q11 : 0u];
-    uint32_t ts00 = texels[all_inside ? bns + q00 : 0u];  // same plane
-    uint32_t ts01 = texels[all_inside ? bns + q01 : 0u];
-    uint32_t ts10 = texels[all_inside ? bns + q10 : 0u];
-    uint32_t ts11 = texels[all_inside ? bns + q11 : 0u];
+    // same plane: a full-height surface -- every face of a whole-cube block, i.e. most surfaces of most all-is-cubes scenes -- interpolates in the front plane only
+    // (sr.rs:339-354: `one_plane`), and the reference never fetches these four texels for it; a wave in which no lane needs them does not either (round 6)
+    uint32_t ts00 = 0u, ts01 = 0u, ts10 = 0u, ts11 = 0u;
+    if (AIC_LM_ANY(!one_plane)) {
+        ts00 = texels[all_inside ? bns + q00 : 0u];
+        ts01 = texels[all_inside ? bns + q01 : 0u];
+        ts10 = texels[all_inside ? bns + q10 : 0u];
+        ts11 = texels[all_inside ? bns + q11 : 0u];
+    }
     uint32_t n_calls = one_plane ? 4u : 8u;
     if (!all_inside) {
         // Rare: a sample outside the space (BlockSky::light_outside on the reassembled cube) or without an i32 cube
