@@ -47,7 +47,7 @@ elif [ "$PHASE" = bench ]; then
     python tools/hip_handoff_summary.py "$O/hip_gather1$mode" "$O/bench_gather1$mode.json" "$mode"
   done | tee "$O/hip_handoff.txt"
 elif [ "$PHASE" = profile ]; then
-  # in-kernel phase counters and per-wave clocks: needs variants/libaic_hip_prof.so, variants/libaic_hip_rayprof.so (tools/build_variants.sh "prof:-DAIC_PROFILE -DAIC_POOL=62" "rayprof:-DAIC_PROFILE -DAIC_RAY_PROF -DAIC_POOL=62": the counters take LDS the pool gives up)
+  # in-kernel phase counters and per-wave clocks: needs variants/libaic_hip_prof.so, variants/libaic_hip_rayprof.so (tools/build_variants.sh "prof:-DAIC_PROFILE -DAIC_POOL=54" "rayprof:-DAIC_PROFILE -DAIC_RAY_PROF -DAIC_POOL=54": the counters take LDS the pool gives up)
   cp all_is_cubes_amd/libaic_hip.so /tmp/libaic_default.so
   cp variants/libaic_hip_prof.so all_is_cubes_amd/libaic_hip.so
   for wl in atrium s256; do echo "== $wl"; python bench.py --workload $wl --steps 1 --warmup 0 --no-cpu-baseline --no-pipeline --no-extras --no-secondary --min-seconds 0 2>&1 | grep PROF | tail -39; done > $O/prof.txt
