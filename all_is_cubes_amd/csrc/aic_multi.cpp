@@ -111,7 +111,10 @@ aic_multi *aic_create_multi(int n_devices, const int *device_ids, int *status) {
 void aic_destroy_multi(aic_multi *m) {
     if (!m) return;
     for (uint32_t s = 0; s < AIC_MULTI_MAX_IN_FLIGHT; s++)
-        if (m->slots[s].busy) (void)aic_multi_render_wait(m, s, nullptr);
+        if (m->slots[s].busy) {
+            m->slots[s].host_out = nullptr;  // (a frame nobody collected: its host target may be gone -- the devices are waited for, nothing is copied out)
+            (void)aic_multi_render_wait(m, s, nullptr);
+        }
     if (!m->dev.empty() && m->xfer) { (void)hipSetDevice(m->dev[0]); (void)hipStreamSynchronize(m->xfer); }
     for (MultiSlot &sl : m->slots) {
         for (size_t i = 0; i < m->ctx.size() && i < sl.local.size(); i++)

@@ -437,11 +437,10 @@ impl HipRtRenderer {
         Self::sync_layer(device, device_light, ffi::AIC_LAYER_UI, &mut self.layers.ui, ui_space.as_ref(), read_tickets.ui, &ui_options)
     }
 
-    /// `RtRenderer::draw_rgba` (renderer.rs:282-308).
-    pub fn draw_rgba(&mut self, info_text: &str) -> Result<Rendering, RenderError> {
+    /// The frame descriptor of the current cameras and the viewport it is drawn for.
+    fn frame_desc(&self) -> (Viewport, ffi::aic_frame_desc) {
         let viewport = (self.size_policy)(self.cameras.viewport()); // renderer.rs:226-233
         let size = viewport.framebuffer_size;
-        let mut data = vec![[0u8; 4]; (size.width as usize) * (size.height as usize)];
         let backdrop = self.cameras.ui_view_state().backdrop;
         let frame = ffi::aic_frame_desc {
             width: size.width,
@@ -457,11 +456,25 @@ impl HipRtRenderer {
             flags: 0,
             tuning: 0, // the library's choices (tile queues, kernel variant); `HipInfo` reports what ran
         };
+        (viewport, frame)
+    }
+
+    /// `RtRenderer::draw_rgba` (renderer.rs:282-308).
+    pub fn draw_rgba(&mut self, info_text: &str) -> Result<Rendering, RenderError> {
+        let (viewport, frame) = self.frame_desc();
+        let size = viewport.framebuffer_size;
+        let mut data = vec![[0u8; 4]; (size.width as usize) * (size.height as usize)];
         let mut info = ffi::aic_frame_info::default();
         if !data.is_empty() {
             // zero-area viewports produce an empty image (cases viewport_zero, cases/src/lib.rs:1167-1212)
             self.device.render(&frame, &mut data, &mut info)?;
         }
+        self.wrap_rendering(viewport, data, info, info_text)
+    }
+
+    /// The finished pixels as the trait's `Rendering`: info text, flaws, info.
+    fn wrap_rendering(&self, viewport: Viewport, mut data: Vec<[u8; 4]>, info: ffi::aic_frame_info, info_text: &str) -> Result<Rendering, RenderError> {
+        let size = viewport.framebuffer_size;
         let options = self.cameras.graphics_options();
         if options.debug_info_text && !info_text.is_empty() && !data.is_empty() {
             // renderer.rs:205-217: the encoder's black and white (exposure and tone mapping applied, as the kernel's encoder does)
@@ -483,6 +496,48 @@ impl HipRtRenderer {
             flaws |= Flaws::NO_CURSOR; // renderer.rs:298-300
         }
         Ok(Rendering { size, data, flaws, info: Arc::new(HipInfo(info)) })
+    }
+
+    /// Queues the current view on `slot` (0..`AIC_MULTI_MAX_IN_FLIGHT`) and returns at once: the streaming half of `draw_rgba` for a caller that renders
+    /// frame after frame (record.rs:97-113 steps the universe, updates and draws in a loop) -- `update_scene` for frame n + 1 and its `begin_frame` may run
+    /// while frame n is still being traced and assembled. On a multi-device renderer this is `aic_multi_render_submit`; a single-device renderer has no
+    /// host-target streaming entry point (`aic_render_submit` writes device memory), so the frame is drawn here and merely handed over by `finish_frame`.
+    ///
+    /// # Errors
+    /// As [`HeadlessRenderer::draw`] for device failures; a busy slot is an error.
+    pub fn begin_frame(&mut self, slot: u32) -> Result<PendingFrame, RenderError> {
+        let (viewport, frame) = self.frame_desc();
+        let size = viewport.framebuffer_size;
+        let mut data = vec![[0u8; 4]; (size.width as usize) * (size.height as usize)];
+        let mut info = ffi::aic_frame_info::default();
+        let streamed = match self.device {
+            // SAFETY: live handle; `data`'s heap buffer is not moved or freed before `finish_frame` (PendingFrame owns it), and holds width * height pixels
+            Device::Many(m) if !data.is_empty() => {
+                self.device.check(unsafe { ffi::aic_multi_render_submit(m.as_ptr(), &frame, data.as_mut_ptr().cast(), 0, slot) })?;
+                true
+            }
+            _ => {
+                if !data.is_empty() {
+                    self.device.render(&frame, &mut data, &mut info)?;
+                }
+                false
+            }
+        };
+        Ok(PendingFrame { slot, streamed, viewport, data, info })
+    }
+
+    /// Waits for the frame `begin_frame` queued and wraps it as `draw_rgba` would.
+    ///
+    /// # Errors
+    /// As [`HeadlessRenderer::draw`] for device failures.
+    pub fn finish_frame(&mut self, mut pending: PendingFrame, info_text: &str) -> Result<Rendering, RenderError> {
+        if pending.streamed {
+            if let Device::Many(m) = self.device {
+                // SAFETY: live handle, `info` is a valid out-pointer; the library writes `pending.data` before this returns
+                self.device.check(unsafe { ffi::aic_multi_render_wait(m.as_ptr(), pending.slot, &mut pending.info) })?;
+            }
+        }
+        self.wrap_rendering(pending.viewport, pending.data, pending.info, info_text)
     }
 
     /// The cameras this renderer draws (as `RtRenderer::cameras`).
@@ -565,6 +620,16 @@ impl HipRtRenderer {
         self.device.evaluate_light_wait(ffi::AIC_LAYER_WORLD, &mut info)?;
         Ok((info.updates, info.queue_left))
     }
+}
+
+/// A frame in flight ([`HipRtRenderer::begin_frame`]): the host buffer the library fills, and what wrapping it needs. Dropping it without
+/// `finish_frame` leaves the slot busy until the renderer is dropped (the library waits for it then).
+pub struct PendingFrame {
+    slot: u32,
+    streamed: bool,
+    viewport: Viewport,
+    data: Vec<[u8; 4]>,
+    info: ffi::aic_frame_info,
 }
 
 /// `draw_info_text` of the reference (raytracer/renderer.rs:659-683, private there): the info text over the finished frame,
