@@ -1324,6 +1324,7 @@ def test_multi_device_streamed_submit_and_wait_equal_single(ctx):
             info = m.render_wait(slot)
             assert (arr == want[kk]["rgba8"]).all() and info.cubes_traced == want[kk]["info"].cubes_traced
         assert m.render_wait(5).cubes_traced == 0  # a slot with nothing in flight
+        m.render_submit(frames[0], 3)  # never collected: destroying the context waits for the devices and copies nothing out
 
 
 @pytest.mark.parametrize("k", [2, 4, 8])
