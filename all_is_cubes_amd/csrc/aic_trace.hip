@@ -58,15 +58,36 @@ AIC_DEV double rem_euclid1(double x) {
     return r < 0.0 ? r + 1.0 : r;
 }
 
-// raycast.rs:797-819
-AIC_DEV double scale_to_integer_step(double s, double ds) {
-    if (ds == 0.0 && !(s != s)) return __longlong_as_double(0x7ff0000000000000LL);
-    if (ds < 0.0) {
-        s = -s;
-        ds = -ds;
-    }
-    s = rem_euclid1(s);
-    return (1.0 - s) / ds;
+// ---- f64 divisions that cost less than the generic sequence, with the generic sequence's bits ----
+// The compiler's a / b is v_div_scale x2, v_rcp_f64 (quarter rate), four fused multiply-adds that refine the reciprocal, a multiply, two more
+// multiply-adds, v_div_fmas, v_div_fixup: 11 instructions, IEEE-correct for every input. Two cheaper forms, each used only where its precondition holds
+// for the lane (checked on the operands' exponent fields) and replaced by the generic quotient, under the lanes' exec mask, where it does not:
+//  * div_known_recip: the divisor's correctly rounded reciprocal y = RN(1 / b) is at hand (a ray's t_delta = 1 / |direction|, raycast.rs:766). Then
+//    q0 = a * y is within 1.5 ulp of a / b, q1 = q0 + (a - b q0) y is a faithful quotient, and one more residual step q2 = q1 + (a - b q1) y is a / b
+//    correctly rounded (Markstein's theorem: a faithful q, the exact residual r = a - b q, and y within half an ulp of 1 / b give RN(q + r y) = RN(a / b),
+//    absent overflow / underflow) -- five multiply-adds, no reciprocal instruction (lvl_init). tests: the probe's step tables and 400 random rays (t bit-exact).
+//  * three quotients by one divisor (the unprojection's x / w, y / w, z / w) share the reciprocal's refinement: with operands whose exponents are far from
+//    the ends of the range v_div_scale scales nothing, v_div_fmas is a plain fused multiply-add and v_div_fixup passes the quotient through, so
+//    the shared form performs the generic sequence's own operations on the same values.
+// A block behind a wave-uniform branch that must STAY a branch: arithmetic without side effects is otherwise speculated -- the compiler computes the rare
+// path for every wave and selects (seen with the generic division below: 11 instructions per quotient, executed always). An empty volatile asm
+// statement cannot be speculated.
+#define AIC_RARE_PATH() asm volatile("" ::: "memory")
+// Exponent window of an operand, on the high dword: biased exponent in [768, 1280), i.e. 2^-255 <= |v| < 2^257; and the wider [512, 1536).
+AIC_DEV bool f64_exp_in_768_1280(double v) { return (((uint32_t)__double2hiint(v) << 1) - (768u << 21)) < (512u << 21); }
+AIC_DEV bool f64_exp_in_512_1536(double v) { return (((uint32_t)__double2hiint(v) << 1) - (512u << 21)) < (1024u << 21); }
+AIC_DEV double div_known_recip(double a, double b, double y) {  // a / b for normal b > 0, y = RN(1 / b); a, b and a / b far from overflow and underflow; a is not -0
+    const double q0 = a * y;
+    const double r0 = fma(-b, q0, a);
+    const double q1 = fma(r0, y, q0);
+    const double r1 = fma(-b, q1, a);
+    return fma(r1, y, q1);
+}
+// raycast.rs:797-819, split around its division: the dividend 1 - s.rem_euclid(1) (s and ds negated together for ds < 0: |ds| is the divisor either way) ...
+AIC_DEV double scale_step_dividend(double s, double ds) { return 1.0 - rem_euclid1(ds < 0.0 ? -s : s); }
+// ... and what becomes of the quotient q = dividend / |ds|
+AIC_DEV double scale_step_result(double q, double s, double ds) {
+    return (ds == 0.0 && !(s != s)) ? __longlong_as_double(0x7ff0000000000000LL) : q;
 }
 
 // cube.rs:97-119
@@ -89,7 +110,12 @@ struct RayDir {
     double dx, dy, dz;     // direction (zeroed if any |component| is not < 1e100)
     double tdx, tdy, tdz;  // t_delta = 1/|d|
     int sx, sy, sz;        // step = signum_101(d)
+    bool fast;             // every component is zero or has its exponent in [768, 1280): divisions by it may use t_delta (div_by_dir)
 };
+AIC_DEV bool raydir_fast(double dx, double dy, double dz) {
+    const int fx = f64_exp_in_768_1280(dx) | (dx == 0.0), fy = f64_exp_in_768_1280(dy) | (dy == 0.0), fz = f64_exp_in_768_1280(dz) | (dz == 0.0);
+    return (fx & fy & fz) != 0;
+}
 
 AIC_DEV RayDir raydir_init(double dx, double dy, double dz) {
     RayDir r;
@@ -99,6 +125,7 @@ AIC_DEV RayDir raydir_init(double dx, double dy, double dz) {
     r.dz = all_small ? dz : 0.0;
     r.sx = signum_101(r.dx); r.sy = signum_101(r.dy); r.sz = signum_101(r.dz);
     r.tdx = 1.0 / fabs(r.dx); r.tdy = 1.0 / fabs(r.dy); r.tdz = 1.0 / fabs(r.dz);
+    r.fast = raydir_fast(r.dx, r.dy, r.dz);
     return r;
 }
 
@@ -155,39 +182,56 @@ AIC_DEV LvlLim lvl_init(double ox, double oy, double oz, const RayDir rd, bool b
         hix = hiy = hiz = I32_MAX_ - 1;
     }
     if (hix <= lox || hiy <= loy || hiz <= loz) return out;
-    bool have_tmax = false;
+    // fast_forward (raycast.rs:632-704): plane_origin takes the upper bound on axes the ray descends, else the lower bound; one ray-plane
+    // intersection per moving axis. If the largest t is positive the ray starts again half a cube short of it (`t_start`), else where it is
+    // (t_start = +0: `ff` is the origin itself, and adding +0 to a t_max -- a quotient that is positive, +0 or infinite -- changes nothing).
+    // One copy of the t_max arithmetic serves both (round 6; it was written twice, each copy behind its own per-lane branch).
+    double t_start = 0.0;
+    double ffx = ox, ffy = oy, ffz = oz;
     if (bounded) {
-        // fast_forward (raycast.rs:632-704): plane_origin takes the upper bound on axes the ray
-        // descends, else the lower bound; one ray-plane intersection per moving axis.
         const double pox = (double)((rd.sx < 0) ? hix : lox);
         const double poy = (double)((rd.sy < 0) ? hiy : loy);
         const double poz = (double)((rd.sz < 0) ? hiz : loz);
         const double relx = pox - ox, rely = poy - oy, relz = poz - oz;
-        // ray_plane_intersection (raycast.rs:821-832) with an axis-aligned unit normal n = ±1:
-        // (rel·n)/(dir·n) == rel_a / dir_a exactly (the ±1 factors and the ±0 terms cancel for the
-        // finite values that reach this point).
+        // ray_plane_intersection (raycast.rs:821-832) with an axis-aligned unit normal n = +-1:
+        // (rel.n)/(dir.n) == rel_a / dir_a exactly (the +-1 factors and the +-0 terms cancel for the
+        // finite values that reach this point). rel_a / dir_a = +-(rel_a / |dir_a|), the quotient by the reciprocal at hand (div_known_recip) for lanes
+        // whose rel_a is neither zero nor tiny (the origin is inside i32, so it is not huge); computed for every lane, used for the moving axes.
+        const int okx = f64_exp_in_512_1536(relx) | (rd.sx == 0), oky = f64_exp_in_512_1536(rely) | (rd.sy == 0), okz = f64_exp_in_512_1536(relz) | (rd.sz == 0);
+        const bool ff_fast = ((int)rd.fast & okx & oky & okz) != 0;
+        double qx = div_known_recip(relx, fabs(rd.dx), rd.tdx), qy = div_known_recip(rely, fabs(rd.dy), rd.tdy), qz = div_known_recip(relz, fabs(rd.dz), rd.tdz);
+        if (__builtin_amdgcn_ballot_w64(!ff_fast) != 0ull) {  // (never, in an ordinary frame)
+            AIC_RARE_PATH();
+            if (!ff_fast) { qx = relx / fabs(rd.dx); qy = rely / fabs(rd.dy); qz = relz / fabs(rd.dz); }
+        }
         double max_t = 0.0;
-        if (rd.sx != 0) max_t = fmax(max_t, relx / rd.dx);
-        if (rd.sy != 0) max_t = fmax(max_t, rely / rd.dy);
-        if (rd.sz != 0) max_t = fmax(max_t, relz / rd.dz);
+        if (rd.sx != 0) max_t = fmax(max_t, rd.sx < 0 ? -qx : qx);
+        if (rd.sy != 0) max_t = fmax(max_t, rd.sy < 0 ? -qy : qy);
+        if (rd.sz != 0) max_t = fmax(max_t, rd.sz < 0 ? -qz : qz);
         if (max_t > 0.0) {  // last_t_distance == 0 at this point
             // 0.5 / direction.length() (raycast.rs:669) is a per-ray constant, computed once by the caller
-            double t_start = max_t - half_over_len;
-            if (!isfinite(t_start)) t_start = max_t;
-            double ff[3] = {ox + rd.dx * t_start, oy + rd.dy * t_start, oz + rd.dz * t_start};
+            double ts = max_t - half_over_len;
+            if (!isfinite(ts)) ts = max_t;
+            t_start = ts;
+            ffx = ox + rd.dx * ts; ffy = oy + rd.dy * ts; ffz = oz + rd.dz * ts;
+            double ff[3] = {ffx, ffy, ffz};
             if (!cube_containing(ff, cube)) return out;
-            s.tx = scale_to_integer_step(ff[0], rd.dx) + t_start;
-            s.ty = scale_to_integer_step(ff[1], rd.dy) + t_start;
-            s.tz = scale_to_integer_step(ff[2], rd.dz) + t_start;
-            s.last_t = t_start;
-            have_tmax = true;
         }
     }
-    if (!have_tmax) {
-        s.tx = scale_to_integer_step(ox, rd.dx);
-        s.ty = scale_to_integer_step(oy, rd.dy);
-        s.tz = scale_to_integer_step(oz, rd.dz);
+    {
+        // scale_to_integer_step on each axis (raycast.rs:797-819). The dividends are in [2^-53, 1] or +0: with a direction in the window (RayDir::fast)
+        // div_known_recip's precondition holds
+        const double ax = scale_step_dividend(ffx, rd.dx), ay = scale_step_dividend(ffy, rd.dy), az = scale_step_dividend(ffz, rd.dz);
+        double qx = div_known_recip(ax, fabs(rd.dx), rd.tdx), qy = div_known_recip(ay, fabs(rd.dy), rd.tdy), qz = div_known_recip(az, fabs(rd.dz), rd.tdz);
+        if (__builtin_amdgcn_ballot_w64(!rd.fast) != 0ull) {
+            AIC_RARE_PATH();
+            if (!rd.fast) { qx = ax / fabs(rd.dx); qy = ay / fabs(rd.dy); qz = az / fabs(rd.dz); }
+        }
+        s.tx = scale_step_result(qx, ffx, rd.dx) + t_start;
+        s.ty = scale_step_result(qy, ffy, rd.dy) + t_start;
+        s.tz = scale_step_result(qz, ffz, rd.dz) + t_start;
     }
+    s.last_t = t_start;
     s.cx = cube[0]; s.cy = cube[1]; s.cz = cube[2];
     // exit coordinate once in bounds: moving up leaves at hi, moving down leaves at lo-1
     lim.x = rd.sx > 0 ? hix : lox - 1;
@@ -821,7 +865,21 @@ AIC_DEV void unproject(MatP m, double x, double y, double z, double out[3]) {
     const double pz = x * m[2] + y * m[6] + z * m[10] + m[14];
     const double pw = x * m[3] + y * m[7] + z * m[11] + m[15];
     if (pw > 0.0) {
-        out[0] = px / pw; out[1] = py / pw; out[2] = pz / pw;
+        // Three quotients by one divisor: the generic division's reciprocal (v_rcp_f64 and its two refinement steps) made once, then each quotient's
+        // multiply and two residual steps -- the generic sequence's own operations when nothing needs scaling, which the exponent window guarantees
+        // (see div_known_recip above); 21 instructions for the three instead of 33. Lanes outside the window divide generically.
+        const bool fast = ((int)f64_exp_in_768_1280(pw) & (int)f64_exp_in_768_1280(px) & (int)f64_exp_in_768_1280(py) & (int)f64_exp_in_768_1280(pz)) != 0;
+        double r = __builtin_amdgcn_rcp(pw);
+        double e = fma(-pw, r, 1.0);
+        r = fma(r, e, r);
+        e = fma(-pw, r, 1.0);
+        r = fma(r, e, r);
+        const double qx = px * r, qy = py * r, qz = pz * r;
+        out[0] = fma(fma(-pw, qx, px), r, qx); out[1] = fma(fma(-pw, qy, py), r, qy); out[2] = fma(fma(-pw, qz, pz), r, qz);
+        if (__builtin_amdgcn_ballot_w64(!fast) != 0ull) {
+            AIC_RARE_PATH();
+            if (!fast) { out[0] = px / pw; out[1] = py / pw; out[2] = pz / pw; }
+        }
     } else {
         const double nan = __longlong_as_double(0x7ff8000000000000LL);
         out[0] = out[1] = out[2] = nan;
@@ -834,20 +892,50 @@ constexpr float NO_WORLD_TO_SHOW = 0.5028865f;  // palette.rs:76 #BCBCBC decoded
 AIC_DEV double fb_x_edge(uint32_t w, uint32_t x) { return ((double)x) / (double)w * 2.0 - 1.0; }
 AIC_DEV double fb_y_edge(uint32_t h, uint32_t y) { return -(((double)y) / (double)h * 2.0 - 1.0); }
 
-// Rgba::to_srgb8 colour channel (color.rs:1038-1054) without powf: `thr[k]` (k = 1..255) is
-// the smallest f32 whose reference encoding is >= k (built on the host with the reference
-// formula), so the encoding of c is the number of thresholds <= c. A fast estimate seeds the
-// search; the thresholds make the result exact.
-AIC_DEV uint32_t srgb8_channel(float c, const float *__restrict__ thr) {
-    if (!(c > 0.f)) return 0u;  // 0, negatives (cannot occur) and NaN encode to 0
-    // v_log_f32 / v_exp_f32 (about 1 ulp each) are plenty for a seed that the thresholds correct
+// Rgba::to_srgb8 colour channels (color.rs:1038-1054) without powf: `thr[k]` (k = 1..255) is the smallest f32 whose reference encoding is >= k (built on
+// the host with the reference formula), so the encoding of c is the number of thresholds <= c. A fast estimate k seeds the count, the thresholds make
+// it exact. The kernel holds them as a WINDOW table `w` of kSrgbWindowWords floats -- w[j] = thr[j - 1], with -inf below thr[1] and NaN above
+// thr[255] -- so that the four thresholds around an estimate, thr[k - 1 .. k + 2], are w[k .. k + 3] for every k in 0..255: c >= -inf always holds,
+// c >= NaN never. The three channels' eight reads are issued together and compared without a branch; the count of thresholds <= c among the four
+// settles the encoding unless it is 0 or 4 (the estimate was off by two or more: v_log_f32 / v_exp_f32 are good to about an ulp, so never seen), and
+// then the thresholds are searched as before round 6 (two dependent LDS reads per step of two loops per channel, for every pixel).
+constexpr uint32_t kSrgbWindowWords = 260u;
+AIC_DEV void srgb_window_to_lds(float *w, const float *thr, uint32_t tid, uint32_t nthreads) {
+    for (uint32_t i = tid; i < kSrgbWindowWords; i += nthreads)
+        w[i] = i < 2u ? __uint_as_float(0xff800000u) : (i <= 256u ? thr[i - 1u] : __uint_as_float(0x7fc00000u));
+}
+AIC_DEV int srgb8_estimate(float c) {  // 0..255 (c > 0)
     const float cc = fminf(c, 1.0f);
-    float e = cc <= 0.0031308f ? cc * 12.92f : 1.055f * __builtin_amdgcn_exp2f(0.41666666f * __builtin_amdgcn_logf(cc)) - 0.055f;
-    int k = (int)(e * 255.f + 0.5f);
-    k = k < 0 ? 0 : (k > 255 ? 255 : k);
-    while (k < 255 && c >= thr[k + 1]) k++;
-    while (k > 0 && c < thr[k]) k--;
+    const float e = cc <= 0.0031308f ? cc * 12.92f : 1.055f * __builtin_amdgcn_exp2f(0.41666666f * __builtin_amdgcn_logf(cc)) - 0.055f;
+    const int k = (int)(e * 255.f + 0.5f);
+    return k < 0 ? 0 : (k > 255 ? 255 : k);
+}
+AIC_DEV uint32_t srgb8_search(float c, int k, const float *__restrict__ w) {  // c > 0; thr[j] = w[j + 1]
+    while (k < 255 && c >= w[k + 2]) k++;
+    while (k > 0 && c < w[k + 1]) k--;
     return (uint32_t)k;
+}
+AIC_DEV void srgb8_rgb(float r, float g, float b, const float *__restrict__ w, uint32_t &R, uint32_t &G, uint32_t &B) {
+    // 0, negatives (cannot occur) and NaN encode to 0
+    const bool pr = r > 0.f, pg = g > 0.f, pb = b > 0.f;
+    const int kr = pr ? srgb8_estimate(r) : 0, kg = pg ? srgb8_estimate(g) : 0, kb = pb ? srgb8_estimate(b) : 0;
+    const float r0 = w[kr], r1 = w[kr + 1], r2 = w[kr + 2], r3 = w[kr + 3];
+    const float g0 = w[kg], g1 = w[kg + 1], g2 = w[kg + 2], g3 = w[kg + 3];
+    const float b0 = w[kb], b1 = w[kb + 1], b2 = w[kb + 2], b3 = w[kb + 3];
+    const int nr = (int)(r >= r0) + (int)(r >= r1) + (int)(r >= r2) + (int)(r >= r3);
+    const int ng = (int)(g >= g0) + (int)(g >= g1) + (int)(g >= g2) + (int)(g >= g3);
+    const int nb = (int)(b >= b0) + (int)(b >= b1) + (int)(b >= b2) + (int)(b >= b3);
+    R = pr ? (uint32_t)(kr - 2 + nr) : 0u;
+    G = pg ? (uint32_t)(kg - 2 + ng) : 0u;
+    B = pb ? (uint32_t)(kb - 2 + nb) : 0u;
+    // (n - 1) > 2 unsigned <=> n is 0 or 4
+    const bool open_r = pr & ((uint32_t)(nr - 1) > 2u), open_g = pg & ((uint32_t)(ng - 1) > 2u), open_b = pb & ((uint32_t)(nb - 1) > 2u);
+    if (__builtin_amdgcn_ballot_w64(open_r | open_g | open_b) != 0ull) {
+        AIC_RARE_PATH();
+        if (open_r) R = srgb8_search(r, kr, w);
+        if (open_g) G = srgb8_search(g, kg, w);
+        if (open_b) B = srgb8_search(b, kb, w);
+    }
 }
 
 // lane event word (ev): what the lane needs next. Values below 4 mean "stepping" (the wave scheduler's test), with
@@ -860,7 +948,8 @@ constexpr uint32_t EV_FRESH = 1u, EV_DEAD = 2u, EV_SHADE = 4u, EV_ENTER = 8u, EV
 //   9-13   flags below;  14-15 the antialiasing sample being traced
 //   16-18  the suspended outer level's Face while inside a block; 21 ST_OUTER_ALIVE: that level can go on stepping
 //   24-26  sign bits of the ray direction (x: 26, y: 25, z: 24; set = component >= 0) = the sky octant
-constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u << 12, ST_TRACED = 1u << 13, ST_OUTER_ALIVE = 1u << 21;
+//   22     ST_DIR_FAST: RayDir::fast of the ray's direction (divisions by it may use t_delta: div_known_recip)
+constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u << 12, ST_TRACED = 1u << 13, ST_OUTER_ALIVE = 1u << 21, ST_DIR_FAST = 1u << 22;
 
 #ifndef AIC_MIN_WAVES
 #define AIC_MIN_WAVES 4  // waves per SIMD the production variants are built for (128 VGPRs; cold lane state lives in LDS)
@@ -964,13 +1053,11 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
     uint32_t tile_x0 = 0, tile_y0 = 0;  // wave-uniform: pixel origin of the tile the refill is drawing from
     // small decode tables live in LDS for the life of the persistent workgroup
     __shared__ float s_lut[256];     // PackedLight scalar decode (light/data.rs:301-354)
-    __shared__ float s_thr[256];     // sRGB8 encode thresholds
+    __shared__ float s_thr[kSrgbWindowWords];  // sRGB8 encode thresholds, as a window table (srgb8_rgb)
     __shared__ double s_pow[64];     // powf tables (powf_table)
     pow_tables_to_lds(s_pow, threadIdx.x, WGT);
-    for (uint32_t i = threadIdx.x; i < 256u; i += WGT) {
-        s_lut[i] = F.light_lut[i];
-        s_thr[i] = F.srgb_thr[i];
-    }
+    for (uint32_t i = threadIdx.x; i < 256u; i += WGT) s_lut[i] = F.light_lut[i];
+    srgb_window_to_lds(s_thr, F.srgb_thr, threadIdx.x, WGT);
     __syncthreads();
     const float *lut = s_lut;
     // Kernel arguments and the persistent loop. The stepping phase needs three scalars of them (the pool pointer and the cube
@@ -1118,6 +1205,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
         r.dx = dx; r.dy = dy; r.dz = dz;
         r.tdx = tdx; r.tdy = tdy; r.tdz = tdz;
         r.sx = signum_101(dx); r.sy = signum_101(dy); r.sz = signum_101(dz);
+        r.fast = (st & ST_DIR_FAST) != 0u;
         return r;
     };
     // coordinate (relative to the level's lower corner) from the steps left along an axis
@@ -2035,9 +2123,8 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                                 r = ps_mul(r, scale); g = ps_mul(g, scale); bl = ps_mul(bl, scale);
                             }
                         }
-                        const uint32_t R = srgb8_channel(r, s_thr);
-                        const uint32_t G = srgb8_channel(g, s_thr);
-                        const uint32_t B = srgb8_channel(bl, s_thr);
+                        uint32_t R, G, B;
+                        srgb8_rgb(r, g, bl, s_thr, R, G, B);
                         const uint32_t A = round_sat_u8(c[3] * 255.0f);
                         S.out[pix] = R | (G << 8) | (B << 16) | (A << 24);
                         }
@@ -2223,7 +2310,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                     thr = outer_thr;
                     const bool dead = !got || lvl_fl(fs) != FL_INBOUNDS;
                     lax = 8u | ((fs.st >> 2) & 7u);
-                    st = ST_TRACED | (octant << 24) | ((uint32_t)sample << 14);
+                    st = ST_TRACED | (octant << 24) | ((uint32_t)sample << 14) | (rd.fast ? ST_DIR_FAST : 0u);
 #ifdef AIC_PROFILE
                     s_ray_t0[col] = (uint32_t)__builtin_readcyclecounter();
 #endif
