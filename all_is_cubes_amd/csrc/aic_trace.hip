@@ -156,23 +156,26 @@ struct LvlLim {
     Lvl s;
     Lim lim;
 };
+// Written without early exits (round 6): every lane computes everything and `valid` decides at the end -- a level that is State::EMPTY comes back as
+// FL_ENDED with unspecified t_max / cube (nothing reads them: Raycaster::next returns None at once). With the exits, each one cost a saved exec mask, a
+// branch and a dozen moves of default values on the path of every lane that did not take it.
+AIC_DEV bool cube_containing_flat(double x, double y, double z, int out[3]) {  // cube.rs:97-119; `out` is unspecified when there is no cube
+    const double MIN_INCLUSIVE = -2147483648.0;
+    const double MAX_EXCLUSIVE = 2147483648.0;
+    const int ok = (int)(MIN_INCLUSIVE <= x) & (int)(MIN_INCLUSIVE <= y) & (int)(MIN_INCLUSIVE <= z) & (int)(x < MAX_EXCLUSIVE) & (int)(y < MAX_EXCLUSIVE) & (int)(z < MAX_EXCLUSIVE);
+    out[0] = (int)floor(x); out[1] = (int)floor(y); out[2] = (int)floor(z);
+    return ok != 0;
+}
 AIC_DEV LvlLim lvl_init(double ox, double oy, double oz, const RayDir rd, bool bounded, int lox, int loy,
                         int loz, int hix, int hiy, int hiz, bool include_exit, double half_over_len) {
     LvlLim out;
     Lvl &s = out.s;
     Lim &lim = out.lim;
-    s.st = FL_ENDED;
-    s.last_t = 0.0;
-    s.tx = s.ty = s.tz = 0.0;
-    s.cx = s.cy = s.cz = 0;
-    lim.x = lim.y = lim.z = 0;
-    double p[3] = {ox, oy, oz};
-    int cube[3];
-    bool ok = cube_containing(p, cube);
-    // MAXIMUM_BOUNDS.contains_cube (raycast.rs:485-499, 521-523)
-    ok = ok && cube[0] >= I32_MIN_ + 1 && cube[0] < I32_MAX_ - 1 && cube[1] >= I32_MIN_ + 1 && cube[1] < I32_MAX_ - 1 &&
-         cube[2] >= I32_MIN_ + 1 && cube[2] < I32_MAX_ - 1;
-    if (!ok) return out;  // State::EMPTY: produces nothing
+    int cube_o[3];
+    int valid = cube_containing_flat(ox, oy, oz, cube_o);
+    // MAXIMUM_BOUNDS.contains_cube (raycast.rs:485-499, 521-523); else State::EMPTY: produces nothing
+    // (c in [MIN + 1, MAX - 2]  <=>  (unsigned)(c - (MIN + 1)) < 2^32 - 3)
+    valid &= (int)((uint32_t)cube_o[0] - 0x80000001u < 0xfffffffdu) & (int)((uint32_t)cube_o[1] - 0x80000001u < 0xfffffffdu) & (int)((uint32_t)cube_o[2] - 0x80000001u < 0xfffffffdu);
     // bounds = MAXIMUM_BOUNDS ∩ given (empty => ORIGIN_EMPTY, which contains no cube)
     if (bounded) {
         lox = max(lox, I32_MIN_ + 1); loy = max(loy, I32_MIN_ + 1); loz = max(loz, I32_MIN_ + 1);
@@ -181,7 +184,7 @@ AIC_DEV LvlLim lvl_init(double ox, double oy, double oz, const RayDir rd, bool b
         lox = loy = loz = I32_MIN_ + 1;
         hix = hiy = hiz = I32_MAX_ - 1;
     }
-    if (hix <= lox || hiy <= loy || hiz <= loz) return out;
+    valid &= (int)(hix > lox) & (int)(hiy > loy) & (int)(hiz > loz);
     // fast_forward (raycast.rs:632-704): plane_origin takes the upper bound on axes the ray descends, else the lower bound; one ray-plane
     // intersection per moving axis. If the largest t is positive the ray starts again half a cube short of it (`t_start`), else where it is
     // (t_start = +0: `ff` is the origin itself, and adding +0 to a t_max -- a quotient that is positive, +0 or infinite -- changes nothing).
@@ -205,19 +208,19 @@ AIC_DEV LvlLim lvl_init(double ox, double oy, double oz, const RayDir rd, bool b
             if (!ff_fast) { qx = relx / fabs(rd.dx); qy = rely / fabs(rd.dy); qz = relz / fabs(rd.dz); }
         }
         double max_t = 0.0;
-        if (rd.sx != 0) max_t = fmax(max_t, rd.sx < 0 ? -qx : qx);
-        if (rd.sy != 0) max_t = fmax(max_t, rd.sy < 0 ? -qy : qy);
-        if (rd.sz != 0) max_t = fmax(max_t, rd.sz < 0 ? -qz : qz);
-        if (max_t > 0.0) {  // last_t_distance == 0 at this point
-            // 0.5 / direction.length() (raycast.rs:669) is a per-ray constant, computed once by the caller
-            double ts = max_t - half_over_len;
-            if (!isfinite(ts)) ts = max_t;
-            t_start = ts;
-            ffx = ox + rd.dx * ts; ffy = oy + rd.dy * ts; ffz = oz + rd.dz * ts;
-            double ff[3] = {ffx, ffy, ffz};
-            if (!cube_containing(ff, cube)) return out;
-        }
+        max_t = rd.sx != 0 ? fmax(max_t, rd.sx < 0 ? -qx : qx) : max_t;
+        max_t = rd.sy != 0 ? fmax(max_t, rd.sy < 0 ? -qy : qy) : max_t;
+        max_t = rd.sz != 0 ? fmax(max_t, rd.sz < 0 ? -qz : qz) : max_t;
+        const bool go = max_t > 0.0;  // last_t_distance == 0 at this point
+        // 0.5 / direction.length() (raycast.rs:669) is a per-ray constant, computed once by the caller
+        double ts = max_t - half_over_len;
+        ts = isfinite(ts) ? ts : max_t;
+        t_start = go ? ts : 0.0;
+        ffx = go ? ox + rd.dx * ts : ox; ffy = go ? oy + rd.dy * ts : oy; ffz = go ? oz + rd.dz * ts : oz;
     }
+    // the cube of the (fast-forwarded) origin; a fast-forwarded origin without one makes the level State::EMPTY
+    int cube[3];
+    valid &= (int)cube_containing_flat(ffx, ffy, ffz, cube);
     {
         // scale_to_integer_step on each axis (raycast.rs:797-819). The dividends are in [2^-53, 1] or +0: with a direction in the window (RayDir::fast)
         // div_known_recip's precondition holds
@@ -237,7 +240,7 @@ AIC_DEV LvlLim lvl_init(double ox, double oy, double oz, const RayDir rd, bool b
     lim.x = rd.sx > 0 ? hix : lox - 1;
     lim.y = rd.sy > 0 ? hiy : loy - 1;
     lim.z = rd.sz > 0 ? hiz : loz - 1;
-    s.st = FL_BEGINNING | ((uint32_t)FACE_WITHIN << 2) | (include_exit ? 256u : 0u);
+    s.st = valid ? (FL_BEGINNING | ((uint32_t)FACE_WITHIN << 2) | (include_exit ? 256u : 0u)) : FL_ENDED;
     return out;
 }
 
@@ -1010,14 +1013,83 @@ constexpr uint32_t ST_IN_BLOCK = 1u << 9, ST_HAS_LAST = 1u << 10, ST_OPAQUE = 1u
 constexpr uint32_t TAG_FREE = 0u, TAG_STEP = 1u, TAG_SHADE = 2u, TAG_ENTER = 3u, TAG_RAY = 4u, TAG_BUSY = 7u;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// Runs Raycaster::next (raycast.rs:239-284) on a freshly initialised level until it yields its
-// first step or ends. Used by the ENTER / RAY events, so that the stepping loop only ever sees
-// levels that are already inside their bounds. On success the returned state is "emitted, step
-// scheduled" (fl = InBounds, pick + need_step set) with ABSOLUTE cube coordinates.
-AIC_DEV Lvl lvl_first(Lvl s, const Lim lim, const RayDir rd, int lox, int loy, int loz, int hix, int hiy, int hiz, bool *got) {
-    const NextResult nr = lvl_next(s, lim, rd, lox, loy, loz, hix, hiy, hiz);
-    *got = nr.got;
-    return nr.s;
+// The first cube of a freshly initialised level, for the ENTER / RAY events: Raycaster::next run until it yields its first step or ends, so that the
+// stepping loop only ever sees levels that are already inside their bounds. Written like the stepping trip (round 6): wave masks for every decision, the per-lane state updated in place by
+// one exec-masked block -- lvl_next above, inlined into ENTER and NEWRAY, was compiled into ~600 instructions of nested exec-mask scaffolding with some
+// thirty register copies per turn of its loop. Raycaster::next from FirstLast::Beginning (raycast.rs:239-284) is: while the cube is outside the bounds on
+// the side the ray comes from and not past them (is_out_of_bounds_ahead, raycast.rs:711-728: "not yet entered"), step (State::step, raycast.rs:577-626:
+// along the axis of the smallest t_max, ties to the later axis; a level whose smallest t_max is not finite cannot step and ends); a cube inside the
+// bounds is emitted -- also by a level that cannot step, if it has not stepped yet (Face7::Within); anything else ends the level with nothing emitted.
+// (`checked_add` of the stepped coordinate cannot fail: a coordinate at i32::MAX with the ray going up, or at MIN going down, is past the bounds.)
+// Returns the emitted cube in the kernel's conventions: `lax` = the axis stepped along last, or 8 | Face7::Within for a cube emitted without a step.
+struct FirstCube {
+    double tx, ty, tz, last_t;
+    int cx, cy, cz;
+    uint32_t lax;
+    bool got, inbounds;  // emitted a cube; the level can go on (FirstLast::InBounds)
+};
+AIC_DEV FirstCube lvl_first_masks(const Lvl s0, const RayDir rd, int lox, int loy, int loz, int hix, int hiy, int hiz) {
+    typedef unsigned long long mask_t;
+    FirstCube f;
+    f.tx = s0.tx; f.ty = s0.ty; f.tz = s0.tz; f.last_t = s0.last_t;
+    f.cx = s0.cx; f.cy = s0.cy; f.cz = s0.cz;
+    f.lax = 8u | (uint32_t)FACE_WITHIN;
+    const mask_t negx = __builtin_amdgcn_ballot_w64(rd.sx < 0), posx = __builtin_amdgcn_ballot_w64(rd.sx > 0);
+    const mask_t negy = __builtin_amdgcn_ballot_w64(rd.sy < 0), posy = __builtin_amdgcn_ballot_w64(rd.sy > 0);
+    const mask_t negz = __builtin_amdgcn_ballot_w64(rd.sz < 0), posz = __builtin_amdgcn_ballot_w64(rd.sz > 0);
+    mask_t active = __builtin_amdgcn_ballot_w64(lvl_fl(s0) != FL_ENDED);
+    mask_t m_got = 0ull, m_inb = 0ull, m_stepped = 0ull;
+    const uint32_t finite_classes = 0x1f8u;  // v_cmp_class: -normal, -denormal, -0, +0, +denormal, +normal
+    while (active != 0ull) {
+        // is_out_of_bounds_ahead: per axis "not yet entered" is below the bounds going up, above going down, either for an axis the ray does not move
+        // along; "left" the other way round
+        const mask_t lowx = __builtin_amdgcn_ballot_w64(f.cx < lox), highx = __builtin_amdgcn_ballot_w64(f.cx >= hix);
+        const mask_t lowy = __builtin_amdgcn_ballot_w64(f.cy < loy), highy = __builtin_amdgcn_ballot_w64(f.cy >= hiy);
+        const mask_t lowz = __builtin_amdgcn_ballot_w64(f.cz < loz), highz = __builtin_amdgcn_ballot_w64(f.cz >= hiz);
+        const mask_t enter = (lowx & ~negx) | (highx & ~posx) | (lowy & ~negy) | (highy & ~posy) | (lowz & ~negz) | (highz & ~posz);
+        const mask_t exit_ = (lowx & ~posx) | (highx & ~negx) | (lowy & ~posy) | (highy & ~negy) | (lowz & ~posz) | (highz & ~negz);
+        const mask_t m_in = active & ~(enter | exit_), m_go = active & enter & ~exit_;
+        const mask_t m_any = m_in | m_go;
+        mask_t m_fin, sv, mx, m_stp;
+        double mn;
+        asm volatile(
+            "s_and_saveexec_b64 %[sv], %[any]\n\t"
+            "v_min_f64 %[mn], %[tx], %[ty]\n\t"
+            "v_min_f64 %[mn], %[mn], %[tz]\n\t"
+            "v_cmp_class_f64 %[fin], %[mn], %[cls]\n\t"   // valid_for_stepping (raycast.rs:563-570): the smallest t_max is finite
+            "s_and_b64 %[stp], %[fin], %[go]\n\t"          // the lanes that step
+            "s_mov_b64 exec, %[stp]\n\t"
+            "v_mov_b64 %[lt], %[mn]\n\t"
+            "v_cmp_eq_f64 %[mx], %[tz], %[mn]\n\t"         // Z
+            "v_cmp_eq_f64 vcc, %[ty], %[mn]\n\t"
+            "s_andn2_b64 vcc, vcc, %[mx]\n\t"              // Y
+            "s_mov_b64 exec, %[mx]\n\t"
+            "v_add_f64 %[tz], %[tz], %[tdz]\n\t"
+            "v_add_u32 %[cz], %[cz], %[sz]\n\t"
+            "v_mov_b32 %[lax], 2\n\t"
+            "s_or_b64 %[mx], %[mx], vcc\n\t"
+            "s_mov_b64 exec, vcc\n\t"
+            "v_add_f64 %[ty], %[ty], %[tdy]\n\t"
+            "v_add_u32 %[cy], %[cy], %[sy]\n\t"
+            "v_mov_b32 %[lax], 1\n\t"
+            "s_andn2_b64 exec, %[stp], %[mx]\n\t"          // X = stepping lanes that took neither
+            "v_add_f64 %[tx], %[tx], %[tdx]\n\t"
+            "v_add_u32 %[cx], %[cx], %[sx]\n\t"
+            "v_mov_b32 %[lax], 0\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
+            : [tx] "+v"(f.tx), [ty] "+v"(f.ty), [tz] "+v"(f.tz), [lt] "+v"(f.last_t), [cx] "+v"(f.cx), [cy] "+v"(f.cy), [cz] "+v"(f.cz), [lax] "+v"(f.lax),
+              [mn] "=&v"(mn), [sv] "=&s"(sv), [mx] "=&s"(mx), [fin] "=&s"(m_fin), [stp] "=&s"(m_stp)
+            : [tdx] "v"(rd.tdx), [tdy] "v"(rd.tdy), [tdz] "v"(rd.tdz), [sx] "v"(rd.sx), [sy] "v"(rd.sy), [sz] "v"(rd.sz), [any] "s"(m_any), [go] "s"(m_go),
+              [cls] "s"(finite_classes)
+            : "vcc", "scc");
+        m_got |= m_in & (m_fin | ~m_stepped);
+        m_inb |= m_in & m_fin;
+        m_stepped |= m_stp;
+        active = m_stp;
+    }
+    f.got = __builtin_amdgcn_inverse_ballot_w64(m_got);
+    f.inbounds = __builtin_amdgcn_inverse_ballot_w64(m_inb);
+    return f;
 }
 
 // How a DDA level is held in registers by the image kernel (both levels -- the cube grid and a block's
@@ -2012,8 +2084,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 const int isx = (int)(blk_vsz & 255u), isy = (int)((blk_vsz >> 8) & 255u), isz = (int)((blk_vsz >> 16) & 255u);
                 const RayDir rd = make_rd(edx, edy, edz);
                 const LvlLim ll = lvl_init(sx_, sy_, sz_, rd, true, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz, true, 0.5 / c64[C_TABS][col]);  // (0.5 / direction.length(), raycast.rs:669: the quotient NEWRAY's fast-forward used)
-                bool got;
-                const Lvl f = lvl_first(ll.s, ll.lim, rd, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz, &got);
+                const FirstCube f = lvl_first_masks(ll.s, rd, ilx, ily, ilz, ilx + isx, ily + isy, ilz + isz);
                 tx = f.tx; ty = f.ty; tz = f.tz; last_t = f.last_t;
                 const int vcx = f.cx - ilx, vcy = f.cy - ily, vcz = f.cz - ilz;
                 rx = posx ? (uint32_t)(isx - 1 - vcx) : (uint32_t)vcx;
@@ -2023,10 +2094,9 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 ssx = posx ? 2 * isy * isz : -2 * isy * isz; ssy = posy ? 2 * isz : -2 * isz; ssz = posz ? 2 : -2;
                 thr = n_invisible;
                 // a produced first voxel still needs its lookup (FRESH); a level that produced nothing, or ended with it, is DEAD
-                const bool dead = !got || lvl_fl(f) != FL_INBOUNDS;
-                lax = 8u | ((f.st >> 2) & 7u);
+                lax = f.lax;
                 st |= ST_IN_BLOCK;
-                ev = (got ? EV_FRESH : 0u) | (dead ? EV_DEAD : 0u);
+                ev = (f.got ? EV_FRESH : 0u) | (f.inbounds ? 0u : EV_DEAD);
             }
             AIC_SECTION(enter_end);
             } else {
@@ -2298,8 +2368,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                     // the sanitised direction equals the original unless it was zeroed, in which case no fast-forward happens
                     const double half_over_len = 0.5 / t_abs;
                     const LvlLim ll = lvl_init(ox, oy, oz, rd, true, olx, oly, olz, ohx, ohy, ohz, true, half_over_len);
-                    bool got;
-                    const Lvl fs = lvl_first(ll.s, ll.lim, rd, olx, oly, olz, ohx, ohy, ohz, &got);
+                    const FirstCube fs = lvl_first_masks(ll.s, rd, olx, oly, olz, ohx, ohy, ohz);
                     tx = fs.tx; ty = fs.ty; tz = fs.tz; last_t = fs.last_t;
                     const int ccx = fs.cx - olx, ccy = fs.cy - oly, ccz = fs.cz - olz;
                     rx = qx ? (uint32_t)(osx_i - 1 - ccx) : (uint32_t)ccx;
@@ -2308,14 +2377,13 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                     boff = 2u * (uint32_t)(((uint32_t)ccx * (uint32_t)osy_i + (uint32_t)ccy) * (uint32_t)osz_i + (uint32_t)ccz);
                     ssx = qx ? ostx : -ostx; ssy = qy ? osty : -osty; ssz = qz ? 2 : -2;
                     thr = outer_thr;
-                    const bool dead = !got || lvl_fl(fs) != FL_INBOUNDS;
-                    lax = 8u | ((fs.st >> 2) & 7u);
+                    lax = fs.lax;
                     st = ST_TRACED | (octant << 24) | ((uint32_t)sample << 14) | (rd.fast ? ST_DIR_FAST : 0u);
 #ifdef AIC_PROFILE
                     s_ray_t0[col] = (uint32_t)__builtin_readcyclecounter();
 #endif
                     if (cb_opaque(acc)) st |= ST_OPAQUE;
-                    ev = (got ? EV_FRESH : 0u) | (dead ? EV_DEAD : 0u);
+                    ev = (fs.got ? EV_FRESH : 0u) | (fs.inbounds ? 0u : EV_DEAD);
                 } else {
                     ev = EV_FINISH;
                 }
@@ -2872,8 +2940,23 @@ __global__ void probe_raycast_kernel(const double *od, int use_bounds, const int
     const Lim lim = ll.lim;
     uint32_t n = 0;
     *ended = 0;
+    // A bounded raycaster with its exit step -- what the image kernel's events set up -- takes its first step through the events' own code
+    // (lvl_first_masks), so that the reference's step tables pin that too; lvl_next goes on from the state it leaves.
+    bool first_by_masks = use_bounds != 0 && include_exit != 0;
     while (n < max_steps) {
-        const NextResult nr = lvl_next(s, lim, rd, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]);
+        NextResult nr;
+        if (first_by_masks) {
+            first_by_masks = false;
+            const FirstCube f = lvl_first_masks(s, rd, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]);
+            nr.got = f.got; nr.is_exit = false;
+            nr.s.tx = f.tx; nr.s.ty = f.ty; nr.s.tz = f.tz; nr.s.last_t = f.last_t;
+            nr.s.cx = f.cx; nr.s.cy = f.cy; nr.s.cz = f.cz;
+            const uint32_t face = (f.lax & 8u) ? (f.lax & 7u) : (((f.lax == 0u ? rd.sx : (f.lax == 1u ? rd.sy : rd.sz)) > 0 ? 1u : 4u) + f.lax);
+            // "emitted, step scheduled" as lvl_next leaves it: InBounds | pick | need_step, or Ended
+            nr.s.st = (face << 2) | 256u | (f.inbounds ? (FL_INBOUNDS | ((uint32_t)pick_axis(f.tx, f.ty, f.tz) << 5) | 128u) : FL_ENDED);
+        } else {
+            nr = lvl_next(s, lim, rd, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]);
+        }
         s = nr.s;
         if (!nr.got) {
             *ended = 1;
