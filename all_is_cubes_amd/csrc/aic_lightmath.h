@@ -98,6 +98,14 @@ AIC_HD void lm_mix4(const float a[4], const float b[4], float amount, float out[
     for (int i = 0; i < 4; i++) out[i] = a[i] + (b[i] - a[i]) * amount;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+AIC_HD int lm_cvt_floor_i32(double v) {  // (int)floor(v), saturating
+    int r;
+    const double f = floor(v);
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+}
+#endif
 // Cube::containing on one coordinate (cube.rs:97-119): is there an i32 cube, and which
 AIC_HD bool lm_cube_coord(double v, int *out) {
     const bool ok = (v >= -2147483648.0) && (v < 2147483648.0);
@@ -166,11 +174,20 @@ AIC_HD void lm_interpolated_light(const LightGridView &G, const float *lut, int 
     // inside the space. Anything else is patched texel by texel below.
     const bool far_from_i32_edge = (fabs(spx) < 2147483646.0) && (fabs(spy) < 2147483646.0) && (fabs(spz) < 2147483646.0);
     int vnf = 0, vns = 0, v1n = 0, v1f = 0, v2n = 0, v2f = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The device converts for every lane -- v_cvt_i32_f64 saturates, and `all_inside` below holds far_from_i32_edge, so what a lane outside the common path
+    // gets here is never used -- instead of six default moves, a saved exec mask and six conditional moves (round 6). (The instruction itself: in C++ the
+    // conversion of a value that does not fit is undefined, which the optimiser may act on.)
+    vnf = lm_cvt_floor_i32(pnf); vns = lm_cvt_floor_i32(pns);
+    v1n = lm_cvt_floor_i32(p1n); v1f = lm_cvt_floor_i32(p1f);
+    v2n = lm_cvt_floor_i32(p2n); v2f = lm_cvt_floor_i32(p2f);
+#else
     if (far_from_i32_edge) {
         vnf = (int)floor(pnf); vns = (int)floor(pns);
         v1n = (int)floor(p1n); v1f = (int)floor(p1f);
         v2n = (int)floor(p2n); v2f = (int)floor(p2f);
     }
+#endif
     const uint32_t dnf = (uint32_t)vnf - (uint32_t)lo_n, dns = (uint32_t)vns - (uint32_t)lo_n;
     const uint32_t d1n = (uint32_t)v1n - (uint32_t)lo_1, d1f = (uint32_t)v1f - (uint32_t)lo_1;
     const uint32_t d2n = (uint32_t)v2n - (uint32_t)lo_2, d2f = (uint32_t)v2f - (uint32_t)lo_2;

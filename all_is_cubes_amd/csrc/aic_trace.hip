@@ -163,7 +163,11 @@ AIC_DEV bool cube_containing_flat(double x, double y, double z, int out[3]) {  /
     const double MIN_INCLUSIVE = -2147483648.0;
     const double MAX_EXCLUSIVE = 2147483648.0;
     const int ok = (int)(MIN_INCLUSIVE <= x) & (int)(MIN_INCLUSIVE <= y) & (int)(MIN_INCLUSIVE <= z) & (int)(x < MAX_EXCLUSIVE) & (int)(y < MAX_EXCLUSIVE) & (int)(z < MAX_EXCLUSIVE);
-    out[0] = (int)floor(x); out[1] = (int)floor(y); out[2] = (int)floor(z);
+    // (v_cvt_i32_f64 itself, which saturates: the C++ conversion of a value that does not fit is undefined, and the optimiser may act on that)
+    const double fx = floor(x), fy = floor(y), fz = floor(z);
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(out[0]) : "v"(fx));
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(out[1]) : "v"(fy));
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(out[2]) : "v"(fz));
     return ok != 0;
 }
 AIC_DEV LvlLim lvl_init(double ox, double oy, double oz, const RayDir rd, bool bounded, int lox, int loy,
@@ -1831,22 +1835,25 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                     if (LMODE >= 2) {
                         // (the origin enters intersection_point only for a lane whose step is Face7::Within or whose ray does not move along some axis --
                         //  raycast.rs:409-439 -- : it is fetched for those lanes, i.e. hardly ever; half of the SHADE event's cold-state traffic)
-                        double ox = 0.0, oy = 0.0, oz = 0.0, dx, dy, dz;
+                        double ox = 0.0, oy = 0.0, oz = 0.0, dx, dy, dz;  // (the origin as the lane's LEVEL sees it: the block's own coordinates inside a block)
                         cold_direction(dx, dy, dz);
                         const bool need_o = (face == FACE_WITHIN) | (dx == 0.0) | (dy == 0.0) | (dz == 0.0);
                         if (__ballot(need_o) != 0ull) {
-                            if (need_o) cold_origin(ox, oy, oz);
+                            if (need_o) {
+                                cold_origin(ox, oy, oz);
+                                if (inb) {
+                                    const double kd = (double)blk_res;
+                                    ox = (ox - (double)ocx) * kd; oy = (oy - (double)ocy) * kd; oz = (oz - (double)ocz) * kd;
+                                }
+                            }
                         }
-                        if (inb) {
-                            const double kd = (double)blk_res;
-                            double vp[3];
-                            intersection_point(ca, (ox - (double)ocx) * kd, (oy - (double)ocy) * kd, (oz - (double)ocz) * kd, dx, dy, dz, vp);
-                            ip[0] = vp[0] * as + (double)ocx;  // surface.rs:406-407
-                            ip[1] = vp[1] * as + (double)ocy;
-                            ip[2] = vp[2] * as + (double)ocz;
-                        } else {
-                            intersection_point(ca, ox, oy, oz, dx, dy, dz, ip);
-                        }
+                        // one copy of intersection_point for both levels (round 6: it was written per level, and a wave shading cube faces and voxel faces
+                        // together ran both); a voxel's point goes back to space coordinates (surface.rs:406-407)
+                        double vp[3];
+                        intersection_point(ca, ox, oy, oz, dx, dy, dz, vp);
+                        ip[0] = inb ? vp[0] * as + (double)ocx : vp[0];
+                        ip[1] = inb ? vp[1] * as + (double)ocy : vp[1];
+                        ip[2] = inb ? vp[2] * as + (double)ocz : vp[2];
                     }
                     if (LMODE == 2) {
                         // get_interpolated_light (sr.rs:248-359; aic_lightmath.h), then rgb / max(weight, 0.1)
