@@ -132,6 +132,41 @@ def test_probe_raycast_random_vs_oracle(ctx):
         assert (g["intersection_point"].view(np.uint64) == r["intersection_point"].view(np.uint64)).all(), case
 
 
+def test_probe_raycast_extreme_exponents_vs_oracle(ctx):
+    """Rays whose operands leave the exponent windows of the cheap divisions (aic_trace.hip div_known_recip: quotients by a direction through its t_delta, taken only for
+    exponents far from the ends of the range) -- tiny and huge direction components, origins a denormal's width from a bounding plane or exactly on it, origins far away --
+    so that the generic division behind the guard, and the guard itself, are compared with the oracle bit for bit like the ordinary rays above."""
+    rng = np.random.default_rng(4242)
+    for case in range(300):
+        origin = rng.uniform(-30, 30, 3)
+        direction = rng.normal(size=3)
+        k = case % 6
+        if k == 0:
+            direction *= 10.0 ** rng.uniform(-300, -80)          # every component tiny
+        elif k == 1:
+            direction[rng.integers(3)] *= 10.0 ** rng.uniform(-300, -80)  # one tiny
+        elif k == 2:
+            direction *= 10.0 ** rng.uniform(60, 99)             # huge (but below the 1e100 cut-off of Parameters::new)
+        elif k == 3:
+            direction[rng.integers(3)] *= 10.0 ** rng.uniform(60, 99)
+        elif k == 4:
+            origin = origin * 10.0 ** rng.uniform(3, 9)          # far from the bounds: a long fast-forward
+        lo = rng.integers(-10, 5, 3)
+        hi = lo + rng.integers(1, 16, 3)
+        if k == 5:
+            a = rng.integers(3)
+            lo[a] = 0
+            origin[a] = [0.0, 5e-324, -5e-324, 1e-200, -1e-200, 1e-160][case // 6 % 6]  # on the plane, or next to it by less than the window allows
+        if case % 7 == 0:
+            direction[rng.integers(3)] = 0.0
+        g, ge = ctx.probe_raycast(origin, direction, bounds=(lo, hi), max_steps=40)
+        r, re_ = oracle.raycast(origin, direction, bounds=(lo, hi), max_steps=40)
+        assert len(g) == len(r) and ge == re_, case
+        assert (g["cube"] == r["cube"]).all() and (g["face"] == r["face"]).all(), case
+        assert (g["t_distance"].view(np.uint64) == r["t_distance"].view(np.uint64)).all(), case
+        assert (g["intersection_point"].view(np.uint64) == r["intersection_point"].view(np.uint64)).all(), case
+
+
 def test_light_lut_matches_reference_table(ctx, golden_dir):
     ref = np.load(golden_dir / "packed_light_lut.npy")
     assert (ctx.probe_light_lut().view(np.uint32) == ref.view(np.uint32)).all()
@@ -203,6 +238,27 @@ def test_synthetic_options_matrix(ctx, synth_space, transparency, lighting):
     opt = oracle.make_options(fog=1, transparency=transparency, threshold=0.6, lighting=lighting)
     got, ref = render_both(ctx, synth_space, opt, (160, 96), SYNTH_EYE, synth_quat())
     assert_parity(got, ref)
+
+
+@pytest.mark.parametrize("scale", [1e-200, 1e-90, 1e120])
+def test_scaled_camera_matrix_takes_the_generic_division(ctx, synth_space, scale):
+    """A camera matrix times a constant unprojects to the same rays up to rounding, with homogeneous coordinates far outside the exponent window in which the
+    unprojection's three quotients share one reciprocal (aic_trace.hip unproject): the guard sends every lane to the generic division, which must give the oracle's
+    bits for that matrix (first-hit t, per-pixel step counts, pixels), on all three kernel variants."""
+    opt = oracle.make_options(fog=1, lighting=3)
+    w, h = 96, 64
+    _, _, inv = oracle.camera_matrices(90.0, opt.view_distance, w / h, synth_quat(), SYNTH_EYE)
+    inv = inv * scale
+    ctx.upload_space(abi.LAYER_WORLD, synth_space)
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.set_options(abi.LAYER_WORLD, to_abi_options(opt))
+    opt.exposure = 1.0
+    frame = ctx.make_frame(w, h, world_inv=inv)
+    got = ctx.render(frame, want_aux=True)
+    assert_production_variants(ctx, frame, got)
+    ref = oracle.render(oracle.Space(synth_space), opt, oracle.make_camera(inv, w, h), want_aux=True)
+    assert_parity(got, ref)
+    assert got["info"].cubes_traced > w * h  # (the scaled camera still sees the scene)
 
 
 @pytest.mark.parametrize("fog", [0, 1, 2, 3])
