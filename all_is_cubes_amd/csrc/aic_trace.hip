@@ -1818,6 +1818,13 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 }
                 // colour record of the surface: the block's single voxel, or the voxel's palette entry
                 const uint32_t shade_ref = inb ? (blk_pal_off + raw) : (0x80000000u | (raw & idx_mask));
+                // ... fetched HERE, ahead of the light: both records begin with rgba and emission (DevBlock, DevPaletteEntry: 32 bytes), so it is one address and
+                // two loads without a branch, and they are in flight beside the light's texel loads. (Written where the record is used, the compiler issued them
+                // there -- behind the wait for the texels: two memory round trips in a row in every SHADE phase; round 6.)
+                static_assert(offsetof(DevBlock, color) == 0 && offsetof(DevBlock, emission) == 16 && offsetof(DevPaletteEntry, color) == 0 && offsetof(DevPaletteEntry, emission) == 16, "one record layout");
+                const char *const rec_p = (shade_ref & 0x80000000u) ? reinterpret_cast<const char *>(&L.blocks[shade_ref & 0xffffu]) : reinterpret_cast<const char *>(&L.palette[shade_ref]);
+                const float4 rec_col = *reinterpret_cast<const float4 *>(rec_p);
+                const float4 rec_em = *reinterpret_cast<const float4 *>(rec_p + 16);  // (.w: DevBlock::kind / the palette entry's pad -- unused)
                 // illumination (surface.rs:113-206)
                 float i0 = 1.0f, i1 = 1.0f, i2 = 1.0f;
                 uint32_t nl = 0;
@@ -1870,19 +1877,7 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                 AIC_TICK(18);
                 AIC_SECTION(shade_colour_span);
                 // colour record
-                float r, g, b, a, e0, e1, e2;
-                if (shade_ref & 0x80000000u) {
-                    const DevBlock *tb = &L.blocks[shade_ref & 0xffffu];
-                    const float4 col = *reinterpret_cast<const float4 *>(tb->color);
-                    r = col.x; g = col.y; b = col.z; a = col.w;
-                    e0 = tb->emission[0]; e1 = tb->emission[1]; e2 = tb->emission[2];
-                } else {
-                    const DevPaletteEntry *pe = &L.palette[shade_ref];
-                    const float4 col = *reinterpret_cast<const float4 *>(pe->color);
-                    const float4 em = *reinterpret_cast<const float4 *>(pe->emission);
-                    r = col.x; g = col.y; b = col.z; a = col.w;
-                    e0 = em.x; e1 = em.y; e2 = em.z;
-                }
+                float r = rec_col.x, g = rec_col.y, b = rec_col.z, a = rec_col.w, e0 = rec_em.x, e1 = rec_em.y, e2 = rec_em.z;
                 bool will_flush = true;
                 if (VOL) {
                     // exit distance = t of the next TraceStep: the next step of this level, or -- if this
