@@ -192,6 +192,10 @@ struct DevFrame {
     // 64 bytes per column, which tripled C3's HBM-side traffic). Sized by the host from trace_ray_cold_bytes(); `ray_cold_groups` workgroups fit.
     uint4 *ray_cold;
     uint32_t ray_cold_groups;
+    // How the kernel derives a ray from its pixel (aic_trace.hip ray_of_pixel), decided by the launcher from the fields above so that the common cameras take ONE scalar
+    // fetch and branch instead of a chain of five dependent ones (round 6): 0 = the layer holds a space, pixel grid, edge tables, one part; 1 = the same with the strip
+    // partition (n_parts > 1); 2 = anything else (pixel centres, patch rectangles, orthographic views, no tables, no space).
+    uint32_t ray_mode;
     uint32_t exchange;       // host-side: launch the exchanging variant (aic_trace.hip "lane exchange") -- a frame with several tiles per persistent wave; a frame of
                              // about one tile per wave (a rank's share at N >= 4, small images) runs the variant without the pool, which it would only pay for
 };

@@ -1678,6 +1678,37 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
             //    (origin only) wherever a later event needs the origin, instead of keeping 24 bytes per ray for the whole of its life: same code, same
             //    inputs (the pixel in K_PXY, the sample in st, the kernel arguments), hence the same bits. Returns false when there is no ray. --
             auto ray_of_pixel = [&](const uint32_t x, const uint32_t lrow, const int sample, const bool want_dir, double o[3], double dir[3]) -> bool {
+                // The common cameras first, behind ONE scalar fetch (DevFrame::ray_mode, made by the launcher): a pixel grid with the host-made edge tables and a layer
+                // that holds a space. (The general form below asks five kernel arguments one after the other -- strips? pixel centres? patches? tables? orthographic? --
+                // each a scalar load and a wait in front of its branch: ~600 cycles of NEWRAY's and ENTER's few thousand.) Same operations on the same values as below.
+                const uint32_t mode = F.ray_mode;
+                if (mode <= 1u) {
+                    const double *const ex = F.edge_x, *const ey = F.edge_y;
+                    uint32_t y = lrow;
+                    if (mode == 1u) {
+                        const uint32_t srows = opaque_s(F.strip_rows);
+                        const uint32_t strip = lrow / srows;
+                        y = (F.part + strip * F.n_parts) * srows + (lrow - strip * srows);
+                    }
+                    const double x0 = ex[x], x1 = ex[x + 1u], y0 = ey[y], y1 = ey[y + 1u];
+                    double px, py;
+                    if (n_samples == 4) {
+                        const double ux = (sample == 0) ? 1. / 8. : (sample == 1) ? 3. / 8. : (sample == 2) ? 5. / 8. : 7. / 8.;
+                        const double uy = (sample == 0) ? 5. / 8. : (sample == 1) ? 1. / 8. : (sample == 2) ? 7. / 8. : 3. / 8.;
+                        px = x0 + (x1 - x0) * ux;
+                        py = y0 + (y1 - y0) * uy;
+                    } else {
+                        px = (x0 + x1) / 2.0;
+                        py = (y0 + y1) / 2.0;
+                    }
+                    unproject(S.inv, px, py, 0.0, o);
+                    if (want_dir) {
+                        double f[3];
+                        unproject(S.inv, px, py, 1.0, f);
+                        dir[0] = f[0] - o[0]; dir[1] = f[1] - o[1]; dir[2] = f[2] - o[2];
+                    }
+                    return true;
+                }
                 const size_t pix = (size_t)lrow * F.width + x;
                 // global row of this local row under the strip partition
                 uint32_t y = lrow;
@@ -3016,7 +3047,9 @@ static void launch_trace_x(const DevFrame &F, hipStream_t stream) {
     if (XCHG && F.antialias && grid > F.ray_cold_groups / n_sub) grid = F.ray_cold_groups / n_sub;  // (the host sizes the antialiasing sums' buffer for the resident grid: trace_ray_cold_bytes)
     grid *= n_sub;
     if (grid == 0) return;
-    hipLaunchKernelGGL((trace_image_kernel<VOL, LMODE, DIAG, BIG, XC>), dim3(grid), dim3(WGT), 0, stream, F);
+    DevFrame G = F;
+    G.ray_mode = (F.layer.present && !F.pixel_centers && !F.patches && !F.ortho_n && F.edge_x && F.edge_y) ? (F.n_parts > 1u ? 1u : 0u) : 2u;  // (DevFrame::ray_mode)
+    hipLaunchKernelGGL((trace_image_kernel<VOL, LMODE, DIAG, BIG, XC>), dim3(grid), dim3(WGT), 0, stream, G);
 }
 
 // The production variants (no per-pixel records, not Bounce) exist twice: with the lane exchange (a frame of many tiles per persistent wave) and without
