@@ -55,6 +55,7 @@ void light_state_cubes_updated(LightState *s, uint64_t version_before, uint64_t 
 namespace {
 
 constexpr uint64_t kMaxPoolElems = 0x7ffffff0ull;  // u16 elements of cube grid + voxel volumes (32-bit byte offsets in the kernel)
+constexpr uint64_t kMaxLightTexels = 0x3ffffff0ull; // cubes of a space: the SHADE event addresses light texels by 32-bit byte offsets (aic_lightmath.h)
 
 template <typename T>
 struct DevBuf {
@@ -368,8 +369,9 @@ int convert_block(aic_ctx *c, const aic_block_desc &d, const uint16_t *voxels, c
             } else e = air;
         }
         out->kind = invisible(e) ? 0x80000000u : 0u;
-        for (int k = 0; k < 4; k++) out->color[k] = e[k];
-        for (int k = 0; k < 3; k++) out->emission[k] = e[4 + k];
+        // (+ 0.0f: a PositiveSign never holds -0.0 -- restricted_number.rs:283 -- and the kernel's ps_mul relies on the sign bit)
+        for (int k = 0; k < 4; k++) out->color[k] = e[k] + 0.0f;
+        for (int k = 0; k < 3; k++) out->emission[k] = e[4 + k] + 0.0f;
         return AIC_OK;
     }
     // recursive block
@@ -385,8 +387,8 @@ int convert_block(aic_ctx *c, const aic_block_desc &d, const uint16_t *voxels, c
         uint32_t dst = invisible(e) ? next_inv++ : next_vis++;
         remap[i] = dst;
         DevPaletteEntry &pe = (*pal_out)[pal_base + dst];
-        for (int k = 0; k < 4; k++) pe.color[k] = e[k];
-        for (int k = 0; k < 3; k++) pe.emission[k] = e[4 + k];
+        for (int k = 0; k < 4; k++) pe.color[k] = e[k] + 0.0f;
+        for (int k = 0; k < 3; k++) pe.emission[k] = e[4 + k] + 0.0f;
         pe.pad = 0.f;
     }
     size_t vox_base = vox_out->size();
@@ -431,7 +433,7 @@ void fill_dev_layer(const aic_ctx *c, const Layer &l, const aic_camera &cam, Dev
     d->opt.maximum_intensity = o.maximum_intensity;
     d->opt.view_distance = o.view_distance;
     std::memcpy(d->inv, cam.inverse_projection_view, sizeof(d->inv));
-    d->exposure = cam.exposure;
+    d->exposure = cam.exposure + 0.0f;
     d->cls_in_code = l.cls_in_code ? 1u : 0u;
     (void)c;
 }
@@ -601,7 +603,12 @@ int aic_upload_space(aic_ctx *c, int layer, const aic_space_desc *s) {
     if (s->n_blocks > 65536) return fail(c, AIC_ERR_INVALID, "more than 65536 blocks");
     // the trace kernel addresses the pool with 32-bit BYTE offsets: at most 2^31 u16 elements (4 GiB)
     if (n + s->n_voxels > kMaxPoolElems) return fail(c, AIC_ERR_INVALID, "space too large (cube grid + voxel pool must stay within 4 GiB)");
+    if (n > kMaxLightTexels) return fail(c, AIC_ERR_INVALID, "space too large (the light volume, 4 bytes per cube, must stay within 4 GiB)");
     if (s->n_blocks && !s->blocks) return fail(c, AIC_ERR_INVALID, "blocks is null");
+    // Sky colours are Rgb = PositiveSign<f32> x 3 (sky.rs:20-41): what that type cannot hold is rejected (as for palette entries, make_dev_block)
+    for (int o = 0; o < 8; o++)
+        for (int k = 0; k < 3; k++)
+            if (!(s->sky[o][k] >= 0.f)) return fail(c, AIC_ERR_INVALID, "sky colour has a negative or NaN component");
 
     // block table + pools
     std::vector<DevBlock> blocks(s->n_blocks);
@@ -665,7 +672,8 @@ int aic_upload_space(aic_ctx *c, int layer, const aic_space_desc *s) {
     l.garbage_vox = l.garbage_pal = 0;
     l.air_index = air_index;
     l.sky_kind = s->sky_kind;
-    std::memcpy(l.sky, s->sky, sizeof(l.sky));
+    for (int o = 0; o < 8; o++)
+        for (int k = 0; k < 3; k++) l.sky[o][k] = s->sky[o][k] + 0.0f;  // (-0.0 becomes +0.0, as in a PositiveSign)
     for (int f = 0; f < 7; f++)
         l.block_sky[f] = (uint32_t)s->block_sky[f][0] | ((uint32_t)s->block_sky[f][1] << 8) | ((uint32_t)s->block_sky[f][2] << 16) |
                          ((uint32_t)s->block_sky[f][3] << 24);
@@ -998,6 +1006,8 @@ int submit_frames(aic_ctx *c, uint32_t k, const aic_frame_desc *frames, uint32_t
     if (!patches)
         for (uint32_t j = 0; j < k; j++) dump_record(c, DUMP_FRAME, slot, {{&frames[j], sizeof(frames[j])}});
     if (f->width > 65535u || local_rows > 65535u) return fail(c, AIC_ERR_INVALID, "aic_render: frame dimensions above 65535 are not supported");
+    for (uint32_t j = 0; j < k; j++)  // Camera::exposure() is a PositiveSign<f32> (camera_struct.rs:365-367)
+        if (!(frames[j].world.exposure >= 0.f) || !(frames[j].ui.exposure >= 0.f)) return fail(c, AIC_ERR_INVALID, "aic_render: exposure is negative or NaN");
 
     uint32_t flaws = 0;
     DevFrame F;
@@ -1117,7 +1127,7 @@ int submit_frames(aic_ctx *c, uint32_t k, const aic_frame_desc *frames, uint32_t
         DevSub &S = F.sub[j];
         std::memcpy(S.backdrop, frames[j].backdrop, sizeof(S.backdrop));
         S.has_backdrop = !(frames[j].backdrop[0] == 0.f && frames[j].backdrop[1] == 0.f && frames[j].backdrop[2] == 0.f && frames[j].backdrop[3] == 0.f);
-        S.exposure = ortho_n ? 1.0f : frames[j].world.exposure;
+        S.exposure = ortho_n ? 1.0f : frames[j].world.exposure + 0.0f;  // (PositiveSign: checked above; -0.0 becomes +0.0)
         S.out = out_devices[j];
         if ((e = sb.counters.ensure(1)) != hipSuccess) return hip_fail(c, "alloc frame counters", e);
         S.counters = sb.counters.p;

@@ -167,8 +167,10 @@ AIC_HD void lm_interpolated_light(const LightGridView &G, const float *lut, int 
     // per-role grid parameters
     const int lo_n = n0 ? glx : (n1 ? gly : glz), lo_1 = t10 ? glx : (t11 ? gly : glz), lo_2 = t20 ? glx : (t21 ? gly : glz);
     const uint32_t sz_n = n0 ? gsx : (n1 ? gsy : gsz), sz_1 = t10 ? gsx : (t11 ? gsy : gsz), sz_2 = t20 ? gsx : (t21 ? gsy : gsz);
-    const uint32_t stride_x = gsy * gsz, stride_y = gsz;
-    const uint32_t st_n = n0 ? stride_x : (n1 ? stride_y : 1u), st_1 = t10 ? stride_x : (t11 ? stride_y : 1u), st_2 = t20 ? stride_x : (t21 ? stride_y : 1u);
+    // BYTE strides: a texel's place is a 32-bit byte offset from the volume's base (aic_upload_space keeps a light volume within 4 GiB), which the
+    // device's loads take as scalar base + 32-bit vector offset -- no 64-bit address arithmetic per texel (round 6: eight v_lshl_add_u64 per SHADE event)
+    const uint32_t stride_x = gsy * gsz * 4u, stride_y = gsz * 4u;
+    const uint32_t st_n = n0 ? stride_x : (n1 ? stride_y : 4u), st_1 = t10 ? stride_x : (t11 ? stride_y : 4u), st_2 = t20 ? stride_x : (t21 ? stride_y : 4u);
 
     // Common path: all three surface-point coordinates far inside i32 (so every sample has a cube) and every sample cube
     // inside the space. Anything else is patched texel by texel below.
@@ -192,22 +194,27 @@ AIC_HD void lm_interpolated_light(const LightGridView &G, const float *lut, int 
     const uint32_t d1n = (uint32_t)v1n - (uint32_t)lo_1, d1f = (uint32_t)v1f - (uint32_t)lo_1;
     const uint32_t d2n = (uint32_t)v2n - (uint32_t)lo_2, d2f = (uint32_t)v2f - (uint32_t)lo_2;
     const bool all_inside = far_from_i32_edge & (dnf < sz_n) & (dns < sz_n) & (d1n < sz_1) & (d1f < sz_1) & (d2n < sz_2) & (d2f < sz_2);
-    const uint32_t bnf = dnf * st_n, bns = dns * st_n, b1n = d1n * st_1, b1f = d1f * st_1, b2n = d2n * st_2, b2f = d2f * st_2;
+    // (off the common path the three strides are zero, hence every offset: always a valid address -- three selects instead of one per texel)
+    const uint32_t zt_n = all_inside ? st_n : 0u, zt_1 = all_inside ? st_1 : 0u, zt_2 = all_inside ? st_2 : 0u;
+    const uint32_t bnf = dnf * zt_n, bns = dns * zt_n, b1n = d1n * zt_1, b1f = d1f * zt_1, b2n = d2n * zt_2, b2f = d2f * zt_2;
     const uint32_t q00 = b1n + b2n, q01 = b1n + b2f, q10 = b1f + b2n, q11 = b1f + b2f;
-    // eight loads issued together (index 0 where the common path does not apply: always a valid address)
-    uint32_t tf00 = texels[all_inside ? bnf + q00 : 0u];  // front plane: near12, near1far2, near2far1, far12
-    uint32_t tf01 = texels[all_inside ? bnf + q01 : 0u];
-    uint32_t tf10 = texels[all_inside ? bnf + q10 : 0u];
-    uint32_t tf11 = texels[all_inside ? bnf + q11 : 0u];
+    const char *const tex_bytes = reinterpret_cast<const char *>(texels);
+#define AIC_LM_TEXEL(off) (*reinterpret_cast<const uint32_t *>(tex_bytes + (uint32_t)(off)))
+    // eight loads issued together
+    uint32_t tf00 = AIC_LM_TEXEL(bnf + q00);  // front plane: near12, near1far2, near2far1, far12
+    uint32_t tf01 = AIC_LM_TEXEL(bnf + q01);
+    uint32_t tf10 = AIC_LM_TEXEL(bnf + q10);
+    uint32_t tf11 = AIC_LM_TEXEL(bnf + q11);
     // same plane: a full-height surface -- every face of a whole-cube block, i.e. most surfaces of most all-is-cubes scenes -- interpolates in the front plane only
     // (sr.rs:339-354: `one_plane`), and the reference never fetches these four texels for it; a wave in which no lane needs them does not either (round 6)
     uint32_t ts00 = 0u, ts01 = 0u, ts10 = 0u, ts11 = 0u;
     if (AIC_LM_ANY(!one_plane)) {
-        ts00 = texels[all_inside ? bns + q00 : 0u];
-        ts01 = texels[all_inside ? bns + q01 : 0u];
-        ts10 = texels[all_inside ? bns + q10 : 0u];
-        ts11 = texels[all_inside ? bns + q11 : 0u];
+        ts00 = AIC_LM_TEXEL(bns + q00);
+        ts01 = AIC_LM_TEXEL(bns + q01);
+        ts10 = AIC_LM_TEXEL(bns + q10);
+        ts11 = AIC_LM_TEXEL(bns + q11);
     }
+#undef AIC_LM_TEXEL
     uint32_t n_calls = one_plane ? 4u : 8u;
     if (!all_inside) {
         // Rare: a sample outside the space (BlockSky::light_outside on the reassembled cube) or without an i32 cube

@@ -388,10 +388,10 @@ AIC_DEV float zo_clamped(float v) {                                        // re
     if (v <= 0.f) return 0.f;
     return 1.f;
 }
-AIC_DEV float ps_mul(float a, float b) {  // PositiveSign::mul: 0*inf => 0
-    float v = a * b;
-    return (v != v) ? 0.f : v;
-}
+// PositiveSign::mul: 0 * inf => 0. Both factors are PositiveSign values (not NaN, sign bit clear: what the reference's type holds and aic_upload_* / the
+// kernel's own clamps guarantee), so the product is >= +0 or the NaN of 0 * inf, and max(product, 0) -- one instruction: it returns the operand that
+// is a number -- is the reference's "NaN becomes zero" (a compare and a select until round 6; fifteen of them in a SHADE event).
+AIC_DEV float ps_mul(float a, float b) { return fmaxf(a * b, 0.0f); }
 
 // f32::powf as the reference's libm computes it on x86-64 Linux. Rust's `f32::powf` is the C library's
 // powf; glibc's (sysdeps/ieee754/flt-32/e_powf.c, from ARM's optimized-routines; not under
@@ -1901,7 +1901,19 @@ __global__ __launch_bounds__((AIC_EXCHANGE && XC && !DIAG && LMODE != 3) ? AIC_X
                         if (__ballot(w != 1.0f) == 0ull) {  // x / 1.0f == x: fully lit neighbourhoods (the usual case) need no division
                             i0 = fin[0]; i1 = fin[1]; i2 = fin[2];
                         } else {
-                            i0 = fin[0] / w; i1 = fin[1] / w; i2 = fin[2] / w;
+                            // Three quotients by the same w in [0.1, 1]: the compiler's own correctly rounded f32 division (v_rcp_f32, one Newton step on the
+                            // reciprocal, q = x r, two residual corrections, a last fused one) with the reciprocal and its refinement made ONCE and without the
+                            // operand scaling and the special-case fix-up, which do nothing here: w is a normal number near one, x is a light value -- zero, or
+                            // between 2^-15 times an interpolation weight and 2^12 --, so v_div_scale_f32 leaves both alone and no operand is infinite or NaN
+                            // (18 instructions instead of 33, one quarter-rate reciprocal instead of three; round 6).
+                            const float r0 = __builtin_amdgcn_rcpf(w);
+                            const float rr = __builtin_fmaf(__builtin_fmaf(-w, r0, 1.0f), r0, r0);
+                            auto quot = [&](const float x) -> float {
+                                float q = x * rr;
+                                q = __builtin_fmaf(__builtin_fmaf(-w, q, x), rr, q);
+                                return __builtin_fmaf(__builtin_fmaf(-w, q, x), rr, q);
+                            };
+                            i0 = quot(fin[0]); i1 = quot(fin[1]); i2 = quot(fin[2]);
                         }
                     }
                 }
