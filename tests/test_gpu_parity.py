@@ -462,6 +462,41 @@ def test_errors_are_reported_not_swallowed(ctx):
         ctx.set_options(abi.LAYER_WORLD, o)
 
 
+def test_positive_sign_inputs_are_checked_and_negative_zero_is_canonical(ctx):
+    """Colours, sky and exposure are PositiveSign<f32> in the reference (restricted_number.rs: not NaN, sign bit clear; -0.0 is stored as +0.0).
+    The kernel's PositiveSign::mul relies on it (max(product, 0)), so the boundary rejects what the type cannot hold and stores -0.0 as +0.0."""
+    sp = scenes.synthetic_space(n=12, resolution=4, n_blocks=4, seed=5)
+    w, h = 48, 32
+    eye = (6.5, 9.5, 20.0)
+    _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, (6.0, 4.0, 6.0)), eye)
+    opt = abi.make_options()
+    ctx.set_options(abi.LAYER_WORLD, opt)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    plain = ctx.render(ctx.make_frame(w, h, world_inv=inv))
+    bad = scenes.synthetic_space(n=12, resolution=4, n_blocks=4, seed=5)
+    bad.sky[0, 1] = -0.25
+    with pytest.raises(abi.AicError):
+        ctx.upload_space(abi.LAYER_WORLD, bad)
+    bad.sky[0, 1] = np.nan
+    with pytest.raises(abi.AicError):
+        ctx.upload_space(abi.LAYER_WORLD, bad)
+    for ex in (-1.0, float("nan")):
+        with pytest.raises(abi.AicError):
+            ctx.render(ctx.make_frame(w, h, world_inv=inv, exposure=ex))
+    # -0.0 where the scene has +0.0: same frame, and equal to the oracle's
+    nz = scenes.synthetic_space(n=12, resolution=4, n_blocks=4, seed=5)
+    nz.sky = np.where(nz.sky == 0, np.float32(-0.0), nz.sky)
+    for b in nz.blocks:
+        pal = getattr(b, "palette", None)
+        if pal is not None and len(pal):
+            pal[...] = np.where(pal == 0, np.float32(-0.0), pal)
+    ctx.upload_space(abi.LAYER_WORLD, nz)
+    got = ctx.render(ctx.make_frame(w, h, world_inv=inv), want_aux=True)
+    assert (got["rgba8"] == plain["rgba8"]).all()
+    ref = oracle.render(oracle.Space(sp), opt, oracle.make_camera(inv, w, h), want_aux=True)
+    assert_parity(got, ref)
+
+
 # --- the C++ host mirror (HeadlessRenderer surface) on the GPU --------------------------------
 def test_hip_rt_renderer_update_and_draw(ctx, synth_space):
     """HipRtRenderer mirrors RtRenderer: update() snapshots (full, then incremental through

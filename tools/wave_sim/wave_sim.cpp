@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <queue>
 #include <deque>
 #include <string>
@@ -177,6 +178,8 @@ extern "C" int simulate(const char *tok, const long *off, const Params *Pp, Out 
         int m = (y / 16) * macros_x + (x / 16);
         cost[m] = std::max(cost[m], len > 48 ? len : 0);
     }
+    // (SIM_COST=<file of n_macro int32>: another cost record -- e.g. an estimate made before the frame -- in place of the true one; a policy experiment)
+    if (const char *cf = getenv("SIM_COST")) { if (FILE *f = fopen(cf, "rb")) { size_t got = fread(cost.data(), 4, (size_t)n_macro, f); fclose(f); if (got != (size_t)n_macro) return 7; } }
     // queues: super-blocks of 128 px (8 macro tiles), (bx + 3 by) mod 8
     const int NQ = 8;
     int sb_px = 1; while (sb_px * 2 <= H / 8) sb_px *= 2;
