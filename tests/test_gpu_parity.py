@@ -493,7 +493,7 @@ def test_positive_sign_inputs_are_checked_and_negative_zero_is_canonical(ctx):
     ctx.upload_space(abi.LAYER_WORLD, nz)
     got = ctx.render(ctx.make_frame(w, h, world_inv=inv), want_aux=True)
     assert (got["rgba8"] == plain["rgba8"]).all()
-    ref = oracle.render(oracle.Space(sp), opt, oracle.make_camera(inv, w, h), want_aux=True)
+    ref = oracle.render(oracle.Space(sp), oracle.make_options(), oracle.make_camera(inv, w, h), want_aux=True)
     assert_parity(got, ref)
 
 
