@@ -1061,6 +1061,22 @@ int submit_frames(aic_ctx *c, uint32_t k, const aic_frame_desc *frames, uint32_t
     F.light_lut = c->lut.p;
     F.n_cus = c->n_cus;
     F.tiles_per_wave = c->sw.tiles_per_wave ? c->sw.tiles_per_wave : (c->streaming_submit ? 4u : 1u);
+    if (!c->sw.tiles_per_wave && c->streaming_submit && k == 1u) {
+        // A streamed frame with several tiles per resident wave (a whole 1080p frame has 7.9) that is submitted while others are in flight gets a PART of the
+        // chip: a third with three others queued, a quarter from four on -- up to 32 tiles per wave, which a 4K frame has on the whole chip. Full-grid launches
+        // run one behind the other and only their tails overlap; part-grid launches are resident side by side, each wave refills its lanes three or four
+        // times as often before its frame runs dry, and a frame's ramp and tail are paid on a part of the chip while the others are in full swing: C2 streamed
+        // 0.376 -> 0.341 ms with four frames in flight, 0.338 with eight (profiles/r06_experiments.txt R). A frame submitted with nothing else in flight (the
+        // first of a stream, or a host that submits slower than the device traces) still takes the whole chip; small frames keep their four tiles per wave.
+        uint32_t busy_others = 0;
+        for (uint32_t i = 0; i < AIC_MAX_IN_FLIGHT; i++) busy_others += (i != slot && c->slots[i].busy) ? 1u : 0u;
+        const uint32_t resident_waves = (uint32_t)c->n_cus * 16u;
+        const uint32_t tpw_full = (F.tiles_x * F.tiles_y + resident_waves - 1u) / resident_waves;
+        if (tpw_full >= 4u && busy_others > 0u) {
+            const uint32_t t = tpw_full * (busy_others < 4u ? busy_others : 4u);
+            F.tiles_per_wave = t < 32u ? t : (tpw_full > 32u ? tpw_full : 32u);
+        }
+    }
     F.srgb_thr = c->srgb_thr.p;
 
     const bool want_aux = allow_aux && (f->flags & AIC_FRAME_AUX) != 0;
