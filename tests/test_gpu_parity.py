@@ -810,6 +810,49 @@ def test_two_frames_in_flight_equal_synchronous_frames(ctx):
     assert (bufs[0].cpu().numpy() == sync[0]).all()
 
 
+@pytest.mark.parametrize("in_flight_n", [3, 4, 8])
+def test_streamed_full_size_frames_on_a_part_of_the_chip_equal_synchronous_frames(ctx, in_flight_n):
+    """A streamed frame with several tiles per resident wave that is submitted while others are in flight is launched on a part of the resident
+    grid (aic_abi.cpp submit_frames: a third with three others queued, a quarter from four on). Same frames, byte for byte, same step totals --
+    whatever the grid: ten 1920x1080 frames of the C2 scene, a different camera each."""
+    import torch
+
+    sp = scenes.atrium_like_space()
+    w, h = 1920, 1080
+    ctx.clear_space(abi.LAYER_UI)
+    ctx.upload_space(abi.LAYER_WORLD, sp)
+    ctx.set_options(abi.LAYER_WORLD, abi.make_options())
+    frames = []
+    for k in range(10):
+        a = 2.0 * np.pi * k / 60.0
+        eye = (0.5 + 7.0 * np.sin(a), 9.91, 7.0 * np.cos(a))
+        _, _, inv = oracle.camera_matrices(90.0, 200.0, w / h, oracle.look_at_y_up(eye, (0.5, 8.0, 0.0)), eye)
+        frames.append(ctx.make_frame(w, h, world_inv=inv))
+    sync, sync_steps = [], []
+    for f in frames:
+        r = ctx.render(f)
+        sync.append(r["rgba8"].copy()); sync_steps.append(r["info"].cubes_traced)
+    bufs = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(in_flight_n)]
+    queue, got = [], {}
+
+    def complete():
+        k, slot = queue.pop(0)
+        info = ctx.render_wait(slot)
+        got[k] = (bufs[slot].cpu().numpy().copy(), info.cubes_traced)
+
+    for k, f in enumerate(frames):
+        if len(queue) == in_flight_n:
+            complete()
+        slot = k % in_flight_n
+        ctx.render_submit(f, bufs[slot].data_ptr(), slot)
+        queue.append((k, slot))
+    while queue:
+        complete()
+    for k in range(len(frames)):
+        assert (got[k][0] == sync[k]).all(), f"frame {k}"
+        assert got[k][1] == sync_steps[k], f"frame {k}: step total"
+
+
 def test_light_reupload_does_not_disturb_a_frame_in_flight(ctx):
     """aic_update_light_volume is double-buffered: a frame submitted before it keeps the light it was
     submitted with, the next frame sees the new volume."""
