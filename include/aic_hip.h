@@ -81,7 +81,8 @@ typedef struct aic_space_desc {
                                   * with pal_len > 0 (or AIC_BLOCK_ONE) needs a non-null palette, one with voxels a non-null voxel pool. */
     uint64_t n_palette;
     int32_t sky_kind;            /* 0 Sky::Uniform(sky[0]); 1 Sky::Octants (sky.rs:16-21) */
-    float sky[8][3];
+    float sky[8][3];             /* Rgb = PositiveSign<f32> x 3: not NaN, not negative (rejected with AIC_ERR_INVALID otherwise; -0.0 is kept as +0.0, as in
+                                  * the reference's type, restricted_number.rs:283 -- palette components likewise) */
     uint8_t block_sky[7][4];     /* Sky::for_blocks(): faces nx,ny,nz,px,py,pz then mean, as texels (sky.rs:45-82) */
 } aic_space_desc;
 
@@ -103,7 +104,7 @@ typedef struct aic_options {
 /* One Camera as the kernel needs it (camera/camera_struct.rs:43-77). */
 typedef struct aic_camera {
     double inverse_projection_view[16]; /* euclid order m11..m44; Camera.inverse_projection_view (412-416) */
-    float exposure;                     /* Camera::exposure() (365-367) */
+    float exposure;                     /* Camera::exposure() (365-367): a PositiveSign<f32> -- a frame with a negative or NaN exposure is rejected */
     int32_t reserved;
 } aic_camera;
 
@@ -198,7 +199,9 @@ int aic_device_name(const aic_ctx *ctx, char *buf, uint32_t buf_len);
 
 /* --- scene snapshot: RtRenderer::update -> UpdatingSpaceRaytracer::update -------------- */
 /* replaces: SpaceRaytracer::new on SpaceChange::EveryBlock / first update
- * (updating.rs:107-126; sr.rs:64-88, prepare_cubes 543-549). */
+ * (updating.rs:107-126; sr.rs:64-88, prepare_cubes 543-549).
+ * Limits (AIC_ERR_INVALID beyond them): the kernel addresses the cube grid + voxel volumes (2 bytes per element) and the light volume (4 bytes per cube)
+ * by 32-bit byte offsets, so cubes + voxels < 2^31 and cubes < 2^30 (a 1024^3 space is one cube too many); at most 65536 blocks. */
 int aic_upload_space(aic_ctx *ctx, int layer, const aic_space_desc *space);
 /* replaces: `rts.<layer> = None` (renderer.rs:134-135). */
 int aic_clear_space(aic_ctx *ctx, int layer);
@@ -236,7 +239,9 @@ int aic_render(aic_ctx *ctx, const aic_frame_desc *frame, void *out_rgba8, int o
  * all-is-cubes-desktop/src/record.rs:97-113): aic_render_submit queues a frame on slot
  * 0..AIC_MAX_IN_FLIGHT-1 and returns at once; aic_render_wait blocks until that slot's frame is in
  * `out_device` and reports it. With several frames in flight the next frame's trace starts filling the
- * GPU while the previous frame's last rays finish. out_device must be a device pointer; the
+ * GPU while the previous frame's last rays finish; a frame of many tiles that is submitted while others are in flight is launched on a part of the
+ * chip (a third with three others in flight, a quarter from four on), so that the frames in flight are resident side by side -- same pixels and counts,
+ * a higher frame rate, a longer life of each frame; a frame submitted with nothing else in flight takes the whole chip. out_device must be a device pointer; the
  * AIC_FRAME_AUX flag is ignored here (use aic_render). Scene updates that change what a frame in flight
  * reads (aic_upload_space, aic_update_cubes, aic_replace_blocks, aic_set_options, aic_compact) wait for every
  * frame in flight first; aic_update_light_volume and aic_evaluate_light do NOT: they write the other half of the
