@@ -602,7 +602,7 @@ class Context:
 
 class MultiContext:
     """`aic_multi`: one object over several devices (ids may repeat), the form a Rust `HipRtRenderer` would hold.
-    Scene calls are replicated; `render` deals 16-row strips to the devices and assembles the frame on the first."""
+    Scene calls are replicated; `render` deals 8-row strips to the devices and assembles the frame on the first."""
 
     def __init__(self, device_ids):
         self._lib = load()

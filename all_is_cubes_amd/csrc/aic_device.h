@@ -209,8 +209,9 @@ struct OrderJobs {
     uint32_t *clear_words[kMaxSub];
 };
 
-// Largest work tile edge in pixels (DevFrame.tile is 8 by default, 16 with AIC_TILE=16); row strips of
-// the multi-GPU partition are a multiple of it.
+// Largest work tile edge in pixels (DevFrame.tile is 8 by default, 16 with AIC_TILE=16). Row strips of the multi-GPU partition are a multiple of the
+// DEFAULT tile (8 rows since the end of round 6): a tile works on the part's local rows, which are contiguous whatever the strips are, so a larger tile
+// or a macro tile that spans two strips is correct, only less local.
 constexpr int kTile = 16;
 constexpr int kClsWords = 4096;  // 65536 blocks x 2 bits
 

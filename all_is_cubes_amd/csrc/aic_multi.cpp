@@ -4,7 +4,7 @@
 // aic_multi owns one aic_ctx per device (device ids may repeat: two contexts on one GPU are how the path is tested on a
 // single-GPU box), replicates every scene call on all of them (the scene is tiny next to 288 GB: SURVEY.md 8e), and
 // renders a frame as the reference's row loop would be split (renderer.rs:537-555 treats rows as independent work
-// items): the image is cut into 16-row strips dealt round-robin to the devices, every device traces its strips into a
+// items): the image is cut into 8-row strips dealt round-robin to the devices, every device traces its strips into a
 // compact local buffer (aic_render_submit on its own stream -- the traces run concurrently), the compact buffers are
 // copied to device 0 over xGMI (hipMemcpyPeerAsync: each peer uses its direct link to device 0, the same exchange the
 // multi-process path does with an RCCL gather), and aic_assemble_strips de-interleaves them into the frame.
@@ -18,7 +18,7 @@
 #include "../../include/aic_hip.h"
 
 namespace {
-constexpr uint32_t kStripRows = 16;
+constexpr uint32_t kStripRows = 8;  // (the kernel's work tile: 135 strips of a 1080-row frame deal evenly, 67.5 sixteen-row strips did not -- profiles/r06_experiments.txt T)
 }
 
 // A frame in flight (aic_multi_render_submit): its buffers and what aic_multi_render_wait needs to finish it

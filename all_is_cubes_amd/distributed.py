@@ -14,7 +14,9 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
-STRIP_ROWS = 16  # rows per strip: a multiple of the kernel's work tile (aic_device.h kTile)
+# rows per strip: the kernel's work tile (8 x 8 pixels). 1080 rows are 135 such strips -- 17 or 16 per rank at N = 8 (136 / 128 rows) -- where 16-row strips (rounds 1-5)
+# made 67.5 of them: 9 or 8 per rank, 144 / 128 rows, and the frame waits for its slowest rank (a rank's share at N = 8: 0.0593 -> 0.0567 ms, profiles/r06_experiments.txt T)
+STRIP_ROWS = 8
 
 
 def partition_rows(height: int, strip_rows: int, n_parts: int, part: int) -> List[int]:

@@ -322,7 +322,7 @@ int aic_render_orthographic(aic_ctx *ctx, int layer, int resolution, void *out_r
 
 /* --- several devices in one process ------------------------------------------------------ */
 /* No reference counterpart: the reference's renderer is one object, and so is this -- an aic_multi owns one context
- * per device (ids may repeat), replicates the scene calls on all of them, and renders a frame by dealing 16-row
+ * per device (ids may repeat), replicates the scene calls on all of them, and renders a frame by dealing 8-row
  * strips round-robin to the devices (rows are independent work items in the reference: renderer.rs:537-555),
  * copying each device's compact strips to device_ids[0] over its direct xGMI link (hipMemcpyPeerAsync) and
  * de-interleaving there. The multi-PROCESS form of the same partition (one rank per GPU, RCCL gather) is what

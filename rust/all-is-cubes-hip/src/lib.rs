@@ -15,7 +15,7 @@
 //! | `draw_info_text` (renderer.rs:659-683)                 | the same few lines, on the host        |
 //!
 //! One renderer may span several GPUs of a node ([`HipRtRenderer::with_devices`]): the scene is replicated, every device
-//! traces its interleaved 16-row strips and device 0 assembles the frame (`aic_create_multi`, csrc/aic_multi.cpp).
+//! traces its interleaved 8-row strips and device 0 assembles the frame (`aic_create_multi`, csrc/aic_multi.cpp).
 //! [`HipRtRenderer::set_device_light`] hands the light itself over to the device: block edits are queued there
 //! (`aic_light_cubes_changed`) and [`HipRtRenderer::evaluate_light_budgeted`] advances the light between frames.
 //!
@@ -319,7 +319,7 @@ impl HipRtRenderer {
     }
 
     /// One renderer over several GPUs of the node: the scene is replicated on each, every device traces its interleaved
-    /// 16-row strips of a frame, the strips go to `device_ids[0]` over the direct links and are assembled there
+    /// 8-row strips of a frame, the strips go to `device_ids[0]` over the direct links and are assembled there
     /// (`aic_create_multi`). With one id this is [`Self::new`].
     ///
     /// # Errors

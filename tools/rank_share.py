@@ -1,5 +1,5 @@
 """How long does ONE rank's share of the frame take on one GPU? (estimates the N-GPU trace rate without N GPUs)
-usage: python tools/rank_share.py [n_parts] [in_flight] [workload] [frames_per_launch]
+usage: python tools/rank_share.py [n_parts] [in_flight] [workload] [frames_per_launch] [strip_rows]
 frames_per_launch k > 1 (1, 2, 4, 8): the rank's shares of k consecutive frames are traced by ONE launch (aic_render_submit_batch), `in_flight` such
 launches overlapping; the figure printed is still ms per FRAME (share)."""
 import os, sys, time
@@ -11,14 +11,16 @@ n_parts = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 depth = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 wl = sys.argv[3] if len(sys.argv) > 3 else "atrium"
 per_launch = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+from all_is_cubes_amd import distributed as D
+strip = int(sys.argv[5]) if len(sys.argv) > 5 else D.STRIP_ROWS  # rows per strip
 sp, (w, h), eye, target, vd, label = bench.build_workload(wl)
 _, _, inv = oracle.camera_matrices(90.0, vd, w / h, oracle.look_at_y_up(eye, target), eye)
 with abi.Context(0) as ctx:
     ctx.upload_space(abi.LAYER_WORLD, sp)
     ctx.set_options(abi.LAYER_WORLD, abi.make_options(view_distance=vd))
     for part in (0, n_parts // 2):
-        fr = ctx.make_frame(w, h, world_inv=inv, partition=(16, n_parts, part))
-        rows = ctx.partition_rows(h, (16, n_parts, part))
+        fr = ctx.make_frame(w, h, world_inv=inv, partition=(strip, n_parts, part))
+        rows = ctx.partition_rows(h, (strip, n_parts, part))
         bufs = [[torch.zeros((rows, w, 4), dtype=torch.uint8, device="cuda") for _ in range(per_launch)] for _ in range(depth)]
         def run(n):  # n launches of per_launch frames each
             fl = []
