@@ -14,6 +14,7 @@
 #include <mutex>
 #include <thread>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <initializer_list>
 #include <string>
@@ -44,6 +45,18 @@ void launch_probe_raycast(const double *od, int use_bounds, const int *lohi, int
 using namespace aic;
 
 static_assert(sizeof(aic_pixel_aux) == sizeof(DevAux), "aux record layout");
+
+// Frame slots are HIP streams, and the runtime deals streams onto GPU_MAX_HW_QUEUES hardware queues; streams that share a queue run their kernels one
+// behind the other. With the variable unset a streamed C2 frame costs 0.86 ms instead of 0.35 (tools/hw_queues.py, profiles/r06_experiments.txt W):
+// the launches of four frames in flight never overlap, and the part-grid sizing of streamed frames (submit_frames) then leaves two thirds of the chip
+// idle. The runtime reads the variable when it starts -- at the process's first HIP call --, so a default is put in place when this library is loaded,
+// which for a host that links it is before main(). A value the caller has set is left alone; AIC_KEEP_HW_QUEUES=1 leaves the runtime's own default.
+// A host that has used HIP before it loads this library has to set the variable itself.
+__attribute__((constructor)) static void aic_default_hw_queues() {
+    const char *keep = std::getenv("AIC_KEEP_HW_QUEUES");
+    if (keep && keep[0] && keep[0] != '0') return;
+    setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
+}
 static_assert(sizeof(aic_block_desc) == 48, "aic_block_desc is 48 bytes");
 
 struct LightState;                       // aic_light_host.inc

@@ -252,7 +252,10 @@ int aic_render(aic_ctx *ctx, const aic_frame_desc *frame, void *out_rgba8, int o
  * stream still prepares the slot's next frame (the frame's cost record becomes a tile order, counters are cleared -- microseconds of
  * work private to the slot). Work the caller orders behind the frame with aic_stream_wait_frame, or issues after the wait returns,
  * never has to wait for that. aic_render_wait does NOT drain the slot's stream: call aic_synchronize before handing aic_stream() to
- * other code that assumes it idle. */
+ * other code that assumes it idle.
+ * Slots are HIP streams; the runtime runs streams that share one of its GPU_MAX_HW_QUEUES hardware queues (4 when unset) one behind the other.
+ * The library sets GPU_MAX_HW_QUEUES=8 when it is loaded unless the caller has set it (AIC_KEEP_HW_QUEUES=1: hands off); a host that has used
+ * HIP before loading the library sets it itself before its first HIP call (INTEGRATION.md "Hardware queues"). */
 #define AIC_MAX_IN_FLIGHT 32u
 int aic_render_submit(aic_ctx *ctx, const aic_frame_desc *frame, void *out_device, uint32_t slot);
 int aic_render_wait(aic_ctx *ctx, uint32_t slot, aic_frame_info *info);

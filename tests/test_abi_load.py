@@ -75,3 +75,24 @@ def test_block_sky_host_matches_oracle():
         got = abi.block_sky_texels(sp.sky_kind, sp.sky)
         ref = oracle.block_sky(oracle.Space(sp))
         assert (got == ref).all()
+
+
+def test_loading_the_library_puts_a_hardware_queue_default_in_place():
+    """Frame slots are HIP streams and the runtime's four hardware queues make slots share one as soon as the host has streams of its own
+    (profiles/r06_hw_queues.txt): the library sets GPU_MAX_HW_QUEUES=8 when it is loaded, leaves a caller's value alone, and keeps its
+    hands off under AIC_KEEP_HW_QUEUES=1."""
+    import os
+    import subprocess
+    import sys
+
+    code = ("import ctypes, os, sys; sys.path.insert(0, %r); from all_is_cubes_amd import abi; abi.load(); "
+            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; print(libc.getenv(b'GPU_MAX_HW_QUEUES'))" % str(ROOT))
+    for given, keep, want in [(None, None, "b'8'"), ("2", None, "b'2'"), (None, "1", "None")]:
+        env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "AIC_KEEP_HW_QUEUES")}
+        if given is not None:
+            env["GPU_MAX_HW_QUEUES"] = given
+        if keep is not None:
+            env["AIC_KEEP_HW_QUEUES"] = keep
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-500:]
+        assert out.stdout.strip().splitlines()[-1] == want, (given, keep, out.stdout)
