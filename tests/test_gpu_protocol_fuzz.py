@@ -157,3 +157,84 @@ def test_random_call_sequences_against_a_synchronous_twin(seed):
     finally:
         a.close()
         b.close()
+
+
+@pytest.mark.parametrize("seed", range(max(2, N_SEEDS // 2)))
+def test_random_call_sequences_on_the_multi_device_context(seed):
+    """The same for `aic_multi` (csrc/aic_multi.cpp; the form the Rust shim's `with_devices` holds): 2 or 3 device entries -- the one GPU,
+    repeated -- with frames streamed through `aic_multi_render_submit / _wait` (host and device targets, up to eight slots), scene calls
+    replicated, blocking light updates on the device that runs the updater; the twin is a single-device context drawing synchronously."""
+    import torch
+
+    rng = np.random.default_rng(5000 + seed)
+    space = scenes.synthetic_space(n=16, resolution=8, n_blocks=6, seed=40 + seed, light="field")
+    n_blocks = len(space.blocks)
+    opts = dict(fog=int(rng.integers(0, 4)), transparency=int(rng.integers(0, 3)), lighting=int(rng.integers(0, 5)), view_distance=200.0)
+    m, b = abi.MultiContext([0] * int(rng.integers(2, 4))), abi.Context(0)
+    try:
+        for c in (m, b):
+            c.upload_space(abi.LAYER_WORLD, space)
+            c.set_options(abi.LAYER_WORLD, abi.make_options(**opts))
+        in_flight = {}  # slot -> (host array or device tensor, expected frame, expected steps)
+        checked = 0
+
+        def collect(slot):
+            nonlocal checked
+            out, want, steps = in_flight.pop(slot)
+            info = m.render_wait(slot)
+            got = out if isinstance(out, np.ndarray) else out.cpu().numpy()
+            assert (got == want).all(), f"seed {seed}: multi slot {slot} differs from the frame at submit time"
+            assert int(info.cubes_traced) == steps
+            checked += 1
+
+        for _ in range(N_CALLS // 2):
+            op = rng.random()
+            if op < 0.5:
+                slot = int(rng.integers(0, 8))
+                if slot in in_flight:
+                    collect(slot)
+                w, h = SIZES[int(rng.integers(0, len(SIZES)))]
+                f = abi.Context.make_frame(w, h, world_inv=cameras(rng, w, h, opts["view_distance"]))
+                ref = b.render(f)
+                if rng.random() < 0.5:
+                    buf = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+                    torch.cuda.synchronize()
+                    m.render_submit(f, slot, buf.data_ptr())
+                else:
+                    buf = m.render_submit(f, slot)
+                in_flight[slot] = (buf, ref["rgba8"].copy(), int(ref["info"].cubes_traced))
+            elif op < 0.65 and in_flight:
+                collect(int(rng.choice(list(in_flight))))
+            elif op < 0.78:
+                n = int(rng.integers(1, 12))
+                xyz = np.stack([rng.integers(0, 16, n), rng.integers(0, 16, n), rng.integers(0, 16, n)], 1).astype(np.int32)
+                blocks = rng.integers(0, n_blocks, n).astype(np.uint16)
+                light = rng.integers(0, 256, (n, 4)).astype(np.uint8)
+                light[:, 3] = rng.choice([1, 128, 255], n)
+                for c in (m, b):
+                    c.update_cubes(abi.LAYER_WORLD, xyz, blocks, light)
+            elif op < 0.86:
+                light = rng.integers(0, 256, tuple(space.size) + (4,)).astype(np.uint8)
+                light[..., 3] = rng.choice([1, 128, 255, 255], tuple(space.size))
+                for c in (m, b):
+                    c.update_light_volume(abi.LAYER_WORLD, light)
+            elif op < 0.93:  # blocks placed and the light brought up to date on the device (blocking; the texels reach the other devices)
+                n = int(rng.integers(1, 5))
+                xyz = np.stack([rng.integers(1, 15, n), rng.integers(1, 15, n), rng.integers(1, 15, n)], 1).astype(np.int32)
+                blocks = rng.integers(0, n_blocks, n).astype(np.uint16)
+                for c in (m, b):
+                    c.update_cubes(abi.LAYER_WORLD, xyz, blocks)
+                    c.light_cubes_changed(abi.LAYER_WORLD, xyz)
+                im = m.evaluate_light(abi.LAYER_WORLD, 6, fast=False)
+                ib = b.evaluate_light(abi.LAYER_WORLD, 6, fast=False)
+                assert im.updates == ib.updates
+            else:
+                opts.update(fog=int(rng.integers(0, 4)), lighting=int(rng.integers(0, 5)))
+                for c in (m, b):
+                    c.set_options(abi.LAYER_WORLD, abi.make_options(**opts))
+        for slot in list(in_flight):
+            collect(slot)
+        assert checked > 5
+    finally:
+        m.close()
+        b.close()
